@@ -1,0 +1,169 @@
+/*
+ * pgrc_match.h -- C ABI of libpgrc_match.so: PgRC's read-to-pseudogenome matching
+ * path as hand-written HIP kernels for MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the reference's DefaultReadsMatcher seam
+ * (matching/ReadsMatchers.h:24-83, :109-143).  The reference has no FFI; the
+ * entry points below are what a `HipReadsApproxMatcher : AbstractReadsApproxMatcher`
+ * adapter binds (INTEGRATION.md shows that adapter and the 6-line change to
+ * mapReadsIntoPg, matching/ReadsMatchers.cpp:716-740).  Plain pointers and
+ * sizes only; no torch / STL types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a PGRC_E_* code otherwise;
+ *     pgrc_match_last_error(ctx) gives the message.  The reference's convention
+ *     is fprintf(stderr)+exit(EXIT_FAILURE) (ReadsMatchers.cpp:738-739,
+ *     CopMEMMatcher.cpp:77-80): the adapter maps non-zero to that.
+ *   - the caller keeps ownership of every host buffer; the context owns all
+ *     device memory (the reference matcher likewise borrows pgPtr / readsSet,
+ *     ReadsMatchers.cpp:71-95).
+ *   - single caller, blocking unless stated; work is issued on the context's
+ *     HIP stream (pgrc_match_set_stream).
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry
+ *     point fails with PGRC_E_NO_DEVICE.
+ *
+ * Symbol values: A0 C1 G2 T3 (utils/helper.cpp:277-283); N (4) exists only in reads.
+ */
+#ifndef PGRC_MATCH_H
+#define PGRC_MATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGRC_NOT_MATCHED_POS UINT64_MAX /* DefaultReadsMatcher::NOT_MATCHED_POSITION, ReadsMatchers.cpp:69 */
+#define PGRC_NOT_MATCHED_CNT 255        /* NOT_MATCHED_COUNT, ReadsMatchers.h:17 */
+
+enum {
+    PGRC_OK = 0,
+    PGRC_E_PARAM = 1,       /* bad argument / unsupported configuration */
+    PGRC_E_SEED_SHORT = 2,  /* copMEM needs seed >= 24 (CopMEMMatcher.cpp:77-80) */
+    PGRC_E_NO_DEVICE = 3,   /* no HIP device / HIP runtime error */
+    PGRC_E_ALLOC = 4,
+    PGRC_E_SYMBOL = 5,      /* symbol outside ACGT (Pg) / ACGNT (reads) */
+    PGRC_E_STATE = 6,       /* call order (e.g. run before set_pg) */
+    PGRC_E_MODE = 7         /* "Unknown matching mode" (ReadsMatchers.cpp:737-739) */
+};
+
+typedef struct pgrc_match_ctx pgrc_match_ctx;
+
+/* Matcher configuration = the constructor arguments of the reference matchers
+ * (ReadsMatchers.h:131-132, :159-160, :178-179, :196-197). */
+typedef struct {
+    uint32_t read_len;      /* readsSet->maxReadLength(), <= 255 */
+    uint32_t seed_len;      /* readsExactMatchingChars (already clipped to read_len) */
+    uint8_t max_mismatches; /* maxMismatches */
+    uint8_t min_mismatches; /* minMismatches (0, or max_mismatches in "shortcut" modes) */
+    char mode;              /* 'c' copMEM (default), 'd', 'i', 'e' exact matcher */
+    int32_t device;         /* HIP device ordinal, -1 = current */
+} pgrc_match_params;
+
+/* mapReadsIntoPg's parameter derivation (ReadsMatchers.cpp:699-723): fills *out from
+ * the CLI-level values (-s [mode]len, -M minCharsPerMismatch). */
+int pgrc_match_derive_params(uint32_t read_len, uint32_t seed_len, uint32_t min_chars_per_mismatch,
+                             char mode_char, pgrc_match_params *out);
+
+int pgrc_match_create(const pgrc_match_params *params, pgrc_match_ctx **out);
+void pgrc_match_destroy(pgrc_match_ctx *ctx);
+const char *pgrc_match_last_error(const pgrc_match_ctx *ctx);
+/* hipStream_t to issue all work on (0 = the null stream). */
+int pgrc_match_set_stream(pgrc_match_ctx *ctx, void *hip_stream);
+
+/* ---- pseudogenome (replaces `char* pgPtr, pgLength`, ReadsMatchers.h:26-27) ---- */
+/* ASCII ACGT text on the host; packed to 2 bits/symbol on the device. */
+int pgrc_match_set_pg_ascii(pgrc_match_ctx *ctx, const char *pg, uint64_t pg_len);
+/* 2-bit packed text already in HBM (16 symbols per little-endian u32, symbol i at
+ * bits 2*(i%16)); e.g. the result of the RCCL all-gather.  Copied into the context. */
+int pgrc_match_set_pg_packed_device(pgrc_match_ctx *ctx, const void *d_words, uint64_t pg_len);
+/* Packs host ASCII pg[first .. first+count) into d_words_out (device), count/16 rounded
+ * up words; `first` must be a multiple of 16.  Used per rank before the all-gather. */
+int pgrc_match_pack_pg_slice(pgrc_match_ctx *ctx, const char *pg_slice, uint64_t count,
+                             void *d_words_out);
+
+/* ---- reads (replaces ConstantLengthReadsSetInterface*, readsset/ReadsSetInterface.h:28-43) ---- */
+/* n rows of read_len ASCII symbols (what readsSet->getRead(i, buf) yields,
+ * ReadsMatchers.cpp:432).  Rows containing 'N' take the byte-compare kernel. */
+int pgrc_match_set_reads_ascii(pgrc_match_ctx *ctx, const char *reads, uint64_t n);
+/* The reference's own packed layout for an ACGT set: ceil(read_len/4) bytes per read,
+ * 4 symbols per byte, first symbol most significant
+ * (PackedConstantLengthReadsSet::getPackedRead, coders/SymbolsPackingFacility.cpp:143-178). */
+int pgrc_match_set_reads_packed(pgrc_match_ctx *ctx, const uint8_t *packed, uint64_t n);
+/* Reads already in HBM in the library's layout: word-major u32 [words_per_read][stride]
+ * (word w of read i at d_words[w*stride + i]), 16 symbols per word.  Borrowed, not copied. */
+int pgrc_match_set_reads_device(pgrc_match_ctx *ctx, const void *d_words, uint64_t n, uint64_t stride);
+uint32_t pgrc_match_words_per_read(uint32_t read_len);
+
+/* ---- matching (DefaultReadsMatcher::matchConstantLengthReads, ReadsMatchers.cpp:162-172) ---- */
+/* initMatching (:97-105, :411-415): pos = NOT_MATCHED, rc = 0, count = 255. */
+int pgrc_match_init_results(pgrc_match_ctx *ctx);
+/* hand-over from a previous phase (transferMatchingResults, :111-133). */
+int pgrc_match_set_results(pgrc_match_ctx *ctx, const uint64_t *pos, const uint8_t *rc,
+                           const uint8_t *mism);
+/* forward pass, then (rev_compl_pg != 0) the pass over the reverse-complemented Pg. */
+int pgrc_match_run(pgrc_match_ctx *ctx, int rev_compl_pg);
+/* readMatchPos / readMatchRC / readMismatchesCount / matchedCountPerMismatches /
+ * matchedReadsCount (ReadsMatchers.h:32-35, :115-116).  Any pointer may be NULL. */
+int pgrc_match_get_results(pgrc_match_ctx *ctx, uint64_t *pos, uint8_t *rc, uint8_t *mism,
+                           uint64_t hist[256], uint64_t *matched);
+/* device-resident result arrays (u64[n], u8[n], u8[n]); valid until the next set_reads/destroy. */
+int pgrc_match_get_results_device(pgrc_match_ctx *ctx, void **d_pos, void **d_rc, void **d_mism);
+
+/* ---- mismatch extraction (AbstractReadsApproxMatcher::updateEntry, ReadsMatchers.cpp:548-559,
+ *      fillEntryWith(Reversed)Mismatches :40-66) ---- */
+/* For every read: cum[i+1]-cum[i] = its mismatch count (0 for unmatched reads); codes[] =
+ * (val(pg)<<4)+val(read), offsets[] as the reference emits them.  reversed_flags[i] != 0
+ * selects the "reversed" form; NULL means reversed = rc (the SE rule; for
+ * revComplPairFile the caller passes rc != (orgIdx & 1), :553).  cum has n+1 entries;
+ * codes/offsets need cum[n] entries: call once with codes == NULL to get cum only. */
+int pgrc_match_extract_mismatches(pgrc_match_ctx *ctx, const uint8_t *reversed_flags, uint64_t *cum,
+                                  uint8_t *codes, uint16_t *offsets);
+
+/* ---- introspection (tests, bench) ---- */
+typedef struct {
+    int32_t K, k1, k2;
+    uint32_t hash_size;
+} pgrc_copmem_params;
+int pgrc_match_copmem_params(uint32_t seed_len, uint64_t pg_len, pgrc_copmem_params *out);
+/* canonical copMEM index of the forward (strand 0) or reverse-complemented (1) Pg in the
+ * reference's layout: cumm[hash_size+2], positions[count].  NULL pointers = query count only. */
+int pgrc_match_export_index(pgrc_match_ctx *ctx, int strand, uint32_t *cumm, uint32_t *positions,
+                            uint64_t *count);
+/* 2-bit packed Pg of either strand, copied to the host (ceil(pg_len/16) words). */
+int pgrc_match_export_pg(pgrc_match_ctx *ctx, int strand, uint32_t *words);
+
+typedef struct {
+    uint64_t searched[2];   /* reads not skipped (count > min_mismatches), per pass */
+    uint64_t candidates[2]; /* verified candidates, per pass */
+    uint64_t probes[2];     /* seed lookups, per pass */
+    uint64_t index_entries[2];
+    /* device time in ms of the last run, by kernel class (HIP events on the ctx stream) */
+    float ms_index[2];
+    float ms_match[2];
+    float ms_other;
+    float ms_total;
+} pgrc_match_counters;
+/* enable per-kernel HIP-event timing + work counters for subsequent runs */
+int pgrc_match_set_profiling(pgrc_match_ctx *ctx, int enabled);
+int pgrc_match_get_counters(pgrc_match_ctx *ctx, pgrc_match_counters *out);
+
+/* ---- synthetic inputs (include/pgrc_synth.h) ---- */
+#include "pgrc_synth.h"
+/* host loops */
+void pgrc_synth_pg_host(const pgrc_synth_pg *g, char *ascii_out);
+void pgrc_synth_reads_host(const pgrc_synth_pg *g, const char *pg_ascii, const pgrc_synth_reads *rs,
+                           uint64_t first_read, uint64_t count, char *ascii_out);
+/* HIP generators: write straight into HBM in the library's packed layouts */
+int pgrc_synth_pg_device(const pgrc_synth_pg *g, void *d_words_out, void *hip_stream);
+int pgrc_synth_reads_device(const pgrc_synth_pg *g, const void *d_pg_words, const pgrc_synth_reads *rs,
+                            uint64_t first_read, uint64_t count, void *d_words_out, uint64_t stride,
+                            void *hip_stream);
+
+const char *pgrc_match_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGRC_MATCH_H */

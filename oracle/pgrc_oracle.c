@@ -1,0 +1,555 @@
+/*
+ * pgrc_oracle.c -- CPU restatement of PgRC's read-to-pseudogenome matching path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see pgrc_oracle.h).  Written from the behavioural
+ * specification of the reference; every
+ * function cites the reference file:line it follows.  Pinned against the real
+ * reference via oracle/_ref (tests/test_oracle_vs_ref.py) and the committed
+ * golden fixtures (tests/golden/).
+ */
+#include "pgrc_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ helpers */
+
+/* utils/helper.cpp:263-276 (complementsLut); unknown symbols map to 0 there. */
+static char complement_of(char c) {
+    switch (c) {
+    case 'A': case 'a': return 'T';
+    case 'C': case 'c': return 'G';
+    case 'G': case 'g': return 'C';
+    case 'T': case 't': return 'A';
+    case 'N': case 'n': return 'N';
+    case 'U': case 'u': return 'A';
+    case 'Y': case 'y': return 'R';
+    case 'R': case 'r': return 'Y';
+    case 'K': case 'k': return 'M';
+    case 'M': case 'm': return 'K';
+    case 'B': case 'b': return 'V';
+    case 'D': case 'd': return 'H';
+    case 'H': case 'h': return 'D';
+    case 'V': case 'v': return 'B';
+    default: return 0;
+    }
+}
+
+/* utils/helper.cpp:383-393 */
+void pgrc_or_revcomp(char *seq, uint64_t n) {
+    uint64_t i = 0, j = n;
+    while (i + 1 < j) {
+        --j;
+        char a = complement_of(seq[i]);
+        seq[i] = complement_of(seq[j]);
+        seq[j] = a;
+        ++i;
+    }
+    if (i + 1 == j) seq[i] = complement_of(seq[i]);
+}
+
+/* utils/helper.cpp:277-283: val2sym "ACGTN" */
+uint8_t pgrc_or_sym2val(char c) {
+    switch (c) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T': return 3;
+    case 'N': return 4;
+    default: return 0xFF;
+    }
+}
+
+static int alphabet_order(const char *alphabet, char c) {
+    const char *p = strchr(alphabet, c);
+    return p ? (int)(p - alphabet) : -1;
+}
+
+static int symbols_per_byte(int sigma) {
+    /* SymbolsPackingFacility::maxSymbolsPerElement (coders/SymbolsPackingFacility.cpp:125-130) */
+    int spe = 0;
+    unsigned long long v = 1;
+    while (v * (unsigned)sigma - 1 <= 255) {
+        v *= (unsigned)sigma;
+        spe++;
+    }
+    return spe;
+}
+
+/* coders/SymbolsPackingFacility.cpp:143-178 (packSequence / packSuffixSymbols) */
+void pgrc_or_pack_read(const char *read, uint32_t read_len, const char *alphabet, uint8_t *dst) {
+    int sigma = (int)strlen(alphabet);
+    int spe = symbols_per_byte(sigma);
+    uint32_t i = 0, o = 0;
+    while (i < read_len) {
+        unsigned v = 0;
+        for (int j = 0; j < spe; j++) {
+            v *= (unsigned)sigma;
+            if (i + (uint32_t)j < read_len) v += (unsigned)alphabet_order(alphabet, read[i + j]);
+        }
+        dst[o++] = (uint8_t)v;
+        i += (uint32_t)spe;
+    }
+}
+
+/* coders/SymbolsPackingFacility.cpp:216-236 (reverseSequence) */
+void pgrc_or_unpack_read(const uint8_t *src, uint32_t read_len, const char *alphabet, char *dst) {
+    int sigma = (int)strlen(alphabet);
+    int spe = symbols_per_byte(sigma);
+    for (uint32_t i = 0; i < read_len; i++) {
+        unsigned v = src[i / (uint32_t)spe];
+        int j = (int)(i % (uint32_t)spe);
+        for (int k = spe - 1; k > j; k--) v /= (unsigned)sigma;
+        dst[i] = alphabet[v % (unsigned)sigma];
+    }
+}
+
+/* ---------------------------------------------------------- copMEM (mode c) */
+
+static int isqrt_floor(int v) {
+    int r = 0;
+    while ((r + 1) * (r + 1) <= v) r++;
+    return r;
+}
+
+/* matching/copmem/CopMEMMatcher.cpp:69-96, :111-137, ctor :571-577 */
+int pgrc_or_copmem_derive(uint32_t seed_len, uint64_t pg_len, pgrc_or_copmem_params *out) {
+    int L = (int)seed_len;
+    int K;
+    if (L > 110) K = 56;
+    else if (L > 62) K = 44;
+    else if (L > 53) K = 40;
+    else if (L > 46) K = 36;
+    else if (L > 42) K = 32;
+    else if (L > 32) K = 28;
+    else K = (L / 4 - 1) * 4;
+    /* minMatchLength defaults to UINT32_MAX and is clipped to L (:574-575) */
+    if (L < 24) return 1; /* "Minimal matching length too short" :77-80 */
+    int kmml = (L / 4 - 1) * 4;
+    if (kmml < K) K = kmml;
+    int t = L - K + 1;
+    if (t <= 0) return 2; /* "L and K mismatch" :115-118 */
+    int k1, k2;
+    if (t >= 20) {
+        k1 = isqrt_floor(t) + 1;
+        k2 = k1 - 1;
+        if (k1 * k2 > t) { --k2; --k1; }
+    } else if (t >= 15) { k1 = 5; k2 = 3; }
+    else if (t >= 12) { k1 = 4; k2 = 3; }
+    else if (t >= 10) { k1 = 5; k2 = 2; }
+    else if (t >= 6) { k1 = 3; k2 = 2; }
+    else { k1 = t; k2 = 1; }
+    uint32_t hs;
+    int i = 24;
+    do {
+        hs = ((uint32_t)1) << (i++);
+    } while (i <= 31 && (uint64_t)hs < pg_len / (uint64_t)k1);
+    out->L = L; out->K = K; out->k1 = k1; out->k2 = k2; out->hash_size = hs;
+    return 0;
+}
+
+/* matching/copmem/Hashes.h:54-76 */
+uint32_t pgrc_or_copmem_hash(int K, const char *str) {
+    uint64_t h = (uint64_t)K;
+    for (uint32_t j = 0; j < (uint32_t)K / 4; j++) {
+        uint32_t w = (uint32_t)(uint8_t)str[4 * j] | ((uint32_t)(uint8_t)str[4 * j + 1] << 8) |
+                     ((uint32_t)(uint8_t)str[4 * j + 2] << 16) |
+                     ((uint32_t)(uint8_t)str[4 * j + 3] << 24);
+        w &= (j < 3) ? 0x00FFFFFFu : 0x0000FFFFu;
+        w += j;
+        h ^= w;
+        h *= 171717u;
+    }
+    return (uint32_t)h;
+}
+
+/* CopMEMMatcher.cpp:140-231, serial semantics (PgHelpers::numberOfThreads == 1):
+ * every position p = 0, k1, 2*k1, ... <= G-K in ascending order; a bucket keeps
+ * the first 13 positions and drops the rest (the reference's skippedList). */
+int pgrc_or_index_build(const char *pg, uint64_t pg_len, uint32_t seed_len, pgrc_or_index *out) {
+    memset(out, 0, sizeof *out);
+    int e = pgrc_or_copmem_derive(seed_len, pg_len, &out->p);
+    if (e) return e;
+    out->pg_len = pg_len;
+    const int K = out->p.K, k1 = out->p.k1;
+    const uint32_t hs = out->p.hash_size, mask = hs - 1;
+    uint32_t *cumm = (uint32_t *)calloc((size_t)hs + 2, sizeof(uint32_t));
+    if (!cumm) return 3;
+    uint64_t npos = (pg_len >= (uint64_t)K) ? (pg_len - (uint64_t)K) / (uint64_t)k1 + 1 : 0;
+    /* pass 1: capped counts at cumm[h+1] */
+    for (uint64_t i = 0; i < npos; i++) {
+        uint32_t h = pgrc_or_copmem_hash(K, pg + i * (uint64_t)k1) & mask;
+        if (cumm[h + 1] < PGRC_OR_BUCKET_CAP) cumm[h + 1]++;
+    }
+    /* exclusive prefix: cumm[h] = start of bucket h */
+    uint64_t run = 0;
+    for (uint64_t h = 0; h <= (uint64_t)hs; h++) {
+        uint32_t c = cumm[h + 1];
+        cumm[h + 1] = (uint32_t)run; /* temporarily: start of bucket h, stored at h+1 */
+        run += c;
+    }
+    /* now cumm[h+1] = start(h); shift down so cumm[h] = start(h), keeping a fill cursor */
+    uint32_t *cursor = (uint32_t *)malloc(((size_t)hs + 1) * sizeof(uint32_t));
+    uint32_t *positions = (uint32_t *)malloc((size_t)(run + 2) * sizeof(uint32_t));
+    if (!cursor || !positions) { free(cumm); free(cursor); free(positions); return 3; }
+    for (uint64_t h = 0; h <= (uint64_t)hs; h++) cursor[h] = cumm[h + 1];
+    for (uint64_t h = 0; h <= (uint64_t)hs; h++) cumm[h] = cursor[h];
+    cumm[hs + 1] = (uint32_t)run;
+    /* pass 2: fill in ascending p; a full bucket drops the position */
+    for (uint64_t i = 0; i < npos; i++) {
+        uint64_t p = i * (uint64_t)k1;
+        uint32_t h = pgrc_or_copmem_hash(K, pg + p) & mask;
+        if (cursor[h] < cumm[h + 1]) positions[cursor[h]++] = (uint32_t)p;
+    }
+    free(cursor);
+    out->cumm = cumm;
+    out->positions = positions;
+    out->count = run;
+    return 0;
+}
+
+void pgrc_or_index_free(pgrc_or_index *idx) {
+    free(idx->cumm);
+    free(idx->positions);
+    idx->cumm = NULL;
+    idx->positions = NULL;
+}
+
+/* CopMEMMatcher.cpp:483-566 (processApproxMatchQueryTight) */
+uint64_t pgrc_or_copmem_match_read(const pgrc_or_index *idx, const char *pg, const char *read,
+                                   uint32_t read_len, uint8_t kmax, uint8_t kmin, uint8_t *cnt,
+                                   uint64_t *falses_out, uint64_t *cand_out) {
+    const int K = idx->p.K, k2 = idx->p.k2;
+    const uint32_t mask = idx->p.hash_size - 1;
+    const uint64_t G = idx->pg_len;
+    uint8_t limit = kmax;
+    if (*cnt < kmax) limit = (uint8_t)(*cnt - 1); /* :488-489 */
+    const uint32_t head = (read_len / 8) * 8;      /* :495 */
+    const uint64_t budget = (uint64_t)((read_len + 1 - (uint32_t)K) / (uint32_t)k2); /* :496-498 */
+    uint64_t falses = 0, cands = 0;
+    uint64_t best = PGRC_OR_NOT_MATCHED_POS;
+    for (uint32_t s = 0; s + (uint32_t)K < read_len + 1; s += (uint32_t)k2) { /* :503 */
+        uint32_t h = pgrc_or_copmem_hash(K, read + s) & mask;
+        uint32_t lo = idx->cumm[h], hi = idx->cumm[h + 1];
+        if (lo == hi) continue;
+        if (budget < falses && hi > lo + PGRC_OR_TRUNC_BUCKET) hi = lo + PGRC_OR_TRUNC_BUCKET; /* :510-514 */
+        for (uint32_t j = lo; j < hi; j++) {
+            uint64_t sp = idx->positions[j];
+            if ((uint64_t)s > sp) continue;                 /* :517-518 */
+            if (sp - s + read_len > G) continue;            /* :519-520 */
+            const char *t = pg + (sp - s);
+            cands++;
+            /* :523-539 -- 8-byte words with early exit; the outcome equals the
+             * full head count compared with the limit (counts are monotone). */
+            uint32_t m = 0;
+            uint32_t i = 0;
+            for (; i < head && m <= limit; i += 8)
+                for (uint32_t b = 0; b < 8; b++) m += (read[i + b] != t[i + b]);
+            if (m > limit) { falses++; continue; }
+            /* :540-551 -- tail bytes; a reject here is counted twice */
+            for (i = head; i < read_len; i++) m += (read[i] != t[i]);
+            if (m > limit) { falses += 2; continue; }
+            *cnt = (uint8_t)m;                              /* :552-555 */
+            best = sp - s;
+            if (m <= kmin) { /* :556-559 */
+                if (falses_out) *falses_out += falses;
+                if (cand_out) *cand_out += cands;
+                return best;
+            }
+            limit = (uint8_t)(m - 1);                       /* :560 */
+        }
+    }
+    if (falses_out) *falses_out += falses;
+    if (cand_out) *cand_out += cands;
+    return best;
+}
+
+static void result_init(pgrc_or_result *res, uint64_t n, int with_counts) {
+    for (uint64_t i = 0; i < n; i++) {
+        res->pos[i] = PGRC_OR_NOT_MATCHED_POS;
+        res->rc[i] = 0;
+        res->mism[i] = PGRC_OR_NOT_MATCHED_CNT;
+    }
+    memset(res->hist, 0, sizeof res->hist);
+    if (with_counts) res->hist[PGRC_OR_NOT_MATCHED_CNT] = n; /* ReadsMatchers.cpp:239 */
+    res->matched = 0;
+    memset(res->searched, 0, sizeof res->searched);
+    memset(res->candidates, 0, sizeof res->candidates);
+    memset(res->falses, 0, sizeof res->falses);
+}
+
+/* ReadsMatchers.cpp:162-172 (two passes) + :421-451 (CopMEMReadsApproxMatcher::executeMatching) */
+int pgrc_or_match_copmem(const char *pg, uint64_t pg_len, const char *reads, uint64_t n,
+                         uint32_t read_len, uint32_t seed_len, uint8_t kmax, uint8_t kmin,
+                         int rev_compl_pg, int threads, int init, pgrc_or_result *res) {
+    if (init) result_init(res, n, 1);
+    char *rcpg = NULL;
+    for (int pass = 0; pass < (rev_compl_pg ? 2 : 1); pass++) {
+        const char *text = pg;
+        if (pass == 1) {
+            rcpg = (char *)malloc(pg_len + 1);
+            if (!rcpg) return 3;
+            memcpy(rcpg, pg, pg_len);
+            rcpg[pg_len] = 0;
+            pgrc_or_revcomp(rcpg, pg_len);
+            text = rcpg;
+        }
+        pgrc_or_index idx;
+        int e = pgrc_or_index_build(text, pg_len, seed_len, &idx);
+        if (e) { free(rcpg); return e; }
+        uint64_t searched = 0, cands = 0, falses = 0, matched = 0;
+        uint64_t hist_delta_dec[256], hist_delta_inc[256];
+        memset(hist_delta_dec, 0, sizeof hist_delta_dec);
+        memset(hist_delta_inc, 0, sizeof hist_delta_inc);
+#ifdef _OPENMP
+        if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+#endif
+        {
+            uint64_t l_searched = 0, l_cands = 0, l_falses = 0, l_matched = 0;
+            uint64_t l_dec[256], l_inc[256];
+            memset(l_dec, 0, sizeof l_dec);
+            memset(l_inc, 0, sizeof l_inc);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1024)
+#endif
+            for (int64_t ii = 0; ii < (int64_t)n; ii++) {
+                uint64_t i = (uint64_t)ii;
+                if (res->mism[i] <= kmin) continue; /* :430 */
+                l_searched++;
+                uint8_t c = res->mism[i];
+                uint64_t p = pgrc_or_copmem_match_read(&idx, text, reads + i * (uint64_t)read_len,
+                                                       read_len, kmax, kmin, &c, &l_falses, &l_cands);
+                if (p == PGRC_OR_NOT_MATCHED_POS) continue; /* :437-438 */
+                if (c < res->mism[i]) {                      /* :439-447 */
+                    if (res->mism[i] == PGRC_OR_NOT_MATCHED_CNT) l_matched++;
+                    l_dec[res->mism[i]]++;
+                    l_inc[c]++;
+                    res->pos[i] = pass ? pg_len - (p + read_len) : p;
+                    res->rc[i] = (uint8_t)pass;
+                    res->mism[i] = c;
+                }
+            }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+            {
+                searched += l_searched; cands += l_cands; falses += l_falses; matched += l_matched;
+                for (int k = 0; k < 256; k++) { hist_delta_dec[k] += l_dec[k]; hist_delta_inc[k] += l_inc[k]; }
+            }
+        }
+        for (int k = 0; k < 256; k++) res->hist[k] = res->hist[k] + hist_delta_inc[k] - hist_delta_dec[k];
+        res->matched += matched;
+        res->searched[pass] = searched;
+        res->candidates[pass] = cands;
+        res->falses[pass] = falses;
+        pgrc_or_index_free(&idx);
+    }
+    free(rcpg);
+    (void)threads;
+    return 0;
+}
+
+/* ------------------------------------------- read-side seed index (d, i, e) */
+
+/* ReadsMatchers.cpp:699-713 */
+int pgrc_or_map_derive(uint32_t read_len, uint32_t seed_len, uint32_t min_chars_per_mismatch,
+                       char mode, pgrc_or_map_params *out) {
+    if (min_chars_per_mismatch == 0 || read_len == 0 || seed_len == 0) return 1;
+    out->kmax = (uint8_t)(read_len / min_chars_per_mismatch);
+    if (seed_len > read_len) seed_len = read_len;
+    out->seed_len = seed_len;
+    int upper = (mode >= 'A' && mode <= 'Z');
+    out->kmin = upper ? out->kmax : 0;
+    out->parts = (uint8_t)(read_len / seed_len);
+    char lower = upper ? (char)(mode - 'A' + 'a') : mode;
+    if (read_len == seed_len) out->matcher = (lower == 'c') ? 'c' : 'e'; /* :715-723 */
+    else if (lower == 'd' || lower == 'i' || lower == 'c') out->matcher = lower;
+    else return 2; /* "Unknown matching mode" :737-739 */
+    return 0;
+}
+
+typedef struct {
+    uint64_t hash;
+    uint32_t idx;
+} seed_ent;
+
+static int seed_ent_cmp(const void *a, const void *b) {
+    const seed_ent *x = (const seed_ent *)a, *y = (const seed_ent *)b;
+    if (x->hash != y->hash) return x->hash < y->hash ? -1 : 1;
+    /* equal keys iterate in reverse insertion order (libstdc++ unordered_multimap,
+     * SURVEY.md Appendix C) => descending pattern index */
+    if (x->idx != y->idx) return x->idx > y->idx ? -1 : 1;
+    return 0;
+}
+
+#define SEED_B 0x9E3779B97F4A7C15ull
+
+static uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+/* Any exact-seed key works here: the reference's CyclicHash is randomly keyed
+ * per run (rollinghash/characterhash.h:51-63), so only exact seed equality is
+ * reproducible.  We use a polynomial hash and verify equality explicitly. */
+static uint64_t poly_hash_strided(const char *s, uint32_t m, uint32_t stride) {
+    uint64_t h = 0;
+    for (uint32_t k = 0; k < m; k++) h = h * SEED_B + (uint8_t)s[(uint64_t)k * stride];
+    return h;
+}
+
+typedef struct {
+    uint64_t key;
+    uint32_t start, count;
+} seed_slot;
+
+int pgrc_or_match_seedindex(char mode, const char *pg, uint64_t pg_len, const char *reads,
+                            uint64_t n, uint32_t read_len, uint32_t seed_len, uint8_t kmax,
+                            uint8_t kmin, int rev_compl_pg, pgrc_or_result *res) {
+    if (mode != 'e' && mode != 'd' && mode != 'i') return 2;
+    if (seed_len > read_len) seed_len = read_len;
+    const uint32_t P = (mode == 'e') ? 1 : read_len / seed_len; /* targetMismatches+1 */
+    const uint32_t m = (mode == 'e') ? read_len : seed_len;     /* pattern length */
+    const uint32_t stride = (mode == 'i') ? P : 1;
+    const uint32_t span = (mode == 'i') ? m * P : m;            /* text window extent */
+    result_init(res, n, mode != 'e');
+    /* index every (read, part): ConstantLength...HashMatcher.cpp:23-42, :76-93 */
+    uint64_t nent = n * P;
+    seed_ent *ent = (seed_ent *)malloc((size_t)(nent ? nent : 1) * sizeof(seed_ent));
+    if (!ent) return 3;
+    for (uint64_t i = 0; i < n; i++)
+        for (uint32_t j = 0; j < P; j++) {
+            const char *part = reads + i * read_len + ((mode == 'i') ? j : j * m);
+            ent[i * P + j].hash = mix64(poly_hash_strided(part, m, stride));
+            ent[i * P + j].idx = (uint32_t)(i * P + j);
+        }
+    qsort(ent, (size_t)nent, sizeof(seed_ent), seed_ent_cmp);
+    uint64_t tsize = 16;
+    while (tsize < 2 * nent) tsize <<= 1;
+    seed_slot *tab = (seed_slot *)calloc((size_t)tsize, sizeof(seed_slot));
+    if (!tab) { free(ent); return 3; }
+    for (uint64_t a = 0; a < nent;) {
+        uint64_t b = a;
+        while (b < nent && ent[b].hash == ent[a].hash) b++;
+        uint64_t s = ent[a].hash & (tsize - 1);
+        while (tab[s].count) s = (s + 1) & (tsize - 1);
+        tab[s].key = ent[a].hash; tab[s].start = (uint32_t)a; tab[s].count = (uint32_t)(b - a);
+        a = b;
+    }
+    /* B^(m-1) for the rolling update */
+    uint64_t bpow = 1;
+    for (uint32_t k = 1; k < m; k++) bpow *= SEED_B;
+
+    char *rcpg = NULL;
+    for (int pass = 0; pass < (rev_compl_pg ? 2 : 1); pass++) {
+        const char *text = pg;
+        if (pass == 1) {
+            rcpg = (char *)malloc(pg_len + 1);
+            if (!rcpg) { free(ent); free(tab); return 3; }
+            memcpy(rcpg, pg, pg_len);
+            rcpg[pg_len] = 0;
+            pgrc_or_revcomp(rcpg, pg_len);
+            text = rcpg;
+        }
+        if (pg_len < span) continue;
+        /* one rolling hash per residue class mod stride (ConstantLength...HashMatcher.h:105-137) */
+        uint64_t *roll = (uint64_t *)malloc(sizeof(uint64_t) * stride);
+        for (uint32_t r = 0; r < stride; r++)
+            roll[r] = (r + (uint64_t)(m - 1) * stride < pg_len) ? poly_hash_strided(text + r, m, stride) : 0;
+        for (uint64_t t = 0; t + span <= pg_len; t++) {
+            uint32_t r = (uint32_t)(t % stride);
+            uint64_t key = mix64(roll[r]);
+            /* advance this residue's hash to window start t+stride */
+            if (t + stride + (uint64_t)(m - 1) * stride < pg_len)
+                roll[r] = (roll[r] - (uint8_t)text[t] * bpow) * SEED_B +
+                          (uint8_t)text[t + (uint64_t)m * stride];
+            uint64_t s = key & (tsize - 1);
+            while (tab[s].count && tab[s].key != key) s = (s + 1) & (tsize - 1);
+            if (!tab[s].count) continue;
+            for (uint32_t a = tab[s].start; a < tab[s].start + tab[s].count; a++) {
+                uint32_t pidx = ent[a].idx;
+                uint64_t ri = pidx / P;
+                uint32_t part = pidx % P;
+                const char *rd = reads + ri * read_len;
+                /* canonical semantics: exact seed equality */
+                const char *pp = rd + ((mode == 'i') ? part : part * m);
+                int eq = 1;
+                for (uint32_t k = 0; k < m && eq; k++) eq = pp[(uint64_t)k * stride] == text[t + (uint64_t)k * stride];
+                if (!eq) continue;
+                if (mode == 'e') { /* ReadsMatchers.cpp:203-224 */
+                    if (res->pos[ri] == PGRC_OR_NOT_MATCHED_POS) {
+                        res->pos[ri] = pass ? pg_len - (t + read_len) : t;
+                        if (pass) res->rc[ri] = 1;
+                        res->mism[ri] = 0;
+                        res->matched++;
+                    }
+                    continue;
+                }
+                /* ReadsMatchers.cpp:301-330 (d) / :368-397 (i) */
+                if (res->mism[ri] <= kmin) continue;
+                uint64_t shift = (mode == 'i') ? part : (uint64_t)part * m;
+                if (shift > t) continue;
+                uint64_t p = t - shift;
+                if (p + read_len > pg_len) continue;
+                uint64_t stored = pass ? pg_len - (p + read_len) : p;
+                if (res->pos[ri] == stored) continue;
+                uint8_t limit = (res->mism[ri] == PGRC_OR_NOT_MATCHED_CNT) ? kmax : (uint8_t)(res->mism[ri] - 1);
+                /* countSequenceMismatchesVsUnpacked, SymbolsPackingFacility.cpp:344-374 */
+                uint32_t mm = 0;
+                for (uint32_t k = 0; k < read_len && mm <= limit; k++) mm += (rd[k] != text[p + k]);
+                uint8_t got = (mm > limit) ? PGRC_OR_NOT_MATCHED_CNT : (uint8_t)mm;
+                if (got < res->mism[ri]) {
+                    if (res->mism[ri] == PGRC_OR_NOT_MATCHED_CNT) res->matched++;
+                    res->hist[res->mism[ri]]--;
+                    res->hist[got]++;
+                    res->pos[ri] = stored;
+                    res->rc[ri] = (uint8_t)pass;
+                    res->mism[ri] = got;
+                }
+            }
+        }
+        free(roll);
+    }
+    if (mode == 'e') { /* DefaultReadsExactMatcher::transferMatchingResults :126-133 */
+        res->hist[0] = res->matched;
+        res->hist[PGRC_OR_NOT_MATCHED_CNT] = n - res->matched;
+    }
+    free(rcpg);
+    free(ent);
+    free(tab);
+    return 0;
+}
+
+/* ---------------------------------------------------- mismatch extraction */
+
+/* ReadsMatchers.cpp:40-66 + :548-559; code = (val(pg) << 4) + val(read), helper.cpp:358-362 */
+void pgrc_or_extract_mismatches(const char *pg, uint64_t pos, const char *read, uint32_t read_len,
+                                int rc, int reversed, uint8_t cnt, uint8_t *codes,
+                                uint16_t *offsets) {
+    char buf[256];
+    memcpy(buf, read, read_len);
+    if (rc) pgrc_or_revcomp(buf, read_len);
+    const char *t = pg + pos;
+    uint8_t c = 0;
+    if (!reversed) {
+        for (uint32_t i = 0; c < cnt && i < read_len; i++)
+            if (buf[i] != t[i]) {
+                codes[c] = (uint8_t)((pgrc_or_sym2val(t[i]) << 4) + pgrc_or_sym2val(buf[i]));
+                offsets[c] = (uint16_t)i;
+                c++;
+            }
+    } else {
+        for (uint32_t i = read_len; c < cnt && i-- > 0;)
+            if (buf[i] != t[i]) {
+                codes[c] = (uint8_t)((pgrc_or_sym2val(complement_of(t[i])) << 4) +
+                                     pgrc_or_sym2val(complement_of(buf[i])));
+                offsets[c] = (uint16_t)(read_len - i - 1);
+                c++;
+            }
+    }
+}

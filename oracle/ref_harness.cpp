@@ -1,0 +1,254 @@
+// ref_harness.cpp -- drives the REAL reference (compiled from /root/reference by
+// oracle/Makefile into oracle/_ref/libpgrc_ref.so) behind a tiny C ABI so that
+// tests/ can pin the CPU restatement (oracle/pgrc_oracle.c) and the HIP path
+// against it, and so that tests/golden/make_golden.py can generate fixtures.
+//
+// TEST INFRASTRUCTURE ONLY.  No reference source is copied or modified: the
+// matchers' protected result fields are reached by subclassing
+// (ReadsMatchers.h:32-43,115-116) and CopMEMMatcher's private index by the
+// access-specifier trick in THIS translation unit only.
+#include <bits/stdc++.h>
+#include <omp.h>
+
+#define private public
+#define protected public
+#include "matching/copmem/CopMEMMatcher.h"
+#undef private
+#undef protected
+
+#include "matching/ReadsMatchers.h"
+#include "readsset/PackedConstantLengthReadsSet.h"
+#include "utils/helper.h"
+
+using namespace PgTools;
+using namespace PgReadsSet;
+
+namespace {
+
+template <class M>
+struct Probe : M {
+    using M::M;
+    using M::matchedReadsCount;
+    using M::readMatchPos;
+    using M::readMatchRC;
+};
+
+template <class M>
+struct ApproxProbe : M {
+    using M::M;
+    using M::matchedCountPerMismatches;
+    using M::matchedReadsCount;
+    using M::readMatchPos;
+    using M::readMatchRC;
+    using M::readMismatchesCount;
+    using M::updateEntry;
+    using M::betterMatchCount;
+    using M::falseMatchCount;
+};
+
+struct Silence {
+    std::ostream *old_log;
+    std::ios::iostate old_state;
+    Silence() : old_log(PgHelpers::logout), old_state(std::cout.rdstate()) {
+        PgHelpers::logout = &null_stream;
+        std::cout.setstate(std::ios::failbit);
+    }
+    ~Silence() {
+        PgHelpers::logout = old_log;
+        std::cout.clear(old_state);
+    }
+};
+
+struct ReadsHolder {
+    PackedConstantLengthReadsSet *lq = nullptr, *nset = nullptr;
+    SumOfConstantLengthReadsSets *sum = nullptr;
+    ConstantLengthReadsSetInterface *iface = nullptr;
+    ReadsHolder(const char *reads, uint64_t n_lq, uint64_t n_n, uint32_t L) {
+        lq = new PackedConstantLengthReadsSet(L, "ACGT", 4);
+        for (uint64_t i = 0; i < n_lq; i++) lq->addRead(reads + i * L, L);
+        iface = lq;
+        if (n_n) {
+            // the N set is packed over ACGNT (readsset/DividedPCLReadsSets.cpp:16-19)
+            nset = new PackedConstantLengthReadsSet(L, "ACGNT", 5);
+            for (uint64_t i = 0; i < n_n; i++) nset->addRead(reads + (n_lq + i) * L, L);
+            if (n_lq) {
+                sum = new SumOfConstantLengthReadsSets(lq, nset); // pgrc-encoder.cpp:349-352
+                iface = sum;
+            } else {
+                iface = nset; // one ACGNT-packed set holding every read (the nReadsLQ configuration)
+            }
+        }
+    }
+    ~ReadsHolder() {
+        delete sum;
+        delete nset;
+        delete lq;
+    }
+};
+
+template <class P>
+void dump_common(P &m, uint64_t n, uint64_t *pos, uint8_t *rc, uint64_t *matched) {
+    for (uint64_t i = 0; i < n; i++) {
+        pos[i] = m.readMatchPos[i];
+        rc[i] = m.readMatchRC[i] ? 1 : 0;
+    }
+    *matched = m.matchedReadsCount;
+}
+
+template <class P>
+void dump_approx(P &m, uint64_t n, uint64_t *pos, uint8_t *rc, uint8_t *mism, uint64_t *hist,
+                 uint64_t *matched, uint64_t *stats) {
+    dump_common(m, n, pos, rc, matched);
+    for (uint64_t i = 0; i < n; i++) mism[i] = m.readMismatchesCount[i];
+    for (int k = 0; k < 256; k++) hist[k] = m.matchedCountPerMismatches[k];
+    if (stats) {
+        stats[0] = m.betterMatchCount;
+        stats[1] = m.falseMatchCount;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+// mode: 'e' exact (DefaultReadsExactMatcher), 'd', 'i', 'c'.  pg is copied (the
+// reference reverse-complements it in place, ReadsMatchers.cpp:167-171).
+// index_threads sets PgHelpers::numberOfThreads (1 => canonical serial copMEM
+// index, CopMEMMatcher.cpp:179-180); omp_threads the width of the per-read loop.
+int pgrc_ref_match(char mode, const char *pg, uint64_t G, const char *reads, uint64_t n_lq,
+                   uint64_t n_n, uint32_t L, uint32_t seed, uint8_t kmax, uint8_t kmin,
+                   int rev_compl, int index_threads, int omp_threads, uint64_t *pos, uint8_t *rc,
+                   uint8_t *mism, uint64_t *hist, uint64_t *matched, uint64_t *stats) {
+    Silence quiet;
+    PgHelpers::numberOfThreads = index_threads;
+    omp_set_num_threads(omp_threads);
+    std::string text(pg, G);
+    ReadsHolder rh(reads, n_lq, n_n, L);
+    const uint64_t n = n_lq + n_n;
+    const uint32_t prefix = DefaultReadsMatcher::DISABLED_PREFIX_MODE;
+    switch (mode) {
+    case 'e': {
+        Probe<DefaultReadsExactMatcher> m((char *)text.data(), G, rev_compl, rh.iface, prefix);
+        m.matchConstantLengthReads();
+        dump_common(m, n, pos, rc, matched);
+        for (uint64_t i = 0; i < n; i++) mism[i] = pos[i] == UINT64_MAX ? 255 : 0;
+        memset(hist, 0, 256 * sizeof(uint64_t));
+        hist[0] = *matched;
+        hist[255] = n - *matched;
+        break;
+    }
+    case 'd': {
+        ApproxProbe<DefaultReadsApproxMatcher> m((char *)text.data(), G, rev_compl, rh.iface,
+                                                 prefix, seed, kmax, kmin);
+        m.matchConstantLengthReads();
+        dump_approx(m, n, pos, rc, mism, hist, matched, stats);
+        break;
+    }
+    case 'i': {
+        ApproxProbe<InterleavedReadsApproxMatcher> m((char *)text.data(), G, rev_compl, rh.iface,
+                                                     prefix, seed, kmax, kmin);
+        m.matchConstantLengthReads();
+        dump_approx(m, n, pos, rc, mism, hist, matched, stats);
+        break;
+    }
+    case 'c': {
+        ApproxProbe<CopMEMReadsApproxMatcher> m((char *)text.data(), G, rev_compl, rh.iface,
+                                                prefix, seed, kmax, kmin);
+        m.matchConstantLengthReads();
+        dump_approx(m, n, pos, rc, mism, hist, matched, stats);
+        break;
+    }
+    default:
+        return 2;
+    }
+    return 0;
+}
+
+// copMEM index internals (CopMEMMatcher.cpp:69-231).  cumm/positions are
+// malloc'ed copies; free with pgrc_ref_free.
+int pgrc_ref_copmem_index(const char *pg, uint64_t G, uint32_t seed, int index_threads, int32_t *K,
+                          int32_t *k1, int32_t *k2, uint32_t *hash_size, uint32_t **cumm,
+                          uint32_t **positions, uint64_t *count) {
+    Silence quiet;
+    PgHelpers::numberOfThreads = index_threads;
+    std::string text(pg, G);
+    CopMEMMatcher m(text.data(), G, seed);
+    if (m.bigRef != 0) return 3;
+    *K = m.K; *k1 = m.k1; *k2 = m.k2; *hash_size = m.hash_size;
+    uint64_t total = m.buffer0.second[m.hash_size];
+    *count = total;
+    *cumm = (uint32_t *)malloc(((size_t)m.hash_size + 2) * sizeof(uint32_t));
+    memcpy(*cumm, m.buffer0.second, ((size_t)m.hash_size + 2) * sizeof(uint32_t));
+    *positions = (uint32_t *)malloc((size_t)(total + 1) * sizeof(uint32_t));
+    memcpy(*positions, m.buffer0.first, (size_t)total * sizeof(uint32_t));
+    return 0;
+}
+
+// raw (unmasked) maRushPrime1HashSparsified<K> through the matcher's own
+// function-pointer table (CopMEMMatcher.cpp:52-62, :84).
+uint32_t pgrc_ref_copmem_hash(uint32_t seed, const char *str, int32_t *K_out) {
+    Silence quiet;
+    PgHelpers::numberOfThreads = 1;
+    static const std::string dummy(4096, 'A');
+    CopMEMMatcher m(dummy.data(), dummy.size(), seed);
+    if (K_out) *K_out = m.K;
+    return m.hashFunc32(str);
+}
+
+// One read against a fresh serial index; exposes the per-read false count
+// (CopMEMMatcher.cpp:483-566) for the known-answer values of SURVEY.md Appendix C.
+uint64_t pgrc_ref_copmem_match_read(const char *pg, uint64_t G, uint32_t seed, const char *read,
+                                    uint32_t L, uint8_t kmax, uint8_t kmin, uint8_t *cnt,
+                                    uint64_t *falses) {
+    Silence quiet;
+    PgHelpers::numberOfThreads = 1;
+    std::string text(pg, G);
+    CopMEMMatcher m(text.data(), G, seed);
+    uint64_t better = 0, f = 0;
+    uint64_t p = m.approxMatchPattern(read, (uint_read_len_max)L, kmax, kmin, *cnt, better, f);
+    *falses = f;
+    return p;
+}
+
+// Mismatch extraction through AbstractReadsApproxMatcher::updateEntry
+// (ReadsMatchers.cpp:548-559).  Returns the number of mismatches written.
+int pgrc_ref_extract(const char *pg, uint64_t G, const char *read, uint32_t L, uint64_t pos, int rc,
+                     uint8_t cnt, uint32_t org_idx, int rev_compl_pair_file, uint8_t *codes,
+                     uint16_t *offsets) {
+    Silence quiet;
+    std::string text(pg, G);
+    bool has_n = memchr(read, 'N', L) != nullptr;
+    ReadsHolder rh(read, has_n ? 0 : 1, has_n ? 1 : 0, L);
+    ApproxProbe<CopMEMReadsApproxMatcher> m((char *)text.data(), G, true, rh.iface,
+                                            DefaultReadsMatcher::DISABLED_PREFIX_MODE, L, 255, 0);
+    m.readMatchPos.assign(1, pos);
+    m.readMatchRC.assign(1, rc != 0);
+    m.readMismatchesCount.assign(1, cnt);
+    DefaultReadsListEntry entry(0);
+    entry.advanceEntryByPosition(pos, org_idx, rc != 0);
+    m.updateEntry(entry, 0, rev_compl_pair_file != 0);
+    for (int i = 0; i < entry.mismatchesCount; i++) {
+        codes[i] = entry.mismatchCode[i];
+        offsets[i] = entry.mismatchOffset[i];
+    }
+    return entry.mismatchesCount;
+}
+
+// SymbolsPackingFacility layout of one read (PackedConstantLengthReadsSet.cpp:36-45).
+int pgrc_ref_pack_read(const char *read, uint32_t L, const char *alphabet, uint8_t *dst) {
+    Silence quiet;
+    PackedConstantLengthReadsSet s(L, alphabet, (uint8_t)strlen(alphabet));
+    s.addRead(read, L);
+    int spe = SymbolsPackingFacility::maxSymbolsPerElement((uint8_t)strlen(alphabet));
+    int bytes = (L + spe - 1) / spe;
+    memcpy(dst, s.getPackedRead(0), bytes);
+    return bytes;
+}
+
+void pgrc_ref_revcomp(char *seq, uint64_t n) { PgHelpers::reverseComplementInPlace(seq, n); }
+
+void pgrc_ref_free(void *p) { free(p); }
+
+int pgrc_ref_max_threads(void) { return omp_get_num_procs(); }
+
+} // extern "C"

@@ -1,0 +1,103 @@
+"""ctypes binding of libpgrc_match.so (include/pgrc_match.h).
+
+The shared library is the product: HIP kernels + C ABI.  This module only loads
+it and declares the prototypes.  There is no Python / CPU fallback: if the
+library is missing, import fails loudly with the build hint.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpgrc_match.so")
+
+NOT_MATCHED_POS = 0xFFFFFFFFFFFFFFFF  # DefaultReadsMatcher::NOT_MATCHED_POSITION (ReadsMatchers.cpp:69)
+NOT_MATCHED_CNT = 255                 # NOT_MATCHED_COUNT (ReadsMatchers.h:17)
+
+ERR_NAMES = {0: "OK", 1: "E_PARAM", 2: "E_SEED_SHORT", 3: "E_NO_DEVICE", 4: "E_ALLOC",
+             5: "E_SYMBOL", 6: "E_STATE", 7: "E_MODE"}
+
+
+class PgrcMatchError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"pgrc_match error {code} ({ERR_NAMES.get(code, '?')}): {msg}")
+        self.code = code
+
+
+class MatchParams(C.Structure):
+    _fields_ = [("read_len", C.c_uint32), ("seed_len", C.c_uint32), ("max_mismatches", C.c_uint8),
+                ("min_mismatches", C.c_uint8), ("mode", C.c_char), ("device", C.c_int32)]
+
+
+class CopmemParams(C.Structure):
+    _fields_ = [("K", C.c_int32), ("k1", C.c_int32), ("k2", C.c_int32), ("hash_size", C.c_uint32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("searched", C.c_uint64 * 2), ("candidates", C.c_uint64 * 2), ("probes", C.c_uint64 * 2),
+                ("index_entries", C.c_uint64 * 2), ("ms_index", C.c_float * 2), ("ms_match", C.c_float * 2),
+                ("ms_other", C.c_float), ("ms_total", C.c_float)]
+
+
+class SynthPg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("pg_len", C.c_uint64), ("grid", C.c_uint32), ("plant_len", C.c_uint32),
+                ("pool_div", C.c_uint32), ("tandem_every", C.c_uint32)]
+
+
+class SynthReads(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n", C.c_uint64), ("read_len", C.c_uint32), ("paired", C.c_uint32),
+                ("n_with_n", C.c_uint64)]
+
+
+# every symbol include/pgrc_match.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_PROTOS = [
+    ("pgrc_match_version", C.c_char_p, []),
+    ("pgrc_match_derive_params", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_char, C.POINTER(MatchParams)]),
+    ("pgrc_match_create", C.c_int, [C.POINTER(MatchParams), C.POINTER(_P)]),
+    ("pgrc_match_destroy", None, [_P]),
+    ("pgrc_match_last_error", C.c_char_p, [_P]),
+    ("pgrc_match_set_stream", C.c_int, [_P, _P]),
+    ("pgrc_match_set_pg_ascii", C.c_int, [_P, _P, C.c_uint64]),
+    ("pgrc_match_set_pg_packed_device", C.c_int, [_P, _P, C.c_uint64]),
+    ("pgrc_match_pack_pg_slice", C.c_int, [_P, _P, C.c_uint64, _P]),
+    ("pgrc_match_set_reads_ascii", C.c_int, [_P, _P, C.c_uint64]),
+    ("pgrc_match_set_reads_packed", C.c_int, [_P, _P, C.c_uint64]),
+    ("pgrc_match_set_reads_device", C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
+    ("pgrc_match_words_per_read", C.c_uint32, [C.c_uint32]),
+    ("pgrc_match_init_results", C.c_int, [_P]),
+    ("pgrc_match_set_results", C.c_int, [_P, _P, _P, _P]),
+    ("pgrc_match_run", C.c_int, [_P, C.c_int]),
+    ("pgrc_match_get_results", C.c_int, [_P, _P, _P, _P, _P, C.POINTER(C.c_uint64)]),
+    ("pgrc_match_get_results_device", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    ("pgrc_match_extract_mismatches", C.c_int, [_P, _P, _P, _P, _P]),
+    ("pgrc_match_copmem_params", C.c_int, [C.c_uint32, C.c_uint64, C.POINTER(CopmemParams)]),
+    ("pgrc_match_export_index", C.c_int, [_P, C.c_int, _P, _P, C.POINTER(C.c_uint64)]),
+    ("pgrc_match_export_pg", C.c_int, [_P, C.c_int, _P]),
+    ("pgrc_match_set_profiling", C.c_int, [_P, C.c_int]),
+    ("pgrc_match_get_counters", C.c_int, [_P, C.POINTER(Counters)]),
+    ("pgrc_synth_pg_host", None, [C.POINTER(SynthPg), _P]),
+    ("pgrc_synth_reads_host", None, [C.POINTER(SynthPg), _P, C.POINTER(SynthReads), C.c_uint64, C.c_uint64, _P]),
+    ("pgrc_synth_pg_device", C.c_int, [C.POINTER(SynthPg), _P, _P]),
+    ("pgrc_synth_reads_device", C.c_int, [C.POINTER(SynthPg), _P, C.POINTER(SynthReads), C.c_uint64, C.c_uint64,
+                                          _P, C.c_uint64, _P]),
+]
+
+EXPORTED_SYMBOLS = [p[0] for p in _PROTOS]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is the product and there is no fallback. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C pgrc_amd/csrc`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in _PROTOS:
+        fn = getattr(lib, name)  # AttributeError here = header / library out of sync: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()

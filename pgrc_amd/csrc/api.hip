@@ -1,0 +1,492 @@
+// api.hip -- the C ABI of libpgrc_match.so (include/pgrc_match.h): context, host<->HBM staging of the
+// pseudogenome and the reads, the two-pass driver (DefaultReadsMatcher::matchConstantLengthReads,
+// matching/ReadsMatchers.cpp:162-172) and result retrieval.  No CPU fallback exists: every compute
+// entry point needs a HIP device.
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "ctx.h"
+#include "devutil.h"
+
+int pgrc_buf_ensure(pgrc_match_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.p && b.bytes >= bytes) return PGRC_OK;
+    if (b.p) {
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        c->err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? PGRC_E_ALLOC : PGRC_E_NO_DEVICE;
+    }
+    b.bytes = bytes;
+    return PGRC_OK;
+}
+
+void pgrc_buf_free(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+static int isqrt_floor(int v) {
+    int r = 0;
+    while ((r + 1) * (r + 1) <= v) r++;
+    return r;
+}
+
+extern "C" {
+
+const char *pgrc_match_version(void) { return "pgrc_match 0.1 (gfx950)"; }
+
+// CopMEMMatcher::initParams / calcCoprimes, matching/copmem/CopMEMMatcher.cpp:69-96, :111-137
+int pgrc_match_copmem_params(uint32_t seed_len, uint64_t pg_len, pgrc_copmem_params *out) {
+    const int L = (int)seed_len;
+    if (L < 24) return PGRC_E_SEED_SHORT;
+    int K = L > 110 ? 56 : L > 62 ? 44 : L > 53 ? 40 : L > 46 ? 36 : L > 42 ? 32 : L > 32 ? 28 : (L / 4 - 1) * 4;
+    const int kmml = (L / 4 - 1) * 4;
+    if (kmml < K) K = kmml;
+    const int t = L - K + 1;
+    if (t <= 0) return PGRC_E_PARAM;
+    int k1, k2;
+    if (t >= 20) {
+        k1 = isqrt_floor(t) + 1;
+        k2 = k1 - 1;
+        if (k1 * k2 > t) { --k1; --k2; }
+    } else if (t >= 15) { k1 = 5; k2 = 3; }
+    else if (t >= 12) { k1 = 4; k2 = 3; }
+    else if (t >= 10) { k1 = 5; k2 = 2; }
+    else if (t >= 6) { k1 = 3; k2 = 2; }
+    else { k1 = t; k2 = 1; }
+    uint32_t hs;
+    int i = 24;
+    do { hs = 1u << (i++); } while (i <= 31 && (uint64_t)hs < pg_len / (uint64_t)k1);
+    out->K = K; out->k1 = k1; out->k2 = k2; out->hash_size = hs;
+    return PGRC_OK;
+}
+
+// mapReadsIntoPg, matching/ReadsMatchers.cpp:699-740
+int pgrc_match_derive_params(uint32_t read_len, uint32_t seed_len, uint32_t min_chars_per_mismatch, char mode_char,
+                             pgrc_match_params *out) {
+    if (!out || read_len == 0 || read_len > 255 || seed_len == 0 || min_chars_per_mismatch == 0) return PGRC_E_PARAM;
+    memset(out, 0, sizeof *out);
+    out->read_len = read_len;
+    out->max_mismatches = (uint8_t)(read_len / min_chars_per_mismatch);
+    out->seed_len = std::min(seed_len, read_len);
+    const bool upper = mode_char >= 'A' && mode_char <= 'Z';
+    const char lower = upper ? (char)(mode_char - 'A' + 'a') : mode_char;
+    out->min_mismatches = upper ? out->max_mismatches : 0;
+    out->device = -1;
+    if (out->seed_len == read_len) out->mode = (lower == 'c') ? 'c' : 'e';
+    else if (lower == 'c' || lower == 'd' || lower == 'i') out->mode = lower;
+    else return PGRC_E_MODE;
+    return PGRC_OK;
+}
+
+uint32_t pgrc_match_words_per_read(uint32_t read_len) { return (read_len + 15) / 16; }
+
+int pgrc_match_create(const pgrc_match_params *p, pgrc_match_ctx **out) {
+    if (!p || !out) return PGRC_E_PARAM;
+    *out = nullptr;
+    if (p->read_len == 0 || p->read_len > 255 || p->seed_len == 0 || p->seed_len > p->read_len) return PGRC_E_PARAM;
+    if (p->mode != 'c' && p->mode != 'd' && p->mode != 'i' && p->mode != 'e') return PGRC_E_MODE;
+    if (p->mode == 'c' && p->seed_len < 24) return PGRC_E_SEED_SHORT;
+    // the reference's u8 mismatch accumulator (CopMEMMatcher.cpp:524-534) cannot wrap while kmax <= 247
+    if (p->mode == 'c' && p->max_mismatches > 247) return PGRC_E_PARAM;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return PGRC_E_NO_DEVICE;
+    int dev = p->device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) return PGRC_E_NO_DEVICE;
+    } else if (dev >= ndev || hipSetDevice(dev) != hipSuccess) {
+        return PGRC_E_NO_DEVICE;
+    }
+    pgrc_match_ctx *c = new pgrc_match_ctx();
+    c->prm = *p;
+    c->device = dev;
+    c->nw = (p->read_len + 15) / 16;
+    if (pgrc_buf_ensure(c, c->d_hist, 256 * sizeof(uint64_t)) || pgrc_buf_ensure(c, c->d_counters, 16 * sizeof(uint64_t))) {
+        delete c;
+        return PGRC_E_NO_DEVICE;
+    }
+    *out = c;
+    return PGRC_OK;
+}
+
+void pgrc_match_destroy(pgrc_match_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    DevBuf *bufs[] = {&c->pg2[0], &c->pg2[1], &c->reads_own, &c->nread_idx, &c->nread_ascii, &c->nread_flag, &c->d_pos,
+                      &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_cnt, &c->d_cumm, &c->d_positions,
+                      &c->d_scan_tmp, &c->s_keys, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp};
+    for (DevBuf *b : bufs) pgrc_buf_free(*b);
+    if (c->have_events)
+        for (auto &e : c->ev) (void)hipEventDestroy(e);
+    delete c;
+}
+
+const char *pgrc_match_last_error(const pgrc_match_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int pgrc_match_set_stream(pgrc_match_ctx *c, void *s) {
+    if (!c) return PGRC_E_PARAM;
+    c->stream = (hipStream_t)s;
+    return PGRC_OK;
+}
+
+int pgrc_match_set_profiling(pgrc_match_ctx *c, int enabled) {
+    if (!c) return PGRC_E_PARAM;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (enabled && !c->have_events) {
+        for (auto &e : c->ev) HIP_TRY(c, hipEventCreate(&e));
+        c->have_events = true;
+    }
+    c->profiling = enabled != 0;
+    return PGRC_OK;
+}
+
+// ------------------------------------------------------------------ pseudogenome
+
+static int alloc_pg(pgrc_match_ctx *c, uint64_t G) {
+    if (G + 256 >= (1ull << 32)) {
+        c->err = "pseudogenome >= 4 Gi symbols needs the 64-bit index variant (not built yet)";
+        return PGRC_E_PARAM;
+    }
+    if (G < c->prm.read_len) {
+        c->err = "pseudogenome shorter than a read";
+        return PGRC_E_PARAM;
+    }
+    c->G = G;
+    c->pg_words = (G + 15) / 16;
+    const size_t bytes = (c->pg_words + PGRC_PG_PAD_WORDS) * sizeof(uint32_t);
+    int e;
+    for (int s = 0; s < 2; s++) {
+        if ((e = pgrc_buf_ensure(c, c->pg2[s], bytes))) return e;
+        HIP_TRY(c, hipMemsetAsync(c->pg2[s].p, 0, bytes, c->stream));
+    }
+    c->have_pg = false;
+    c->have_rc = false;
+    c->index_strand = -1;
+    if (c->prm.mode == 'c') {
+        int r = pgrc_match_copmem_params(c->prm.seed_len, G, &c->cp);
+        if (r) { c->err = "copMEM parameter derivation failed (seed too short?)"; return r; }
+    }
+    return PGRC_OK;
+}
+
+int pgrc_match_pack_pg_slice(pgrc_match_ctx *c, const char *pg, uint64_t count, void *d_words_out) {
+    if (!c || (!pg && count) || !d_words_out) return PGRC_E_PARAM;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t CH = 64ull << 20; // 64 Mi symbols per staging chunk (multiple of 16)
+    DevBuf stage, flag;
+    int e;
+    if ((e = pgrc_buf_ensure(c, stage, (size_t)std::min(CH, count ? count : 16)))) return e;
+    if ((e = pgrc_buf_ensure(c, flag, sizeof(uint32_t)))) { pgrc_buf_free(stage); return e; }
+    (void)hipMemsetAsync(flag.p, 0, sizeof(uint32_t), c->stream);
+    int rcode = PGRC_OK;
+    for (uint64_t off = 0; off < count && rcode == PGRC_OK; off += CH) {
+        const uint64_t len = std::min(CH, count - off);
+        if (hipMemcpyAsync(stage.p, pg + off, len, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_NO_DEVICE; break; }
+        rcode = pgrc_launch_pack_ascii(c, (const uint8_t *)stage.p, len, (uint32_t *)d_words_out + off / 16, (uint32_t *)flag.p);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_NO_DEVICE;
+    }
+    uint32_t bad = 0;
+    if (rcode == PGRC_OK && hipMemcpy(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) rcode = PGRC_E_NO_DEVICE;
+    pgrc_buf_free(stage);
+    pgrc_buf_free(flag);
+    if (rcode == PGRC_OK && bad) {
+        c->err = "pseudogenome contains a symbol outside ACGT";
+        return PGRC_E_SYMBOL;
+    }
+    if (rcode != PGRC_OK && c->err.empty()) c->err = "pack_pg_slice: HIP error";
+    return rcode;
+}
+
+int pgrc_match_set_pg_ascii(pgrc_match_ctx *c, const char *pg, uint64_t G) {
+    if (!c || !pg) return PGRC_E_PARAM;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int e = alloc_pg(c, G);
+    if (e) return e;
+    if ((e = pgrc_match_pack_pg_slice(c, pg, G, c->pg2[0].p))) return e;
+    c->have_pg = true;
+    return PGRC_OK;
+}
+
+int pgrc_match_set_pg_packed_device(pgrc_match_ctx *c, const void *d_words, uint64_t G) {
+    if (!c || !d_words) return PGRC_E_PARAM;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int e = alloc_pg(c, G);
+    if (e) return e;
+    HIP_TRY(c, hipMemcpyAsync(c->pg2[0].p, d_words, c->pg_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    // clear the bits after symbol G-1 in the last word: padding must read as zero
+    if (G % 16) {
+        uint32_t last;
+        HIP_TRY(c, hipMemcpyAsync(&last, (const uint32_t *)d_words + c->pg_words - 1, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        last &= (1u << (2 * (G % 16))) - 1u;
+        HIP_TRY(c, hipMemcpyAsync((uint32_t *)c->pg2[0].p + c->pg_words - 1, &last, 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->have_pg = true;
+    return PGRC_OK;
+}
+
+int pgrc_match_export_pg(pgrc_match_ctx *c, int strand, uint32_t *words) {
+    if (!c || !words || strand < 0 || strand > 1) return PGRC_E_PARAM;
+    if (!c->have_pg) { c->err = "export_pg: no pseudogenome set"; return PGRC_E_STATE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (strand == 1 && !c->have_rc) {
+        int e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G);
+        if (e) return e;
+        c->have_rc = true;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(words, c->pg2[strand].p, c->pg_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return PGRC_OK;
+}
+
+// ------------------------------------------------------------------ reads
+
+static int alloc_results(pgrc_match_ctx *c, uint64_t n) {
+    int e;
+    if ((e = pgrc_buf_ensure(c, c->d_pos, n * sizeof(uint64_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->d_rc, n))) return e;
+    if ((e = pgrc_buf_ensure(c, c->d_mism, n))) return e;
+    c->have_results = false;
+    return PGRC_OK;
+}
+
+static int begin_reads(pgrc_match_ctx *c, uint64_t n, bool own) {
+    if (n >= (1ull << 32) - 1) { c->err = "reads count must stay below 2^32-1 (uint_reads_cnt_max, pg-config.h:21-22)"; return PGRC_E_PARAM; }
+    c->n = n;
+    c->n_nreads = 0;
+    c->have_reads = false;
+    int e;
+    if (own) {
+        c->stride = (n + 63) & ~63ull;
+        if ((e = pgrc_buf_ensure(c, c->reads_own, (size_t)c->nw * std::max<uint64_t>(c->stride, 64) * sizeof(uint32_t)))) return e;
+        c->reads2 = (const uint32_t *)c->reads_own.p;
+    }
+    return alloc_results(c, n);
+}
+
+int pgrc_match_set_reads_ascii(pgrc_match_ctx *c, const char *reads, uint64_t n) {
+    if (!c || (!reads && n)) return PGRC_E_PARAM;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int e = begin_reads(c, n, true);
+    if (e) return e;
+    const uint32_t L = c->prm.read_len;
+    if ((e = pgrc_buf_ensure(c, c->nread_flag, n))) return e;
+    HIP_TRY(c, hipMemsetAsync(c->nread_flag.p, 0, n ? n : 1, c->stream));
+    DevBuf stage, flag;
+    const uint64_t CHR = std::max<uint64_t>(1, (256ull << 20) / L); // reads per staging chunk (~256 MiB)
+    if ((e = pgrc_buf_ensure(c, stage, (size_t)std::min(CHR, std::max<uint64_t>(n, 1)) * L))) return e;
+    if ((e = pgrc_buf_ensure(c, flag, sizeof(uint32_t)))) { pgrc_buf_free(stage); return e; }
+    (void)hipMemsetAsync(flag.p, 0, sizeof(uint32_t), c->stream);
+    int rcode = PGRC_OK;
+    for (uint64_t off = 0; off < n && rcode == PGRC_OK; off += CHR) {
+        const uint64_t cnt = std::min(CHR, n - off);
+        if (hipMemcpyAsync(stage.p, reads + off * L, cnt * L, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_NO_DEVICE; break; }
+        rcode = pgrc_launch_pack_reads_ascii(c, (const uint8_t *)stage.p, off, cnt, L, (uint32_t *)c->reads_own.p, c->stride,
+                                             (uint8_t *)c->nread_flag.p, (uint32_t *)flag.p);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_NO_DEVICE;
+    }
+    uint32_t bad = 0;
+    if (rcode == PGRC_OK && hipMemcpy(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) rcode = PGRC_E_NO_DEVICE;
+    pgrc_buf_free(stage);
+    pgrc_buf_free(flag);
+    if (rcode != PGRC_OK) { if (c->err.empty()) c->err = "set_reads_ascii: HIP error"; return rcode; }
+    if (bad) { c->err = "reads contain a symbol outside ACGNT"; return PGRC_E_SYMBOL; }
+    // reads with 'N' -> byte path: gather their rows (host side; they are a small minority)
+    std::vector<uint8_t> nf(n);
+    if (n) HIP_TRY(c, hipMemcpy(nf.data(), c->nread_flag.p, n, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> idx;
+    for (uint64_t i = 0; i < n; i++)
+        if (nf[i]) idx.push_back((uint32_t)i);
+    c->n_nreads = idx.size();
+    if (c->n_nreads) {
+        std::vector<char> rows(c->n_nreads * (size_t)L);
+        for (size_t t = 0; t < idx.size(); t++) memcpy(rows.data() + t * L, reads + (uint64_t)idx[t] * L, L);
+        if ((e = pgrc_buf_ensure(c, c->nread_idx, idx.size() * sizeof(uint32_t)))) return e;
+        if ((e = pgrc_buf_ensure(c, c->nread_ascii, rows.size()))) return e;
+        HIP_TRY(c, hipMemcpy(c->nread_idx.p, idx.data(), idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->nread_ascii.p, rows.data(), rows.size(), hipMemcpyHostToDevice));
+    }
+    c->have_reads = true;
+    return PGRC_OK;
+}
+
+int pgrc_match_set_reads_packed(pgrc_match_ctx *c, const uint8_t *packed, uint64_t n) {
+    if (!c || (!packed && n)) return PGRC_E_PARAM;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int e = begin_reads(c, n, true);
+    if (e) return e;
+    const uint32_t L = c->prm.read_len, pb = (L + 3) / 4;
+    DevBuf stage;
+    const uint64_t CHR = std::max<uint64_t>(1, (256ull << 20) / pb);
+    if ((e = pgrc_buf_ensure(c, stage, (size_t)std::min(CHR, std::max<uint64_t>(n, 1)) * pb))) return e;
+    int rcode = PGRC_OK;
+    for (uint64_t off = 0; off < n && rcode == PGRC_OK; off += CHR) {
+        const uint64_t cnt = std::min(CHR, n - off);
+        if (hipMemcpyAsync(stage.p, packed + off * pb, cnt * pb, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_NO_DEVICE; break; }
+        rcode = pgrc_launch_repack_reads_ref(c, (const uint8_t *)stage.p, off, cnt, L, (uint32_t *)c->reads_own.p, c->stride);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_NO_DEVICE;
+    }
+    pgrc_buf_free(stage);
+    if (rcode != PGRC_OK) { if (c->err.empty()) c->err = "set_reads_packed: HIP error"; return rcode; }
+    c->have_reads = true;
+    return PGRC_OK;
+}
+
+int pgrc_match_set_reads_device(pgrc_match_ctx *c, const void *d_words, uint64_t n, uint64_t stride) {
+    if (!c || (!d_words && n) || stride < n) return PGRC_E_PARAM;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int e = begin_reads(c, n, false);
+    if (e) return e;
+    c->reads2 = (const uint32_t *)d_words;
+    c->stride = stride;
+    c->have_reads = true;
+    return PGRC_OK;
+}
+
+// ------------------------------------------------------------------ matching
+
+int pgrc_match_init_results(pgrc_match_ctx *c) {
+    if (!c) return PGRC_E_PARAM;
+    if (!c->have_reads) { c->err = "init_results: no reads set"; return PGRC_E_STATE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    int e = pgrc_launch_init_results(c);
+    if (e) return e;
+    c->have_results = true;
+    return PGRC_OK;
+}
+
+int pgrc_match_set_results(pgrc_match_ctx *c, const uint64_t *pos, const uint8_t *rc, const uint8_t *mism) {
+    if (!c || !pos || !rc || !mism) return PGRC_E_PARAM;
+    if (!c->have_reads) { c->err = "set_results: no reads set"; return PGRC_E_STATE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->n) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_pos.p, pos, c->n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_rc.p, rc, c->n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_mism.p, mism, c->n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->have_results = true;
+    return PGRC_OK;
+}
+
+int pgrc_match_run(pgrc_match_ctx *c, int rev_compl_pg) {
+    if (!c) return PGRC_E_PARAM;
+    if (!c->have_pg || !c->have_reads) { c->err = "run: set the pseudogenome and the reads first"; return PGRC_E_STATE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    int e;
+    if (!c->have_results && (e = pgrc_match_init_results(c))) return e;
+    HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, 16 * sizeof(uint64_t), c->stream));
+    const bool prof = c->profiling && c->have_events;
+    int evi = 0;
+    auto mark = [&]() { if (prof) (void)hipEventRecord(c->ev[evi], c->stream); evi++; };
+    mark(); // 0
+    if (c->prm.mode == 'c') {
+        for (int pass = 0; pass < (rev_compl_pg ? 2 : 1); pass++) {
+            if (pass == 1) {
+                // PgHelpers::reverseComplementInPlace(pgPtr), ReadsMatchers.cpp:168 -- rebuilt every run like the reference
+                if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) return e;
+                c->have_rc = true;
+            }
+            mark(); // 1 / 4
+            if ((e = pgrc_copmem_build_index(c, pass))) return e;
+            mark(); // 2 / 5
+            if ((e = pgrc_copmem_match_pass(c, pass))) return e;
+            mark(); // 3 / 6
+        }
+    } else {
+        if ((e = pgrc_seedidx_run(c, rev_compl_pg))) return e;
+    }
+    const int ev_end_match = evi;
+    if ((e = pgrc_launch_hist(c))) return e; // synchronises the stream
+    mark();
+    uint64_t ctr[16];
+    HIP_TRY(c, hipMemcpy(ctr, c->d_counters.p, sizeof ctr, hipMemcpyDeviceToHost));
+    memset(&c->ctr, 0, sizeof c->ctr);
+    for (int s = 0; s < 2; s++) {
+        c->ctr.searched[s] = ctr[3 * s + 0];
+        c->ctr.candidates[s] = ctr[3 * s + 1];
+        c->ctr.probes[s] = ctr[3 * s + 2];
+    }
+    if (prof) {
+        HIP_TRY(c, hipEventSynchronize(c->ev[evi - 1]));
+        float ms = 0;
+        if (c->prm.mode == 'c') {
+            for (int pass = 0; pass < (rev_compl_pg ? 2 : 1); pass++) {
+                const int b = 1 + 3 * pass;
+                (void)hipEventElapsedTime(&ms, c->ev[b], c->ev[b + 1]);
+                c->ctr.ms_index[pass] = ms;
+                (void)hipEventElapsedTime(&ms, c->ev[b + 1], c->ev[b + 2]);
+                c->ctr.ms_match[pass] = ms;
+            }
+        }
+        (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[evi - 1]);
+        c->ctr.ms_total = ms;
+        c->ctr.ms_other = ms - c->ctr.ms_index[0] - c->ctr.ms_index[1] - c->ctr.ms_match[0] - c->ctr.ms_match[1];
+        (void)ev_end_match;
+    }
+    return PGRC_OK;
+}
+
+int pgrc_match_get_results(pgrc_match_ctx *c, uint64_t *pos, uint8_t *rc, uint8_t *mism, uint64_t hist[256], uint64_t *matched) {
+    if (!c) return PGRC_E_PARAM;
+    if (!c->have_results) { c->err = "get_results: nothing computed"; return PGRC_E_STATE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->n) {
+        if (pos) HIP_TRY(c, hipMemcpy(pos, c->d_pos.p, c->n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        if (rc) HIP_TRY(c, hipMemcpy(rc, c->d_rc.p, c->n, hipMemcpyDeviceToHost));
+        if (mism) HIP_TRY(c, hipMemcpy(mism, c->d_mism.p, c->n, hipMemcpyDeviceToHost));
+    }
+    if (hist) memcpy(hist, c->hist, sizeof c->hist);
+    if (matched) *matched = c->matched;
+    return PGRC_OK;
+}
+
+int pgrc_match_get_results_device(pgrc_match_ctx *c, void **d_pos, void **d_rc, void **d_mism) {
+    if (!c) return PGRC_E_PARAM;
+    if (!c->have_reads) { c->err = "get_results_device: no reads set"; return PGRC_E_STATE; }
+    if (d_pos) *d_pos = c->d_pos.p;
+    if (d_rc) *d_rc = c->d_rc.p;
+    if (d_mism) *d_mism = c->d_mism.p;
+    return PGRC_OK;
+}
+
+int pgrc_match_get_counters(pgrc_match_ctx *c, pgrc_match_counters *out) {
+    if (!c || !out) return PGRC_E_PARAM;
+    *out = c->ctr;
+    out->index_entries[0] = out->index_entries[1] = c->npos;
+    return PGRC_OK;
+}
+
+int pgrc_match_extract_mismatches(pgrc_match_ctx *c, const uint8_t *reversed_flags, uint64_t *cum, uint8_t *codes,
+                                  uint16_t *offsets) {
+    if (!c || !cum) return PGRC_E_PARAM;
+    if (!c->have_results || !c->have_pg) { c->err = "extract_mismatches: run first"; return PGRC_E_STATE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    return pgrc_extract_mismatches(c, reversed_flags, cum, codes, offsets);
+}
+
+int pgrc_match_export_index(pgrc_match_ctx *c, int strand, uint32_t *cumm, uint32_t *positions, uint64_t *count) {
+    if (!c || strand < 0 || strand > 1) return PGRC_E_PARAM;
+    if (!c->have_pg || c->prm.mode != 'c') { c->err = "export_index: mode c with a pseudogenome only"; return PGRC_E_STATE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    int e;
+    if (strand == 1 && !c->have_rc) {
+        if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) return e;
+        c->have_rc = true;
+    }
+    if (c->index_strand != strand && (e = pgrc_copmem_build_index(c, strand))) return e;
+    return pgrc_copmem_export_index(c, cumm, positions, count);
+}
+
+} // extern "C"

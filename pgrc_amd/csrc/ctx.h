@@ -1,0 +1,110 @@
+// ctx.h -- shared declarations of libpgrc_match.so (host side of the HIP path).
+//
+// Data layout in HBM:
+//   pg2[strand]   u32[ceil(G/16)+PG_PAD]   2-bit text, symbol i at bits 2*(i%16) of word i/16
+//   reads2        u32[NW][stride]          word-major ("transposed") reads: thread i of a wave
+//                                          reads word w of read i at reads2[w*stride+i] => every
+//                                          wave-level load is one coalesced 256-B line
+//   cumm          u32[hash_size+2]         copMEM bucket starts (uncapped CSR)
+//   positions     u32[npos]                sampled Pg positions, each bucket's 13 smallest first
+//   pos/rc/mism   u64[n] / u8[n] / u8[n]   per-read results (ReadsMatchers.h:32-35,115)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "pgrc_match.h"
+
+#define PGRC_PG_PAD_WORDS 32u   // zero words after the text so NW+1-word windows never fault
+#define PGRC_MAX_NW 16          // ceil(255/16)
+#define PGRC_BUCKET_CAP 13u     // HASH_COLLISIONS_PER_POSITION_LIMIT + 1 (CopMEMMatcher.h:11)
+#define PGRC_TRUNC_BUCKET 4u    // UNLIMITED_NUMBER_OF_HASH_COLLISIONS_PER_POSITION (CopMEMMatcher.h:13)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct pgrc_match_ctx {
+    pgrc_match_params prm{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // pseudogenome
+    uint64_t G = 0;
+    uint64_t pg_words = 0;
+    DevBuf pg2[2];          // [0] forward, [1] reverse complement
+    bool have_pg = false, have_rc = false;
+
+    // reads
+    uint64_t n = 0, stride = 0;
+    uint32_t nw = 0;
+    DevBuf reads_own;       // owned copy (set_reads_ascii / _packed)
+    const uint32_t *reads2 = nullptr; // active pointer (owned or borrowed)
+    bool have_reads = false;
+    // reads with 'N': byte path
+    uint64_t n_nreads = 0;
+    DevBuf nread_idx;       // u32[n_nreads] read index
+    DevBuf nread_ascii;     // u8[n_nreads][read_len]
+    DevBuf nread_flag;      // u8[n] 1 = handled by the byte path
+
+    // results
+    DevBuf d_pos, d_rc, d_mism, d_hist, d_counters;
+    bool have_results = false;
+    uint64_t hist[256]{};
+    uint64_t matched = 0;
+
+    // copMEM index (rebuilt per pass, buffers reused)
+    pgrc_copmem_params cp{};
+    uint64_t npos = 0;
+    DevBuf d_cnt, d_cumm, d_positions, d_scan_tmp;
+    int index_strand = -1;  // which strand the buffers currently describe
+
+    // read-side seed index (modes d / i / e)
+    DevBuf s_keys, s_vals, s_tab, s_hits, s_tmp;
+
+    // profiling
+    bool profiling = false;
+    pgrc_match_counters ctr{};
+    hipEvent_t ev[16]{};
+    bool have_events = false;
+};
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                 \
+            return PGRC_E_NO_DEVICE;                                                         \
+        }                                                                                    \
+    } while (0)
+
+int pgrc_buf_ensure(pgrc_match_ctx *c, DevBuf &b, size_t bytes);
+void pgrc_buf_free(DevBuf &b);
+
+// pack.hip
+int pgrc_launch_pack_ascii(pgrc_match_ctx *c, const uint8_t *d_ascii, uint64_t count, uint32_t *d_words,
+                           uint32_t *d_errflag);
+int pgrc_launch_revcomp(pgrc_match_ctx *c, const uint32_t *d_fw, uint32_t *d_rc, uint64_t G);
+int pgrc_launch_pack_reads_ascii(pgrc_match_ctx *c, const uint8_t *d_ascii, uint64_t first, uint64_t count,
+                                 uint32_t L, uint32_t *d_words, uint64_t stride, uint8_t *d_nflag,
+                                 uint32_t *d_errflag);
+int pgrc_launch_repack_reads_ref(pgrc_match_ctx *c, const uint8_t *d_packed, uint64_t first, uint64_t count,
+                                 uint32_t L, uint32_t *d_words, uint64_t stride);
+
+// copmem.hip
+int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand);
+int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand);
+int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_positions, uint64_t *count);
+
+// seedidx.hip (modes d / i / e)
+int pgrc_seedidx_run(pgrc_match_ctx *c, int rev_compl_pg);
+
+// results.hip
+int pgrc_launch_init_results(pgrc_match_ctx *c);
+int pgrc_launch_hist(pgrc_match_ctx *c);
+int pgrc_extract_mismatches(pgrc_match_ctx *c, const uint8_t *reversed_flags, uint64_t *cum, uint8_t *codes,
+                            uint16_t *offsets);

@@ -1,0 +1,332 @@
+"""Host-side mirror of the reference's matcher classes over the C ABI.
+
+Names, argument meaning and error behaviour follow matching/ReadsMatchers.h:
+`DefaultReadsMatcher.matchConstantLengthReads()` (ReadsMatchers.cpp:162-172), the result fields
+`readMatchPos / readMatchRC / readMismatchesCount / matchedReadsCount /
+matchedCountPerMismatches` (ReadsMatchers.h:32-35,115-116), `getMatchedReadsBitmap`
+(:677-691), `continueMatchingConstantLengthReads` (:174-184) and the factory `mapReadsIntoPg`
+(:693-796).  All compute happens in libpgrc_match.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import Counters, CopmemParams, MatchParams, PgrcMatchError, lib
+
+DISABLED_PREFIX_MODE = 0xFFFF  # (uint_read_len_max) -1, ReadsMatchers.cpp:68
+
+
+def _as_ascii_2d(reads, read_len: Optional[int] = None) -> np.ndarray:
+    """reads -> contiguous uint8 [n, L] (accepts list[str], bytes rows, or an ndarray)."""
+    if isinstance(reads, np.ndarray):
+        a = np.ascontiguousarray(reads, dtype=np.uint8)
+        if a.ndim != 2:
+            raise ValueError("reads array must be [n, read_len] uint8 ASCII")
+        return a
+    rows = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    if not rows:
+        return np.zeros((0, read_len or 0), dtype=np.uint8)
+    L = len(rows[0])
+    if any(len(r) != L for r in rows):
+        raise ValueError("Unsupported variable length reads.")  # PackedConstantLengthReadsSet.cpp:37-40
+    return np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), L).copy()
+
+
+def _as_ascii_1d(pg) -> np.ndarray:
+    if isinstance(pg, np.ndarray):
+        return np.ascontiguousarray(pg, dtype=np.uint8).reshape(-1)
+    if isinstance(pg, str):
+        pg = pg.encode()
+    return np.frombuffer(bytes(pg), dtype=np.uint8).copy()
+
+
+def copmem_params(seed_len: int, pg_len: int) -> dict:
+    """CopMEMMatcher::initParams (CopMEMMatcher.cpp:69-96, :111-137)."""
+    p = CopmemParams()
+    rc = lib.pgrc_match_copmem_params(seed_len, pg_len, C.byref(p))
+    if rc:
+        raise PgrcMatchError(rc, "copMEM parameter derivation")
+    return {"K": p.K, "k1": p.k1, "k2": p.k2, "hash_size": p.hash_size}
+
+
+class MatchContext:
+    """RAII wrapper of `pgrc_match_ctx*`."""
+
+    def __init__(self, read_len: int, seed_len: int, max_mismatches: int, min_mismatches: int, mode: str,
+                 device: int = -1):
+        prm = MatchParams(read_len, seed_len, max_mismatches, min_mismatches, mode.encode(), device)
+        self._h = C.c_void_p()
+        rc = lib.pgrc_match_create(C.byref(prm), C.byref(self._h))
+        if rc:
+            self._h = C.c_void_p()
+            raise PgrcMatchError(rc, "pgrc_match_create failed (no HIP device? bad parameters?)")
+        self.read_len, self.seed_len, self.mode = read_len, seed_len, mode
+        self.n = 0
+        self.pg_len = 0
+        self._keep = []  # keeps borrowed device tensors alive
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib.pgrc_match_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _ck(self, rc: int):
+        if rc:
+            raise PgrcMatchError(rc, (lib.pgrc_match_last_error(self._h) or b"").decode())
+
+    # ---- inputs
+    def set_stream(self, stream_ptr: int):
+        self._ck(lib.pgrc_match_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_pg_ascii(self, pg):
+        a = _as_ascii_1d(pg)
+        self._ck(lib.pgrc_match_set_pg_ascii(self._h, a.ctypes.data_as(C.c_void_p), a.size))
+        self.pg_len = int(a.size)
+
+    def set_pg_packed_device(self, dev_ptr: int, pg_len: int, keep=None):
+        self._ck(lib.pgrc_match_set_pg_packed_device(self._h, C.c_void_p(dev_ptr), pg_len))
+        self.pg_len = int(pg_len)
+
+    def pack_pg_slice(self, pg_slice, dev_out_ptr: int):
+        a = _as_ascii_1d(pg_slice)
+        self._ck(lib.pgrc_match_pack_pg_slice(self._h, a.ctypes.data_as(C.c_void_p), a.size, C.c_void_p(dev_out_ptr)))
+
+    def set_reads_ascii(self, reads):
+        a = _as_ascii_2d(reads, self.read_len)
+        if a.shape[0] and a.shape[1] != self.read_len:
+            raise ValueError("Unsupported variable length reads.")
+        self._ck(lib.pgrc_match_set_reads_ascii(self._h, a.ctypes.data_as(C.c_void_p), a.shape[0]))
+        self.n = int(a.shape[0])
+
+    def set_reads_packed(self, packed: np.ndarray, n: int):
+        a = np.ascontiguousarray(packed, dtype=np.uint8)
+        self._ck(lib.pgrc_match_set_reads_packed(self._h, a.ctypes.data_as(C.c_void_p), n))
+        self.n = int(n)
+
+    def set_reads_device(self, dev_ptr: int, n: int, stride: int, keep=None):
+        self._ck(lib.pgrc_match_set_reads_device(self._h, C.c_void_p(dev_ptr), n, stride))
+        self.n = int(n)
+        if keep is not None:
+            self._keep.append(keep)
+
+    # ---- matching
+    def init_results(self):
+        self._ck(lib.pgrc_match_init_results(self._h))
+
+    def set_results(self, pos, rc, mism):
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        rc = np.ascontiguousarray(rc, dtype=np.uint8)
+        mism = np.ascontiguousarray(mism, dtype=np.uint8)
+        self._ck(lib.pgrc_match_set_results(self._h, pos.ctypes.data_as(C.c_void_p), rc.ctypes.data_as(C.c_void_p),
+                                            mism.ctypes.data_as(C.c_void_p)))
+
+    def run(self, rev_compl_pg: bool = True):
+        self._ck(lib.pgrc_match_run(self._h, 1 if rev_compl_pg else 0))
+
+    def get_results(self, arrays: bool = True):
+        n = self.n
+        hist = np.zeros(256, dtype=np.uint64)
+        matched = C.c_uint64(0)
+        if arrays:
+            pos = np.empty(n, dtype=np.uint64)
+            rc = np.empty(n, dtype=np.uint8)
+            mism = np.empty(n, dtype=np.uint8)
+            self._ck(lib.pgrc_match_get_results(self._h, pos.ctypes.data_as(C.c_void_p), rc.ctypes.data_as(C.c_void_p),
+                                                mism.ctypes.data_as(C.c_void_p), hist.ctypes.data_as(C.c_void_p),
+                                                C.byref(matched)))
+        else:
+            pos = rc = mism = None
+            self._ck(lib.pgrc_match_get_results(self._h, None, None, None, hist.ctypes.data_as(C.c_void_p),
+                                                C.byref(matched)))
+        return pos, rc, mism, hist, int(matched.value)
+
+    def results_device_ptrs(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._ck(lib.pgrc_match_get_results_device(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def extract_mismatches(self, reversed_flags=None):
+        """-> (cum[n+1] u64, codes u8, offsets u16), see pgrc_match_extract_mismatches."""
+        n = self.n
+        cum = np.zeros(n + 1, dtype=np.uint64)
+        fl = None
+        flp = None
+        if reversed_flags is not None:
+            fl = np.ascontiguousarray(reversed_flags, dtype=np.uint8)
+            flp = fl.ctypes.data_as(C.c_void_p)
+        self._ck(lib.pgrc_match_extract_mismatches(self._h, flp, cum.ctypes.data_as(C.c_void_p), None, None))
+        total = int(cum[n])
+        codes = np.zeros(total, dtype=np.uint8)
+        offs = np.zeros(total, dtype=np.uint16)
+        if total:
+            self._ck(lib.pgrc_match_extract_mismatches(self._h, flp, cum.ctypes.data_as(C.c_void_p),
+                                                       codes.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p)))
+        return cum, codes, offs
+
+    # ---- introspection
+    def export_index(self, strand: int = 0):
+        cnt = C.c_uint64(0)
+        self._ck(lib.pgrc_match_export_index(self._h, strand, None, None, C.byref(cnt)))
+        hs = copmem_params(self.seed_len, self.pg_len)["hash_size"]
+        cumm = np.empty(hs + 2, dtype=np.uint32)
+        positions = np.empty(int(cnt.value), dtype=np.uint32)
+        self._ck(lib.pgrc_match_export_index(self._h, strand, cumm.ctypes.data_as(C.c_void_p),
+                                             positions.ctypes.data_as(C.c_void_p), C.byref(cnt)))
+        return cumm, positions
+
+    def export_pg(self, strand: int = 0) -> np.ndarray:
+        w = np.empty((self.pg_len + 15) // 16, dtype=np.uint32)
+        self._ck(lib.pgrc_match_export_pg(self._h, strand, w.ctypes.data_as(C.c_void_p)))
+        return w
+
+    def set_profiling(self, on: bool = True):
+        self._ck(lib.pgrc_match_set_profiling(self._h, 1 if on else 0))
+
+    def counters(self) -> dict:
+        c = Counters()
+        self._ck(lib.pgrc_match_get_counters(self._h, C.byref(c)))
+        return {"searched": list(c.searched), "candidates": list(c.candidates), "probes": list(c.probes),
+                "index_entries": list(c.index_entries), "ms_index": list(c.ms_index), "ms_match": list(c.ms_match),
+                "ms_other": c.ms_other, "ms_total": c.ms_total}
+
+
+class DefaultReadsMatcher:
+    """matching/ReadsMatchers.h:24-83.  Subclasses fix the matcher kind ('mode')."""
+
+    MODE = None
+    NOT_MATCHED_POSITION = _lib.NOT_MATCHED_POS
+    DISABLED_PREFIX_MODE = DISABLED_PREFIX_MODE
+
+    def __init__(self, pg, revComplPg: bool, readsSet, matchPrefixLength: int = DISABLED_PREFIX_MODE,
+                 readsExactMatchingChars: Optional[int] = None, maxMismatches: int = 0, minMismatches: int = 0,
+                 device: int = -1):
+        if matchPrefixLength != DISABLED_PREFIX_MODE:
+            # the hot path is only ever entered with DISABLED_PREFIX_MODE (pgrc-encoder.cpp:362)
+            raise PgrcMatchError(1, "prefix matching mode is not part of the accelerated path")
+        self.reads = _as_ascii_2d(readsSet)
+        self.readsCount, self.readLength = int(self.reads.shape[0]), int(self.reads.shape[1])
+        self.matchingLength = self.readLength
+        self.pg = _as_ascii_1d(pg)
+        self.pgLength = int(self.pg.size)
+        self.revComplPg = bool(revComplPg)
+        seed = self.readLength if readsExactMatchingChars is None else int(readsExactMatchingChars)
+        self.maxMismatches, self.minMismatches = int(maxMismatches), int(minMismatches)
+        self.ctx = MatchContext(self.readLength, seed, self.maxMismatches, self.minMismatches, self.MODE, device)
+        self.ctx.set_pg_ascii(self.pg)
+        self.ctx.set_reads_ascii(self.reads)
+        self.readMatchPos = self.readMatchRC = self.readMismatchesCount = None
+        self.matchedReadsCount = 0
+        self.matchedCountPerMismatches = np.zeros(256, dtype=np.uint64)
+
+    def _fetch(self):
+        (self.readMatchPos, rc, self.readMismatchesCount, self.matchedCountPerMismatches,
+         self.matchedReadsCount) = self.ctx.get_results()
+        self.readMatchRC = rc.astype(bool)
+
+    def matchConstantLengthReads(self):
+        """initMatching(); executeMatching(false); [RC(pg); executeMatching(true); RC(pg)]"""
+        self.ctx.init_results()
+        self.ctx.run(self.revComplPg)
+        self._fetch()
+
+    def getMatchedReadsBitmap(self, maxMismatches: int = _lib.NOT_MATCHED_CNT - 1) -> np.ndarray:
+        return self.readMatchPos != np.uint64(_lib.NOT_MATCHED_POS)  # ReadsMatchers.cpp:677-683
+
+
+class DefaultReadsExactMatcher(DefaultReadsMatcher):
+    """ReadsMatchers.h:85-107 (mode 'e': whole-read seed, first hit in scan order wins)."""
+    MODE = "e"
+
+    def __init__(self, pg, revComplPg, readsSet, matchPrefixLength=DISABLED_PREFIX_MODE, device=-1):
+        super().__init__(pg, revComplPg, readsSet, matchPrefixLength, None, 0, 0, device)
+
+
+class AbstractReadsApproxMatcher(DefaultReadsMatcher):
+    """ReadsMatchers.h:109-143."""
+
+    def __init__(self, pg, revComplPg, readsSet, matchPrefixLength, readsExactMatchingChars, maxMismatches,
+                 minMismatches=0, device=-1):
+        super().__init__(pg, revComplPg, readsSet, matchPrefixLength, readsExactMatchingChars, maxMismatches,
+                         minMismatches, device)
+        self.targetMismatches = self.readLength // int(readsExactMatchingChars) - 1
+
+    def getMatchedReadsBitmap(self, maxMismatches: int = _lib.NOT_MATCHED_CNT - 1) -> np.ndarray:
+        return self.readMismatchesCount <= maxMismatches  # ReadsMatchers.cpp:685-691
+
+    def continueMatchingConstantLengthReads(self, pMatcher: DefaultReadsMatcher):
+        """Second phase (ReadsMatchers.cpp:174-184): take over pMatcher's results, then both passes."""
+        mism = pMatcher.readMismatchesCount
+        self.ctx.set_results(pMatcher.readMatchPos, pMatcher.readMatchRC.astype(np.uint8), mism)
+        self.ctx.run(self.revComplPg)
+        self._fetch()
+
+    def getMismatches(self, reversed_flags=None):
+        """updateEntry for every matched read (ReadsMatchers.cpp:548-559): (cum, codes, offsets)."""
+        return self.ctx.extract_mismatches(reversed_flags)
+
+
+class DefaultReadsApproxMatcher(AbstractReadsApproxMatcher):
+    MODE = "d"
+
+
+class InterleavedReadsApproxMatcher(AbstractReadsApproxMatcher):
+    MODE = "i"
+
+
+class CopMEMReadsApproxMatcher(AbstractReadsApproxMatcher):
+    MODE = "c"
+
+
+def mapReadsIntoPg(pg, revComplPg: bool, readsSet, readsExactMatchingChars: int, minCharsPerMismatch: int,
+                   matchingMode: str = "c", preReadsExactMatchingChars: int = 0, preMatchingMode: str = "c",
+                   matchPrefixLength: int = DISABLED_PREFIX_MODE, device: int = -1):
+    """PgTools::mapReadsIntoPg (ReadsMatchers.cpp:693-796) up to the export step.
+
+    Returns (matched bitmap, matcher).  The export into reads-list streams (:785-792) is the
+    reference's own code consuming the matcher's result fields.
+    """
+    reads = _as_ascii_2d(readsSet)
+    readLength = int(reads.shape[1])
+    prm = MatchParams()
+
+    def derive(seed, mode):
+        rc = lib.pgrc_match_derive_params(readLength, seed, minCharsPerMismatch, mode.encode(), C.byref(prm))
+        if rc == 7:
+            raise PgrcMatchError(rc, f"Unknown matching mode: {mode}.")  # ReadsMatchers.cpp:738
+        if rc:
+            raise PgrcMatchError(rc, "bad matching parameters")
+        return prm.seed_len, prm.max_mismatches, prm.min_mismatches, prm.mode.decode()
+
+    def build(seed, kmax, kmin, kind):
+        if kind == "e":
+            return DefaultReadsExactMatcher(pg, revComplPg, reads, matchPrefixLength, device)
+        cls = {"c": CopMEMReadsApproxMatcher, "d": DefaultReadsApproxMatcher, "i": InterleavedReadsApproxMatcher}[kind]
+        return cls(pg, revComplPg, reads, matchPrefixLength, seed, kmax, kmin, device)
+
+    if preReadsExactMatchingChars > 0:
+        seed, kmax, kmin, kind = derive(preReadsExactMatchingChars, preMatchingMode)
+    else:
+        seed, kmax, kmin, kind = derive(readsExactMatchingChars, matchingMode)
+    matcher = build(seed, kmax, kmin, kind)
+    matcher.matchConstantLengthReads()
+    if preReadsExactMatchingChars > 0:
+        # 2nd phase, ReadsMatchers.cpp:749-779: minMismatches = shortcut ? max : targetMismatches+1
+        seed2 = min(readsExactMatchingChars, readLength)
+        shortcut = matchingMode.upper() == matchingMode
+        target = readLength // seed2 - 1
+        kmin2 = kmax if shortcut else target + 1
+        kind2 = matchingMode.lower()
+        if kind2 not in "cdi":
+            raise PgrcMatchError(7, f"Unknown mismatches mode: {matchingMode}.")
+        if isinstance(matcher, DefaultReadsExactMatcher):
+            matcher.readMismatchesCount = np.where(matcher.readMatchPos == np.uint64(_lib.NOT_MATCHED_POS), 255, 0).astype(np.uint8)
+        approx = build(seed2, kmax, kmin2, kind2)
+        approx.continueMatchingConstantLengthReads(matcher)
+        matcher = approx
+    return matcher.getMatchedReadsBitmap(), matcher

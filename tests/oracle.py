@@ -1,0 +1,207 @@
+"""ctypes bindings of the TEST-ONLY checkers: oracle/libpgrc_oracle.so (our CPU restatement) and,
+when present, oracle/_ref/libpgrc_ref.so (the real reference compiled by oracle/Makefile).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "libpgrc_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libpgrc_ref.so")
+
+NOT_MATCHED_POS = 0xFFFFFFFFFFFFFFFF
+_P = C.c_void_p
+
+
+class CopmemParams(C.Structure):
+    _fields_ = [("L", C.c_int32), ("K", C.c_int32), ("k1", C.c_int32), ("k2", C.c_int32), ("hash_size", C.c_uint32)]
+
+
+class Index(C.Structure):
+    _fields_ = [("p", CopmemParams), ("pg_len", C.c_uint64), ("cumm", C.POINTER(C.c_uint32)),
+                ("positions", C.POINTER(C.c_uint32)), ("count", C.c_uint64)]
+
+
+class Result(C.Structure):
+    _fields_ = [("pos", _P), ("rc", _P), ("mism", _P), ("hist", C.c_uint64 * 256), ("matched", C.c_uint64),
+                ("searched", C.c_uint64 * 2), ("candidates", C.c_uint64 * 2), ("falses", C.c_uint64 * 2)]
+
+
+class MapParams(C.Structure):
+    _fields_ = [("kmax", C.c_uint8), ("kmin", C.c_uint8), ("seed_len", C.c_uint32), ("parts", C.c_uint8),
+                ("matcher", C.c_char)]
+
+
+_or = None
+
+
+def oracle():
+    global _or
+    if _or is None:
+        lib = C.CDLL(ORACLE_SO)
+        lib.pgrc_or_copmem_derive.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(CopmemParams)]
+        lib.pgrc_or_copmem_hash.argtypes = [C.c_int, C.c_char_p]
+        lib.pgrc_or_copmem_hash.restype = C.c_uint32
+        lib.pgrc_or_index_build.argtypes = [_P, C.c_uint64, C.c_uint32, C.POINTER(Index)]
+        lib.pgrc_or_index_free.argtypes = [C.POINTER(Index)]
+        lib.pgrc_or_copmem_match_read.argtypes = [C.POINTER(Index), _P, _P, C.c_uint32, C.c_uint8, C.c_uint8,
+                                                  C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        lib.pgrc_or_copmem_match_read.restype = C.c_uint64
+        lib.pgrc_or_match_copmem.argtypes = [_P, C.c_uint64, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint8,
+                                             C.c_uint8, C.c_int, C.c_int, C.c_int, C.POINTER(Result)]
+        lib.pgrc_or_match_seedindex.argtypes = [C.c_char, _P, C.c_uint64, _P, C.c_uint64, C.c_uint32, C.c_uint32,
+                                                C.c_uint8, C.c_uint8, C.c_int, C.POINTER(Result)]
+        lib.pgrc_or_map_derive.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_char, C.POINTER(MapParams)]
+        lib.pgrc_or_extract_mismatches.argtypes = [_P, C.c_uint64, _P, C.c_uint32, C.c_int, C.c_int, C.c_uint8, _P, _P]
+        lib.pgrc_or_revcomp.argtypes = [_P, C.c_uint64]
+        lib.pgrc_or_pack_read.argtypes = [_P, C.c_uint32, C.c_char_p, _P]
+        lib.pgrc_or_unpack_read.argtypes = [_P, C.c_uint32, C.c_char_p, _P]
+        _or = lib
+    return _or
+
+
+_ref = None
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        lib = C.CDLL(REF_SO)
+        lib.pgrc_ref_match.argtypes = [C.c_char, _P, C.c_uint64, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                                       C.c_uint8, C.c_uint8, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P,
+                                       C.POINTER(C.c_uint64), _P]
+        lib.pgrc_ref_copmem_index.argtypes = [_P, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_int32),
+                                              C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32),
+                                              C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)),
+                                              C.POINTER(C.c_uint64)]
+        lib.pgrc_ref_copmem_hash.argtypes = [C.c_uint32, C.c_char_p, C.POINTER(C.c_int32)]
+        lib.pgrc_ref_copmem_hash.restype = C.c_uint32
+        lib.pgrc_ref_copmem_match_read.argtypes = [_P, C.c_uint64, C.c_uint32, _P, C.c_uint32, C.c_uint8, C.c_uint8,
+                                                   C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]
+        lib.pgrc_ref_copmem_match_read.restype = C.c_uint64
+        lib.pgrc_ref_extract.argtypes = [_P, C.c_uint64, _P, C.c_uint32, C.c_uint64, C.c_int, C.c_uint8, C.c_uint32,
+                                         C.c_int, _P, _P]
+        lib.pgrc_ref_pack_read.argtypes = [_P, C.c_uint32, C.c_char_p, _P]
+        lib.pgrc_ref_revcomp.argtypes = [_P, C.c_uint64]
+        lib.pgrc_ref_free.argtypes = [_P]
+        _ref = lib
+    return _ref
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_P)
+
+
+def _new_result(n):
+    pos = np.empty(n, dtype=np.uint64)
+    rc = np.empty(n, dtype=np.uint8)
+    mism = np.empty(n, dtype=np.uint8)
+    r = Result()
+    r.pos, r.rc, r.mism = _ptr(pos), _ptr(rc), _ptr(mism)
+    return r, pos, rc, mism
+
+
+def _pack_result(r, pos, rc, mism):
+    return {"pos": pos, "rc": rc, "mism": mism, "hist": np.array(r.hist[:], dtype=np.uint64), "matched": int(r.matched),
+            "searched": list(r.searched), "candidates": list(r.candidates), "falses": list(r.falses)}
+
+
+def oracle_match(mode, pg, reads, seed_len, kmax, kmin, rev_compl=True, threads=8, state=None):
+    """mode in 'c','d','i','e'. pg: uint8[G] ASCII, reads: uint8[n, L] ASCII."""
+    pg = np.ascontiguousarray(pg, dtype=np.uint8)
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    n, L = reads.shape
+    r, pos, rc, mism = _new_result(n)
+    if mode == "c":
+        init = 1
+        if state is not None:
+            pos[:], rc[:], mism[:] = state
+            r.hist = (C.c_uint64 * 256)(*[int(x) for x in np.bincount(mism, minlength=256)])
+            r.matched = int((mism != 255).sum())
+            init = 0
+        e = oracle().pgrc_or_match_copmem(_ptr(pg), pg.size, _ptr(reads), n, L, seed_len, kmax, kmin,
+                                          1 if rev_compl else 0, threads, init, C.byref(r))
+    else:
+        e = oracle().pgrc_or_match_seedindex(mode.encode(), _ptr(pg), pg.size, _ptr(reads), n, L, seed_len, kmax, kmin,
+                                             1 if rev_compl else 0, C.byref(r))
+    if e:
+        raise RuntimeError(f"oracle returned {e}")
+    return _pack_result(r, pos, rc, mism)
+
+
+def oracle_index(pg, seed_len):
+    pg = np.ascontiguousarray(pg, dtype=np.uint8)
+    idx = Index()
+    e = oracle().pgrc_or_index_build(_ptr(pg), pg.size, seed_len, C.byref(idx))
+    if e:
+        raise RuntimeError(f"oracle index returned {e}")
+    hs = idx.p.hash_size
+    cumm = np.ctypeslib.as_array(idx.cumm, shape=(hs + 2,)).copy()
+    positions = np.ctypeslib.as_array(idx.positions, shape=(max(int(idx.count), 1),))[: int(idx.count)].copy()
+    prm = {"K": idx.p.K, "k1": idx.p.k1, "k2": idx.p.k2, "hash_size": hs}
+    oracle().pgrc_or_index_free(C.byref(idx))
+    return prm, cumm, positions
+
+
+def oracle_extract(pg, pos, read, rc, reversed_, cnt):
+    pg = np.ascontiguousarray(pg, dtype=np.uint8)
+    read = np.ascontiguousarray(read, dtype=np.uint8)
+    codes = np.zeros(max(cnt, 1), dtype=np.uint8)
+    offs = np.zeros(max(cnt, 1), dtype=np.uint16)
+    oracle().pgrc_or_extract_mismatches(_ptr(pg), int(pos), _ptr(read), read.size, int(rc), int(reversed_), int(cnt),
+                                        _ptr(codes), _ptr(offs))
+    return codes[:cnt], offs[:cnt]
+
+
+def ref_match(mode, pg, reads, seed_len, kmax, kmin, rev_compl=True, n_nset=0, index_threads=1, omp_threads=8):
+    pg = np.ascontiguousarray(pg, dtype=np.uint8)
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    n, L = reads.shape
+    pos = np.empty(n, dtype=np.uint64)
+    rc = np.empty(n, dtype=np.uint8)
+    mism = np.empty(n, dtype=np.uint8)
+    hist = np.zeros(256, dtype=np.uint64)
+    stats = np.zeros(2, dtype=np.uint64)
+    matched = C.c_uint64(0)
+    e = ref().pgrc_ref_match(mode.encode(), _ptr(pg), pg.size, _ptr(reads), n - n_nset, n_nset, L, seed_len, kmax, kmin,
+                             1 if rev_compl else 0, index_threads, omp_threads, _ptr(pos), _ptr(rc), _ptr(mism),
+                             _ptr(hist), C.byref(matched), _ptr(stats))
+    if e:
+        raise RuntimeError(f"ref returned {e}")
+    return {"pos": pos, "rc": rc, "mism": mism, "hist": hist, "matched": int(matched.value),
+            "better": int(stats[0]), "falses": int(stats[1])}
+
+
+def ref_index(pg, seed_len, index_threads=1):
+    pg = np.ascontiguousarray(pg, dtype=np.uint8)
+    K, k1, k2 = C.c_int32(), C.c_int32(), C.c_int32()
+    hs = C.c_uint32()
+    cumm = C.POINTER(C.c_uint32)()
+    positions = C.POINTER(C.c_uint32)()
+    cnt = C.c_uint64()
+    e = ref().pgrc_ref_copmem_index(_ptr(pg), pg.size, seed_len, index_threads, C.byref(K), C.byref(k1), C.byref(k2),
+                                    C.byref(hs), C.byref(cumm), C.byref(positions), C.byref(cnt))
+    if e:
+        raise RuntimeError(f"ref index returned {e}")
+    c = np.ctypeslib.as_array(cumm, shape=(hs.value + 2,)).copy()
+    p = np.ctypeslib.as_array(positions, shape=(max(int(cnt.value), 1),))[: int(cnt.value)].copy()
+    ref().pgrc_ref_free(cumm)
+    ref().pgrc_ref_free(positions)
+    return {"K": K.value, "k1": k1.value, "k2": k2.value, "hash_size": hs.value}, c, p
+
+
+def ref_extract(pg, pos, read, rc, cnt, org_idx=0, rev_compl_pair_file=False):
+    pg = np.ascontiguousarray(pg, dtype=np.uint8)
+    read = np.ascontiguousarray(read, dtype=np.uint8)
+    codes = np.zeros(256, dtype=np.uint8)
+    offs = np.zeros(256, dtype=np.uint16)
+    k = ref().pgrc_ref_extract(_ptr(pg), pg.size, _ptr(read), read.size, int(pos), int(rc), int(cnt), int(org_idx),
+                               1 if rev_compl_pair_file else 0, _ptr(codes), _ptr(offs))
+    return codes[:k], offs[:k]
