@@ -87,11 +87,31 @@ _PROTOS = [
 EXPORTED_SYMBOLS = [p[0] for p in _PROTOS]
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7, the same as /opt/rocm's).  If our library pulled in the system copy first and
+    torch its bundled copy later, two runtimes would fight over the device (the second one reports no
+    devices).  Loading torch's copy first -- without importing torch -- makes both resolve to it.
+    Processes without torch (e.g. the C++ reference with the adapter) use the system runtime."""
+    if os.environ.get("PGRC_USE_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(p):
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except Exception:  # torch absent or unloadable: fall through to the system runtime
+        pass
+
+
 def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension is the product and there is no fallback. "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C pgrc_amd/csrc`.")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, res, args in _PROTOS:
         fn = getattr(lib, name)  # AttributeError here = header / library out of sync: fail loudly

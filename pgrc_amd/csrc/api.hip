@@ -34,6 +34,8 @@ void pgrc_buf_free(DevBuf &b) {
     b.bytes = 0;
 }
 
+static thread_local std::string g_create_err; // reported by pgrc_match_last_error(NULL)
+
 static int isqrt_floor(int v) {
     int r = 0;
     while ((r + 1) * (r + 1) <= v) r++;
@@ -99,18 +101,26 @@ int pgrc_match_create(const pgrc_match_params *p, pgrc_match_ctx **out) {
     // the reference's u8 mismatch accumulator (CopMEMMatcher.cpp:524-534) cannot wrap while kmax <= 247
     if (p->mode == 'c' && p->max_mismatches > 247) return PGRC_E_PARAM;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return PGRC_E_NO_DEVICE;
-    int dev = p->device;
-    if (dev < 0) {
-        if (hipGetDevice(&dev) != hipSuccess) return PGRC_E_NO_DEVICE;
-    } else if (dev >= ndev || hipSetDevice(dev) != hipSuccess) {
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || ndev == 0) {
+        g_create_err = std::string("hipGetDeviceCount: ") + hipGetErrorString(he) + " (devices: " + std::to_string(ndev) + ")";
         return PGRC_E_NO_DEVICE;
     }
+    int dev = p->device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= ndev || (he = hipSetDevice(dev)) != hipSuccess) {
+        g_create_err = std::string("hipSetDevice(") + std::to_string(dev) + "): " + hipGetErrorString(he);
+        return PGRC_E_NO_DEVICE;
+    }
+    (void)hipGetLastError(); // start from a clean sticky-error state
     pgrc_match_ctx *c = new pgrc_match_ctx();
     c->prm = *p;
     c->device = dev;
     c->nw = (p->read_len + 15) / 16;
     if (pgrc_buf_ensure(c, c->d_hist, 256 * sizeof(uint64_t)) || pgrc_buf_ensure(c, c->d_counters, 16 * sizeof(uint64_t))) {
+        g_create_err = c->err;
         delete c;
         return PGRC_E_NO_DEVICE;
     }
@@ -130,7 +140,7 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
     delete c;
 }
 
-const char *pgrc_match_last_error(const pgrc_match_ctx *c) { return c ? c->err.c_str() : "null context"; }
+const char *pgrc_match_last_error(const pgrc_match_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
 int pgrc_match_set_stream(pgrc_match_ctx *c, void *s) {
     if (!c) return PGRC_E_PARAM;

@@ -63,7 +63,7 @@ class MatchContext:
         rc = lib.pgrc_match_create(C.byref(prm), C.byref(self._h))
         if rc:
             self._h = C.c_void_p()
-            raise PgrcMatchError(rc, "pgrc_match_create failed (no HIP device? bad parameters?)")
+            raise PgrcMatchError(rc, "pgrc_match_create: " + (lib.pgrc_match_last_error(None) or b"").decode())
         self.read_len, self.seed_len, self.mode = read_len, seed_len, mode
         self.n = 0
         self.pg_len = 0

@@ -1,0 +1,209 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle -- and against the
+real reference where oracle/_ref is present -- on the same seeded inputs.  Bit-exact: positions,
+RC flags, mismatch counts, histogram, matched count, index arrays, mismatch lists."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from util import assert_same_results, gpu_match, make_inputs, pack2, revcomp
+
+pytestmark = pytest.mark.gpu
+
+
+def test_extension_is_the_loaded_native_code():
+    import pgrc_amd
+    assert pgrc_amd.LIB_PATH.endswith("pgrc_amd/libpgrc_match.so")
+    with open("/proc/self/maps") as f:
+        assert "libpgrc_match.so" in f.read()
+
+
+@pytest.mark.parametrize("G", [100000, 100003, 65536 + 7, 1000])
+def test_pack_and_revcomp(G):
+    from pgrc_amd import MatchContext
+    pg, _ = make_inputs(max(G, 1000), 1, 100, seed=G)
+    pg = pg[:G]
+    ctx = MatchContext(100, 38, 2, 0, "c")
+    ctx.set_pg_ascii(pg)
+    assert np.array_equal(ctx.export_pg(0), pack2(pg))
+    assert np.array_equal(ctx.export_pg(1), pack2(revcomp(pg)))
+
+
+@pytest.mark.parametrize("seed_len", [24, 28, 38, 45, 64, 100, 150, 250])
+def test_index_matches_oracle(seed_len):
+    from pgrc_amd import MatchContext, copmem_params
+    L = max(seed_len, 100)
+    pg, _ = make_inputs(300000, 1, L, seed=seed_len)
+    prm, cumm, positions = orc.oracle_index(pg, seed_len)
+    assert copmem_params(seed_len, pg.size) == prm
+    ctx = MatchContext(L, seed_len, 2, 0, "c")
+    ctx.set_pg_ascii(pg)
+    c, p = ctx.export_index(0)
+    assert np.array_equal(c, cumm)
+    assert np.array_equal(p, positions)
+    pgr = revcomp(pg)
+    _, cumm_r, positions_r = orc.oracle_index(pgr, seed_len)
+    c, p = ctx.export_index(1)
+    assert np.array_equal(c, cumm_r)
+    assert np.array_equal(p, positions_r)
+
+
+def test_index_bucket_cap_on_low_complexity_text():
+    """poly-A / tandem tracts overflow buckets: the 13 smallest positions must survive, ascending."""
+    from pgrc_amd import MatchContext
+    rng = np.random.default_rng(5)
+    pg = rng.choice(list(b"ACGT"), size=200000).astype(np.uint8)
+    pg[1000:9000] = ord("A")
+    pg[50000:54000] = np.resize(np.frombuffer(b"ACG", dtype=np.uint8), 4000)
+    pg[120000:121500] = np.resize(np.frombuffer(b"TTGCA", dtype=np.uint8), 1500)
+    _, cumm, positions = orc.oracle_index(pg, 38)
+    assert (np.diff(cumm[:-1].astype(np.int64)) == 13).any()
+    ctx = MatchContext(100, 38, 2, 0, "c")
+    ctx.set_pg_ascii(pg)
+    c, p = ctx.export_index(0)
+    assert np.array_equal(c, cumm) and np.array_equal(p, positions)
+
+
+CASES = [
+    # L, seed, M, mode, G, n
+    (100, 38, 50, "c", 400000, 20000),
+    (100, 38, 3, "c", 400000, 20000),
+    (100, 38, 50, "C", 400000, 20000),
+    (150, 38, 50, "c", 400000, 20000),
+    (250, 38, 50, "c", 400000, 12000),
+    (100, 100, 50, "c", 300000, 10000),
+    (150, 150, 3, "c", 300000, 10000),
+    (64, 32, 10, "c", 200000, 10000),
+    (40, 24, 8, "c", 100000, 8000),
+    (255, 45, 20, "c", 300000, 6000),
+]
+
+
+@pytest.mark.parametrize("L,seed_len,M,mode,G,n", CASES)
+def test_copmem_parity(L, seed_len, M, mode, G, n):
+    pg, reads = make_inputs(G, n, L, seed=1000 + L + seed_len + M)
+    kmax = L // M
+    kmin = kmax if mode.isupper() else 0
+    o = orc.oracle_match("c", pg, reads, seed_len, kmax, kmin)
+    g = gpu_match("c", pg, reads, seed_len, kmax, kmin)
+    assert_same_results(g, o, f"L={L} seed={seed_len} M={M} {mode}")
+    ctr = g["ctx"].counters()
+    assert ctr["searched"] == o["searched"]
+    assert ctr["candidates"] == o["candidates"]
+    if orc.have_ref():
+        r = orc.ref_match("c", pg, reads, seed_len, kmax, kmin)
+        assert_same_results(g, r, "vs real reference")
+
+
+def test_copmem_forward_only_and_ragged_sizes():
+    for n in (0, 1, 63, 64, 65, 257):
+        pg, reads = make_inputs(50000, max(n, 1), 100, seed=77 + n)
+        reads = reads[:n]
+        o = orc.oracle_match("c", pg, reads, 38, 2, 0, rev_compl=False)
+        g = gpu_match("c", pg, reads, 38, 2, 0, rev_compl=False)
+        assert_same_results(g, o, f"n={n}")
+
+
+def test_copmem_reads_hanging_over_pg_ends_and_repeats():
+    pg, reads = make_inputs(60000, 4000, 100, seed=5, pool_div=64)
+    # reads that overlap the Pg ends: their seeds hit but the window is rejected (:517-520)
+    for k in range(50):
+        reads[k, :60] = pg[-60:]
+        reads[50 + k, 40:] = pg[:60]
+    o = orc.oracle_match("c", pg, reads, 38, 33, 0)
+    g = gpu_match("c", pg, reads, 38, 33, 0)
+    assert_same_results(g, o, "ends/repeats")
+
+
+def test_copmem_n_reads_take_the_byte_path():
+    pg, reads = make_inputs(200000, 6000, 100, seed=31, n_with_n=700)
+    o = orc.oracle_match("c", pg, reads, 38, 33, 0)
+    g = gpu_match("c", pg, reads, 38, 33, 0)
+    assert_same_results(g, o, "N reads")
+    if orc.have_ref():
+        r = orc.ref_match("c", pg, reads, 38, 33, 0, n_nset=700)
+        assert_same_results(g, r, "N reads vs reference")
+
+
+def test_reference_packed_reads_entry_point():
+    pg, reads = make_inputs(150000, 3000, 150, seed=8)
+    o = orc.oracle_match("c", pg, reads, 38, 3, 0)
+    g = gpu_match("c", pg, reads, 38, 3, 0, packed_ref=True)
+    assert_same_results(g, o, "set_reads_packed")
+
+
+def test_bad_symbols_and_errors():
+    from pgrc_amd import MatchContext, PgrcMatchError
+    pg, reads = make_inputs(50000, 10, 100, seed=1)
+    ctx = MatchContext(100, 38, 2, 0, "c")
+    bad = pg.copy()
+    bad[777] = ord("N")
+    with pytest.raises(PgrcMatchError) as e:
+        ctx.set_pg_ascii(bad)
+    assert e.value.code == 5
+    ctx.set_pg_ascii(pg)
+    r2 = reads.copy()
+    r2[3, 5] = ord("X")
+    with pytest.raises(PgrcMatchError) as e:
+        ctx.set_reads_ascii(r2)
+    assert e.value.code == 5
+    with pytest.raises(PgrcMatchError) as e:
+        MatchContext(100, 20, 2, 0, "c")  # "Minimal matching length too short" CopMEMMatcher.cpp:77-80
+    assert e.value.code == 2
+    with pytest.raises(PgrcMatchError):
+        MatchContext(100, 38, 2, 0, "x")
+
+
+def test_mismatch_extraction():
+    pg, reads = make_inputs(200000, 5000, 100, seed=44, n_with_n=300)
+    g = gpu_match("c", pg, reads, 38, 33, 0)
+    ctx = g["ctx"]
+    n = reads.shape[0]
+    for flags in (None, (g["rc"] != (np.arange(n) & 1)).astype(np.uint8)):
+        cum, codes, offs = ctx.extract_mismatches(flags)
+        cnt = np.where(g["mism"] == 255, 0, g["mism"]).astype(np.uint64)
+        assert np.array_equal(np.diff(cum), cnt)
+        for i in np.flatnonzero(cnt)[:1500]:
+            rev = bool(g["rc"][i]) if flags is None else bool(flags[i])
+            co, oo = orc.oracle_extract(pg, g["pos"][i], reads[i], g["rc"][i], rev, int(cnt[i]))
+            s, e = int(cum[i]), int(cum[i + 1])
+            assert np.array_equal(codes[s:e], co) and np.array_equal(offs[s:e], oo), i
+
+
+def test_two_phase_continuation():
+    """-l pre-matching flow: exact-ish copMEM first, then the approximate phase takes the results over
+    (ReadsMatchers.cpp:749-779)."""
+    from pgrc_amd import mapReadsIntoPg
+    pg, reads = make_inputs(200000, 5000, 100, seed=91)
+    bitmap, m = mapReadsIntoPg(pg, True, reads, 38, 50, "c", preReadsExactMatchingChars=100, preMatchingMode="c")
+    o1 = orc.oracle_match("c", pg, reads, 100, 2, 0)
+    o2 = orc.oracle_match("c", pg, reads, 38, 2, 100 // 38 - 1 + 1, state=(o1["pos"], o1["rc"], o1["mism"]))
+    assert np.array_equal(m.readMatchPos, o2["pos"])
+    assert np.array_equal(m.readMismatchesCount, o2["mism"])
+    assert np.array_equal(m.readMatchRC.astype(np.uint8), o2["rc"])
+    assert np.array_equal(bitmap, o2["mism"] <= 254)
+
+
+def test_device_generators_equal_host_generators():
+    import torch
+    from pgrc_amd import MatchContext, synth
+    G, n, L = 300000, 5000, 150
+    g = synth.pg_params(G, seed=4, tandem_every=2)
+    pg = synth.pg_host(g)
+    rs = synth.reads_params(n, L, seed=4, paired=True)
+    reads = synth.reads_host(g, pg, rs)
+    d_pg = torch.zeros((G + 15) // 16 + 64, dtype=torch.int32, device="cuda")
+    synth.pg_device(g, d_pg.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_pg.cpu().numpy().view(np.uint32)[: (G + 15) // 16], pack2(pg))
+    nw, stride = (L + 15) // 16, 5056
+    d_rd = torch.zeros(nw * stride, dtype=torch.int32, device="cuda")
+    synth.reads_device(g, d_pg.data_ptr(), rs, 0, n, d_rd.data_ptr(), stride)
+    torch.cuda.synchronize()
+    ctx = MatchContext(L, 38, 3, 0, "c")
+    ctx.set_pg_packed_device(d_pg.data_ptr(), G)
+    ctx.set_reads_device(d_rd.data_ptr(), n, stride, keep=d_rd)
+    ctx.init_results()
+    ctx.run(True)
+    pos, rc, mism, hist, matched = ctx.get_results()
+    o = orc.oracle_match("c", pg, reads, 38, 3, 0)
+    assert_same_results({"pos": pos, "rc": rc, "mism": mism, "hist": hist, "matched": matched}, o, "device inputs")
