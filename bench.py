@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- reads matched/sec of PgRC's read-to-pseudogenome matching path on MI355X.
+
+One "step" = one full pass of the hot path over one batch: DefaultReadsMatcher::matchConstantLengthReads
+(matching/ReadsMatchers.cpp:162-172) = [copMEM index build + per-read probe/verify] on the forward Pg, the
+2-bit reverse complement, the same on the RC'd Pg, and the result histogram.  Inputs (2-bit packed Pg and reads)
+are resident in HBM before the timed region; they are synthetic (include/pgrc_synth.h).
+
+Workload at N=1: BASELINE.json configs[2] ("C3": 100M x 150 bp SE, mode c, seed 38, -M 50 => k<=3), the
+configuration the metric is quoted on.  At N>1 every rank gets its own 100M reads (weak scaling: reads shard
+with no data-path collective) and the packed Pg is shared by ONE all-gather (RCCL over xGMI) per step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (reads per GPU, read_len, pg_len, seed_len, min_chars_per_mismatch, mode, paired)
+    "C3": (100_000_000, 150, 1_875_000_000, 38, 50, "c", False),
+    "C2": (10_000_000, 100, 125_000_000, 38, 50, "c", False),
+    "C3-PE": (100_000_000, 150, 1_875_000_000, 38, 50, "c", True),
+    "tiny": (1_000_000, 150, 18_750_000, 38, 50, "c", False),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("PGRC_BENCH_WORKLOAD", "C3"), choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from pgrc_amd import MatchContext, copmem_params, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n_per, L, G, seed_len, M, mode, paired = WORKLOADS[args.workload]
+    kmax = L // M
+    nw = (L + 15) // 16
+    stride = (n_per + 63) & ~63
+    pg_words = (G + 15) // 16
+
+    # ---- inputs straight into HBM
+    g = synth.pg_params(G, seed=12345)
+    rs = synth.reads_params(n_per * world, L, seed=12345, paired=paired)
+    d_pg = torch.zeros(pg_words + 64, dtype=torch.int32, device=dev)
+    synth.pg_device(g, d_pg.data_ptr())
+    d_reads = torch.empty(nw * stride, dtype=torch.int32, device=dev)
+    synth.reads_device(g, d_pg.data_ptr(), rs, rank * n_per, n_per, d_reads.data_ptr(), stride)
+    torch.cuda.synchronize()
+
+    ctx = MatchContext(L, seed_len, kmax, 0, mode, device=local_rank)
+    ctx.set_reads_device(d_reads.data_ptr(), n_per, stride, keep=d_reads)
+    ctx.set_profiling(True)
+
+    # multi-GPU: every rank owns 1/world of the packed Pg (what it would pack from its slice of the host text);
+    # one all-gather per step rebuilds the replicated text
+    if world > 1:
+        slice_words = (pg_words + world - 1) // world
+        d_slice = torch.zeros(slice_words, dtype=torch.int32, device=dev)
+        lo = rank * slice_words
+        hi = min(pg_words, lo + slice_words)
+        if hi > lo:
+            d_slice[: hi - lo] = d_pg[lo:hi]
+        d_full = torch.zeros(slice_words * world + 64, dtype=torch.int32, device=dev)
+        del d_pg
+    else:
+        ctx.set_pg_packed_device(d_pg.data_ptr(), G)
+
+    def step():
+        if world > 1:
+            dist.all_gather_into_tensor(d_full[: slice_words * world], d_slice)
+            torch.cuda.current_stream().synchronize()
+            ctx.set_pg_packed_device(d_full.data_ptr(), G)
+        ctx.init_results()
+        ctx.run(True)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    _, _, _, hist, matched = ctx.get_results(arrays=False)
+    ctr = ctx.counters()
+    cp = copmem_params(seed_len, G)
+
+    if rank == 0:
+        total_reads = n_per * world * args.steps
+        value = total_reads / dt
+        # ---- roofline of the dominant kernel: the forward-pass match kernel (k_copmem_match)
+        # algorithmic bytes: per searched read its packed words and
+        # the 10-B result; per executed seed probe one 8-B bucket range; per verified candidate a 4-B position
+        # and the (L/4 + 1)-B text window.
+        rb = (L + 3) // 4
+        dom = 0 if ctr["ms_match"][0] >= ctr["ms_match"][1] else 1
+        alg_bytes = ctr["searched"][dom] * (rb + 10) + ctr["probes"][dom] * 8 + ctr["candidates"][dom] * (5 + rb)
+        ms = ctr["ms_match"][dom]
+        achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out = {
+            "metric": "reads matched/sec (150 bp) at 1/2/4/8 MI355X; achieved HBM GB/s",
+            "value": value,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 (2-bit packed symbols)",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {n_per} x {L} bp {'PE' if paired else 'SE'} reads per GPU vs Pg of "
+                                   f"{G} bp, mode {mode}, seed {seed_len}, -M {M} (k<={kmax}), both strands",
+                       "reads_per_gpu": n_per, "read_len": L, "pg_len": G, "seed_len": seed_len, "max_mismatches": kmax,
+                       "copmem": cp, "matched_fraction": matched / n_per,
+                       "parallelism": f"reads sharded x{world}, Pg replicated" + (" (1 all-gather/step)" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_copmem_match" + ("(fwd)" if dom == 0 else "(rc)"),
+                         "kernel_ms": ms, "algorithmic_bytes": alg_bytes},
+            "phases_ms": {"index_fwd": ctr["ms_index"][0], "match_fwd": ctr["ms_match"][0], "index_rc": ctr["ms_index"][1],
+                          "match_rc": ctr["ms_match"][1], "other": ctr["ms_other"], "total_device": ctr["ms_total"]},
+            "counters": {k: ctr[k] for k in ("searched", "candidates", "probes", "index_entries")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def unpack_pg_to_ascii(words):
+    import numpy as np
+    lut = np.zeros((256, 4), dtype=np.uint8)
+    for b in range(256):
+        for k in range(4):
+            lut[b, k] = b"ACGT"[(b >> (2 * k)) & 3]
+    return lut[words.view(np.uint8)].reshape(-1)
+
+
+def cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax):
+    """The CPU path timed on this box's host cores, on a bounded sample: the WHOLE pseudogenome (so index size and
+    cache behaviour are the real ones) and the first `cpu_sample_reads` reads of the same read set.  Whole-job
+    rate for the full read set is extrapolated from two runs (fixed cost a = 2 index builds + RC sweeps, slope b
+    per read):  value = N / (a + b*N).  kind "reference" = the real PgRC code (oracle/_ref); "port" = oracle/."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as orc
+    from pgrc_amd import synth
+    threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+    t_prep = time.perf_counter()
+    pg = unpack_pg_to_ascii(ctx.export_pg(0))[:G]
+    ns = min(args.cpu_sample_reads, n_per)
+    reads = synth.reads_host(g, pg, rs, 0, ns)
+    prep_s = time.perf_counter() - t_prep
+    n_small = max(1000, ns // 100)
+    if orc.have_ref():
+        kind = "reference"
+
+        def run(n):
+            t = time.perf_counter()
+            r = orc.ref_match("c", pg, reads[:n], seed_len, kmax, 0, True, 0, threads, threads)
+            return time.perf_counter() - t, r
+    else:
+        kind = "port"
+
+        def run(n):
+            t = time.perf_counter()
+            r = orc.oracle_match("c", pg, reads[:n], seed_len, kmax, 0, True, threads)
+            return time.perf_counter() - t, r
+    t_small, _ = run(n_small)
+    t_big, r = run(ns)
+    b = max((t_big - t_small) / (ns - n_small), 1e-12)
+    a = max(t_small - b * n_small, 0.0)
+    value = n_per / (a + b * n_per)
+    # the sample also cross-checks the GPU result on the same reads (matched set / counts are
+    # thread-count independent in the reference; positions only with the serial index build)
+    pos, rc, mism, _, _ = ctx.get_results()
+    agree = bool(np.array_equal(mism[:ns], r["mism"]) and np.array_equal(rc[:ns], r["rc"]))
+    return {"value": value, "unit": "reads/s", "cores": threads, "kind": kind,
+            "sample": f"whole {G}-bp Pg, first {ns} reads of the workload, both strands incl. index builds; two runs "
+                      f"(n={n_small}: {t_small:.2f}s, n={ns}: {t_big:.2f}s) => fixed {a:.2f}s + {b * 1e6:.3f}us/read, "
+                      f"extrapolated to {n_per} reads; sample-only rate {ns / t_big:.0f} reads/s",
+            "fixed_s": a, "per_read_us": b * 1e6, "sample_counts_match_gpu": agree, "prep_s": prep_s}
+
+
+if __name__ == "__main__":
+    main()
