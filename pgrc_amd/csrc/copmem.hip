@@ -14,12 +14,20 @@
 //     13-smallest selection; the racy order of the scatter is erased by the selection, so the
 //     result is the canonical serial index, bit for bit.  Pg windows are staged through LDS in
 //     coalesced tiles (adjacent sampled positions overlap by K-k1 symbols).
+//   * the index is laid out for 64-B HBM sectors, not as the reference's CSR: a 1-bit-per-bucket
+//     occupancy bitmap (64 MiB at 2^29 buckets: served from L2 / Infinity Cache) answers the ~50 %
+//     of probes that hit an empty bucket; an 8-B bucket head holds a single-entry bucket inline
+//     (70 % of the non-empty ones); every entry carries a 24-bit fingerprint of the symbols the
+//     sparsified hash ignores, so a false candidate is rejected -- with exactly the reference's
+//     head-reject accounting -- without fetching its text window.
 //   * match = one read per lane; the reference's sequential per-read state machine (limit
 //     tightening, false-candidate budget, early exit) is kept exactly, so results are
 //     bit-identical.  The seed window is kept at the low bits of a shifting copy of the read
 //     (v_alignbit), so no register array is ever indexed dynamically.  Hamming distance on
 //     2-bit words: xor, fold pair bits, v_bcnt (popcount) under head/tail symbol masks.
 //   * all of it is HBM/latency bound integer work: no MFMA.
+#include <stdlib.h>
+
 #include "ctx.h"
 #include "devutil.h"
 
@@ -34,7 +42,7 @@ template <bool FILL>
 __global__ void __launch_bounds__(IDX_TPB)
 k_copmem_index_pass(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, uint64_t npos, uint32_t k1, uint32_t K,
                     uint32_t mask, uint32_t *__restrict__ cnt, const uint32_t *__restrict__ cumm,
-                    uint32_t *__restrict__ positions) {
+                    uint64_t *__restrict__ ent) {
     __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
     __shared__ uint32_t tile[IDX_TILE_WORDS + 8];
     hash_lut_init(lut);
@@ -54,13 +62,14 @@ k_copmem_index_pass(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, ui
             const uint32_t q = (uint32_t)((p >> 4) - w0);
             const uint32_t sh = ((uint32_t)p & 15u) * 2u;
             const uint32_t a0 = tile[q], a1 = tile[q + 1], a2 = tile[q + 2], a3 = tile[q + 3], a4 = tile[q + 4];
-            const uint32_t h = copmem_hash32(funnel_r(a0, a1, sh), funnel_r(a1, a2, sh), funnel_r(a2, a3, sh),
-                                             funnel_r(a3, a4, sh), K, lut) & mask;
+            uint32_t fp;
+            const uint32_t h = copmem_hash32_fp(funnel_r(a0, a1, sh), funnel_r(a1, a2, sh), funnel_r(a2, a3, sh),
+                                                funnel_r(a3, a4, sh), K, lut, &fp) & mask;
             if (!FILL) {
                 atomicAdd(&cnt[h], 1u);
             } else {
                 const uint32_t slot = cumm[h] + atomicAdd(&cnt[h], 1u);
-                positions[slot] = (uint32_t)p;
+                ent[slot] = (p << PGRC_FP_BITS) | fp; // position in the high bits: u64 order = position order
             }
         }
     }
@@ -169,30 +178,51 @@ k_scan_write(const uint32_t *__restrict__ in, uint64_t n, const uint32_t *__rest
     }
 }
 
-// Per bucket: move its min(count,13) smallest positions, ascending, to the front.  This turns the
-// racy scatter order into the reference's serial order (ascending p, later p dropped).
+// Per bucket: move its min(count,13) smallest entries (= smallest positions), ascending, to the front
+// -- this turns the racy scatter order into the reference's serial order (ascending p, later p
+// dropped) -- and emit the bucket head and the occupancy bitmap.
+#define ENT_MASK ((1ull << 56) - 1)
+#define HEAD_COUNT(w0) ((uint32_t)((w0) >> 56) & 15u)
+
+// 16-B bucket head (a random 16-B gather costs the same as an 8-B one on gfx950: the limit is
+// lane-addresses per second, tools/ubench/gather2.hip):
+//   w0 = entry0 | count << 56          count = min(n, 13); w0 == 0 <=> empty bucket
+//   w1 = entry1                        when count == 2
+//      = start of the bucket in ent[]  when count >= 3 (entries 1.. are fetched from there)
 __global__ void __launch_bounds__(256)
-k_bucket_select(const uint32_t *__restrict__ cumm, uint64_t hash_size, uint32_t *__restrict__ positions) {
-    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < hash_size;
-         h += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t lo = cumm[h], n = cumm[h + 1] - lo;
-        if (n < 2) continue;
-        uint32_t a[PGRC_BUCKET_CAP];
+k_bucket_finalize(const uint32_t *__restrict__ cumm, uint64_t hash_size, uint64_t *__restrict__ ent,
+                  ulonglong2 *__restrict__ head) {
+    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // grid covers hash_size exactly
+    const uint32_t lo = cumm[h], n = cumm[h + 1] - lo;
+    ulonglong2 hd = make_ulonglong2(0ull, 0ull);
+    if (n == 1) {
+        hd.x = ent[lo] | (1ull << 56);
+    } else if (n == 2) {
+        const uint64_t x = ent[lo], y = ent[lo + 1];
+        hd.x = min(x, y) | (2ull << 56);
+        hd.y = max(x, y);
+        ent[lo] = min(x, y);
+        ent[lo + 1] = max(x, y);
+    } else if (n > 2) {
+        uint64_t a[PGRC_BUCKET_CAP];
 #pragma unroll
-        for (int k = 0; k < (int)PGRC_BUCKET_CAP; k++) a[k] = 0xFFFFFFFFu;
+        for (int k = 0; k < (int)PGRC_BUCKET_CAP; k++) a[k] = ~0ull;
         for (uint32_t j = 0; j < n; j++) {
-            uint32_t x = positions[lo + j];
+            uint64_t x = ent[lo + j];
 #pragma unroll
             for (int k = 0; k < (int)PGRC_BUCKET_CAP; k++) {
-                const uint32_t m = min(a[k], x);
+                const uint64_t m = min(a[k], x);
                 x = max(a[k], x);
                 a[k] = m;
             }
         }
 #pragma unroll
         for (int k = 0; k < (int)PGRC_BUCKET_CAP; k++)
-            if ((uint32_t)k < n) positions[lo + k] = a[k];
+            if ((uint32_t)k < n) ent[lo + k] = a[k];
+        hd.x = a[0] | ((uint64_t)min(n, PGRC_BUCKET_CAP) << 56);
+        hd.y = lo;
     }
+    head[h] = hd;
 }
 
 static int run_scan(pgrc_match_ctx *c, bool cap, const uint32_t *in, uint64_t n, uint32_t *out) {
@@ -221,8 +251,10 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     int e;
     if ((e = pgrc_buf_ensure(c, c->d_cnt, (hs + 2) * sizeof(uint32_t)))) return e;
     if ((e = pgrc_buf_ensure(c, c->d_cumm, (hs + 2) * sizeof(uint32_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->d_positions, (c->npos + 16) * sizeof(uint32_t)))) return e;
-    uint32_t *cnt = (uint32_t *)c->d_cnt.p, *cumm = (uint32_t *)c->d_cumm.p, *positions = (uint32_t *)c->d_positions.p;
+    if ((e = pgrc_buf_ensure(c, c->d_ent, (c->npos + 16) * sizeof(uint64_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->d_head, hs * 2 * sizeof(uint64_t)))) return e;
+    uint32_t *cnt = (uint32_t *)c->d_cnt.p, *cumm = (uint32_t *)c->d_cumm.p;
+    uint64_t *ent = (uint64_t *)c->d_ent.p;
     const uint32_t *pg = (const uint32_t *)c->pg2[strand].p;
     const uint64_t pg_alloc = c->pg_words + PGRC_PG_PAD_WORDS;
     HIP_TRY(c, hipMemsetAsync(cnt, 0, (hs + 2) * sizeof(uint32_t), c->stream));
@@ -230,15 +262,14 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     const uint32_t grid = (uint32_t)(ntiles < 256u * 16u ? (ntiles ? ntiles : 1) : 256u * 16u);
     if (c->npos)
         hipLaunchKernelGGL(k_copmem_index_pass<false>, dim3(grid), dim3(IDX_TPB), 0, c->stream, pg, pg_alloc, c->npos, k1, K,
-                           (uint32_t)(hs - 1), cnt, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+                           (uint32_t)(hs - 1), cnt, (const uint32_t *)nullptr, (uint64_t *)nullptr);
     if ((e = run_scan(c, false, cnt, hs, cumm))) return e;
     HIP_TRY(c, hipMemsetAsync(cnt, 0, (hs + 2) * sizeof(uint32_t), c->stream));
-    if (c->npos) {
+    if (c->npos)
         hipLaunchKernelGGL(k_copmem_index_pass<true>, dim3(grid), dim3(IDX_TPB), 0, c->stream, pg, pg_alloc, c->npos, k1, K,
-                           (uint32_t)(hs - 1), cnt, (const uint32_t *)cumm, positions);
-        const uint32_t sgrid = (uint32_t)((hs + 255) / 256 < 65536u * 8u ? (hs + 255) / 256 : 65536u * 8u);
-        hipLaunchKernelGGL(k_bucket_select, dim3(sgrid), dim3(256), 0, c->stream, (const uint32_t *)cumm, hs, positions);
-    }
+                           (uint32_t)(hs - 1), cnt, (const uint32_t *)cumm, ent);
+    hipLaunchKernelGGL(k_bucket_finalize, dim3((uint32_t)(hs / 256)), dim3(256), 0, c->stream, (const uint32_t *)cumm, hs, ent,
+                       (ulonglong2 *)c->d_head.p);
     HIP_TRY(c, hipGetLastError());
     c->index_strand = strand;
     return PGRC_OK;
@@ -247,11 +278,11 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
 // canonical layout for tests: capped CSR exactly as the reference leaves cumm / sampledPositions
 __global__ void __launch_bounds__(256)
 k_export_compact(const uint32_t *__restrict__ cumm_full, const uint32_t *__restrict__ cumm_cap, uint64_t hash_size,
-                 const uint32_t *__restrict__ pos_full, uint32_t *__restrict__ pos_cap) {
+                 const uint64_t *__restrict__ ent, uint32_t *__restrict__ pos_cap) {
     for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < hash_size;
          h += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t lo = cumm_full[h], lc = cumm_cap[h], n = cumm_cap[h + 1] - lc;
-        for (uint32_t k = 0; k < n; k++) pos_cap[lc + k] = pos_full[lo + k];
+        for (uint32_t k = 0; k < n; k++) pos_cap[lc + k] = (uint32_t)(ent[lo + k] >> PGRC_FP_BITS);
     }
 }
 
@@ -271,7 +302,7 @@ int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_po
         if ((e = pgrc_buf_ensure(c, pc, (size_t)total * sizeof(uint32_t)))) { pgrc_buf_free(cc); return e; }
         const uint32_t sgrid = (uint32_t)((hs + 255) / 256 < 65536u * 8u ? (hs + 255) / 256 : 65536u * 8u);
         hipLaunchKernelGGL(k_export_compact, dim3(sgrid), dim3(256), 0, c->stream, (const uint32_t *)c->d_cumm.p,
-                           (const uint32_t *)cc.p, hs, (const uint32_t *)c->d_positions.p, (uint32_t *)pc.p);
+                           (const uint32_t *)cc.p, hs, (const uint64_t *)c->d_ent.p, (uint32_t *)pc.p);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipMemcpy(h_positions, pc.p, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -289,7 +320,8 @@ struct MatchArgs {
     const uint32_t *reads;
     uint64_t n, stride;
     const uint8_t *nflag;
-    const uint32_t *cumm, *positions;
+    const ulonglong2 *head;
+    const uint64_t *ent;
     uint64_t *pos;
     uint8_t *rc, *mism;
     unsigned long long *counters; // [0] searched [1] candidates [2] probes
@@ -297,6 +329,49 @@ struct MatchArgs {
 };
 
 #define MATCH_TPB 256
+
+// Per-read state of the reference's sequential query (CopMEMMatcher.cpp:483-566).
+struct ReadState {
+    uint32_t limit, falses, cur;
+    uint64_t best;
+    bool done;
+};
+
+// One candidate entry against read `rd` (2-bit words).  Order of the checks = the reference's:
+// bounds (:517-520), head count vs limit (:523-539, +1 false), tail (:540-551, +2 falses), accept
+// (:552-560).  The fingerprint test decides most head rejects without touching the text: its
+// symbols are head symbols of the window (mask fpm), so fp mismatches > limit => head count > limit.
+template <int NW>
+__device__ __forceinline__ void try_candidate(const MatchArgs &a, const uint32_t (&rd)[NW], uint64_t e, uint32_t s,
+                                              uint32_t fp_read, uint32_t fpm, int H, ReadState &st,
+                                              uint64_t &n_cand) {
+    const uint64_t sp = e >> PGRC_FP_BITS;
+    if ((uint64_t)s > sp) return;
+    const uint64_t p = sp - s;
+    if (p + a.L > a.G) return;
+    n_cand++;
+    const uint32_t x = ((uint32_t)e ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
+    if ((uint32_t)__popc((x | (x >> 1)) & fpm) > st.limit) { st.falses += 1; return; }
+    const uint32_t *src = a.pg + (p >> 4);
+    const uint32_t b = ((uint32_t)p & 15u) * 2u;
+    uint32_t pw[NW + 1];
+#pragma unroll
+    for (int k = 0; k <= NW; k++) pw[k] = src[k];
+    uint32_t mh = 0, mt = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        const uint32_t tw = funnel_r(pw[k], pw[k + 1], b);
+        mh += mism2(tw, rd[k], sym_mask(k, 0, H));
+        mt += mism2(tw, rd[k], sym_mask(k, H, (int)a.L));
+    }
+    if (mh > st.limit) { st.falses += 1; return; }
+    const uint32_t m = mh + mt;
+    if (m > st.limit) { st.falses += 2; return; }
+    st.cur = m;
+    st.best = p;
+    if (m <= a.kmin) { st.done = true; return; }
+    st.limit = m - 1u;
+}
 
 template <int NW>
 __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match(const MatchArgs a) {
@@ -306,68 +381,224 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match(const MatchArgs a) {
 
     const uint64_t i = (uint64_t)blockIdx.x * MATCH_TPB + threadIdx.x;
     bool active = i < a.n;
-    uint32_t cin = active ? a.mism[i] : 0u;
+    const uint32_t cin = active ? a.mism[i] : 0u;
     if (active && a.nflag && a.nflag[i]) active = false; // 'N' reads: byte-path kernel
     if (cin <= a.kmin) active = false;                    // ReadsMatchers.cpp:430
 
     uint64_t n_cand = 0, n_probe = 0;
     if (active) {
-        const int L = (int)a.L, H = (L / 8) * 8; // head = whole 8-symbol groups (CopMEMMatcher.cpp:495)
+        const int H = ((int)a.L / 8) * 8; // head = whole 8-symbol groups (CopMEMMatcher.cpp:495)
         uint32_t rd[NW], sh[NW];
 #pragma unroll
         for (int k = 0; k < NW; k++) sh[k] = rd[k] = a.reads[(uint64_t)k * a.stride + i];
 
-        uint32_t limit = (cin < a.kmax) ? cin - 1u : a.kmax;           // :488-489
+        ReadState st;
+        st.limit = (cin < a.kmax) ? cin - 1u : a.kmax;                 // :488-489
+        st.falses = 0;
+        st.cur = cin;
+        st.best = PGRC_NOT_MATCHED_POS;
+        st.done = false;
         const uint32_t budget = (a.L + 1u - a.K) / a.k2;               // :496-498
-        uint32_t falses = 0, cur = cin;
-        uint64_t best = PGRC_NOT_MATCHED_POS;
         const uint32_t sbits = 2u * a.k2;
-        bool done = false;
 
-        for (uint32_t s = 0; s + a.K <= a.L && !done; s += a.k2) {     // :503
-            const uint32_t h = copmem_hash32(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
-                                             NW > 3 ? sh[3 % NW] : 0u, a.K, lut) & a.mask;
+        for (uint32_t s = 0; s + a.K <= a.L && !st.done; s += a.k2) {  // :503
+            uint32_t fp_read;
+            const uint32_t h = copmem_hash32_fp(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
+                                                NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
             n_probe++;
-            const uint32_t lo = a.cumm[h];
-            uint32_t nb = a.cumm[h + 1] - lo;
-            nb = min(nb, PGRC_BUCKET_CAP);
-            if (falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET);       // :510-514
-            for (uint32_t j = 0; j < nb; j++) {
-                const uint32_t sp = a.positions[lo + j];
-                if (s > sp) continue;                                   // :517-518
-                const uint64_t p = (uint64_t)sp - s;
-                if (p + a.L > a.G) continue;                            // :519-520
-                n_cand++;
-                const uint32_t *src = a.pg + (p >> 4);
-                const uint32_t b = ((uint32_t)p & 15u) * 2u;
-                uint32_t pw[NW + 1];
-#pragma unroll
-                for (int k = 0; k <= NW; k++) pw[k] = src[k];
-                uint32_t mh = 0, mt = 0;
-#pragma unroll
-                for (int k = 0; k < NW; k++) {
-                    const uint32_t tw = funnel_r(pw[k], pw[k + 1], b);
-                    mh += mism2(tw, rd[k], sym_mask(k, 0, H));
-                    mt += mism2(tw, rd[k], sym_mask(k, H, L));
+            const ulonglong2 hd = a.head[h];
+            if (hd.x) {
+                const uint32_t fpm = fp_head_mask(a.K, s, (uint32_t)H);
+                const uint32_t cnt = HEAD_COUNT(hd.x);
+                uint32_t nb = cnt;
+                if (st.falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET);     // :510-514
+                for (uint32_t j = 0; j < nb && !st.done; j++) {
+                    const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (cnt == 2 ? hd.y : a.ent[(uint32_t)hd.y + j]);
+                    try_candidate<NW>(a, rd, e, s, fp_read, fpm, H, st, n_cand);
                 }
-                if (mh > limit) { falses += 1; continue; }              // :536-539
-                const uint32_t m = mh + mt;
-                if (m > limit) { falses += 2; continue; }               // :542-551 (counted twice)
-                cur = m;                                                // :552-555
-                best = p;
-                if (m <= a.kmin) { done = true; break; }                // :556-559
-                limit = m - 1u;                                         // :560
             }
             // slide the seed window by k2 symbols
 #pragma unroll
             for (int k = 0; k < NW - 1; k++) sh[k] = funnel_r(sh[k], sh[k + 1], sbits);
             sh[NW - 1] >>= sbits;
         }
-        if (best != PGRC_NOT_MATCHED_POS && cur < cin) {                // ReadsMatchers.cpp:437-447
-            a.pos[i] = a.strand ? a.G - (best + a.L) : best;
+        if (st.best != PGRC_NOT_MATCHED_POS && st.cur < cin) {         // ReadsMatchers.cpp:437-447
+            a.pos[i] = a.strand ? a.G - (st.best + a.L) : st.best;
             a.rc[i] = (uint8_t)a.strand;
-            a.mism[i] = (uint8_t)cur;
+            a.mism[i] = (uint8_t)st.cur;
         }
+    }
+    if (a.counters) {
+        const uint64_t s0 = wave_sum_u64(active ? 1ull : 0ull), s1 = wave_sum_u64(n_cand), s2 = wave_sum_u64(n_probe);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)s0);
+            atomicAdd(&a.counters[1], (unsigned long long)s1);
+            atomicAdd(&a.counters[2], (unsigned long long)s2);
+        }
+    }
+}
+
+// Per-lane state machine version of the same query.  The sequential kernel above makes a whole wave
+// wait out up to three dependent memory latencies per seed (bucket head -> bucket entry -> text
+// window) whenever ANY of its 64 reads needs them.  Here every lane advances its own read by one
+// memory access per iteration -- a head (mode 0), the next entry of a multi-entry bucket (mode 1) or
+// a text window to verify (mode 2) -- and all lanes' loads of an iteration are issued together, so an
+// iteration costs one latency.  The per-read order of events is exactly the reference's.
+#define SM_MAX_SEEDS 240
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) U32x4A4 { u32x4 v; }; // 16-B load that only needs 4-B alignment
+template <int NW>
+__global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a) {
+    __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
+    __shared__ uint32_t fpm_tab[SM_MAX_SEEDS];
+    hash_lut_init(lut);
+    const int H = ((int)a.L / 8) * 8;
+    const uint32_t nseeds = (a.L - a.K) / a.k2 + 1; // seeds s = 0, k2, ... with s + K <= L
+    for (uint32_t t = threadIdx.x; t < nseeds && t < SM_MAX_SEEDS; t += blockDim.x)
+        fpm_tab[t] = fp_head_mask(a.K, t * a.k2, (uint32_t)H);
+    __syncthreads();
+
+    const uint64_t i = (uint64_t)blockIdx.x * MATCH_TPB + threadIdx.x;
+    bool active = i < a.n;
+    const uint32_t cin = active ? a.mism[i] : 0u;
+    if (active && a.nflag && a.nflag[i]) active = false;
+    if (cin <= a.kmin) active = false;
+
+    uint64_t n_cand = 0, n_probe = 0;
+    uint32_t rd[NW], sh[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) sh[k] = rd[k] = active ? a.reads[(uint64_t)k * a.stride + i] : 0u;
+
+    ReadState st;
+    st.limit = (cin < a.kmax) ? cin - 1u : a.kmax;
+    st.falses = 0;
+    st.cur = cin;
+    st.best = PGRC_NOT_MATCHED_POS;
+    st.done = false;
+    const uint32_t budget = (a.L + 1u - a.K) / a.k2;
+    const uint32_t sbits = 2u * a.k2;
+
+    enum { M_PROBE = 0, M_ENTRY = 1, M_VERIFY = 2, M_FIN = 3, M_ADV = 4 };
+    uint32_t mode = active ? M_PROBE : M_FIN;
+    uint32_t si = 0;              // seed index: s = si * k2
+    uint32_t lo = 0, nb = 0, j = 0, fp_read = 0;
+    uint64_t cand_p = 0, e_inline1 = 0;
+    bool inline1 = false; // entry 1 of the current bucket sits in e_inline1 (2-entry bucket)
+    // the last verified alignment and its head/tail counts: a read accepted with m > 0 mismatches meets
+    // its own alignment again at every later seed that is sampled there; the counts cannot change, only
+    // the limit they are judged against does -- no need to fetch the text window again
+    uint64_t last_p = PGRC_NOT_MATCHED_POS;
+    uint32_t last_mh = 0, last_mt = 0;
+    constexpr int PWN = ((NW + 1 + 3) / 4) * 4;
+
+    // judge a verified alignment (head count mh, tail count mt) exactly as CopMEMMatcher.cpp:536-560
+    auto judge = [&](uint32_t mh, uint32_t mt, uint64_t p) {
+        const uint32_t m = mh + mt;
+        if (mh > st.limit) st.falses += 1;                       // :536-539
+        else if (m > st.limit) st.falses += 2;                   // :542-551 (counted twice)
+        else {
+            st.cur = m;                                          // :552-555
+            st.best = p;
+            if (m <= a.kmin) st.done = true;                     // :556-559
+            else st.limit = m - 1u;                              // :560
+        }
+    };
+
+    while (__any(mode != M_FIN)) {
+        const uint32_t m0 = mode;
+        const uint32_t s = si * a.k2;
+        // ---- issue this iteration's loads
+        ulonglong2 hd = make_ulonglong2(0ull, 0ull);
+        uint64_t v = 0;
+        if (m0 == M_PROBE) {
+            const uint32_t h = copmem_hash32_fp(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
+                                                NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
+            hd = a.head[h];
+            n_probe++;
+        } else if (m0 == M_ENTRY) {
+            v = inline1 ? e_inline1 : a.ent[lo + j];
+        }
+        uint32_t pw[PWN];
+        const uint32_t b = ((uint32_t)cand_p & 15u) * 2u;
+        if (m0 == M_VERIFY) {
+            const uint32_t *src = a.pg + (cand_p >> 4); // the text is padded: PWN words are always in bounds
+#pragma unroll
+            for (int k = 0; k < PWN; k += 4) {
+                const u32x4 q = reinterpret_cast<const U32x4A4 *>(src + k)->v;
+                pw[k] = q.x; pw[k + 1] = q.y; pw[k + 2] = q.z; pw[k + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PWN; k++) pw[k] = 0;
+        }
+        // ---- consume
+        uint32_t next = m0;
+        if (m0 == M_VERIFY) {
+            uint32_t mh = 0, mt = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const uint32_t tw = funnel_r(pw[k], pw[k + 1], b);
+                mh += mism2(tw, rd[k], sym_mask(k, 0, H));
+                mt += mism2(tw, rd[k], sym_mask(k, H, (int)a.L));
+            }
+            last_p = cand_p;
+            last_mh = mh;
+            last_mt = mt;
+            judge(mh, mt, cand_p);
+            next = st.done ? M_FIN : (j < nb ? M_ENTRY : M_ADV);
+        } else if (m0 <= M_ENTRY) {
+            bool have = false;
+            uint64_t e = 0;
+            if (m0 == M_PROBE) {
+                if (hd.x) {
+                    const uint32_t cnt = HEAD_COUNT(hd.x);
+                    nb = cnt;
+                    if (st.falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET); // :510-514
+                    inline1 = cnt == 2;
+                    e_inline1 = hd.y;
+                    lo = (uint32_t)hd.y;
+                    e = hd.x & ENT_MASK;
+                    have = true;
+                    j = 1;
+                } else {
+                    next = M_ADV;
+                }
+            } else {
+                e = v;
+                have = true;
+                j++;
+            }
+            if (have) {
+                next = (j < nb) ? M_ENTRY : M_ADV;
+                const uint64_t sp = e >> PGRC_FP_BITS;
+                if ((uint64_t)s <= sp && sp - s + a.L <= a.G) {      // :517-520
+                    n_cand++;
+                    const uint32_t x = ((uint32_t)e ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
+                    if ((uint32_t)__popc((x | (x >> 1)) & fpm_tab[si]) > st.limit) {
+                        st.falses += 1;                              // certain head reject
+                    } else if (sp - s == last_p) {
+                        judge(last_mh, last_mt, last_p);
+                        if (st.done) next = M_FIN;
+                    } else {
+                        cand_p = sp - s;
+                        next = M_VERIFY;
+                    }
+                }
+            }
+        }
+        if (next == M_ADV) {
+            si++;
+#pragma unroll
+            for (int k = 0; k < NW - 1; k++) sh[k] = funnel_r(sh[k], sh[k + 1], sbits);
+            sh[NW - 1] >>= sbits;
+            next = (si < nseeds) ? M_PROBE : M_FIN;
+        }
+        mode = next;
+    }
+    if (active && st.best != PGRC_NOT_MATCHED_POS && st.cur < cin) {
+        a.pos[i] = a.strand ? a.G - (st.best + a.L) : st.best;
+        a.rc[i] = (uint8_t)a.strand;
+        a.mism[i] = (uint8_t)st.cur;
     }
     if (a.counters) {
         const uint64_t s0 = wave_sum_u64(active ? 1ull : 0ull), s1 = wave_sum_u64(n_cand), s2 = wave_sum_u64(n_probe);
@@ -407,13 +638,16 @@ k_copmem_match_ascii(const MatchArgs a, const uint32_t *__restrict__ nidx, const
             }
             h &= a.mask;
             n_probe++;
-            const uint32_t lo = a.cumm[h];
-            uint32_t nb = min(a.cumm[h + 1] - lo, PGRC_BUCKET_CAP);
+            const ulonglong2 hd = a.head[h];
+            if (!hd.x) continue;
+            const uint32_t cnt = HEAD_COUNT(hd.x);
+            uint32_t nb = cnt;
             if (falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET);
             for (uint32_t j = 0; j < nb; j++) {
-                const uint32_t sp = a.positions[lo + j];
-                if (s > sp) continue;
-                const uint64_t p = (uint64_t)sp - s;
+                const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (cnt == 2 ? hd.y : a.ent[(uint32_t)hd.y + j]);
+                const uint64_t sp = e >> PGRC_FP_BITS;
+                if ((uint64_t)s > sp) continue;
+                const uint64_t p = sp - s;
                 if (p + a.L > a.G) continue;
                 n_cand++;
                 uint32_t mh = 0, mt = 0;
@@ -451,7 +685,11 @@ k_copmem_match_ascii(const MatchArgs a, const uint32_t *__restrict__ nidx, const
 template <int NW>
 static void launch_match(pgrc_match_ctx *c, const MatchArgs &a) {
     const uint32_t grid = (uint32_t)((a.n + MATCH_TPB - 1) / MATCH_TPB);
-    hipLaunchKernelGGL(k_copmem_match<NW>, dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+    const char *ev = getenv("PGRC_MATCH_KERNEL"); // tuning knob: "seq" = wave-sequential variant
+    if (ev && ev[0] == 's')
+        hipLaunchKernelGGL(k_copmem_match<NW>, dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL(k_copmem_match_sm<NW>, dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
 }
 
 int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
@@ -463,8 +701,8 @@ int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
     a.n = c->n;
     a.stride = c->stride;
     a.nflag = c->n_nreads ? (const uint8_t *)c->nread_flag.p : nullptr;
-    a.cumm = (const uint32_t *)c->d_cumm.p;
-    a.positions = (const uint32_t *)c->d_positions.p;
+    a.head = (const ulonglong2 *)c->d_head.p;
+    a.ent = (const uint64_t *)c->d_ent.p;
     a.pos = (uint64_t *)c->d_pos.p;
     a.rc = (uint8_t *)c->d_rc.p;
     a.mism = (uint8_t *)c->d_mism.p;

@@ -47,6 +47,54 @@ __device__ __forceinline__ uint32_t copmem_hash32(uint32_t t0, uint32_t t1, uint
     return h;
 }
 
+// Same fold, additionally returning a FINGERPRINT of the window: the symbols the sparsified hash
+// ignores (symbol 3 of steps 0..2, symbols 2,3 of the later steps), packed 2 bits each in step
+// order, at most 24 bits.  Stored next to every indexed position, it lets the match kernel reject a
+// false candidate without touching the pseudogenome: the fingerprint symbols are ordinary window
+// symbols, so their mismatches are a lower bound of the Hamming distance.
+#define PGRC_FP_BITS 24u
+__device__ __forceinline__ uint32_t copmem_hash32_fp(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3,
+                                                     uint32_t K, const uint32_t *lut, uint32_t *fp_out) {
+    uint32_t h = K, fp = 0, fb = 0;
+    const uint32_t kq = K >> 2;
+    for (uint32_t j = 0; j < kq; j++) {
+        uint32_t b = t0 & 0xFFu;
+        uint32_t w = (j < 3) ? lut[b & 63u] : lut[64u + (b & 15u)];
+        h = (h ^ (w + j)) * 171717u;
+        const uint32_t width = (j < 3) ? 2u : 4u;
+        if (fb + width <= PGRC_FP_BITS) {
+            fp |= ((j < 3) ? (b >> 6) : (b >> 4)) << fb;
+            fb += width;
+        }
+        t0 = funnel_r(t0, t1, 8);
+        t1 = funnel_r(t1, t2, 8);
+        t2 = funnel_r(t2, t3, 8);
+        t3 >>= 8;
+    }
+    *fp_out = fp;
+    return h;
+}
+
+// Per-symbol mask (bits at even positions) of the fingerprint symbols whose READ offset s+u lies
+// below `head` -- i.e. those that belong to the head part of the reference's two-stage Hamming
+// count (CopMEMMatcher.cpp:495, :528-551).  Uniform per seed offset s.
+__device__ __forceinline__ uint32_t fp_head_mask(uint32_t K, uint32_t s, uint32_t head) {
+    uint32_t m = 0, fb = 0;
+    const uint32_t kq = K >> 2;
+    for (uint32_t j = 0; j < kq; j++) {
+        const uint32_t width = (j < 3) ? 2u : 4u;
+        if (fb + width > PGRC_FP_BITS) break;
+        if (j < 3) {
+            if (s + 4 * j + 3 < head) m |= 1u << fb;
+        } else {
+            if (s + 4 * j + 2 < head) m |= 1u << fb;
+            if (s + 4 * j + 3 < head) m |= 1u << (fb + 2);
+        }
+        fb += width;
+    }
+    return m;
+}
+
 // mismatching symbols of two 2-bit words under a per-symbol mask (mask bits at even positions)
 __device__ __forceinline__ uint32_t mism2(uint32_t a, uint32_t b, uint32_t mask) {
     uint32_t x = a ^ b;

@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage: tools/pmc_groups.sh <outdir> "<grp1>" "<grp2>" ... -- <bench args...>
+set -u
+OUT=$1; shift
+GROUPS_=()
+while [ "$1" != "--" ]; do GROUPS_+=("$1"); shift; done
+shift
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+i=0
+for grp in "${GROUPS_[@]}"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pass$i" -- python3 bench.py "$@" > "$OUT/pass$i.json" 2> "$OUT/pass$i.err" || echo "pass $i failed"
+  echo "pass $i ($grp) done"
+done
+python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.txt"
