@@ -386,21 +386,47 @@ static int seed_ent_cmp(const void *a, const void *b) {
     return 0;
 }
 
-#define SEED_B 0x9E3779B97F4A7C15ull
-
 static uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
 
-/* Any exact-seed key works here: the reference's CyclicHash is randomly keyed
- * per run (rollinghash/characterhash.h:51-63), so only exact seed equality is
- * reproducible.  We use a polynomial hash and verify equality explicitly. */
-static uint64_t poly_hash_strided(const char *s, uint32_t m, uint32_t stride) {
-    uint64_t h = 0;
-    for (uint32_t k = 0; k < m; k++) h = h * SEED_B + (uint8_t)s[(uint64_t)k * stride];
-    return h;
+/* Seed key.  The reference keys its multimap with CyclicHash<uint32> (rollinghash/cyclichash.h:100-123):
+ * h = XOR_i rotl32(T[c_i], (n-1-i) mod 32) with a per-run random table T (characterhash.h:51-63), so the
+ * VALUES are not reproducible -- but the EQUIVALENCE the hash induces is, and it is coarser than string
+ * equality when n > 32: symbols at distance 32 share a rotation, so two seeds collide for every table iff,
+ * per rotation class, every symbol occurs with the same parity (e.g. "A...C" ~ "C...A", "A...A" ~ "G...G"
+ * across 32 positions).  Those candidates are real in the reference (they are verified and, in the approximate
+ * modes, can be accepted), so the canonical key must reproduce exactly this equivalence: we evaluate the same
+ * cyclic polynomial with two fixed, independent tables (64 key bits; non-equivalent seeds collide with
+ * probability 2^-64, the reference's own accidental collisions with 2^-32 per comparison are not canonical). */
+static uint32_t cyc_tab[2][256];
+static int cyc_tab_ready = 0;
+static void cyc_init(void) {
+    if (cyc_tab_ready) return;
+    for (int t = 0; t < 2; t++)
+        for (int c = 0; c < 256; c++) cyc_tab[t][c] = (uint32_t)(mix64(0xC0FFEEull * (t + 1) + (uint64_t)c * 0x9E3779B97F4A7C15ull) >> 16);
+    cyc_tab_ready = 1;
+}
+static uint32_t rotl32(uint32_t x, uint32_t r) { r &= 31; return r ? (x << r) | (x >> (32 - r)) : x; }
+
+/* eat() over m symbols at the given stride (cyclichash.h:119-122) */
+static uint64_t cyc_hash_strided(const char *s, uint32_t m, uint32_t stride) {
+    uint32_t h0 = 0, h1 = 0;
+    for (uint32_t k = 0; k < m; k++) {
+        uint8_t c = (uint8_t)s[(uint64_t)k * stride];
+        h0 = rotl32(h0, 1) ^ cyc_tab[0][c];
+        h1 = rotl32(h1, 1) ^ cyc_tab[1][c];
+    }
+    return ((uint64_t)h0 << 32) | h1;
+}
+/* update(out, in) (cyclichash.h:100-107): rotl1(h) ^ rotl(T[out], n mod 32) ^ T[in] */
+static uint64_t cyc_roll(uint64_t h, uint32_t m, uint8_t out, uint8_t in) {
+    uint32_t h0 = (uint32_t)(h >> 32), h1 = (uint32_t)h;
+    h0 = rotl32(h0, 1) ^ rotl32(cyc_tab[0][out], m) ^ cyc_tab[0][in];
+    h1 = rotl32(h1, 1) ^ rotl32(cyc_tab[1][out], m) ^ cyc_tab[1][in];
+    return ((uint64_t)h0 << 32) | h1;
 }
 
 typedef struct {
@@ -418,6 +444,7 @@ int pgrc_or_match_seedindex(char mode, const char *pg, uint64_t pg_len, const ch
     const uint32_t stride = (mode == 'i') ? P : 1;
     const uint32_t span = (mode == 'i') ? m * P : m;            /* text window extent */
     result_init(res, n, mode != 'e');
+    cyc_init();
     /* index every (read, part): ConstantLength...HashMatcher.cpp:23-42, :76-93 */
     uint64_t nent = n * P;
     seed_ent *ent = (seed_ent *)malloc((size_t)(nent ? nent : 1) * sizeof(seed_ent));
@@ -425,7 +452,7 @@ int pgrc_or_match_seedindex(char mode, const char *pg, uint64_t pg_len, const ch
     for (uint64_t i = 0; i < n; i++)
         for (uint32_t j = 0; j < P; j++) {
             const char *part = reads + i * read_len + ((mode == 'i') ? j : j * m);
-            ent[i * P + j].hash = mix64(poly_hash_strided(part, m, stride));
+            ent[i * P + j].hash = cyc_hash_strided(part, m, stride);
             ent[i * P + j].idx = (uint32_t)(i * P + j);
         }
     qsort(ent, (size_t)nent, sizeof(seed_ent), seed_ent_cmp);
@@ -436,14 +463,11 @@ int pgrc_or_match_seedindex(char mode, const char *pg, uint64_t pg_len, const ch
     for (uint64_t a = 0; a < nent;) {
         uint64_t b = a;
         while (b < nent && ent[b].hash == ent[a].hash) b++;
-        uint64_t s = ent[a].hash & (tsize - 1);
+        uint64_t s = mix64(ent[a].hash) & (tsize - 1);
         while (tab[s].count) s = (s + 1) & (tsize - 1);
         tab[s].key = ent[a].hash; tab[s].start = (uint32_t)a; tab[s].count = (uint32_t)(b - a);
         a = b;
     }
-    /* B^(m-1) for the rolling update */
-    uint64_t bpow = 1;
-    for (uint32_t k = 1; k < m; k++) bpow *= SEED_B;
 
     char *rcpg = NULL;
     for (int pass = 0; pass < (rev_compl_pg ? 2 : 1); pass++) {
@@ -460,15 +484,14 @@ int pgrc_or_match_seedindex(char mode, const char *pg, uint64_t pg_len, const ch
         /* one rolling hash per residue class mod stride (ConstantLength...HashMatcher.h:105-137) */
         uint64_t *roll = (uint64_t *)malloc(sizeof(uint64_t) * stride);
         for (uint32_t r = 0; r < stride; r++)
-            roll[r] = (r + (uint64_t)(m - 1) * stride < pg_len) ? poly_hash_strided(text + r, m, stride) : 0;
+            roll[r] = (r + (uint64_t)(m - 1) * stride < pg_len) ? cyc_hash_strided(text + r, m, stride) : 0;
         for (uint64_t t = 0; t + span <= pg_len; t++) {
             uint32_t r = (uint32_t)(t % stride);
-            uint64_t key = mix64(roll[r]);
+            uint64_t key = roll[r];
             /* advance this residue's hash to window start t+stride */
             if (t + stride + (uint64_t)(m - 1) * stride < pg_len)
-                roll[r] = (roll[r] - (uint8_t)text[t] * bpow) * SEED_B +
-                          (uint8_t)text[t + (uint64_t)m * stride];
-            uint64_t s = key & (tsize - 1);
+                roll[r] = cyc_roll(roll[r], m, (uint8_t)text[t], (uint8_t)text[t + (uint64_t)m * stride]);
+            uint64_t s = mix64(key) & (tsize - 1);
             while (tab[s].count && tab[s].key != key) s = (s + 1) & (tsize - 1);
             if (!tab[s].count) continue;
             for (uint32_t a = tab[s].start; a < tab[s].start + tab[s].count; a++) {
@@ -476,12 +499,10 @@ int pgrc_or_match_seedindex(char mode, const char *pg, uint64_t pg_len, const ch
                 uint64_t ri = pidx / P;
                 uint32_t part = pidx % P;
                 const char *rd = reads + ri * read_len;
-                /* canonical semantics: exact seed equality */
-                const char *pp = rd + ((mode == 'i') ? part : part * m);
-                int eq = 1;
-                for (uint32_t k = 0; k < m && eq; k++) eq = pp[(uint64_t)k * stride] == text[t + (uint64_t)k * stride];
-                if (!eq) continue;
-                if (mode == 'e') { /* ReadsMatchers.cpp:203-224 */
+                if (mode == 'e') { /* ReadsMatchers.cpp:203-224: a key hit must pass compareReadWithPattern == 0 */
+                    int eq = 1;
+                    for (uint32_t k = 0; k < m && eq; k++) eq = rd[k] == text[t + k];
+                    if (!eq) continue;
                     if (res->pos[ri] == PGRC_OR_NOT_MATCHED_POS) {
                         res->pos[ri] = pass ? pg_len - (t + read_len) : t;
                         if (pass) res->rc[ri] = 1;

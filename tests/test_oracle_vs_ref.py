@@ -135,3 +135,29 @@ def test_pack_layout_and_revcomp():
     orc.ref().pgrc_ref_revcomp(x.ctypes.data_as(C.c_void_p), x.size)
     orc.oracle().pgrc_or_revcomp(y.ctypes.data_as(C.c_void_p), y.size)
     assert np.array_equal(x, y)
+
+
+def test_cyclic_hash_equivalence_candidates_are_canonical():
+    """CyclicHash<uint32> rotates by one bit per symbol, so symbols 32 apart share a rotation: seeds longer than 32
+    collide DETERMINISTICALLY when, per rotation class, every symbol has the same parity (cyclichash.h:100-123).
+    Such candidates are verified and can be accepted in modes d/i -- the canonical seed key must reproduce them."""
+    pg, reads0 = make_inputs(120000, 600, 100, seed=77)
+    rng = np.random.default_rng(7)
+    starts = rng.integers(0, pg.size - 100, size=600)
+    for mode in ("d", "i"):
+        reads = reads0.copy()
+        for k in range(600):
+            r = pg[starts[k]: starts[k] + 100].copy()
+            q = k % 6  # seed positions q and q+32 share a rotation (38-symbol seeds)
+            if mode == "d":   # parts = read[0:38], read[38:76]
+                pairs = [(0 + q, 0 + q + 32), (38 + q, 38 + q + 32)]
+            else:             # parts = read[j::2][:38], j = 0, 1
+                pairs = [(0 + 2 * q, 0 + 2 * (q + 32)), (1 + 2 * q, 1 + 2 * (q + 32))]
+            for a, b in pairs:
+                r[a], r[b] = r[b], r[a]
+            reads[k] = r
+        r = orc.ref_match(mode, pg, reads, 38, 33, 0)
+        o = orc.oracle_match(mode, pg, reads, 38, 33, 0)
+        assert_same(r, o, f"cyclic equivalence mode {mode}")
+        # 9/16 of these reads have both parts broken as strings: only the collision candidates reach them
+        assert r["matched"] > 550
