@@ -1,8 +1,339 @@
-// seedidx.hip -- modes 'd' / 'i' / 'e' (read-side seed index).  Placeholder until built.
+// seedidx.hip -- modes 'd', 'i' and the exact matcher 'e': the reference indexes the READS' seed parts and
+// streams the pseudogenome past that index (serial code, node-based unordered_multimap).
+//
+// Reference behaviour restated:
+//   index   : Default/InterleavedConstantLengthPatternsOnTextHashMatcher::addReadsSetOfPatterns / addPackedPatterns,
+//             matching/ConstantLengthPatternsOnTextHashMatcher.cpp:23-42, :76-93 (part j of read i -> pattern i*P+j)
+//   scan    : iterateOver / moveNext, ConstantLengthPatternsOnTextHashMatcher.h:42-68, :105-137
+//   key     : CyclicHash<uint32>, rollinghash/cyclichash.h:100-123 -- randomly keyed per run, so only the
+//             EQUIVALENCE it induces is canonical: XOR of per-symbol words rotated by (n-1-i) mod 32, i.e. seeds
+//             longer than 32 collide when every rotation class has equal symbol parities.  We evaluate the same
+//             cyclic polynomial with two fixed tables (64 key bits).
+//   verify  : DefaultReadsExactMatcher::executeMatching ReadsMatchers.cpp:198-230 (first exact hit in scan order),
+//             DefaultReadsApproxMatcher :297-341, InterleavedReadsApproxMatcher :364-409 (strict improvement, the
+//             stored-position skip, limit = count-1), countSequenceMismatchesVsUnpacked SymbolsPackingFacility.cpp:344-374
+//
+// MI355X design: the read-part keys go into an open-addressing table in HBM (atomicCAS insert, chained duplicates);
+// one thread per text position computes its window key from the 2-bit text and emits a HIT record
+// (read << 36 | text position << 4 | 15 - part) for every chained pattern; the hits are radix-sorted
+// (rocPRIM device radix sort -- a plain library primitive) so that each read's candidates come out in exactly the
+// reference's order (ascending text position, equal positions in descending part index); one thread per read then
+// replays the reference's sequential rule over its candidates with popcount Hamming on 2-bit words.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "ctx.h"
+#include "devutil.h"
+
+#define SX_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define SX_NIL 0xFFFFFFFFu
+
+// two fixed 32-bit tables over the symbol values A0 C1 G2 T3 N4
+__device__ __forceinline__ uint32_t cyc_t0(uint32_t v) {
+    return v == 0 ? 0x9E3779B9u : v == 1 ? 0x7F4A7C15u : v == 2 ? 0xF39CC060u : v == 3 ? 0x5CEDC834u : 0x1082276Bu;
+}
+__device__ __forceinline__ uint32_t cyc_t1(uint32_t v) {
+    return v == 0 ? 0xBF58476Du : v == 1 ? 0x1CE4E5B9u : v == 2 ? 0x94D049BBu : v == 3 ? 0x133111EBu : 0x2545F491u;
+}
+__device__ __forceinline__ uint32_t rotl1(uint32_t x) { return (x << 1) | (x >> 31); }
+__device__ __forceinline__ uint64_t mix64d(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint64_t key_fix(uint32_t h0, uint32_t h1) {
+    uint64_t k = ((uint64_t)h0 << 32) | h1;
+    return k == SX_EMPTY ? SX_EMPTY - 1 : k;
+}
+
+struct SeedArgs {
+    const uint32_t *pg;
+    uint64_t G;
+    const uint32_t *reads;
+    uint64_t n, stride;
+    const uint8_t *nflag;
+    const uint32_t *nidx;
+    const uint8_t *nascii;
+    uint64_t nn;
+    uint32_t L, m, P, cstride; // m = pattern length, P = parts, cstride = symbol stride inside a part (P for mode i)
+    uint32_t mode;             // 'd', 'i', 'e'
+    uint32_t kmax, kmin, strand;
+    uint64_t *tkeys;
+    uint32_t *theads;
+    uint64_t tmask;
+    uint32_t *next;
+    uint64_t *pos;
+    uint8_t *rc, *mism;
+};
+
+__device__ __forceinline__ uint32_t read_code(const SeedArgs &a, uint64_t i, uint32_t x) {
+    return (a.reads[(uint64_t)(x >> 4) * a.stride + i] >> (2u * (x & 15u))) & 3u;
+}
+__device__ __forceinline__ uint32_t ascii_val(uint8_t ch) { return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u; }
+__device__ __forceinline__ uint32_t part_offset(const SeedArgs &a, uint32_t j) { return a.mode == 'i' ? j : j * a.m; }
+
+// ---- 1. insert every (read, part) key
+__device__ __forceinline__ void table_insert(const SeedArgs &a, uint64_t key, uint32_t e) {
+    uint64_t slot = mix64d(key) & a.tmask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS((unsigned long long *)&a.tkeys[slot], (unsigned long long)SX_EMPTY, (unsigned long long)key);
+        if (prev == SX_EMPTY || prev == key) {
+            a.next[e] = atomicExch(&a.theads[slot], e);
+            return;
+        }
+        slot = (slot + 1) & a.tmask;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_seed_insert(const SeedArgs a) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.n * a.P) return;
+    const uint64_t i = e / a.P;
+    const uint32_t j = (uint32_t)(e % a.P);
+    if (a.nflag && a.nflag[i]) return; // byte-path reads are inserted by k_seed_insert_ascii
+    const uint32_t off = part_offset(a, j);
+    uint32_t h0 = 0, h1 = 0;
+    for (uint32_t k = 0; k < a.m; k++) {
+        const uint32_t c = read_code(a, i, off + k * a.cstride);
+        h0 = rotl1(h0) ^ cyc_t0(c);
+        h1 = rotl1(h1) ^ cyc_t1(c);
+    }
+    table_insert(a, key_fix(h0, h1), (uint32_t)e);
+}
+
+__global__ void __launch_bounds__(256) k_seed_insert_ascii(const SeedArgs a) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= a.nn * a.P) return;
+    const uint64_t t = x / a.P;
+    const uint32_t j = (uint32_t)(x % a.P);
+    const uint64_t i = a.nidx[t];
+    const uint8_t *row = a.nascii + t * a.L;
+    const uint32_t off = part_offset(a, j);
+    uint32_t h0 = 0, h1 = 0;
+    for (uint32_t k = 0; k < a.m; k++) {
+        const uint32_t c = ascii_val(row[off + k * a.cstride]);
+        h0 = rotl1(h0) ^ cyc_t0(c);
+        h1 = rotl1(h1) ^ cyc_t1(c);
+    }
+    table_insert(a, key_fix(h0, h1), (uint32_t)(i * a.P + j));
+}
+
+// ---- 2. stream the text: one thread per window start; COUNT pass sizes the hit buffer, FILL pass writes it
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_seed_scan(const SeedArgs a, uint64_t nwin, unsigned long long *cursor, uint64_t *hits) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nwin) return;
+    uint32_t h0 = 0, h1 = 0;
+    for (uint32_t k = 0; k < a.m; k++) {
+        const uint64_t x = t + (uint64_t)k * a.cstride;
+        const uint32_t c = (a.pg[x >> 4] >> (2u * ((uint32_t)x & 15u))) & 3u;
+        h0 = rotl1(h0) ^ cyc_t0(c);
+        h1 = rotl1(h1) ^ cyc_t1(c);
+    }
+    const uint64_t key = key_fix(h0, h1);
+    uint64_t slot = mix64d(key) & a.tmask;
+    for (;;) {
+        const uint64_t k = a.tkeys[slot];
+        if (k == SX_EMPTY) return;
+        if (k == key) break;
+        slot = (slot + 1) & a.tmask;
+    }
+    for (uint32_t e = a.theads[slot]; e != SX_NIL; e = a.next[e]) {
+        const uint64_t i = e / a.P;
+        const uint32_t j = e % a.P;
+        const uint64_t shift = part_offset(a, j);
+        if (shift > t) continue;                    // ReadsMatchers.cpp:308-309 / :375-376
+        if (t - shift + a.L > a.G) continue;        // :311-312 / :378-379
+        const unsigned long long o = atomicAdd(cursor, 1ull);
+        if (FILL) hits[o] = (i << 36) | (t << 4) | (15u - j);
+    }
+}
+
+// ---- 3. per-read sequential replay over its sorted candidates
+template <bool ASCII>
+__device__ __forceinline__ uint32_t hamming_vs_text(const SeedArgs &a, uint64_t i, uint64_t trow, uint64_t p) {
+    uint32_t mm = 0;
+    if (ASCII) {
+        const uint8_t *row = a.nascii + trow * a.L;
+        for (uint32_t k = 0; k < a.L; k++) {
+            const uint64_t x = p + k;
+            const uint32_t c = (a.pg[x >> 4] >> (2u * ((uint32_t)x & 15u))) & 3u;
+            mm += code2ascii(c) != (uint32_t)row[k];
+        }
+    } else {
+        const uint32_t *src = a.pg + (p >> 4);
+        const uint32_t b = ((uint32_t)p & 15u) * 2u;
+        const uint32_t nw = (a.L + 15) / 16;
+        uint32_t lo = src[0];
+        for (uint32_t w = 0; w < nw; w++) {
+            const uint32_t hi = src[w + 1];
+            const uint32_t tw = funnel_r(lo, hi, b);
+            const uint32_t rw = a.reads[(uint64_t)w * a.stride + i];
+            mm += mism2(tw, rw, sym_mask((int)w, 0, (int)a.L));
+            lo = hi;
+        }
+    }
+    return mm;
+}
+
+__device__ __forceinline__ uint64_t lower_bound_u64(const uint64_t *v, uint64_t n, uint64_t x) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (v[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <bool ASCII>
+__global__ void __launch_bounds__(256) k_seed_replay(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhits) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i, trow = 0;
+    if (ASCII) {
+        if (t >= a.nn) return;
+        i = a.nidx[t];
+        trow = t;
+    } else {
+        if (t >= a.n) return;
+        i = t;
+        if (a.nflag && a.nflag[i]) return;
+    }
+    uint32_t c = a.mism[i];
+    uint64_t stored = a.pos[i];
+    uint32_t rcflag = a.rc[i];
+    const bool exact = a.mode == 'e';
+    if (exact ? (stored != PGRC_NOT_MATCHED_POS) : (c <= a.kmin)) return;
+    const uint64_t lo = lower_bound_u64(hits, nhits, i << 36), hi = lower_bound_u64(hits, nhits, (i + 1) << 36);
+    bool changed = false;
+    for (uint64_t x = lo; x < hi; x++) {
+        const uint64_t hkey = hits[x];
+        const uint64_t tp = (hkey >> 4) & 0xFFFFFFFFull;
+        const uint32_t j = 15u - (uint32_t)(hkey & 15u);
+        const uint64_t p = tp - part_offset(a, j);
+        const uint64_t cand = a.strand ? a.G - (p + a.L) : p;
+        if (exact) {
+            if (hamming_vs_text<ASCII>(a, i, trow, p) != 0) continue; // compareReadWithPattern == 0, :207
+            stored = cand;                                              // first hit in scan order wins, :209-212
+            rcflag = a.strand;
+            c = 0;
+            changed = true;
+            break;
+        }
+        if (c <= a.kmin) break;                                         // :304-305 (every later hit is skipped too)
+        if (stored == cand) continue;                                   // :313-314
+        const uint32_t limit = (c == PGRC_NOT_MATCHED_CNT) ? a.kmax : c - 1u; // :315-316
+        const uint32_t mm = hamming_vs_text<ASCII>(a, i, trow, p);
+        if (mm <= limit) {                                              // got < count  (:319-328)
+            c = mm;
+            stored = cand;
+            rcflag = a.strand;
+            changed = true;
+        }
+    }
+    if (changed) {
+        a.pos[i] = stored;
+        a.rc[i] = (uint8_t)rcflag;
+        a.mism[i] = (uint8_t)c;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_seed_table_init(uint64_t *keys, uint32_t *heads, uint64_t n) {
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (uint64_t)gridDim.x * blockDim.x) {
+        keys[s] = SX_EMPTY;
+        heads[s] = SX_NIL;
+    }
+}
 
 int pgrc_seedidx_run(pgrc_match_ctx *c, int rev_compl_pg) {
-    (void)rev_compl_pg;
-    c->err = "modes d/i/e are not built yet";
-    return PGRC_E_MODE;
+    const uint32_t L = c->prm.read_len;
+    const char mode = c->prm.mode;
+    SeedArgs a;
+    a.L = L;
+    a.mode = (uint32_t)mode;
+    a.P = (mode == 'e') ? 1u : L / c->prm.seed_len;   // targetMismatches + 1 (ReadsMatchers.cpp:236)
+    a.m = (mode == 'e') ? L : c->prm.seed_len;
+    a.cstride = (mode == 'i') ? a.P : 1u;
+    const uint64_t span = (uint64_t)a.m * a.cstride;  // extent of a text window
+    if (a.P == 0 || a.P > 15) { c->err = "modes d/i: 1..15 seed parts supported"; return PGRC_E_PARAM; }
+    if (c->n >= (1ull << 28)) { c->err = "modes d/i/e: fewer than 2^28 reads per call"; return PGRC_E_PARAM; }
+    a.pg = nullptr;
+    a.G = c->G;
+    a.reads = c->reads2;
+    a.n = c->n;
+    a.stride = c->stride;
+    a.nflag = c->n_nreads ? (const uint8_t *)c->nread_flag.p : nullptr;
+    a.nidx = (const uint32_t *)c->nread_idx.p;
+    a.nascii = (const uint8_t *)c->nread_ascii.p;
+    a.nn = c->n_nreads;
+    a.kmax = c->prm.max_mismatches;
+    a.kmin = c->prm.min_mismatches;
+    a.pos = (uint64_t *)c->d_pos.p;
+    a.rc = (uint8_t *)c->d_rc.p;
+    a.mism = (uint8_t *)c->d_mism.p;
+    if (c->n == 0) return PGRC_OK;
+
+    // read-part table
+    const uint64_t nent = c->n * a.P;
+    uint64_t tsize = 1024;
+    while (tsize < 2 * nent) tsize <<= 1;
+    int e;
+    if ((e = pgrc_buf_ensure(c, c->s_keys, tsize * sizeof(uint64_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->s_vals, tsize * sizeof(uint32_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->s_tab, nent * sizeof(uint32_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->s_tmp, 64))) return e;
+    a.tkeys = (uint64_t *)c->s_keys.p;
+    a.theads = (uint32_t *)c->s_vals.p;
+    a.tmask = tsize - 1;
+    a.next = (uint32_t *)c->s_tab.p;
+    hipLaunchKernelGGL(k_seed_table_init, dim3(4096), dim3(256), 0, c->stream, a.tkeys, a.theads, tsize);
+    hipLaunchKernelGGL(k_seed_insert, dim3((uint32_t)((nent + 255) / 256)), dim3(256), 0, c->stream, a);
+    if (c->n_nreads)
+        hipLaunchKernelGGL(k_seed_insert_ascii, dim3((uint32_t)((c->n_nreads * a.P + 255) / 256)), dim3(256), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+
+    unsigned long long *cursor = (unsigned long long *)c->s_tmp.p;
+    for (int pass = 0; pass < (rev_compl_pg ? 2 : 1); pass++) {
+        if (pass == 1) {
+            if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) return e;
+            c->have_rc = true;
+        }
+        a.pg = (const uint32_t *)c->pg2[pass].p;
+        a.strand = (uint32_t)pass;
+        if (c->G < span) continue; // no window fits (the reference's scan loops are empty / undefined there)
+        const uint64_t nwin = c->G - span + 1;
+        const uint32_t grid = (uint32_t)((nwin + 255) / 256);
+        HIP_TRY(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(k_seed_scan<false>, dim3(grid), dim3(256), 0, c->stream, a, nwin, cursor, (uint64_t *)nullptr);
+        unsigned long long nhits = 0;
+        HIP_TRY(c, hipMemcpyAsync(&nhits, cursor, sizeof nhits, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (nhits == 0) continue;
+        size_t temp_bytes = 0;
+        HIP_TRY(c, rocprim::radix_sort_keys(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)nhits, 0, 64, c->stream));
+        DevBuf sorted, temp;
+        if ((e = pgrc_buf_ensure(c, c->s_hits, nhits * sizeof(uint64_t)))) return e;
+        if ((e = pgrc_buf_ensure(c, sorted, nhits * sizeof(uint64_t)))) return e;
+        if ((e = pgrc_buf_ensure(c, temp, temp_bytes))) { pgrc_buf_free(sorted); return e; }
+        hipError_t he = hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream);
+        hipLaunchKernelGGL(k_seed_scan<true>, dim3(grid), dim3(256), 0, c->stream, a, nwin, cursor, (uint64_t *)c->s_hits.p);
+        if (he == hipSuccess) he = hipGetLastError();
+        if (he == hipSuccess)
+            he = rocprim::radix_sort_keys(temp.p, temp_bytes, (uint64_t *)c->s_hits.p, (uint64_t *)sorted.p, (size_t)nhits, 0, 64, c->stream);
+        if (he == hipSuccess) {
+            hipLaunchKernelGGL(k_seed_replay<false>, dim3((uint32_t)((c->n + 255) / 256)), dim3(256), 0, c->stream, a,
+                               (const uint64_t *)sorted.p, (uint64_t)nhits);
+            if (c->n_nreads)
+                hipLaunchKernelGGL(k_seed_replay<true>, dim3((uint32_t)((c->n_nreads + 255) / 256)), dim3(256), 0, c->stream, a,
+                                   (const uint64_t *)sorted.p, (uint64_t)nhits);
+            he = hipGetLastError();
+        }
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        pgrc_buf_free(sorted);
+        pgrc_buf_free(temp);
+        if (he != hipSuccess) { c->err = std::string("seed-index pass: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
+        c->ctr.searched[pass] = c->n;
+        c->ctr.candidates[pass] = nhits;
+    }
+    return PGRC_OK;
 }

@@ -207,3 +207,82 @@ def test_device_generators_equal_host_generators():
     pos, rc, mism, hist, matched = ctx.get_results()
     o = orc.oracle_match("c", pg, reads, 38, 3, 0)
     assert_same_results({"pos": pos, "rc": rc, "mism": mism, "hist": hist, "matched": matched}, o, "device inputs")
+
+
+SEED_CASES = [
+    # mode, L, seed, M, kmin_shortcut, G, n, n_with_n
+    ("e", 100, 100, 50, False, 300000, 15000, 0),
+    ("e", 150, 150, 50, False, 300000, 10000, 0),
+    ("d", 100, 38, 50, False, 300000, 15000, 0),
+    ("d", 100, 38, 3, False, 300000, 15000, 0),
+    ("d", 100, 38, 50, True, 300000, 15000, 0),
+    ("d", 150, 38, 50, False, 300000, 10000, 0),
+    ("d", 250, 45, 20, False, 300000, 6000, 0),
+    ("d", 100, 25, 10, False, 200000, 8000, 0),
+    ("i", 100, 38, 50, False, 300000, 15000, 0),
+    ("i", 100, 38, 3, False, 300000, 15000, 0),
+    ("i", 100, 38, 50, True, 300000, 15000, 0),
+    ("i", 150, 38, 50, False, 300000, 10000, 0),
+    ("i", 250, 45, 20, False, 300000, 6000, 0),
+    ("i", 100, 25, 10, False, 200000, 8000, 0),
+    ("d", 100, 38, 3, False, 200000, 8000, 600),
+    ("i", 100, 38, 3, False, 200000, 8000, 600),
+    ("e", 100, 100, 50, False, 200000, 8000, 600),
+]
+
+
+@pytest.mark.parametrize("mode,L,seed_len,M,shortcut,G,n,n_with_n", SEED_CASES)
+def test_seedindex_modes_parity(mode, L, seed_len, M, shortcut, G, n, n_with_n):
+    pg, reads = make_inputs(G, n, L, seed=2000 + L + seed_len + M + n_with_n)
+    reads[100] = reads[50]
+    reads[101] = reads[50]
+    reads[200, : L // 2] = reads[200, L // 2: 2 * (L // 2)]
+    for k in range(20):  # reads hanging over the Pg ends
+        reads[300 + k, : L - 7] = pg[-(L - 7):]
+        reads[330 + k, 7:] = pg[: L - 7]
+    kmax = L // M
+    kmin = kmax if shortcut else 0
+    o = orc.oracle_match(mode, pg, reads, seed_len, kmax, kmin)
+    g = gpu_match(mode, pg, reads, seed_len, kmax, kmin)
+    assert_same_results(g, o, f"mode {mode} L={L} seed={seed_len} M={M} shortcut={shortcut}")
+    if orc.have_ref():
+        r = orc.ref_match(mode, pg, reads, seed_len, kmax, kmin, n_nset=(n if n_with_n else 0))
+        assert_same_results(g, r, "vs real reference")
+
+
+def test_seedindex_cyclic_equivalence_candidates():
+    """seeds longer than 32: the reference's CyclicHash collides deterministically for symbol swaps 32 apart;
+    the GPU key must yield the same candidates (see tests/test_oracle_vs_ref.py)."""
+    pg, reads0 = make_inputs(120000, 600, 100, seed=77)
+    rng = np.random.default_rng(7)
+    starts = rng.integers(0, pg.size - 100, size=600)
+    for mode in ("d", "i"):
+        reads = reads0.copy()
+        for k in range(600):
+            r = pg[starts[k]: starts[k] + 100].copy()
+            q = k % 6
+            pairs = [(q, q + 32), (38 + q, 38 + q + 32)] if mode == "d" else [(2 * q, 2 * (q + 32)), (1 + 2 * q, 1 + 2 * (q + 32))]
+            for a, b in pairs:
+                r[a], r[b] = r[b], r[a]
+            reads[k] = r
+        o = orc.oracle_match(mode, pg, reads, 38, 33, 0)
+        g = gpu_match(mode, pg, reads, 38, 33, 0)
+        assert_same_results(g, o, f"cyclic {mode}")
+        assert g["matched"] > 550
+
+
+def test_map_reads_into_pg_factory():
+    """mapReadsIntoPg picks the matcher exactly like ReadsMatchers.cpp:715-740."""
+    from pgrc_amd import (CopMEMReadsApproxMatcher, DefaultReadsApproxMatcher, DefaultReadsExactMatcher,
+                          InterleavedReadsApproxMatcher, PgrcMatchError, mapReadsIntoPg)
+    pg, reads = make_inputs(100000, 2000, 100, seed=12)
+    for mode, seed_len, cls, okind in (("c", 38, CopMEMReadsApproxMatcher, "c"), ("d", 38, DefaultReadsApproxMatcher, "d"),
+                                       ("i", 38, InterleavedReadsApproxMatcher, "i"), ("d", 100, DefaultReadsExactMatcher, "e"),
+                                       ("c", 120, CopMEMReadsApproxMatcher, "c")):
+        bitmap, m = mapReadsIntoPg(pg, True, reads, seed_len, 50, mode)
+        assert type(m) is cls
+        o = orc.oracle_match(okind, pg, reads, min(seed_len, 100), 2, 0)
+        assert np.array_equal(m.readMatchPos, o["pos"]) and np.array_equal(m.readMatchRC.astype(np.uint8), o["rc"])
+        assert m.matchedReadsCount == o["matched"] and np.array_equal(bitmap, o["pos"] != np.uint64(2**64 - 1))
+    with pytest.raises(PgrcMatchError):
+        mapReadsIntoPg(pg, True, reads, 38, 50, "x")
