@@ -87,6 +87,10 @@ int pgrc_match_pack_pg_slice(pgrc_match_ctx *ctx, const char *pg_slice, uint64_t
 /* n rows of read_len ASCII symbols (what readsSet->getRead(i, buf) yields,
  * ReadsMatchers.cpp:432).  Rows containing 'N' take the byte-compare kernel. */
 int pgrc_match_set_reads_ascii(pgrc_match_ctx *ctx, const char *reads, uint64_t n);
+/* The same, streamed: begin(n), then append consecutive blocks of rows, then end. */
+int pgrc_match_begin_reads(pgrc_match_ctx *ctx, uint64_t n);
+int pgrc_match_append_reads_ascii(pgrc_match_ctx *ctx, const char *reads, uint64_t count);
+int pgrc_match_end_reads(pgrc_match_ctx *ctx);
 /* The reference's own packed layout for an ACGT set: ceil(read_len/4) bytes per read,
  * 4 symbols per byte, first symbol most significant
  * (PackedConstantLengthReadsSet::getPackedRead, coders/SymbolsPackingFacility.cpp:143-178). */
@@ -104,6 +108,9 @@ int pgrc_match_set_results(pgrc_match_ctx *ctx, const uint64_t *pos, const uint8
                            const uint8_t *mism);
 /* forward pass, then (rev_compl_pg != 0) the pass over the reverse-complemented Pg. */
 int pgrc_match_run(pgrc_match_ctx *ctx, int rev_compl_pg);
+/* a single executeMatching(revCompMode) (ReadsMatchers.h:46): strand 0 = the text as given, 1 = its
+ * reverse complement (built on the device; the host text is never modified). */
+int pgrc_match_run_pass(pgrc_match_ctx *ctx, int strand);
 /* readMatchPos / readMatchRC / readMismatchesCount / matchedCountPerMismatches /
  * matchedReadsCount (ReadsMatchers.h:32-35, :115-116).  Any pointer may be NULL. */
 int pgrc_match_get_results(pgrc_match_ctx *ctx, uint64_t *pos, uint8_t *rc, uint8_t *mism,

@@ -1,0 +1,119 @@
+#include "HipReadsMatcher.h"
+
+#include "pgrc_match.h"
+#include "readsset/PackedConstantLengthReadsSet.h"
+
+namespace PgTools {
+
+    HipReadsMatcher::HipReadsMatcher(char *pgPtr, const uint_pg_len_max pgLength, bool revComplPg,
+                                     ConstantLengthReadsSetInterface *readsSet, uint32_t matchPrefixLength,
+                                     uint16_t readsExactMatchingChars, uint8_t maxMismatches, uint8_t minMismatches,
+                                     char hipMode)
+            : AbstractReadsApproxMatcher(pgPtr, pgLength, revComplPg, readsSet, matchPrefixLength,
+                                         readsExactMatchingChars, maxMismatches, minMismatches),
+              hipMode(hipMode), seedChars(readsExactMatchingChars) {
+        if (matchPrefixLength != DISABLED_PREFIX_MODE) {
+            fprintf(stderr, "HipReadsMatcher: prefix matching mode is not supported.\n");
+            exit(EXIT_FAILURE);
+        }
+        pgrc_match_params prm;
+        prm.read_len = readLength;
+        prm.seed_len = readsExactMatchingChars > readLength ? readLength : readsExactMatchingChars;
+        prm.max_mismatches = maxMismatches;
+        prm.min_mismatches = minMismatches;
+        prm.mode = hipMode;
+        prm.device = -1;
+        int e = pgrc_match_create(&prm, &ctx);
+        if (e) {
+            fprintf(stderr, "HipReadsMatcher: %s (error %d)\n", pgrc_match_last_error(nullptr), e);
+            exit(EXIT_FAILURE); // the reference's error convention (ReadsMatchers.cpp:738-739)
+        }
+    }
+
+    HipReadsMatcher::~HipReadsMatcher() {
+        pgrc_match_destroy(ctx);
+    }
+
+    void HipReadsMatcher::failOn(int code, const char *what) {
+        if (!code) return;
+        fprintf(stderr, "HipReadsMatcher: %s failed: %s (error %d)\n", what, pgrc_match_last_error(ctx), code);
+        exit(EXIT_FAILURE);
+    }
+
+    void HipReadsMatcher::upload() {
+        if (uploaded) return;
+        failOn(pgrc_match_set_pg_ascii(ctx, pgPtr, pgLength), "set_pg_ascii");
+        auto *packed = dynamic_cast<PackedConstantLengthReadsSet *>(readsSet);
+        if (packed && packed->getReadsSetProperties()->symbolsCount == 4 &&
+            strncmp(packed->getReadsSetProperties()->symbolsList, "ACGT", 4) == 0) {
+            // the LQ set alone: hand over the reference's own packed rows, no unpacking
+            failOn(pgrc_match_set_reads_packed(ctx, readsCount ? packed->getPackedRead(0) : nullptr, readsCount),
+                   "set_reads_packed");
+        } else {
+            // any other ConstantLengthReadsSetInterface (e.g. the LQ + N sum set, pgrc-encoder.cpp:349-352):
+            // stream the rows through getRead(i, buf) in bounded blocks
+            const uint_reads_cnt_max block = 1u << 20;
+            std::vector<char> buf((size_t) std::min<uint64_t>(block, readsCount ? readsCount : 1) * readLength);
+            failOn(pgrc_match_begin_reads(ctx, readsCount), "begin_reads");
+            for (uint_reads_cnt_max first = 0; first < readsCount; first += block) {
+                const uint_reads_cnt_max cnt = std::min<uint64_t>(block, (uint64_t) readsCount - first);
+                #pragma omp parallel for
+                for (uint_reads_cnt_max k = 0; k < cnt; k++)
+                    readsSet->getRead(first + k, buf.data() + (size_t) k * readLength);
+                failOn(pgrc_match_append_reads_ascii(ctx, buf.data(), cnt), "append_reads_ascii");
+            }
+            failOn(pgrc_match_end_reads(ctx), "end_reads");
+        }
+        uploaded = true;
+    }
+
+    void HipReadsMatcher::fetchResults() {
+        readMatchPos.resize(readsCount);
+        readMismatchesCount.resize(readsCount);
+        std::vector<uint8_t> rc(readsCount);
+        uint64_t hist[NOT_MATCHED_COUNT + 1];
+        uint64_t matched = 0;
+        failOn(pgrc_match_get_results(ctx, readMatchPos.data(), rc.data(), readMismatchesCount.data(), hist, &matched),
+               "get_results");
+        readMatchRC.assign(readsCount, false);
+        for (uint_reads_cnt_max i = 0; i < readsCount; i++)
+            readMatchRC[i] = rc[i] != 0;
+        matchedReadsCount = matched;
+        for (int k = 0; k <= NOT_MATCHED_COUNT; k++)
+            matchedCountPerMismatches[k] = hist[k];
+    }
+
+    void HipReadsMatcher::initMatching() {
+        DefaultReadsMatcher::initMatching();
+        readMismatchesCount.clear();
+        readMismatchesCount.insert(readMismatchesCount.end(), readsCount, NOT_MATCHED_COUNT);
+        upload();
+        failOn(pgrc_match_init_results(ctx), "init_results");
+    }
+
+    void HipReadsMatcher::initMatchingContinuation(DefaultReadsMatcher *pMatcher) {
+        AbstractReadsApproxMatcher::initMatchingContinuation(pMatcher); // takes the result vectors over (:111-133)
+        upload();
+        std::vector<uint8_t> rc(readsCount);
+        for (uint_reads_cnt_max i = 0; i < readsCount; i++)
+            rc[i] = readMatchRC[i] ? 1 : 0;
+        failOn(pgrc_match_set_results(ctx, readMatchPos.data(), rc.data(), readMismatchesCount.data()), "set_results");
+    }
+
+    void HipReadsMatcher::executeMatching(bool revCompMode) {
+        failOn(pgrc_match_run_pass(ctx, revCompMode ? 1 : 0), "run_pass");
+        fetchResults();
+    }
+
+    void HipReadsMatcher::matchConstantLengthReadsOnDevice() {
+        initMatching();
+        failOn(pgrc_match_run(ctx, revComplPg ? 1 : 0), "run");
+        fetchResults();
+    }
+
+    void HipReadsMatcher::continueMatchingConstantLengthReadsOnDevice(DefaultReadsMatcher *pMatcher) {
+        initMatchingContinuation(pMatcher);
+        failOn(pgrc_match_run(ctx, revComplPg ? 1 : 0), "run");
+        fetchResults();
+    }
+}

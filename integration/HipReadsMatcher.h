@@ -1,0 +1,53 @@
+// HipReadsMatcher -- the reference-side binding of libpgrc_match.so: a matcher class that plugs into
+// PgRC's DefaultReadsMatcher seam (matching/ReadsMatchers.h:24-83, :109-143) and forwards the matching to
+// the MI355X library through the C ABI of include/pgrc_match.h.
+//
+// This file is NEW code for the PgRC tree (it is not part of the reference); it is compiled against the
+// reference's headers.  Everything downstream of the matcher -- getMatchedReadsBitmap, exportMatchesInPgOrder /
+// exportMatchesInOriginalOrder, updateEntry -- is inherited unchanged and consumes the result fields this class
+// fills (readMatchPos, readMatchRC, readMismatchesCount, matchedReadsCount, matchedCountPerMismatches).
+#ifndef PGTOOLS_HIPREADSMATCHER_H
+#define PGTOOLS_HIPREADSMATCHER_H
+
+#include "matching/ReadsMatchers.h"
+
+struct pgrc_match_ctx;
+
+namespace PgTools {
+
+    class HipReadsMatcher : public AbstractReadsApproxMatcher {
+    private:
+        pgrc_match_ctx *ctx = nullptr;
+        const char hipMode;                  // 'c', 'd', 'i' or 'e' (the matcher the reference would have built)
+        const uint16_t seedChars;
+        bool uploaded = false;
+
+        void failOn(int code, const char *what);
+        void upload();
+        void fetchResults();
+
+    protected:
+        void initMatching() override;
+        void initMatchingContinuation(DefaultReadsMatcher *pMatcher) override;
+        // one pass on the device; the text handed to the library at initMatching() is the forward one, the
+        // reverse complement is derived on the GPU (the in-place RC of pgPtr by the caller is not needed).
+        void executeMatching(bool revCompMode = false) override;
+
+    public:
+        HipReadsMatcher(char *pgPtr, const uint_pg_len_max pgLength, bool revComplPg,
+                        ConstantLengthReadsSetInterface *readsSet, uint32_t matchPrefixLength,
+                        uint16_t readsExactMatchingChars, uint8_t maxMismatches, uint8_t minMismatches,
+                        char hipMode);
+
+        ~HipReadsMatcher() override;
+
+        // Same contract as DefaultReadsMatcher::matchConstantLengthReads() (ReadsMatchers.cpp:162-172) without
+        // its two host-side sweeps PgHelpers::reverseComplementInPlace(pgPtr, pgLength).
+        void matchConstantLengthReadsOnDevice();
+
+        // Same contract as continueMatchingConstantLengthReads (ReadsMatchers.cpp:174-184).
+        void continueMatchingConstantLengthReadsOnDevice(DefaultReadsMatcher *pMatcher);
+    };
+}
+
+#endif //PGTOOLS_HIPREADSMATCHER_H

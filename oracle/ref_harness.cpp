@@ -19,6 +19,9 @@
 #include "matching/ReadsMatchers.h"
 #include "readsset/PackedConstantLengthReadsSet.h"
 #include "utils/helper.h"
+#ifdef PGRC_WITH_HIP_ADAPTER
+#include "HipReadsMatcher.h"
+#endif
 
 using namespace PgTools;
 using namespace PgReadsSet;
@@ -163,6 +166,27 @@ int pgrc_ref_match(char mode, const char *pg, uint64_t G, const char *reads, uin
     }
     return 0;
 }
+
+#ifdef PGRC_WITH_HIP_ADAPTER
+// The drop-in itself: the reference's own flow with integration/HipReadsMatcher in the matcher seam.
+// entry 0 = DefaultReadsMatcher::matchConstantLengthReads() (base-class driver: initMatching, executeMatching(false),
+// in-place RC of the host text, executeMatching(true), RC back); entry 1 = matchConstantLengthReadsOnDevice().
+int pgrc_ref_match_via_adapter(char mode, const char *pg, uint64_t G, const char *reads, uint64_t n_lq,
+                               uint64_t n_n, uint32_t L, uint32_t seed, uint8_t kmax, uint8_t kmin, int rev_compl,
+                               int entry, uint64_t *pos, uint8_t *rc, uint8_t *mism, uint64_t *hist,
+                               uint64_t *matched) {
+    Silence quiet;
+    std::string text(pg, G);
+    ReadsHolder rh(reads, n_lq, n_n, L);
+    ApproxProbe<HipReadsMatcher> m((char *)text.data(), G, rev_compl, rh.iface,
+                                   DefaultReadsMatcher::DISABLED_PREFIX_MODE, seed, kmax, kmin, mode);
+    if (entry == 0) m.matchConstantLengthReads();
+    else m.matchConstantLengthReadsOnDevice();
+    if (memcmp(text.data(), pg, G) != 0) return 9; // the caller's text must come back unchanged
+    dump_approx(m, n_lq + n_n, pos, rc, mism, hist, matched, nullptr);
+    return 0;
+}
+#endif
 
 // copMEM index internals (CopMEMMatcher.cpp:69-231).  cumm/positions are
 // malloc'ed copies; free with pgrc_ref_free.

@@ -63,12 +63,16 @@ _PROTOS = [
     ("pgrc_match_set_pg_packed_device", C.c_int, [_P, _P, C.c_uint64]),
     ("pgrc_match_pack_pg_slice", C.c_int, [_P, _P, C.c_uint64, _P]),
     ("pgrc_match_set_reads_ascii", C.c_int, [_P, _P, C.c_uint64]),
+    ("pgrc_match_begin_reads", C.c_int, [_P, C.c_uint64]),
+    ("pgrc_match_append_reads_ascii", C.c_int, [_P, _P, C.c_uint64]),
+    ("pgrc_match_end_reads", C.c_int, [_P]),
     ("pgrc_match_set_reads_packed", C.c_int, [_P, _P, C.c_uint64]),
     ("pgrc_match_set_reads_device", C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
     ("pgrc_match_words_per_read", C.c_uint32, [C.c_uint32]),
     ("pgrc_match_init_results", C.c_int, [_P]),
     ("pgrc_match_set_results", C.c_int, [_P, _P, _P, _P]),
     ("pgrc_match_run", C.c_int, [_P, C.c_int]),
+    ("pgrc_match_run_pass", C.c_int, [_P, C.c_int]),
     ("pgrc_match_get_results", C.c_int, [_P, _P, _P, _P, _P, C.POINTER(C.c_uint64)]),
     ("pgrc_match_get_results_device", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     ("pgrc_match_extract_mismatches", C.c_int, [_P, _P, _P, _P, _P]),

@@ -284,50 +284,90 @@ static int begin_reads(pgrc_match_ctx *c, uint64_t n, bool own) {
     return alloc_results(c, n);
 }
 
-int pgrc_match_set_reads_ascii(pgrc_match_ctx *c, const char *reads, uint64_t n) {
-    if (!c || (!reads && n)) return PGRC_E_PARAM;
+// Chunked upload of ASCII rows: begin(n) -> append(rows, count)* -> end().  Lets a caller that can only
+// produce reads one by one (ConstantLengthReadsSetInterface::getRead, ReadsSetInterface.h:41) stream them
+// through a bounded host buffer.
+int pgrc_match_begin_reads(pgrc_match_ctx *c, uint64_t n) {
+    if (!c) return PGRC_E_PARAM;
     HIP_TRY(c, hipSetDevice(c->device));
     int e = begin_reads(c, n, true);
     if (e) return e;
-    const uint32_t L = c->prm.read_len;
     if ((e = pgrc_buf_ensure(c, c->nread_flag, n))) return e;
     HIP_TRY(c, hipMemsetAsync(c->nread_flag.p, 0, n ? n : 1, c->stream));
+    c->up_next = 0;
+    c->up_nidx.clear();
+    c->up_nrows.clear();
+    c->up_open = true;
+    return PGRC_OK;
+}
+
+int pgrc_match_append_reads_ascii(pgrc_match_ctx *c, const char *reads, uint64_t count) {
+    if (!c || (!reads && count)) return PGRC_E_PARAM;
+    if (!c->up_open || c->up_next + count > c->n) { c->err = "append_reads: outside begin/end or too many rows"; return PGRC_E_STATE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t L = c->prm.read_len;
     DevBuf stage, flag;
+    int e;
     const uint64_t CHR = std::max<uint64_t>(1, (256ull << 20) / L); // reads per staging chunk (~256 MiB)
-    if ((e = pgrc_buf_ensure(c, stage, (size_t)std::min(CHR, std::max<uint64_t>(n, 1)) * L))) return e;
+    if ((e = pgrc_buf_ensure(c, stage, (size_t)std::min(CHR, std::max<uint64_t>(count, 1)) * L))) return e;
     if ((e = pgrc_buf_ensure(c, flag, sizeof(uint32_t)))) { pgrc_buf_free(stage); return e; }
     (void)hipMemsetAsync(flag.p, 0, sizeof(uint32_t), c->stream);
     int rcode = PGRC_OK;
-    for (uint64_t off = 0; off < n && rcode == PGRC_OK; off += CHR) {
-        const uint64_t cnt = std::min(CHR, n - off);
+    std::vector<uint8_t> nf;
+    for (uint64_t off = 0; off < count && rcode == PGRC_OK; off += CHR) {
+        const uint64_t cnt = std::min(CHR, count - off);
+        const uint64_t first = c->up_next + off;
         if (hipMemcpyAsync(stage.p, reads + off * L, cnt * L, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_NO_DEVICE; break; }
-        rcode = pgrc_launch_pack_reads_ascii(c, (const uint8_t *)stage.p, off, cnt, L, (uint32_t *)c->reads_own.p, c->stride,
+        rcode = pgrc_launch_pack_reads_ascii(c, (const uint8_t *)stage.p, first, cnt, L, (uint32_t *)c->reads_own.p, c->stride,
                                              (uint8_t *)c->nread_flag.p, (uint32_t *)flag.p);
         if (hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_NO_DEVICE;
+        if (rcode != PGRC_OK) break;
+        // reads with 'N' -> byte path: keep their rows (they are a small minority)
+        nf.resize(cnt);
+        if (hipMemcpy(nf.data(), (const uint8_t *)c->nread_flag.p + first, cnt, hipMemcpyDeviceToHost) != hipSuccess) { rcode = PGRC_E_NO_DEVICE; break; }
+        for (uint64_t k = 0; k < cnt; k++)
+            if (nf[k]) {
+                c->up_nidx.push_back((uint32_t)(first + k));
+                c->up_nrows.insert(c->up_nrows.end(), reads + (off + k) * L, reads + (off + k + 1) * L);
+            }
     }
     uint32_t bad = 0;
     if (rcode == PGRC_OK && hipMemcpy(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) rcode = PGRC_E_NO_DEVICE;
     pgrc_buf_free(stage);
     pgrc_buf_free(flag);
-    if (rcode != PGRC_OK) { if (c->err.empty()) c->err = "set_reads_ascii: HIP error"; return rcode; }
+    if (rcode != PGRC_OK) { if (c->err.empty()) c->err = "append_reads_ascii: HIP error"; return rcode; }
     if (bad) { c->err = "reads contain a symbol outside ACGNT"; return PGRC_E_SYMBOL; }
-    // reads with 'N' -> byte path: gather their rows (host side; they are a small minority)
-    std::vector<uint8_t> nf(n);
-    if (n) HIP_TRY(c, hipMemcpy(nf.data(), c->nread_flag.p, n, hipMemcpyDeviceToHost));
-    std::vector<uint32_t> idx;
-    for (uint64_t i = 0; i < n; i++)
-        if (nf[i]) idx.push_back((uint32_t)i);
-    c->n_nreads = idx.size();
+    c->up_next += count;
+    return PGRC_OK;
+}
+
+int pgrc_match_end_reads(pgrc_match_ctx *c) {
+    if (!c) return PGRC_E_PARAM;
+    if (!c->up_open || c->up_next != c->n) { c->err = "end_reads: fewer rows appended than announced"; return PGRC_E_STATE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    int e;
+    c->n_nreads = c->up_nidx.size();
     if (c->n_nreads) {
-        std::vector<char> rows(c->n_nreads * (size_t)L);
-        for (size_t t = 0; t < idx.size(); t++) memcpy(rows.data() + t * L, reads + (uint64_t)idx[t] * L, L);
-        if ((e = pgrc_buf_ensure(c, c->nread_idx, idx.size() * sizeof(uint32_t)))) return e;
-        if ((e = pgrc_buf_ensure(c, c->nread_ascii, rows.size()))) return e;
-        HIP_TRY(c, hipMemcpy(c->nread_idx.p, idx.data(), idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->nread_ascii.p, rows.data(), rows.size(), hipMemcpyHostToDevice));
+        if ((e = pgrc_buf_ensure(c, c->nread_idx, c->up_nidx.size() * sizeof(uint32_t)))) return e;
+        if ((e = pgrc_buf_ensure(c, c->nread_ascii, c->up_nrows.size()))) return e;
+        HIP_TRY(c, hipMemcpy(c->nread_idx.p, c->up_nidx.data(), c->up_nidx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->nread_ascii.p, c->up_nrows.data(), c->up_nrows.size(), hipMemcpyHostToDevice));
     }
+    c->up_nidx.clear();
+    c->up_nidx.shrink_to_fit();
+    c->up_nrows.clear();
+    c->up_nrows.shrink_to_fit();
+    c->up_open = false;
     c->have_reads = true;
     return PGRC_OK;
+}
+
+int pgrc_match_set_reads_ascii(pgrc_match_ctx *c, const char *reads, uint64_t n) {
+    if (!c || (!reads && n)) return PGRC_E_PARAM;
+    int e = pgrc_match_begin_reads(c, n);
+    if (e) return e;
+    if ((e = pgrc_match_append_reads_ascii(c, reads, n))) return e;
+    return pgrc_match_end_reads(c);
 }
 
 int pgrc_match_set_reads_packed(pgrc_match_ctx *c, const uint8_t *packed, uint64_t n) {
@@ -389,7 +429,7 @@ int pgrc_match_set_results(pgrc_match_ctx *c, const uint64_t *pos, const uint8_t
     return PGRC_OK;
 }
 
-int pgrc_match_run(pgrc_match_ctx *c, int rev_compl_pg) {
+static int run_passes(pgrc_match_ctx *c, int first, int last) {
     if (!c) return PGRC_E_PARAM;
     if (!c->have_pg || !c->have_reads) { c->err = "run: set the pseudogenome and the reads first"; return PGRC_E_STATE; }
     HIP_TRY(c, hipSetDevice(c->device));
@@ -401,7 +441,7 @@ int pgrc_match_run(pgrc_match_ctx *c, int rev_compl_pg) {
     auto mark = [&]() { if (prof) (void)hipEventRecord(c->ev[evi], c->stream); evi++; };
     mark(); // 0
     if (c->prm.mode == 'c') {
-        for (int pass = 0; pass < (rev_compl_pg ? 2 : 1); pass++) {
+        for (int pass = first; pass <= last; pass++) {
             if (pass == 1) {
                 // PgHelpers::reverseComplementInPlace(pgPtr), ReadsMatchers.cpp:168 -- rebuilt every run like the reference
                 if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) return e;
@@ -414,9 +454,8 @@ int pgrc_match_run(pgrc_match_ctx *c, int rev_compl_pg) {
             mark(); // 3 / 6
         }
     } else {
-        if ((e = pgrc_seedidx_run(c, rev_compl_pg))) return e;
+        if ((e = pgrc_seedidx_run(c, first, last))) return e;
     }
-    const int ev_end_match = evi;
     if ((e = pgrc_launch_hist(c))) return e; // synchronises the stream
     mark();
     uint64_t ctr[16];
@@ -431,8 +470,8 @@ int pgrc_match_run(pgrc_match_ctx *c, int rev_compl_pg) {
         HIP_TRY(c, hipEventSynchronize(c->ev[evi - 1]));
         float ms = 0;
         if (c->prm.mode == 'c') {
-            for (int pass = 0; pass < (rev_compl_pg ? 2 : 1); pass++) {
-                const int b = 1 + 3 * pass;
+            int b = 1;
+            for (int pass = first; pass <= last; pass++, b += 3) {
                 (void)hipEventElapsedTime(&ms, c->ev[b], c->ev[b + 1]);
                 c->ctr.ms_index[pass] = ms;
                 (void)hipEventElapsedTime(&ms, c->ev[b + 1], c->ev[b + 2]);
@@ -442,9 +481,16 @@ int pgrc_match_run(pgrc_match_ctx *c, int rev_compl_pg) {
         (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[evi - 1]);
         c->ctr.ms_total = ms;
         c->ctr.ms_other = ms - c->ctr.ms_index[0] - c->ctr.ms_index[1] - c->ctr.ms_match[0] - c->ctr.ms_match[1];
-        (void)ev_end_match;
     }
     return PGRC_OK;
+}
+
+int pgrc_match_run(pgrc_match_ctx *c, int rev_compl_pg) { return run_passes(c, 0, rev_compl_pg ? 1 : 0); }
+
+// One executeMatching(revCompMode) (ReadsMatchers.h:46): strand 0 = the text as given, 1 = its reverse complement.
+int pgrc_match_run_pass(pgrc_match_ctx *c, int strand) {
+    if (strand < 0 || strand > 1) return PGRC_E_PARAM;
+    return run_passes(c, strand, strand);
 }
 
 int pgrc_match_get_results(pgrc_match_ctx *c, uint64_t *pos, uint8_t *rc, uint8_t *mism, uint64_t hist[256], uint64_t *matched) {

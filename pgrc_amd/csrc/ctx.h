@@ -16,6 +16,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "pgrc_match.h"
 
@@ -52,6 +53,12 @@ struct pgrc_match_ctx {
     DevBuf nread_idx;       // u32[n_nreads] read index
     DevBuf nread_ascii;     // u8[n_nreads][read_len]
     DevBuf nread_flag;      // u8[n] 1 = handled by the byte path
+
+    // chunked upload state (pgrc_match_begin_reads / _append_ / _end_)
+    bool up_open = false;
+    uint64_t up_next = 0;
+    std::vector<uint32_t> up_nidx;
+    std::vector<char> up_nrows;
 
     // results
     DevBuf d_pos, d_rc, d_mism, d_hist, d_counters;
@@ -103,7 +110,7 @@ int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand);
 int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_positions, uint64_t *count);
 
 // seedidx.hip (modes d / i / e)
-int pgrc_seedidx_run(pgrc_match_ctx *c, int rev_compl_pg);
+int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand);
 
 // results.hip
 int pgrc_launch_init_results(pgrc_match_ctx *c);

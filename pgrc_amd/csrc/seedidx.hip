@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) k_seed_table_init(uint64_t *keys, uint32_
     }
 }
 
-int pgrc_seedidx_run(pgrc_match_ctx *c, int rev_compl_pg) {
+int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
     const uint32_t L = c->prm.read_len;
     const char mode = c->prm.mode;
     SeedArgs a;
@@ -293,7 +293,7 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int rev_compl_pg) {
     HIP_TRY(c, hipGetLastError());
 
     unsigned long long *cursor = (unsigned long long *)c->s_tmp.p;
-    for (int pass = 0; pass < (rev_compl_pg ? 2 : 1); pass++) {
+    for (int pass = first_strand; pass <= last_strand; pass++) {
         if (pass == 1) {
             if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) return e;
             c->have_rc = true;

@@ -73,7 +73,14 @@ def have_ref() -> bool:
 def ref():
     global _ref
     if _ref is None:
+        # libpgrc_ref.so links the product library (for the adapter test): load that first so that both
+        # resolve to ONE HIP runtime (see pgrc_amd/_lib.py)
+        import pgrc_amd  # noqa: F401
         lib = C.CDLL(REF_SO)
+        if hasattr(lib, "pgrc_ref_match_via_adapter"):
+            lib.pgrc_ref_match_via_adapter.argtypes = [C.c_char, _P, C.c_uint64, _P, C.c_uint64, C.c_uint64, C.c_uint32,
+                                                       C.c_uint32, C.c_uint8, C.c_uint8, C.c_int, C.c_int, _P, _P, _P, _P,
+                                                       C.POINTER(C.c_uint64)]
         lib.pgrc_ref_match.argtypes = [C.c_char, _P, C.c_uint64, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                        C.c_uint8, C.c_uint8, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P,
                                        C.POINTER(C.c_uint64), _P]
@@ -205,3 +212,25 @@ def ref_extract(pg, pos, read, rc, cnt, org_idx=0, rev_compl_pair_file=False):
     k = ref().pgrc_ref_extract(_ptr(pg), pg.size, _ptr(read), read.size, int(pos), int(rc), int(cnt), int(org_idx),
                                1 if rev_compl_pair_file else 0, _ptr(codes), _ptr(offs))
     return codes[:k], offs[:k]
+
+
+def have_adapter() -> bool:
+    return have_ref() and hasattr(ref(), "pgrc_ref_match_via_adapter")
+
+
+def ref_match_via_adapter(mode, pg, reads, seed_len, kmax, kmin, rev_compl=True, n_nset=0, entry=1):
+    """The reference's own flow with integration/HipReadsMatcher plugged into the matcher seam (needs a GPU)."""
+    pg = np.ascontiguousarray(pg, dtype=np.uint8)
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    n, L = reads.shape
+    pos = np.empty(n, dtype=np.uint64)
+    rc = np.empty(n, dtype=np.uint8)
+    mism = np.empty(n, dtype=np.uint8)
+    hist = np.zeros(256, dtype=np.uint64)
+    matched = C.c_uint64(0)
+    e = ref().pgrc_ref_match_via_adapter(mode.encode(), _ptr(pg), pg.size, _ptr(reads), n - n_nset, n_nset, L, seed_len,
+                                         kmax, kmin, 1 if rev_compl else 0, entry, _ptr(pos), _ptr(rc), _ptr(mism),
+                                         _ptr(hist), C.byref(matched))
+    if e:
+        raise RuntimeError(f"adapter returned {e}")
+    return {"pos": pos, "rc": rc, "mism": mism, "hist": hist, "matched": int(matched.value)}

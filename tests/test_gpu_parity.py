@@ -286,3 +286,18 @@ def test_map_reads_into_pg_factory():
         assert m.matchedReadsCount == o["matched"] and np.array_equal(bitmap, o["pos"] != np.uint64(2**64 - 1))
     with pytest.raises(PgrcMatchError):
         mapReadsIntoPg(pg, True, reads, 38, 50, "x")
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="needs oracle/_ref (the compiled reference)")
+@pytest.mark.parametrize("mode,seed_len,n_nset", [("c", 38, 0), ("c", 38, 500), ("d", 38, 0), ("i", 38, 0), ("e", 100, 0)])
+@pytest.mark.parametrize("entry", [0, 1])
+def test_reference_adapter_drop_in(mode, seed_len, n_nset, entry):
+    """integration/HipReadsMatcher inside the REFERENCE's matcher hierarchy (compiled against its headers, its own
+    PackedConstantLengthReadsSet / SumOfConstantLengthReadsSets feeding it) against the reference's CPU matcher."""
+    if not orc.have_adapter():
+        pytest.skip("oracle/_ref was built without the adapter")
+    pg, reads = make_inputs(200000, 5000, 100, seed=61 + n_nset, n_with_n=n_nset)
+    kmax = 2 if mode != "e" else 0
+    r = orc.ref_match(mode, pg, reads, seed_len, kmax, 0, n_nset=n_nset)
+    a = orc.ref_match_via_adapter(mode, pg, reads, seed_len, kmax, 0, n_nset=n_nset, entry=entry)
+    assert_same_results(a, r, f"adapter mode {mode} entry {entry}")
