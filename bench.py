@@ -28,6 +28,7 @@ WORKLOADS = {
     "C3-PE": (100_000_000, 150, 1_875_000_000, 38, 50, "c", True),
     "tiny": (1_000_000, 150, 18_750_000, 38, 50, "c", False),
 }
+GATHER_CEILING_GPS = 51.0  # measured: tools/ubench/gather2.hip, profiles/r01_ubench_gather_width_ilp.txt
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -134,6 +135,11 @@ def main():
         alg_bytes = ctr["searched"][dom] * (rb + 10) + ctr["probes"][dom] * 8 + ctr["candidates"][dom] * (5 + rb)
         ms = ctr["ms_match"][dom]
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        # random lane-addresses issued by that launch: one 16-B head per probe, one 8-B entry per fetched entry,
+        # PW x 16-B per verified text window (tools/ubench: the chip sustains ~51 G of them per second)
+        pw = ((nw + 1 + 3) // 4)
+        gathers = ctr["probes"][dom] + ctr["entry_fetches"][dom] + ctr["verifies"][dom] * pw
+        gather_rate = gathers / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         out = {
             "metric": "reads matched/sec (150 bp) at 1/2/4/8 MI355X; achieved HBM GB/s",
             "value": value,
@@ -155,10 +161,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_copmem_match" + ("(fwd)" if dom == 0 else "(rc)"),
-                         "kernel_ms": ms, "algorithmic_bytes": alg_bytes},
+                         "kernel_ms": ms, "algorithmic_bytes": alg_bytes,
+                         "random_gathers": gathers, "gather_rate_G_per_s": gather_rate,
+                         "gather_ceiling_G_per_s": GATHER_CEILING_GPS, "gather_frac": gather_rate / GATHER_CEILING_GPS},
             "phases_ms": {"index_fwd": ctr["ms_index"][0], "match_fwd": ctr["ms_match"][0], "index_rc": ctr["ms_index"][1],
                           "match_rc": ctr["ms_match"][1], "other": ctr["ms_other"], "total_device": ctr["ms_total"]},
-            "counters": {k: ctr[k] for k in ("searched", "candidates", "probes", "index_entries")},
+            "counters": {k: ctr[k] for k in ("searched", "candidates", "probes", "entry_fetches", "verifies", "index_entries")},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax)

@@ -145,6 +145,8 @@ typedef struct {
     uint64_t searched[2];   /* reads not skipped (count > min_mismatches), per pass */
     uint64_t candidates[2]; /* verified candidates, per pass */
     uint64_t probes[2];     /* seed lookups, per pass */
+    uint64_t entry_fetches[2]; /* index entries fetched beyond the inline ones (mode c) */
+    uint64_t verifies[2];   /* text windows fetched and compared (mode c) */
     uint64_t index_entries[2];
     /* device time in ms of the last run, by kernel class (HIP events on the ctx stream) */
     float ms_index[2];

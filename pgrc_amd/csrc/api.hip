@@ -462,9 +462,11 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
     HIP_TRY(c, hipMemcpy(ctr, c->d_counters.p, sizeof ctr, hipMemcpyDeviceToHost));
     memset(&c->ctr, 0, sizeof c->ctr);
     for (int s = 0; s < 2; s++) {
-        c->ctr.searched[s] = ctr[3 * s + 0];
-        c->ctr.candidates[s] = ctr[3 * s + 1];
-        c->ctr.probes[s] = ctr[3 * s + 2];
+        c->ctr.searched[s] = ctr[8 * s + 0];
+        c->ctr.candidates[s] = ctr[8 * s + 1];
+        c->ctr.probes[s] = ctr[8 * s + 2];
+        c->ctr.entry_fetches[s] = ctr[8 * s + 3];
+        c->ctr.verifies[s] = ctr[8 * s + 4];
     }
     if (prof) {
         HIP_TRY(c, hipEventSynchronize(c->ev[evi - 1]));

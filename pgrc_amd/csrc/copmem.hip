@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
     if (active && a.nflag && a.nflag[i]) active = false;
     if (cin <= a.kmin) active = false;
 
-    uint64_t n_cand = 0, n_probe = 0;
+    uint64_t n_cand = 0, n_probe = 0, n_ent = 0, n_ver = 0;
     uint32_t rd[NW], sh[NW];
 #pragma unroll
     for (int k = 0; k < NW; k++) sh[k] = rd[k] = active ? a.reads[(uint64_t)k * a.stride + i] : 0u;
@@ -517,6 +517,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
             n_probe++;
         } else if (m0 == M_ENTRY) {
             v = inline1 ? e_inline1 : a.ent[lo + j];
+            n_ent += inline1 ? 0 : 1;
         }
         uint32_t pw[PWN];
         const uint32_t b = ((uint32_t)cand_p & 15u) * 2u;
@@ -541,6 +542,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                 mh += mism2(tw, rd[k], sym_mask(k, 0, H));
                 mt += mism2(tw, rd[k], sym_mask(k, H, (int)a.L));
             }
+            n_ver++;
             last_p = cand_p;
             last_mh = mh;
             last_mt = mt;
@@ -602,10 +604,13 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
     }
     if (a.counters) {
         const uint64_t s0 = wave_sum_u64(active ? 1ull : 0ull), s1 = wave_sum_u64(n_cand), s2 = wave_sum_u64(n_probe);
+        const uint64_t s3 = wave_sum_u64(n_ent), s4 = wave_sum_u64(n_ver);
         if ((threadIdx.x & 63) == 0) {
             atomicAdd(&a.counters[0], (unsigned long long)s0);
             atomicAdd(&a.counters[1], (unsigned long long)s1);
             atomicAdd(&a.counters[2], (unsigned long long)s2);
+            atomicAdd(&a.counters[3], (unsigned long long)s3);
+            atomicAdd(&a.counters[4], (unsigned long long)s4);
         }
     }
 }
@@ -706,7 +711,7 @@ int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
     a.pos = (uint64_t *)c->d_pos.p;
     a.rc = (uint8_t *)c->d_rc.p;
     a.mism = (uint8_t *)c->d_mism.p;
-    a.counters = (unsigned long long *)c->d_counters.p + 3 * strand;
+    a.counters = (unsigned long long *)c->d_counters.p + 8 * strand;
     a.L = c->prm.read_len;
     a.K = (uint32_t)c->cp.K;
     a.k2 = (uint32_t)c->cp.k2;
