@@ -132,7 +132,7 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf *bufs[] = {&c->pg2[0], &c->pg2[1], &c->reads_own, &c->nread_idx, &c->nread_ascii, &c->nread_flag, &c->d_pos,
-                      &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_cnt, &c->d_cumm, &c->d_ent, &c->d_head,
+                      &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_ent, &c->d_head, &c->d_ovf_key, &c->d_ovf_fp, &c->d_ovf_key2, &c->d_ovf_fp2, &c->d_mark,
                       &c->d_scan_tmp, &c->s_keys, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp};
     for (DevBuf *b : bufs) pgrc_buf_free(*b);
     if (c->have_events)

@@ -8,56 +8,83 @@
 //   query  : CopMEMMatcher::processApproxMatchQueryTight, CopMEMMatcher.cpp:483-566
 //   driver : CopMEMReadsApproxMatcher::executeMatching, matching/ReadsMatchers.cpp:421-451
 //
-// MI355X design
+// MI355X design (DESIGN.md section 4)
 //   * text and reads live 2-bit packed in HBM; a read is 10 dwords (L=150) held in VGPRs.
-//   * index build = count (atomics) -> exclusive scan -> scatter (atomics) -> per-bucket
-//     13-smallest selection; the racy order of the scatter is erased by the selection, so the
-//     result is the canonical serial index, bit for bit.  Pg windows are staged through LDS in
-//     coalesced tiles (adjacent sampled positions overlap by K-k1 symbols).
-//   * the index is laid out for 64-B HBM sectors, not as the reference's CSR: a 1-bit-per-bucket
-//     occupancy bitmap (64 MiB at 2^29 buckets: served from L2 / Infinity Cache) answers the ~50 %
-//     of probes that hit an empty bucket; an 8-B bucket head holds a single-entry bucket inline
-//     (70 % of the non-empty ones); every entry carries a 24-bit fingerprint of the symbols the
+//   * what bounds hash probing on gfx950 is the number of random lane-addresses per second (~51 G/s,
+//     the same for 4-, 8- and 16-byte accesses: tools/ubench/gather2.hip), not HBM bytes.  The index
+//     is therefore laid out so that a probe is ONE 16-byte gather: a bucket head holding the bucket's
+//     two smallest entries; every entry carries a 24-bit fingerprint of the window symbols the
 //     sparsified hash ignores, so a false candidate is rejected -- with exactly the reference's
 //     head-reject accounting -- without fetching its text window.
-//   * match = one read per lane; the reference's sequential per-read state machine (limit
-//     tightening, false-candidate budget, early exit) is kept exactly, so results are
-//     bit-identical.  The seed window is kept at the low bits of a shifting copy of the read
-//     (v_alignbit), so no register array is ever indexed dynamically.  Hamming distance on
-//     2-bit words: xor, fold pair bits, v_bcnt (popcount) under head/tail symbol masks.
-//   * all of it is HBM/latency bound integer work: no MFMA.
+//   * index build in ONE pass over the text: each sampled position cascades through its bucket head
+//     with two 64-bit atomicMin (the loser of slot 0 tries slot 1, the loser of slot 1 is appended to
+//     an overflow list); only the ~6 % of entries that overflow are sorted (rocPRIM radix sort) and
+//     laid out per bucket.  Minimum selection makes the result independent of execution order: it
+//     is the reference's SERIAL index (ascending positions, the 13 smallest kept), bit for bit.
+//   * match = one read per lane, as a per-lane state machine; the reference's sequential per-read
+//     semantics (limit tightening, false-candidate budget, early exit) are kept exactly.
+//   * all of it is random-access bound integer work: no MFMA.
 #include <stdlib.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "ctx.h"
 #include "devutil.h"
+
+#define HEAD_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define ENT_MASK ((1ull << 56) - 1)
+
+// 16-B bucket head:
+//   w0 = HEAD_EMPTY                         empty bucket
+//   w0 = entry0 [| count << 56], w1 = HEAD_EMPTY            one entry
+//   w0 = entry0,                 w1 = entry1                two entries
+//   w0 = entry0 | count << 56,   w1 = base                  count = min(n, 13) >= 3: entries 1.. at ent[base + j - 1]
+// entry = position << 24 | fingerprint (56 bits), so u64 order = position order.
+__device__ __forceinline__ uint32_t head_count(const ulonglong2 hd) {
+    if (hd.x == HEAD_EMPTY) return 0u;
+    const uint32_t c = (uint32_t)(hd.x >> 56) & 15u;
+    return c ? c : (hd.y == HEAD_EMPTY ? 1u : 2u);
+}
 
 // ----------------------------------------------------------------------------- index build
 
 #define IDX_TPB 256
 #define IDX_TILE_WORDS (IDX_TPB + 16) // 256 positions * k1(<=16) symbols / 16 + K/16 + slack
 
-// One block walks tiles of IDX_TPB consecutive sampled positions; the tile's text words are
-// loaded once, coalesced, into LDS; every thread then hashes its K-symbol window from LDS.
-template <bool FILL>
+// One block walks tiles of IDX_TPB consecutive sampled positions; the tile's text words are loaded once,
+// coalesced, into LDS; every thread hashes its K-symbol window from LDS.  Three sweeps, because on gfx950 a
+// random atomic WITHOUT return value runs ~2.5x faster than one whose result is used (measured: 375 M
+// returning 64-bit atomicMin cascades took 63 ms, the three sweeps below 36 ms):
+//   PASS 0  atomicMin(slot0, entry)                              -> slot0 = the bucket's smallest entry
+//   PASS 1  entry != slot0 ?  atomicMin(slot1, entry), mark it   -> slot1 = the second smallest
+//   PASS 2  marked and entry != slot1 ?  append to the overflow list
+// Minimum selection makes the outcome independent of execution order.
+template <int PASS>
 __global__ void __launch_bounds__(IDX_TPB)
-k_copmem_index_pass(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, uint64_t npos, uint32_t k1, uint32_t K,
-                    uint32_t mask, uint32_t *__restrict__ cnt, const uint32_t *__restrict__ cumm,
-                    uint64_t *__restrict__ ent) {
+k_copmem_index_build(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, uint64_t npos, uint32_t k1, uint32_t K,
+                     uint32_t mask, ulonglong2 *__restrict__ head, uint8_t *__restrict__ mark,
+                     unsigned long long *__restrict__ ovf_count, uint64_t *__restrict__ ovf_key,
+                     uint32_t *__restrict__ ovf_fp, uint64_t ovf_cap) {
     __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
     __shared__ uint32_t tile[IDX_TILE_WORDS + 8];
     hash_lut_init(lut);
     const uint64_t ntiles = (npos + IDX_TPB - 1) / IDX_TPB;
     for (uint64_t tIdx = blockIdx.x; tIdx < ntiles; tIdx += gridDim.x) {
         const uint64_t t0 = tIdx * IDX_TPB;
+        const uint64_t t = t0 + threadIdx.x;
         const uint64_t p0 = t0 * k1;
         const uint64_t w0 = p0 >> 4;
-        // symbols needed: [p0, p0 + (IDX_TPB-1)*k1 + K)  (+16 for the funnel's upper word)
         const uint32_t need = (uint32_t)((((p0 & 15) + (uint64_t)(IDX_TPB - 1) * k1 + K + 15) >> 4) + 5);
         __syncthreads();
         for (uint32_t w = threadIdx.x; w < need; w += IDX_TPB) tile[w] = (w0 + w < pg_words_alloc) ? pg[w0 + w] : 0u;
         __syncthreads();
-        const uint64_t t = t0 + threadIdx.x;
-        if (t < npos) {
+        bool push = false;     // PASS 2: this lane's entry overflows its bucket head
+        uint32_t push_h = 0, push_fp = 0;
+        uint64_t push_p = 0;
+        if (t < npos && (PASS != 2 || mark[t])) {
             const uint64_t p = t * k1;
             const uint32_t q = (uint32_t)((p >> 4) - w0);
             const uint32_t sh = ((uint32_t)p & 15u) * 2u;
@@ -65,250 +92,278 @@ k_copmem_index_pass(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, ui
             uint32_t fp;
             const uint32_t h = copmem_hash32_fp(funnel_r(a0, a1, sh), funnel_r(a1, a2, sh), funnel_r(a2, a3, sh),
                                                 funnel_r(a3, a4, sh), K, lut, &fp) & mask;
-            if (!FILL) {
-                atomicAdd(&cnt[h], 1u);
+            unsigned long long *slot = reinterpret_cast<unsigned long long *>(head + h);
+            const unsigned long long e = (p << PGRC_FP_BITS) | fp;
+            if (PASS == 0) {
+                atomicMin(slot, e);
+            } else if (PASS == 1) {
+                const bool loser = slot[0] != e;
+                if (loser) atomicMin(slot + 1, e);
+                mark[t] = loser ? 1 : 0;
             } else {
-                const uint32_t slot = cumm[h] + atomicAdd(&cnt[h], 1u);
-                ent[slot] = (p << PGRC_FP_BITS) | fp; // position in the high bits: u64 order = position order
+                push = slot[1] != e;
+                push_h = h;
+                push_fp = fp;
+                push_p = p;
+            }
+        }
+        if (PASS == 2) {
+            // wave-aggregated append into THIS BLOCK's region: every block owns a cursor (64 B apart) and a slice
+            // of the overflow arrays, so no two blocks ever contend for an address (a single shared cursor
+            // serialises ~5 M same-address atomics: measured 57 ms instead of 3)
+            const unsigned long long m = __ballot(push);
+            if (m) {
+                const uint32_t lane = threadIdx.x & 63u;
+                const int leader = __ffsll((long long)m) - 1;
+                unsigned long long base = 0;
+                if ((int)lane == leader) base = atomicAdd(ovf_count + 8ull * blockIdx.x, (unsigned long long)__popcll(m));
+                base = __shfl(base, leader, 64);
+                if (push) {
+                    const unsigned long long idx = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                    if (idx < ovf_cap) {
+                        ovf_key[(uint64_t)blockIdx.x * ovf_cap + idx] = ((uint64_t)push_h << 32) | push_p;
+                        ovf_fp[(uint64_t)blockIdx.x * ovf_cap + idx] = push_fp;
+                    }
+                }
             }
         }
     }
 }
 
-// ---- exclusive scan of u32 counts (optionally capped at 13), 4096 elements per block ----
-#define SCAN_TPB 256
-#define SCAN_EPT 16
-#define SCAN_EPB (SCAN_TPB * SCAN_EPT)
-
-template <bool CAP>
-__device__ __forceinline__ uint32_t scan_val(uint32_t v) {
-    return CAP ? (v < PGRC_BUCKET_CAP ? v : PGRC_BUCKET_CAP) : v;
-}
-
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *smem /*[SCAN_TPB/64+1]*/, uint32_t *total) {
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t inc = v;
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t u = __shfl_up(inc, o, 64);
-        if (lane >= (uint32_t)o) inc += u;
-    }
-    if (lane == 63) smem[wv] = inc;
-    __syncthreads();
-    uint32_t woff = 0, tot = 0;
-    for (uint32_t k = 0; k < SCAN_TPB / 64; k++) {
-        uint32_t s = smem[k];
-        if (k < wv) woff += s;
-        tot += s;
-    }
-    __syncthreads();
-    *total = tot;
-    return woff + inc - v;
-}
-
-template <bool CAP>
-__global__ void __launch_bounds__(SCAN_TPB) k_scan_sums(const uint32_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ bsum) {
-    __shared__ uint32_t smem[SCAN_TPB / 64 + 1];
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_EPB + (uint64_t)threadIdx.x * SCAN_EPT;
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_EPT; k++)
-        if (base + k < n) s += scan_val<CAP>(in[base + k]);
-    uint32_t tot;
-    block_exclusive_scan(s, smem, &tot);
-    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
-}
-
-// single block: exclusive scan of the block sums in place; writes the grand total to bsum[nb]
-__global__ void __launch_bounds__(1024) k_scan_bsums(uint32_t *bsum, uint64_t nb) {
-    __shared__ uint32_t smem[1024 / 64 + 1];
-    __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint64_t base = 0; base < nb; base += 1024) {
-        const uint64_t i = base + threadIdx.x;
-        uint32_t v = i < nb ? bsum[i] : 0;
-        // wave scan + cross-wave
-        const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        uint32_t inc = v;
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t u = __shfl_up(inc, o, 64);
-            if (lane >= (uint32_t)o) inc += u;
-        }
-        if (lane == 63) smem[wv] = inc;
-        __syncthreads();
-        uint32_t woff = 0, tot = 0;
-        for (uint32_t k = 0; k < 16; k++) {
-            uint32_t s = smem[k];
-            if (k < wv) woff += s;
-            tot += s;
-        }
-        const uint32_t carry = carry_s;
-        if (i < nb) bsum[i] = carry + woff + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) bsum[nb] = carry_s;
-}
-
-// out[i] = exclusive prefix; out[n] = out[n+1] = total  (cumm has hash_size+2 entries)
-template <bool CAP>
-__global__ void __launch_bounds__(SCAN_TPB)
-k_scan_write(const uint32_t *__restrict__ in, uint64_t n, const uint32_t *__restrict__ bsum, uint64_t nb,
-             uint32_t *__restrict__ out) {
-    __shared__ uint32_t smem[SCAN_TPB / 64 + 1];
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_EPB + (uint64_t)threadIdx.x * SCAN_EPT;
-    uint32_t v[SCAN_EPT];
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_EPT; k++) {
-        v[k] = (base + k < n) ? scan_val<CAP>(in[base + k]) : 0;
+// exclusive prefix of the per-block overflow counts (nblk <= 4096), total and the largest count
+__global__ void __launch_bounds__(1024) k_ovf_prefix(const unsigned long long *__restrict__ cursors, uint32_t nblk,
+                                                     unsigned long long *__restrict__ prefix /*[nblk+2]*/) {
+    __shared__ unsigned long long sh[1024];
+    unsigned long long v[4], s = 0, mx = 0;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t b = threadIdx.x * 4 + k;
+        v[k] = b < nblk ? cursors[8ull * b] : 0ull;
         s += v[k];
+        mx = max(mx, v[k]);
     }
-    uint32_t tot;
-    uint32_t off = block_exclusive_scan(s, smem, &tot) + bsum[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < SCAN_EPT; k++) {
-        if (base + k < n) out[base + k] = off;
-        off += v[k];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        unsigned long long u = threadIdx.x >= (uint32_t)o ? sh[threadIdx.x - o] : 0ull;
+        __syncthreads();
+        sh[threadIdx.x] += u;
+        __syncthreads();
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        out[n] = bsum[nb];
-        out[n + 1] = bsum[nb];
+    unsigned long long run = sh[threadIdx.x] - s;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t b = threadIdx.x * 4 + k;
+        if (b < nblk) prefix[b] = run;
+        run += v[k];
     }
+    if (threadIdx.x == 1023) prefix[nblk] = sh[1023];
+    // largest per-block count (regions must not overflow): reduce through the now free shared array
+    __syncthreads();
+    sh[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (threadIdx.x < (uint32_t)o) sh[threadIdx.x] = max(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) prefix[nblk + 1] = sh[0];
 }
 
-// Per bucket: move its min(count,13) smallest entries (= smallest positions), ascending, to the front
-// -- this turns the racy scatter order into the reference's serial order (ascending p, later p
-// dropped) -- and emit the bucket head and the occupancy bitmap.
-#define ENT_MASK ((1ull << 56) - 1)
-#define HEAD_COUNT(w0) ((uint32_t)((w0) >> 56) & 15u)
-
-// 16-B bucket head (a random 16-B gather costs the same as an 8-B one on gfx950: the limit is
-// lane-addresses per second, tools/ubench/gather2.hip):
-//   w0 = entry0 | count << 56          count = min(n, 13); w0 == 0 <=> empty bucket
-//   w1 = entry1                        when count == 2
-//      = start of the bucket in ent[]  when count >= 3 (entries 1.. are fetched from there)
 __global__ void __launch_bounds__(256)
-k_bucket_finalize(const uint32_t *__restrict__ cumm, uint64_t hash_size, uint64_t *__restrict__ ent,
-                  ulonglong2 *__restrict__ head) {
-    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // grid covers hash_size exactly
-    const uint32_t lo = cumm[h], n = cumm[h + 1] - lo;
-    ulonglong2 hd = make_ulonglong2(0ull, 0ull);
-    if (n == 1) {
-        hd.x = ent[lo] | (1ull << 56);
-    } else if (n == 2) {
-        const uint64_t x = ent[lo], y = ent[lo + 1];
-        hd.x = min(x, y) | (2ull << 56);
-        hd.y = max(x, y);
-        ent[lo] = min(x, y);
-        ent[lo + 1] = max(x, y);
-    } else if (n > 2) {
-        uint64_t a[PGRC_BUCKET_CAP];
-#pragma unroll
-        for (int k = 0; k < (int)PGRC_BUCKET_CAP; k++) a[k] = ~0ull;
-        for (uint32_t j = 0; j < n; j++) {
-            uint64_t x = ent[lo + j];
-#pragma unroll
-            for (int k = 0; k < (int)PGRC_BUCKET_CAP; k++) {
-                const uint64_t m = min(a[k], x);
-                x = max(a[k], x);
-                a[k] = m;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < (int)PGRC_BUCKET_CAP; k++)
-            if ((uint32_t)k < n) ent[lo + k] = a[k];
-        hd.x = a[0] | ((uint64_t)min(n, PGRC_BUCKET_CAP) << 56);
-        hd.y = lo;
+k_ovf_compact(const unsigned long long *__restrict__ cursors, const unsigned long long *__restrict__ prefix,
+              uint64_t region_cap, const uint64_t *__restrict__ key_in, const uint32_t *__restrict__ fp_in,
+              uint64_t *__restrict__ key_out, uint32_t *__restrict__ fp_out) {
+    const uint64_t n = min((uint64_t)cursors[8ull * blockIdx.x], region_cap), dst = prefix[blockIdx.x];
+    const uint64_t src = (uint64_t)blockIdx.x * region_cap;
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        key_out[dst + i] = key_in[src + i];
+        fp_out[dst + i] = fp_in[src + i];
     }
-    head[h] = hd;
 }
 
-static int run_scan(pgrc_match_ctx *c, bool cap, const uint32_t *in, uint64_t n, uint32_t *out) {
-    const uint64_t nb = (n + SCAN_EPB - 1) / SCAN_EPB;
-    int e = pgrc_buf_ensure(c, c->d_scan_tmp, (nb + 2) * sizeof(uint32_t));
-    if (e) return e;
-    uint32_t *bsum = (uint32_t *)c->d_scan_tmp.p;
-    if (cap) {
-        hipLaunchKernelGGL(k_scan_sums<true>, dim3((uint32_t)nb), dim3(SCAN_TPB), 0, c->stream, in, n, bsum);
-        hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, c->stream, bsum, nb);
-        hipLaunchKernelGGL(k_scan_write<true>, dim3((uint32_t)nb), dim3(SCAN_TPB), 0, c->stream, in, n, bsum, nb, out);
-    } else {
-        hipLaunchKernelGGL(k_scan_sums<false>, dim3((uint32_t)nb), dim3(SCAN_TPB), 0, c->stream, in, n, bsum);
-        hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, c->stream, bsum, nb);
-        hipLaunchKernelGGL(k_scan_write<false>, dim3((uint32_t)nb), dim3(SCAN_TPB), 0, c->stream, in, n, bsum, nb, out);
+__global__ void __launch_bounds__(256) k_ovf_flags(const uint64_t *__restrict__ key, uint64_t n, uint32_t *__restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || (key[i] >> 32) != (key[i - 1] >> 32)) ? 1u : 0u;
+}
+
+// sorted overflow records -> per-bucket segments [entry1, overflow entries ascending] in ent[], head fix-up
+__global__ void __launch_bounds__(256)
+k_ovf_finalize(const uint64_t *__restrict__ key, const uint32_t *__restrict__ fp, const uint32_t *__restrict__ runidx,
+               uint64_t n, ulonglong2 *__restrict__ head, uint64_t *__restrict__ ent) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = key[i];
+    const uint32_t h = (uint32_t)(k >> 32);
+    const uint64_t r = runidx[i] - 1u;                       // ordinal of this record's run
+    ent[i + r + 1] = ((k & 0xFFFFFFFFull) << PGRC_FP_BITS) | fp[i];
+    if (i == 0 || (uint32_t)(key[i - 1] >> 32) != h) {       // first record of its bucket
+        uint32_t len = 1;
+        while (len < PGRC_BUCKET_CAP - 2 && i + len < n && (uint32_t)(key[i + len] >> 32) == h) len++;
+        ulonglong2 hd = head[h];
+        ent[i + r] = hd.y;                                   // entry1 opens the segment
+        hd.x |= (uint64_t)(2u + len) << 56;                  // len is capped so that count <= 13
+        hd.y = i + r;
+        head[h] = hd;
     }
+}
+
+#define IDX_MAX_BLOCKS 4096u
+
+// Sweeps 0-2; leaves the overflow records compacted in d_ovf_key2 / d_ovf_fp2 and their number in *nrec_out.
+// Returns PGRC_OK with *region_overflow = true when a block's region was too small (caller retries bigger).
+static int build_once(pgrc_match_ctx *c, int strand, uint64_t region_cap, uint64_t *nrec_out, bool *region_overflow) {
+    const uint32_t K = (uint32_t)c->cp.K, k1 = (uint32_t)c->cp.k1;
+    const uint64_t hs = c->cp.hash_size;
+    const uint64_t ntiles = (c->npos + IDX_TPB - 1) / IDX_TPB;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ntiles, 1), IDX_MAX_BLOCKS);
+    int e;
+    if ((e = pgrc_buf_ensure(c, c->d_head, hs * 2 * sizeof(uint64_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->d_ovf_key, ((uint64_t)grid * region_cap + 16) * sizeof(uint64_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->d_ovf_fp, ((uint64_t)grid * region_cap + 16) * sizeof(uint32_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->d_scan_tmp, (8ull * IDX_MAX_BLOCKS + IDX_MAX_BLOCKS + 8) * sizeof(uint64_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->d_mark, c->npos + 16))) return e;
+    unsigned long long *cursors = (unsigned long long *)c->d_scan_tmp.p;
+    unsigned long long *prefix = cursors + 8ull * IDX_MAX_BLOCKS;
+    HIP_TRY(c, hipMemsetAsync(c->d_head.p, 0xFF, hs * 2 * sizeof(uint64_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(cursors, 0, (8ull * IDX_MAX_BLOCKS + IDX_MAX_BLOCKS + 8) * sizeof(uint64_t), c->stream));
+    *nrec_out = 0;
+    *region_overflow = false;
+    if (!c->npos) return PGRC_OK;
+#define LAUNCH_PASS(P)                                                                                                   \
+    hipLaunchKernelGGL(k_copmem_index_build<P>, dim3(grid), dim3(IDX_TPB), 0, c->stream, (const uint32_t *)c->pg2[strand].p, \
+                       c->pg_words + PGRC_PG_PAD_WORDS, c->npos, k1, K, (uint32_t)(hs - 1), (ulonglong2 *)c->d_head.p,       \
+                       (uint8_t *)c->d_mark.p, cursors, (uint64_t *)c->d_ovf_key.p, (uint32_t *)c->d_ovf_fp.p, region_cap)
+    LAUNCH_PASS(0);
+    LAUNCH_PASS(1);
+    LAUNCH_PASS(2);
+#undef LAUNCH_PASS
+    hipLaunchKernelGGL(k_ovf_prefix, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long *)cursors, grid, prefix);
     HIP_TRY(c, hipGetLastError());
+    unsigned long long tail[2] = {0, 0}; // total, largest region count
+    HIP_TRY(c, hipMemcpyAsync(tail, prefix + grid, sizeof tail, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (tail[1] > region_cap) { *region_overflow = true; *nrec_out = tail[1]; return PGRC_OK; }
+    *nrec_out = tail[0];
+    if (tail[0]) {
+        if ((e = pgrc_buf_ensure(c, c->d_ovf_key2, (tail[0] + 16) * sizeof(uint64_t)))) return e;
+        if ((e = pgrc_buf_ensure(c, c->d_ovf_fp2, (tail[0] + 16) * sizeof(uint32_t)))) return e;
+        hipLaunchKernelGGL(k_ovf_compact, dim3(grid), dim3(256), 0, c->stream, (const unsigned long long *)cursors,
+                           (const unsigned long long *)prefix, region_cap, (const uint64_t *)c->d_ovf_key.p,
+                           (const uint32_t *)c->d_ovf_fp.p, (uint64_t *)c->d_ovf_key2.p, (uint32_t *)c->d_ovf_fp2.p);
+        HIP_TRY(c, hipGetLastError());
+    }
     return PGRC_OK;
 }
 
 int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
-    const uint64_t G = c->G;
     const uint32_t K = (uint32_t)c->cp.K, k1 = (uint32_t)c->cp.k1;
-    const uint64_t hs = c->cp.hash_size;
-    c->npos = (G >= K) ? (G - K) / k1 + 1 : 0;
-    int e;
-    if ((e = pgrc_buf_ensure(c, c->d_cnt, (hs + 2) * sizeof(uint32_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->d_cumm, (hs + 2) * sizeof(uint32_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->d_ent, (c->npos + 16) * sizeof(uint64_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->d_head, hs * 2 * sizeof(uint64_t)))) return e;
-    uint32_t *cnt = (uint32_t *)c->d_cnt.p, *cumm = (uint32_t *)c->d_cumm.p;
-    uint64_t *ent = (uint64_t *)c->d_ent.p;
-    const uint32_t *pg = (const uint32_t *)c->pg2[strand].p;
-    const uint64_t pg_alloc = c->pg_words + PGRC_PG_PAD_WORDS;
-    HIP_TRY(c, hipMemsetAsync(cnt, 0, (hs + 2) * sizeof(uint32_t), c->stream));
+    c->npos = (c->G >= K) ? (c->G - K) / k1 + 1 : 0;
     const uint64_t ntiles = (c->npos + IDX_TPB - 1) / IDX_TPB;
-    const uint32_t grid = (uint32_t)(ntiles < 256u * 16u ? (ntiles ? ntiles : 1) : 256u * 16u);
-    if (c->npos)
-        hipLaunchKernelGGL(k_copmem_index_pass<false>, dim3(grid), dim3(IDX_TPB), 0, c->stream, pg, pg_alloc, c->npos, k1, K,
-                           (uint32_t)(hs - 1), cnt, (const uint32_t *)nullptr, (uint64_t *)nullptr);
-    if ((e = run_scan(c, false, cnt, hs, cumm))) return e;
-    HIP_TRY(c, hipMemsetAsync(cnt, 0, (hs + 2) * sizeof(uint32_t), c->stream));
-    if (c->npos)
-        hipLaunchKernelGGL(k_copmem_index_pass<true>, dim3(grid), dim3(IDX_TPB), 0, c->stream, pg, pg_alloc, c->npos, k1, K,
-                           (uint32_t)(hs - 1), cnt, (const uint32_t *)cumm, ent);
-    hipLaunchKernelGGL(k_bucket_finalize, dim3((uint32_t)(hs / 256)), dim3(256), 0, c->stream, (const uint32_t *)cumm, hs, ent,
-                       (ulonglong2 *)c->d_head.p);
-    HIP_TRY(c, hipGetLastError());
+    const uint64_t grid = std::min<uint64_t>(std::max<uint64_t>(ntiles, 1), IDX_MAX_BLOCKS);
+    // on uniform text ~6 % of the entries overflow their two inline slots; every block's region starts with
+    // room for 25 % of its positions and grows to whatever a low-complexity text needs
+    uint64_t region_cap = std::max<uint64_t>((c->npos / grid) / 4 + 1024, c->ovf_cap_hint);
+    uint64_t nrec = 0;
+    bool again = false;
+    int e = build_once(c, strand, region_cap, &nrec, &again);
+    if (e) return e;
+    if (again) {
+        region_cap = nrec + 1024; // nrec = the largest per-block count seen
+        c->ovf_cap_hint = region_cap;
+        if ((e = build_once(c, strand, region_cap, &nrec, &again))) return e;
+        if (again) { c->err = "index build: overflow regions did not converge"; return PGRC_E_ALLOC; }
+    }
+    c->n_ovf = nrec;
+    if (nrec) {
+        DevBuf skey, sfp, flag, runidx, temp;
+        auto cleanup = [&]() { pgrc_buf_free(skey); pgrc_buf_free(sfp); pgrc_buf_free(flag); pgrc_buf_free(runidx); pgrc_buf_free(temp); };
+        size_t t1 = 0, t2 = 0;
+        hipError_t he = rocprim::radix_sort_pairs(nullptr, t1, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                                                  (uint32_t *)nullptr, (size_t)nrec, 0, 64, c->stream);
+        if (he == hipSuccess)
+            he = rocprim::inclusive_scan(nullptr, t2, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)nrec, rocprim::plus<uint32_t>(), c->stream);
+        if (he != hipSuccess) { c->err = "rocprim size query failed"; return PGRC_E_NO_DEVICE; }
+        if ((e = pgrc_buf_ensure(c, skey, nrec * sizeof(uint64_t))) || (e = pgrc_buf_ensure(c, sfp, nrec * sizeof(uint32_t))) ||
+            (e = pgrc_buf_ensure(c, flag, nrec * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, runidx, nrec * sizeof(uint32_t))) ||
+            (e = pgrc_buf_ensure(c, temp, std::max(t1, t2))) || (e = pgrc_buf_ensure(c, c->d_ent, (2 * nrec + 16) * sizeof(uint64_t)))) {
+            cleanup();
+            return e;
+        }
+        const uint32_t grid2 = (uint32_t)((nrec + 255) / 256);
+        he = rocprim::radix_sort_pairs(temp.p, t1, (uint64_t *)c->d_ovf_key2.p, (uint64_t *)skey.p, (uint32_t *)c->d_ovf_fp2.p,
+                                       (uint32_t *)sfp.p, (size_t)nrec, 0, 64, c->stream);
+        if (he == hipSuccess) {
+            hipLaunchKernelGGL(k_ovf_flags, dim3(grid2), dim3(256), 0, c->stream, (const uint64_t *)skey.p, (uint64_t)nrec, (uint32_t *)flag.p);
+            he = rocprim::inclusive_scan(temp.p, t2, (uint32_t *)flag.p, (uint32_t *)runidx.p, (size_t)nrec, rocprim::plus<uint32_t>(), c->stream);
+        }
+        if (he == hipSuccess) {
+            hipLaunchKernelGGL(k_ovf_finalize, dim3(grid2), dim3(256), 0, c->stream, (const uint64_t *)skey.p, (const uint32_t *)sfp.p,
+                               (const uint32_t *)runidx.p, (uint64_t)nrec, (ulonglong2 *)c->d_head.p, (uint64_t *)c->d_ent.p);
+            he = hipGetLastError();
+        }
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        cleanup();
+        if (he != hipSuccess) { c->err = std::string("index overflow pass: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
+    } else if ((e = pgrc_buf_ensure(c, c->d_ent, 64))) {
+        return e;
+    }
     c->index_strand = strand;
     return PGRC_OK;
 }
 
-// canonical layout for tests: capped CSR exactly as the reference leaves cumm / sampledPositions
+// ---- canonical export for tests: the reference's (cumm, sampledPositions) from heads + ent ----
+#define SCAN_TPB 256
+#define SCAN_EPT 16
+#define SCAN_EPB (SCAN_TPB * SCAN_EPT)
+
+__global__ void __launch_bounds__(256) k_export_counts(const ulonglong2 *__restrict__ head, uint64_t hs, uint32_t *__restrict__ cnt) {
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < hs; h += (uint64_t)gridDim.x * blockDim.x)
+        cnt[h] = head_count(head[h]);
+}
+
 __global__ void __launch_bounds__(256)
-k_export_compact(const uint32_t *__restrict__ cumm_full, const uint32_t *__restrict__ cumm_cap, uint64_t hash_size,
-                 const uint64_t *__restrict__ ent, uint32_t *__restrict__ pos_cap) {
-    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < hash_size;
-         h += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t lo = cumm_full[h], lc = cumm_cap[h], n = cumm_cap[h + 1] - lc;
-        for (uint32_t k = 0; k < n; k++) pos_cap[lc + k] = (uint32_t)(ent[lo + k] >> PGRC_FP_BITS);
+k_export_positions(const ulonglong2 *__restrict__ head, const uint64_t *__restrict__ ent, const uint32_t *__restrict__ cumm,
+                   uint64_t hs, uint32_t *__restrict__ positions) {
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < hs; h += (uint64_t)gridDim.x * blockDim.x) {
+        const ulonglong2 hd = head[h];
+        const uint32_t c = head_count(hd), lo = cumm[h];
+        for (uint32_t j = 0; j < c; j++) {
+            const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (c == 2 ? hd.y : ent[(uint32_t)hd.y + j - 1]);
+            positions[lo + j] = (uint32_t)(e >> PGRC_FP_BITS);
+        }
     }
 }
 
 int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_positions, uint64_t *count) {
     const uint64_t hs = c->cp.hash_size;
-    DevBuf cc, pc;
+    DevBuf cnt, cumm, pos, temp;
+    auto cleanup = [&]() { pgrc_buf_free(cnt); pgrc_buf_free(cumm); pgrc_buf_free(pos); pgrc_buf_free(temp); };
     int e;
-    if ((e = pgrc_buf_ensure(c, cc, (hs + 2) * sizeof(uint32_t)))) return e;
-    // after the fill pass d_cnt again holds the raw (uncapped) bucket counts
-    if ((e = run_scan(c, true, (const uint32_t *)c->d_cnt.p, hs, (uint32_t *)cc.p))) { pgrc_buf_free(cc); return e; }
+    if ((e = pgrc_buf_ensure(c, cnt, (hs + 2) * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, cumm, (hs + 2) * sizeof(uint32_t)))) { cleanup(); return e; }
+    HIP_TRY(c, hipMemsetAsync(cnt.p, 0, (hs + 2) * sizeof(uint32_t), c->stream));
+    const uint32_t sgrid = (uint32_t)((hs + 255) / 256 < 65536u * 8u ? (hs + 255) / 256 : 65536u * 8u);
+    hipLaunchKernelGGL(k_export_counts, dim3(sgrid), dim3(256), 0, c->stream, (const ulonglong2 *)c->d_head.p, hs, (uint32_t *)cnt.p);
+    size_t tb = 0;
+    hipError_t he = rocprim::exclusive_scan(nullptr, tb, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)(hs + 2), rocprim::plus<uint32_t>(), c->stream);
+    if (he == hipSuccess && (e = pgrc_buf_ensure(c, temp, tb))) { cleanup(); return e; }
+    if (he == hipSuccess)
+        he = rocprim::exclusive_scan(temp.p, tb, (uint32_t *)cnt.p, (uint32_t *)cumm.p, 0u, (size_t)(hs + 2), rocprim::plus<uint32_t>(), c->stream);
     uint32_t total = 0;
-    HIP_TRY(c, hipMemcpyAsync(&total, (uint32_t *)cc.p + hs, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (he == hipSuccess) he = hipMemcpyAsync(&total, (uint32_t *)cumm.p + hs, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    if (he != hipSuccess) { cleanup(); c->err = std::string("export_index: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
     if (count) *count = total;
-    if (h_cumm) HIP_TRY(c, hipMemcpy(h_cumm, cc.p, (hs + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (h_cumm && hipMemcpy(h_cumm, cumm.p, (hs + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return PGRC_E_NO_DEVICE; }
     if (h_positions && total) {
-        if ((e = pgrc_buf_ensure(c, pc, (size_t)total * sizeof(uint32_t)))) { pgrc_buf_free(cc); return e; }
-        const uint32_t sgrid = (uint32_t)((hs + 255) / 256 < 65536u * 8u ? (hs + 255) / 256 : 65536u * 8u);
-        hipLaunchKernelGGL(k_export_compact, dim3(sgrid), dim3(256), 0, c->stream, (const uint32_t *)c->d_cumm.p,
-                           (const uint32_t *)cc.p, hs, (const uint64_t *)c->d_ent.p, (uint32_t *)pc.p);
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipMemcpy(h_positions, pc.p, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if ((e = pgrc_buf_ensure(c, pos, (size_t)total * sizeof(uint32_t)))) { cleanup(); return e; }
+        hipLaunchKernelGGL(k_export_positions, dim3(sgrid), dim3(256), 0, c->stream, (const ulonglong2 *)c->d_head.p,
+                           (const uint64_t *)c->d_ent.p, (const uint32_t *)cumm.p, hs, (uint32_t *)pos.p);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+            hipMemcpy(h_positions, pos.p, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+            cleanup();
+            c->err = "export_index: positions";
+            return PGRC_E_NO_DEVICE;
+        }
     }
-    pgrc_buf_free(cc);
-    pgrc_buf_free(pc);
+    cleanup();
     return PGRC_OK;
 }
 
@@ -337,110 +392,9 @@ struct ReadState {
     bool done;
 };
 
-// One candidate entry against read `rd` (2-bit words).  Order of the checks = the reference's:
-// bounds (:517-520), head count vs limit (:523-539, +1 false), tail (:540-551, +2 falses), accept
-// (:552-560).  The fingerprint test decides most head rejects without touching the text: its
-// symbols are head symbols of the window (mask fpm), so fp mismatches > limit => head count > limit.
-template <int NW>
-__device__ __forceinline__ void try_candidate(const MatchArgs &a, const uint32_t (&rd)[NW], uint64_t e, uint32_t s,
-                                              uint32_t fp_read, uint32_t fpm, int H, ReadState &st,
-                                              uint64_t &n_cand) {
-    const uint64_t sp = e >> PGRC_FP_BITS;
-    if ((uint64_t)s > sp) return;
-    const uint64_t p = sp - s;
-    if (p + a.L > a.G) return;
-    n_cand++;
-    const uint32_t x = ((uint32_t)e ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
-    if ((uint32_t)__popc((x | (x >> 1)) & fpm) > st.limit) { st.falses += 1; return; }
-    const uint32_t *src = a.pg + (p >> 4);
-    const uint32_t b = ((uint32_t)p & 15u) * 2u;
-    uint32_t pw[NW + 1];
-#pragma unroll
-    for (int k = 0; k <= NW; k++) pw[k] = src[k];
-    uint32_t mh = 0, mt = 0;
-#pragma unroll
-    for (int k = 0; k < NW; k++) {
-        const uint32_t tw = funnel_r(pw[k], pw[k + 1], b);
-        mh += mism2(tw, rd[k], sym_mask(k, 0, H));
-        mt += mism2(tw, rd[k], sym_mask(k, H, (int)a.L));
-    }
-    if (mh > st.limit) { st.falses += 1; return; }
-    const uint32_t m = mh + mt;
-    if (m > st.limit) { st.falses += 2; return; }
-    st.cur = m;
-    st.best = p;
-    if (m <= a.kmin) { st.done = true; return; }
-    st.limit = m - 1u;
-}
-
-template <int NW>
-__global__ void __launch_bounds__(MATCH_TPB) k_copmem_match(const MatchArgs a) {
-    __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
-    hash_lut_init(lut);
-    __syncthreads();
-
-    const uint64_t i = (uint64_t)blockIdx.x * MATCH_TPB + threadIdx.x;
-    bool active = i < a.n;
-    const uint32_t cin = active ? a.mism[i] : 0u;
-    if (active && a.nflag && a.nflag[i]) active = false; // 'N' reads: byte-path kernel
-    if (cin <= a.kmin) active = false;                    // ReadsMatchers.cpp:430
-
-    uint64_t n_cand = 0, n_probe = 0;
-    if (active) {
-        const int H = ((int)a.L / 8) * 8; // head = whole 8-symbol groups (CopMEMMatcher.cpp:495)
-        uint32_t rd[NW], sh[NW];
-#pragma unroll
-        for (int k = 0; k < NW; k++) sh[k] = rd[k] = a.reads[(uint64_t)k * a.stride + i];
-
-        ReadState st;
-        st.limit = (cin < a.kmax) ? cin - 1u : a.kmax;                 // :488-489
-        st.falses = 0;
-        st.cur = cin;
-        st.best = PGRC_NOT_MATCHED_POS;
-        st.done = false;
-        const uint32_t budget = (a.L + 1u - a.K) / a.k2;               // :496-498
-        const uint32_t sbits = 2u * a.k2;
-
-        for (uint32_t s = 0; s + a.K <= a.L && !st.done; s += a.k2) {  // :503
-            uint32_t fp_read;
-            const uint32_t h = copmem_hash32_fp(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
-                                                NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
-            n_probe++;
-            const ulonglong2 hd = a.head[h];
-            if (hd.x) {
-                const uint32_t fpm = fp_head_mask(a.K, s, (uint32_t)H);
-                const uint32_t cnt = HEAD_COUNT(hd.x);
-                uint32_t nb = cnt;
-                if (st.falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET);     // :510-514
-                for (uint32_t j = 0; j < nb && !st.done; j++) {
-                    const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (cnt == 2 ? hd.y : a.ent[(uint32_t)hd.y + j]);
-                    try_candidate<NW>(a, rd, e, s, fp_read, fpm, H, st, n_cand);
-                }
-            }
-            // slide the seed window by k2 symbols
-#pragma unroll
-            for (int k = 0; k < NW - 1; k++) sh[k] = funnel_r(sh[k], sh[k + 1], sbits);
-            sh[NW - 1] >>= sbits;
-        }
-        if (st.best != PGRC_NOT_MATCHED_POS && st.cur < cin) {         // ReadsMatchers.cpp:437-447
-            a.pos[i] = a.strand ? a.G - (st.best + a.L) : st.best;
-            a.rc[i] = (uint8_t)a.strand;
-            a.mism[i] = (uint8_t)st.cur;
-        }
-    }
-    if (a.counters) {
-        const uint64_t s0 = wave_sum_u64(active ? 1ull : 0ull), s1 = wave_sum_u64(n_cand), s2 = wave_sum_u64(n_probe);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&a.counters[0], (unsigned long long)s0);
-            atomicAdd(&a.counters[1], (unsigned long long)s1);
-            atomicAdd(&a.counters[2], (unsigned long long)s2);
-        }
-    }
-}
-
-// Per-lane state machine version of the same query.  The sequential kernel above makes a whole wave
-// wait out up to three dependent memory latencies per seed (bucket head -> bucket entry -> text
-// window) whenever ANY of its 64 reads needs them.  Here every lane advances its own read by one
+// The query as a per-lane state machine.  A plain loop over seeds makes a whole wave wait out up to
+// three dependent memory latencies per seed (bucket head -> bucket entry -> text window) whenever ANY
+// of its 64 reads needs them.  Here every lane advances its own read by one
 // memory access per iteration -- a head (mode 0), the next entry of a multi-entry bucket (mode 1) or
 // a text window to verify (mode 2) -- and all lanes' loads of an iteration are issued together, so an
 // iteration costs one latency.  The per-read order of events is exactly the reference's.
@@ -464,7 +418,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
     if (active && a.nflag && a.nflag[i]) active = false;
     if (cin <= a.kmin) active = false;
 
-    uint64_t n_cand = 0, n_probe = 0, n_ent = 0, n_ver = 0;
+    uint32_t n_cand = 0, n_probe = 0, n_ent = 0, n_ver = 0;
     uint32_t rd[NW], sh[NW];
 #pragma unroll
     for (int k = 0; k < NW; k++) sh[k] = rd[k] = active ? a.reads[(uint64_t)k * a.stride + i] : 0u;
@@ -508,7 +462,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
         const uint32_t m0 = mode;
         const uint32_t s = si * a.k2;
         // ---- issue this iteration's loads
-        ulonglong2 hd = make_ulonglong2(0ull, 0ull);
+        ulonglong2 hd = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
         uint64_t v = 0;
         if (m0 == M_PROBE) {
             const uint32_t h = copmem_hash32_fp(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
@@ -516,7 +470,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
             hd = a.head[h];
             n_probe++;
         } else if (m0 == M_ENTRY) {
-            v = inline1 ? e_inline1 : a.ent[lo + j];
+            v = inline1 ? e_inline1 : a.ent[lo + j - 1];
             n_ent += inline1 ? 0 : 1;
         }
         uint32_t pw[PWN];
@@ -552,13 +506,13 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
             bool have = false;
             uint64_t e = 0;
             if (m0 == M_PROBE) {
-                if (hd.x) {
-                    const uint32_t cnt = HEAD_COUNT(hd.x);
+                const uint32_t cnt = head_count(hd);
+                if (cnt) {
                     nb = cnt;
                     if (st.falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET); // :510-514
                     inline1 = cnt == 2;
                     e_inline1 = hd.y;
-                    lo = (uint32_t)hd.y;
+                    lo = (uint32_t)hd.y;   // count >= 3: entries 1.. live at ent[lo + j - 1]
                     e = hd.x & ENT_MASK;
                     have = true;
                     j = 1;
@@ -644,12 +598,12 @@ k_copmem_match_ascii(const MatchArgs a, const uint32_t *__restrict__ nidx, const
             h &= a.mask;
             n_probe++;
             const ulonglong2 hd = a.head[h];
-            if (!hd.x) continue;
-            const uint32_t cnt = HEAD_COUNT(hd.x);
+            const uint32_t cnt = head_count(hd);
+            if (!cnt) continue;
             uint32_t nb = cnt;
             if (falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET);
             for (uint32_t j = 0; j < nb; j++) {
-                const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (cnt == 2 ? hd.y : a.ent[(uint32_t)hd.y + j]);
+                const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (cnt == 2 ? hd.y : a.ent[(uint32_t)hd.y + j - 1]);
                 const uint64_t sp = e >> PGRC_FP_BITS;
                 if ((uint64_t)s > sp) continue;
                 const uint64_t p = sp - s;
@@ -690,11 +644,7 @@ k_copmem_match_ascii(const MatchArgs a, const uint32_t *__restrict__ nidx, const
 template <int NW>
 static void launch_match(pgrc_match_ctx *c, const MatchArgs &a) {
     const uint32_t grid = (uint32_t)((a.n + MATCH_TPB - 1) / MATCH_TPB);
-    const char *ev = getenv("PGRC_MATCH_KERNEL"); // tuning knob: "seq" = wave-sequential variant
-    if (ev && ev[0] == 's')
-        hipLaunchKernelGGL(k_copmem_match<NW>, dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
-    else
-        hipLaunchKernelGGL(k_copmem_match_sm<NW>, dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+    hipLaunchKernelGGL(k_copmem_match_sm<NW>, dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
 }
 
 int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {

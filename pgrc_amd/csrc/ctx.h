@@ -5,10 +5,10 @@
 //   reads2        u32[NW][stride]          word-major ("transposed") reads: thread i of a wave
 //                                          reads word w of read i at reads2[w*stride+i] => every
 //                                          wave-level load is one coalesced 256-B line
-//   head          2 x u64[hash_size]       w0 = entry0 | count<<56 (0 = empty); w1 = entry1 (count 2) or the
-//                                          bucket's start in ent[] (count >= 3): one 16-B gather per probe
-//   ent           u64[npos]                (pos << 24 | 24-bit fingerprint), per bucket the 13 smallest first
-//   cumm / cnt    u32[hash_size+2]         build-time CSR starts / counters
+//   head          2 x u64[hash_size]       the bucket's two smallest entries (pos << 24 | 24-bit fingerprint); for
+//                                          buckets with >= 3 entries w0 also carries the count, w1 the segment base
+//                                          in ent[]: one 16-B gather per probe (copmem.hip)
+//   ent           u64[<= 2 * overflow]     per overflowing bucket: [entry1, entries 2..12 ascending]
 //   pos/rc/mism   u64[n] / u8[n] / u8[n]   per-read results (ReadsMatchers.h:32-35,115)
 #pragma once
 
@@ -69,7 +69,8 @@ struct pgrc_match_ctx {
     // copMEM index (rebuilt per pass, buffers reused)
     pgrc_copmem_params cp{};
     uint64_t npos = 0;
-    DevBuf d_cnt, d_cumm, d_ent, d_head, d_scan_tmp;
+    DevBuf d_ent, d_head, d_ovf_key, d_ovf_fp, d_ovf_key2, d_ovf_fp2, d_mark, d_scan_tmp;
+    uint64_t n_ovf = 0, ovf_cap_hint = 0;
     int index_strand = -1;  // which strand the buffers currently describe
 
     // read-side seed index (modes d / i / e)
