@@ -40,7 +40,9 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("PGRC_BENCH_WORKLOAD", "C3"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=3_000_000)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + PGRC_BENCH_FORCE_DEVICE=0 rehearses the N>1 path on a one-GPU box (collectives staged through the host)")
     args = ap.parse_args()
 
     import numpy as np
@@ -54,11 +56,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if "PGRC_BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["PGRC_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n_per, L, G, seed_len, M, mode, paired = WORKLOADS[args.workload]
     kmax = L // M
@@ -95,7 +102,12 @@ def main():
 
     def step():
         if world > 1:
-            dist.all_gather_into_tensor(d_full[: slice_words * world], d_slice)
+            if args.dist_backend == "nccl":
+                dist.all_gather_into_tensor(d_full[: slice_words * world], d_slice)
+            else:
+                host = torch.empty(slice_words * world, dtype=torch.int32)
+                dist.all_gather_into_tensor(host, d_slice.cpu())
+                d_full[: slice_words * world].copy_(host)
             torch.cuda.current_stream().synchronize()
             ctx.set_pg_packed_device(d_full.data_ptr(), G)
         ctx.init_results()
@@ -115,7 +127,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -220,15 +232,21 @@ def cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax):
     b = max((t_big - t_small) / (ns - n_small), 1e-12)
     a = max(t_small - b * n_small, 0.0)
     value = n_per / (a + b * n_per)
-    # the sample also cross-checks the GPU result on the same reads (matched set / counts are
-    # thread-count independent in the reference; positions only with the serial index build)
+    # The sample is also compared with the GPU result on the same reads.  NOTE: timed at `threads` > 1 the
+    # reference builds its copMEM index with its racy multithreaded code (CopMEMMatcher.cpp:238-254, :284-305;
+    # which of a crowded bucket's entries survive the 13-entry cap varies from run to run), so a small number
+    # of reads in repeats legitimately differ; bit-parity is pinned against the SERIAL index build
+    # (tools/fullscale_parity.py, tests/).
     pos, rc, mism, _, _ = ctx.get_results()
-    agree = bool(np.array_equal(mism[:ns], r["mism"]) and np.array_equal(rc[:ns], r["rc"]))
+    diff = int((mism[:ns] != r["mism"]).sum())
     return {"value": value, "unit": "reads/s", "cores": threads, "kind": kind,
             "sample": f"whole {G}-bp Pg, first {ns} reads of the workload, both strands incl. index builds; two runs "
                       f"(n={n_small}: {t_small:.2f}s, n={ns}: {t_big:.2f}s) => fixed {a:.2f}s + {b * 1e6:.3f}us/read, "
                       f"extrapolated to {n_per} reads; sample-only rate {ns / t_big:.0f} reads/s",
-            "fixed_s": a, "per_read_us": b * 1e6, "sample_counts_match_gpu": agree, "prep_s": prep_s}
+            "fixed_s": a, "per_read_us": b * 1e6, "prep_s": prep_s,
+            "sample_reads_with_other_mismatch_count_than_gpu": diff,
+            "note": "reference timed as shipped at -t %d (racy multithreaded index build); bit-parity is pinned against "
+                    "its serial index build elsewhere" % threads}
 
 
 if __name__ == "__main__":

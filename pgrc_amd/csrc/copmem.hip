@@ -386,30 +386,42 @@ struct MatchArgs {
 #define MATCH_TPB 256
 
 // Per-read state of the reference's sequential query (CopMEMMatcher.cpp:483-566).
+#define POS_NONE 0xFFFFFFFFu // text positions are < 2^32 - 256 (api.hip: alloc_pg)
 struct ReadState {
-    uint32_t limit, falses, cur;
-    uint64_t best;
+    uint32_t limit, falses, cur, best;
     bool done;
 };
 
 // The query as a per-lane state machine.  A plain loop over seeds makes a whole wave wait out up to
 // three dependent memory latencies per seed (bucket head -> bucket entry -> text window) whenever ANY
-// of its 64 reads needs them.  Here every lane advances its own read by one
-// memory access per iteration -- a head (mode 0), the next entry of a multi-entry bucket (mode 1) or
-// a text window to verify (mode 2) -- and all lanes' loads of an iteration are issued together, so an
-// iteration costs one latency.  The per-read order of events is exactly the reference's.
+// of its 64 reads needs them.  Here every lane advances its own read by one memory access per
+// iteration -- a head (M_PROBE), the next entries of a long bucket (M_ENTRY) or a text window to verify
+// (M_VERIFY) -- and all lanes' loads of an iteration are issued together, so an iteration costs one
+// latency.  The per-read order of events is exactly the reference's.
+//
+// Every random access costs one of the chip's ~50 G line requests per second whatever its width, so:
+//   * bucket entries beyond the two in the head are fetched two at a time (one 16-B gather);
+//   * verified alignments are remembered per read in a small LDS cache (8 direct-mapped slots): a read
+//     accepted with m > 0 mismatches -- or lying in a repeat -- meets the same alignments again at every
+//     later seed sampled there; their head/tail counts cannot change, only the limit they are judged
+//     against does, so the text window is fetched once.
 #define SM_MAX_SEEDS 240
+#define VC_SLOTS 8
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) U32x4A4 { u32x4 v; }; // 16-B load that only needs 4-B alignment
+struct __attribute__((packed, aligned(8))) U64x2A8 { unsigned long long x, y; }; // 16-B load, 8-B aligned
 template <int NW>
 __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a) {
     __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
     __shared__ uint32_t fpm_tab[SM_MAX_SEEDS];
+    __shared__ uint2 vcache[VC_SLOTS][MATCH_TPB]; // {position, head count | tail count << 16}
     hash_lut_init(lut);
     const int H = ((int)a.L / 8) * 8;
     const uint32_t nseeds = (a.L - a.K) / a.k2 + 1; // seeds s = 0, k2, ... with s + K <= L
     for (uint32_t t = threadIdx.x; t < nseeds && t < SM_MAX_SEEDS; t += blockDim.x)
         fpm_tab[t] = fp_head_mask(a.K, t * a.k2, (uint32_t)H);
+#pragma unroll
+    for (int k = 0; k < VC_SLOTS; k++) vcache[k][threadIdx.x] = make_uint2(POS_NONE, 0u);
     __syncthreads();
 
     const uint64_t i = (uint64_t)blockIdx.x * MATCH_TPB + threadIdx.x;
@@ -427,7 +439,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
     st.limit = (cin < a.kmax) ? cin - 1u : a.kmax;
     st.falses = 0;
     st.cur = cin;
-    st.best = PGRC_NOT_MATCHED_POS;
+    st.best = POS_NONE;
     st.done = false;
     const uint32_t budget = (a.L + 1u - a.K) / a.k2;
     const uint32_t sbits = 2u * a.k2;
@@ -435,18 +447,13 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
     enum { M_PROBE = 0, M_ENTRY = 1, M_VERIFY = 2, M_FIN = 3, M_ADV = 4 };
     uint32_t mode = active ? M_PROBE : M_FIN;
     uint32_t si = 0;              // seed index: s = si * k2
-    uint32_t lo = 0, nb = 0, j = 0, fp_read = 0;
-    uint64_t cand_p = 0, e_inline1 = 0;
-    bool inline1 = false; // entry 1 of the current bucket sits in e_inline1 (2-entry bucket)
-    // the last verified alignment and its head/tail counts: a read accepted with m > 0 mismatches meets
-    // its own alignment again at every later seed that is sampled there; the counts cannot change, only
-    // the limit they are judged against does -- no need to fetch the text window again
-    uint64_t last_p = PGRC_NOT_MATCHED_POS;
-    uint32_t last_mh = 0, last_mt = 0;
+    uint32_t lo = 0, nb = 0, j = 0, fp_read = 0, cand_p = 0;
+    uint64_t pend_e = 0;          // an entry already in registers (entry 1 of the head / second half of a pair)
+    bool has_pend = false;
     constexpr int PWN = ((NW + 1 + 3) / 4) * 4;
 
     // judge a verified alignment (head count mh, tail count mt) exactly as CopMEMMatcher.cpp:536-560
-    auto judge = [&](uint32_t mh, uint32_t mt, uint64_t p) {
+    auto judge = [&](uint32_t mh, uint32_t mt, uint32_t p) {
         const uint32_t m = mh + mt;
         if (mh > st.limit) st.falses += 1;                       // :536-539
         else if (m > st.limit) st.falses += 2;                   // :542-551 (counted twice)
@@ -470,11 +477,20 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
             hd = a.head[h];
             n_probe++;
         } else if (m0 == M_ENTRY) {
-            v = inline1 ? e_inline1 : a.ent[lo + j - 1];
-            n_ent += inline1 ? 0 : 1;
+            if (has_pend) {
+                v = pend_e;
+                has_pend = false;
+            } else {
+                // entries j, j+1 of the bucket in one gather (the second is kept only if the bucket has it)
+                const U64x2A8 q = *reinterpret_cast<const U64x2A8 *>(a.ent + lo + j - 1);
+                v = q.x;
+                pend_e = q.y;
+                has_pend = j + 1 < nb;
+                n_ent++;
+            }
         }
         uint32_t pw[PWN];
-        const uint32_t b = ((uint32_t)cand_p & 15u) * 2u;
+        const uint32_t b = (cand_p & 15u) * 2u;
         if (m0 == M_VERIFY) {
             const uint32_t *src = a.pg + (cand_p >> 4); // the text is padded: PWN words are always in bounds
 #pragma unroll
@@ -497,9 +513,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                 mt += mism2(tw, rd[k], sym_mask(k, H, (int)a.L));
             }
             n_ver++;
-            last_p = cand_p;
-            last_mh = mh;
-            last_mt = mt;
+            vcache[(cand_p * 0x9E3779B1u) >> 29][threadIdx.x] = make_uint2(cand_p, mh | (mt << 16));
             judge(mh, mt, cand_p);
             next = st.done ? M_FIN : (j < nb ? M_ENTRY : M_ADV);
         } else if (m0 <= M_ENTRY) {
@@ -510,9 +524,9 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                 if (cnt) {
                     nb = cnt;
                     if (st.falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET); // :510-514
-                    inline1 = cnt == 2;
-                    e_inline1 = hd.y;
-                    lo = (uint32_t)hd.y;   // count >= 3: entries 1.. live at ent[lo + j - 1]
+                    has_pend = cnt == 2 && nb > 1; // entry 1 of a two-entry bucket sits in the head
+                    pend_e = hd.y;
+                    lo = (uint32_t)hd.y;            // count >= 3: entries 1.. live at ent[lo + j - 1]
                     e = hd.x & ENT_MASK;
                     have = true;
                     j = 1;
@@ -529,21 +543,26 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                 const uint64_t sp = e >> PGRC_FP_BITS;
                 if ((uint64_t)s <= sp && sp - s + a.L <= a.G) {      // :517-520
                     n_cand++;
+                    const uint32_t p = (uint32_t)(sp - s);
                     const uint32_t x = ((uint32_t)e ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
                     if ((uint32_t)__popc((x | (x >> 1)) & fpm_tab[si]) > st.limit) {
                         st.falses += 1;                              // certain head reject
-                    } else if (sp - s == last_p) {
-                        judge(last_mh, last_mt, last_p);
-                        if (st.done) next = M_FIN;
                     } else {
-                        cand_p = sp - s;
-                        next = M_VERIFY;
+                        const uint2 cv = vcache[(p * 0x9E3779B1u) >> 29][threadIdx.x];
+                        if (cv.x == p) {
+                            judge(cv.y & 0xFFFFu, cv.y >> 16, p);
+                            if (st.done) next = M_FIN;
+                        } else {
+                            cand_p = p;
+                            next = M_VERIFY;
+                        }
                     }
                 }
             }
         }
         if (next == M_ADV) {
             si++;
+            has_pend = false;
 #pragma unroll
             for (int k = 0; k < NW - 1; k++) sh[k] = funnel_r(sh[k], sh[k + 1], sbits);
             sh[NW - 1] >>= sbits;
@@ -551,8 +570,8 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
         }
         mode = next;
     }
-    if (active && st.best != PGRC_NOT_MATCHED_POS && st.cur < cin) {
-        a.pos[i] = a.strand ? a.G - (st.best + a.L) : st.best;
+    if (active && st.best != POS_NONE && st.cur < cin) {
+        a.pos[i] = a.strand ? a.G - ((uint64_t)st.best + a.L) : (uint64_t)st.best;
         a.rc[i] = (uint8_t)a.strand;
         a.mism[i] = (uint8_t)st.cur;
     }
