@@ -119,7 +119,11 @@ int pgrc_match_create(const pgrc_match_params *p, pgrc_match_ctx **out) {
     c->prm = *p;
     c->device = dev;
     c->nw = (p->read_len + 15) / 16;
-    if (pgrc_buf_ensure(c, c->d_hist, 256 * sizeof(uint64_t)) || pgrc_buf_ensure(c, c->d_counters, 16 * sizeof(uint64_t))) {
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
+    }
+    if (pgrc_buf_ensure(c, c->d_hist, 256 * sizeof(uint64_t)) || pgrc_buf_ensure(c, c->d_counters, 32 * sizeof(uint64_t))) {
         g_create_err = c->err;
         delete c;
         return PGRC_E_NO_DEVICE;
@@ -132,7 +136,7 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf *bufs[] = {&c->pg2[0], &c->pg2[1], &c->reads_own, &c->nread_idx, &c->nread_ascii, &c->nread_flag, &c->d_pos,
-                      &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_ent, &c->d_head, &c->d_ovf_key, &c->d_ovf_fp, &c->d_ovf_key2, &c->d_ovf_fp2, &c->d_mark,
+                      &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_ent, &c->d_head, &c->d_ovf_key, &c->d_ovf_fp, &c->d_ovf_key2, &c->d_ovf_fp2, &c->d_mark, &c->d_skey, &c->d_sfp, &c->d_flag, &c->d_runidx, &c->d_sorttmp,
                       &c->d_scan_tmp, &c->s_keys, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp};
     for (DevBuf *b : bufs) pgrc_buf_free(*b);
     if (c->have_events)
@@ -435,7 +439,7 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
     HIP_TRY(c, hipSetDevice(c->device));
     int e;
     if (!c->have_results && (e = pgrc_match_init_results(c))) return e;
-    HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, 16 * sizeof(uint64_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, 32 * sizeof(uint64_t), c->stream));
     const bool prof = c->profiling && c->have_events;
     int evi = 0;
     auto mark = [&]() { if (prof) (void)hipEventRecord(c->ev[evi], c->stream); evi++; };

@@ -273,8 +273,9 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     }
     c->n_ovf = nrec;
     if (nrec) {
-        DevBuf skey, sfp, flag, runidx, temp;
-        auto cleanup = [&]() { pgrc_buf_free(skey); pgrc_buf_free(sfp); pgrc_buf_free(flag); pgrc_buf_free(runidx); pgrc_buf_free(temp); };
+        // scratch lives in the context (grow-only): no hipMalloc / hipFree (= device synchronisation) per build
+        DevBuf &skey = c->d_skey, &sfp = c->d_sfp, &flag = c->d_flag, &runidx = c->d_runidx, &temp = c->d_sorttmp;
+        auto cleanup = [&]() {};
         size_t t1 = 0, t2 = 0;
         hipError_t he = rocprim::radix_sort_pairs(nullptr, t1, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr,
                                                   (uint32_t *)nullptr, (size_t)nrec, 0, 64, c->stream);
@@ -380,6 +381,7 @@ struct MatchArgs {
     uint64_t *pos;
     uint8_t *rc, *mism;
     unsigned long long *counters; // [0] searched [1] candidates [2] probes
+    unsigned long long *work;     // global read cursor of the persistent match kernel
     uint32_t L, K, k2, mask, kmax, kmin, strand;
 };
 
@@ -406,15 +408,47 @@ struct ReadState {
 //     later seed sampled there; their head/tail counts cannot change, only the limit they are judged
 //     against does, so the text window is fetched once.
 #define SM_MAX_SEEDS 240
-#define VC_SLOTS 8
+#define VC_SLOTS 4
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) U32x4A4 { u32x4 v; }; // 16-B load that only needs 4-B alignment
 struct __attribute__((packed, aligned(8))) U64x2A8 { unsigned long long x, y; }; // 16-B load, 8-B aligned
-template <int NW>
+// KQ = K/4 when known at compile time (7 for the default seed 38), 0 = run-time loop.
+template <int KQ>
+__device__ __forceinline__ uint32_t hash_fp_window(const uint32_t w0, const uint32_t w1, const uint32_t w2, const uint32_t w3,
+                                                   uint32_t K, const uint32_t *lut, uint32_t *fp_out) {
+    if (KQ == 0) return copmem_hash32_fp(w0, w1, w2, w3, K, lut, fp_out);
+    const uint32_t w[4] = {w0, w1, w2, w3};
+    uint32_t h = 4u * KQ, fp = 0, fb = 0;
+#pragma unroll
+    for (int j = 0; j < KQ; j++) {
+        const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;   // static register, static shift
+        const uint32_t x = (j < 3) ? lut[b & 63u] : lut[64u + (b & 15u)];
+        h = (h ^ (x + (uint32_t)j)) * 171717u;
+        const uint32_t width = (j < 3) ? 2u : 4u;
+        if (fb + width <= PGRC_FP_BITS) {
+            fp |= ((j < 3) ? (b >> 6) : (b >> 4)) << fb;
+            fb += width;
+        }
+    }
+    *fp_out = fp;
+    return h;
+}
+
+#define MATCH_CHUNK 256u // reads a wave reserves per visit to the global work counter
+
+// Persistent, self-refilling lanes.  With one read per lane for the lifetime of a wave, ~35 % of the
+// lane-iterations are idle: reads that match exactly leave after a few seeds (30 % of the reads in the forward
+// pass, 43 % in the RC pass) while their wave runs on for the full seed list -- and the memory system is only
+// kept busy by lanes that have a gather in flight.  Here a lane that finishes its read immediately takes the
+// next one of its wave's chunk (ranks by ballot/popcount, no atomics; a wave reserves MATCH_CHUNK reads at a time
+// from one global counter), so every resident lane always has a gather in flight until the read set is
+// exhausted.  The per-read sequence of events is untouched.
+template <int NW, int KQ>
 __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a) {
     __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
     __shared__ uint32_t fpm_tab[SM_MAX_SEEDS];
-    __shared__ uint2 vcache[VC_SLOTS][MATCH_TPB]; // {position, head count | tail count << 16}
+    __shared__ uint2 vcache[VC_SLOTS][MATCH_TPB]; // {position, head count | tail count << 8 | epoch << 16}
+    __shared__ uint32_t rd_lds[NW][MATCH_TPB];    // the read itself: only needed when a window is verified
     hash_lut_init(lut);
     const int H = ((int)a.L / 8) * 8;
     const uint32_t nseeds = (a.L - a.K) / a.k2 + 1; // seeds s = 0, k2, ... with s + K <= L
@@ -424,28 +458,22 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
     for (int k = 0; k < VC_SLOTS; k++) vcache[k][threadIdx.x] = make_uint2(POS_NONE, 0u);
     __syncthreads();
 
-    const uint64_t i = (uint64_t)blockIdx.x * MATCH_TPB + threadIdx.x;
-    bool active = i < a.n;
-    const uint32_t cin = active ? a.mism[i] : 0u;
-    if (active && a.nflag && a.nflag[i]) active = false;
-    if (cin <= a.kmin) active = false;
-
-    uint32_t n_cand = 0, n_probe = 0, n_ent = 0, n_ver = 0;
-    uint32_t rd[NW], sh[NW];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t n_search = 0, n_cand = 0, n_probe = 0, n_ent = 0, n_ver = 0; // wave-uniform (ballot popcounts): SGPRs
+    uint32_t sh[NW];              // the read, shifted so that the current seed window starts at bit 0
 #pragma unroll
-    for (int k = 0; k < NW; k++) sh[k] = rd[k] = active ? a.reads[(uint64_t)k * a.stride + i] : 0u;
+    for (int k = 0; k < NW; k++) sh[k] = 0u;
 
     ReadState st;
-    st.limit = (cin < a.kmax) ? cin - 1u : a.kmax;
-    st.falses = 0;
-    st.cur = cin;
-    st.best = POS_NONE;
-    st.done = false;
+    st.limit = 0; st.falses = 0; st.cur = 0; st.best = POS_NONE; st.done = false;
     const uint32_t budget = (a.L + 1u - a.K) / a.k2;
     const uint32_t sbits = 2u * a.k2;
 
-    enum { M_PROBE = 0, M_ENTRY = 1, M_VERIFY = 2, M_FIN = 3, M_ADV = 4 };
-    uint32_t mode = active ? M_PROBE : M_FIN;
+    enum { M_PROBE = 0, M_ENTRY = 1, M_VERIFY = 2, M_NEED = 3, M_ADV = 4, M_DEAD = 5 };
+    uint32_t mode = M_NEED;
+    uint32_t idx = 0;             // the read this lane works on (reads are counted in 32 bits, pg-config.h:21-22)
+    uint32_t cin = 0, epoch = 0;
+    uint32_t cnext = 0, cend = 0; // this wave's reserved range of reads (wave-uniform: kept in SGPRs)
     uint32_t si = 0;              // seed index: s = si * k2
     uint32_t lo = 0, nb = 0, j = 0, fp_read = 0, cand_p = 0;
     uint64_t pend_e = 0;          // an entry already in registers (entry 1 of the head / second half of a pair)
@@ -465,17 +493,59 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
         }
     };
 
-    while (__any(mode != M_FIN)) {
+    for (;;) {
+        // ---- refill: lanes without a read take the next ones of the wave's chunk
+        const unsigned long long need = __ballot(mode == M_NEED);
+        if (need) {
+            if (cnext == cend) { // reserve another chunk (one atomic per wave and MATCH_CHUNK reads)
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(a.work, (unsigned long long)MATCH_CHUNK);
+                base = __shfl(base, 0, 64);
+                cnext = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base, a.n));
+                cend = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base + MATCH_CHUNK, a.n));
+            }
+            const uint32_t avail = cend - cnext;
+            if (avail == 0) {
+                if (mode == M_NEED) mode = M_DEAD;               // the read set is exhausted
+            } else {
+                const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                const uint32_t take = min((uint32_t)__popcll(need), avail);
+                bool started = false;
+                if (mode == M_NEED && rank < take) {
+                    idx = cnext + rank;
+                    cin = a.mism[idx];
+                    const bool skip = (a.nflag && a.nflag[idx]) || cin <= a.kmin; // ReadsMatchers.cpp:430; 'N' reads: byte path
+                    if (!skip) {
+#pragma unroll
+                        for (int k = 0; k < NW; k++) rd_lds[k][threadIdx.x] = sh[k] = a.reads[(uint64_t)k * a.stride + idx];
+                        st.limit = (cin < a.kmax) ? cin - 1u : a.kmax;   // :488-489
+                        st.falses = 0;
+                        st.cur = cin;
+                        st.best = POS_NONE;
+                        st.done = false;
+                        si = 0;
+                        has_pend = false;
+                        epoch = (epoch + 1u) & 0xFFFFu;              // invalidates this lane's verify-cache entries
+                        started = true;
+                        mode = M_PROBE;
+                    }
+                }
+                cnext = __builtin_amdgcn_readfirstlane(cnext + take);
+                n_search += (uint32_t)__popcll(__ballot(started));
+            }
+        }
+        if (!__any(mode != M_DEAD)) break;
+
         const uint32_t m0 = mode;
         const uint32_t s = si * a.k2;
         // ---- issue this iteration's loads
         ulonglong2 hd = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
         uint64_t v = 0;
+        bool counted_ent = false, counted_cand = false;
         if (m0 == M_PROBE) {
-            const uint32_t h = copmem_hash32_fp(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
-                                                NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
+            const uint32_t h = hash_fp_window<KQ>(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
+                                                  NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
             hd = a.head[h];
-            n_probe++;
         } else if (m0 == M_ENTRY) {
             if (has_pend) {
                 v = pend_e;
@@ -486,36 +556,31 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                 v = q.x;
                 pend_e = q.y;
                 has_pend = j + 1 < nb;
-                n_ent++;
+                counted_ent = true;
             }
         }
-        uint32_t pw[PWN];
-        const uint32_t b = (cand_p & 15u) * 2u;
+        // ---- consume
+        uint32_t next = m0;
         if (m0 == M_VERIFY) {
+            uint32_t pw[PWN];
+            const uint32_t b = (cand_p & 15u) * 2u;
             const uint32_t *src = a.pg + (cand_p >> 4); // the text is padded: PWN words are always in bounds
 #pragma unroll
             for (int k = 0; k < PWN; k += 4) {
                 const u32x4 q = reinterpret_cast<const U32x4A4 *>(src + k)->v;
                 pw[k] = q.x; pw[k + 1] = q.y; pw[k + 2] = q.z; pw[k + 3] = q.w;
             }
-        } else {
-#pragma unroll
-            for (int k = 0; k < PWN; k++) pw[k] = 0;
-        }
-        // ---- consume
-        uint32_t next = m0;
-        if (m0 == M_VERIFY) {
             uint32_t mh = 0, mt = 0;
 #pragma unroll
             for (int k = 0; k < NW; k++) {
                 const uint32_t tw = funnel_r(pw[k], pw[k + 1], b);
-                mh += mism2(tw, rd[k], sym_mask(k, 0, H));
-                mt += mism2(tw, rd[k], sym_mask(k, H, (int)a.L));
+                const uint32_t rw = rd_lds[k][threadIdx.x];
+                mh += mism2(tw, rw, sym_mask(k, 0, H));
+                mt += mism2(tw, rw, sym_mask(k, H, (int)a.L));
             }
-            n_ver++;
-            vcache[(cand_p * 0x9E3779B1u) >> 29][threadIdx.x] = make_uint2(cand_p, mh | (mt << 16));
+            vcache[(cand_p * 0x9E3779B1u) >> 30][threadIdx.x] = make_uint2(cand_p, mh | (mt << 8) | (epoch << 16));
             judge(mh, mt, cand_p);
-            next = st.done ? M_FIN : (j < nb ? M_ENTRY : M_ADV);
+            next = st.done ? M_NEED : (j < nb ? M_ENTRY : M_ADV);
         } else if (m0 <= M_ENTRY) {
             bool have = false;
             uint64_t e = 0;
@@ -542,16 +607,16 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                 next = (j < nb) ? M_ENTRY : M_ADV;
                 const uint64_t sp = e >> PGRC_FP_BITS;
                 if ((uint64_t)s <= sp && sp - s + a.L <= a.G) {      // :517-520
-                    n_cand++;
+                    counted_cand = true;
                     const uint32_t p = (uint32_t)(sp - s);
                     const uint32_t x = ((uint32_t)e ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
                     if ((uint32_t)__popc((x | (x >> 1)) & fpm_tab[si]) > st.limit) {
                         st.falses += 1;                              // certain head reject
                     } else {
-                        const uint2 cv = vcache[(p * 0x9E3779B1u) >> 29][threadIdx.x];
-                        if (cv.x == p) {
-                            judge(cv.y & 0xFFFFu, cv.y >> 16, p);
-                            if (st.done) next = M_FIN;
+                        const uint2 cv = vcache[(p * 0x9E3779B1u) >> 30][threadIdx.x];
+                        if (cv.x == p && (cv.y >> 16) == epoch) {
+                            judge(cv.y & 0xFFu, (cv.y >> 8) & 0xFFu, p);
+                            if (st.done) next = M_NEED;
                         } else {
                             cand_p = p;
                             next = M_VERIFY;
@@ -566,24 +631,30 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
 #pragma unroll
             for (int k = 0; k < NW - 1; k++) sh[k] = funnel_r(sh[k], sh[k + 1], sbits);
             sh[NW - 1] >>= sbits;
-            next = (si < nseeds) ? M_PROBE : M_FIN;
+            next = (si < nseeds) ? M_PROBE : M_NEED;
+        }
+        // work counters, wave-wide (scalar popcounts instead of five per-lane registers)
+        n_probe += (uint32_t)__popcll(__ballot(m0 == M_PROBE));
+        n_ent += (uint32_t)__popcll(__ballot(counted_ent));
+        n_ver += (uint32_t)__popcll(__ballot(m0 == M_VERIFY));
+        n_cand += (uint32_t)__popcll(__ballot(counted_cand));
+        if (next == M_NEED && m0 <= M_VERIFY) {
+            // this read is finished (ReadsMatchers.cpp:437-447)
+            if (st.best != POS_NONE && st.cur < cin) {
+                a.pos[idx] = a.strand ? a.G - ((uint64_t)st.best + a.L) : (uint64_t)st.best;
+                a.rc[idx] = (uint8_t)a.strand;
+                a.mism[idx] = (uint8_t)st.cur;
+            }
         }
         mode = next;
     }
-    if (active && st.best != POS_NONE && st.cur < cin) {
-        a.pos[i] = a.strand ? a.G - ((uint64_t)st.best + a.L) : (uint64_t)st.best;
-        a.rc[i] = (uint8_t)a.strand;
-        a.mism[i] = (uint8_t)st.cur;
-    }
     if (a.counters) {
-        const uint64_t s0 = wave_sum_u64(active ? 1ull : 0ull), s1 = wave_sum_u64(n_cand), s2 = wave_sum_u64(n_probe);
-        const uint64_t s3 = wave_sum_u64(n_ent), s4 = wave_sum_u64(n_ver);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&a.counters[0], (unsigned long long)s0);
-            atomicAdd(&a.counters[1], (unsigned long long)s1);
-            atomicAdd(&a.counters[2], (unsigned long long)s2);
-            atomicAdd(&a.counters[3], (unsigned long long)s3);
-            atomicAdd(&a.counters[4], (unsigned long long)s4);
+        if (lane == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)n_search);
+            atomicAdd(&a.counters[1], (unsigned long long)n_cand);
+            atomicAdd(&a.counters[2], (unsigned long long)n_probe);
+            atomicAdd(&a.counters[3], (unsigned long long)n_ent);
+            atomicAdd(&a.counters[4], (unsigned long long)n_ver);
         }
     }
 }
@@ -662,8 +733,12 @@ k_copmem_match_ascii(const MatchArgs a, const uint32_t *__restrict__ nidx, const
 
 template <int NW>
 static void launch_match(pgrc_match_ctx *c, const MatchArgs &a) {
-    const uint32_t grid = (uint32_t)((a.n + MATCH_TPB - 1) / MATCH_TPB);
-    hipLaunchKernelGGL(k_copmem_match_sm<NW>, dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+    // persistent grid: what the chip can hold (8 blocks of 4 waves per CU is the register/LDS limit at most)
+    const uint64_t want = (a.n + MATCH_TPB - 1) / MATCH_TPB;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)c->num_cus * 8u);
+    const char *hs = getenv("PGRC_HASH_STATIC"); // tuning knob (A/B): 0 = always the run-time K loop
+    if (a.K == 28 && !(hs && hs[0] == '0')) hipLaunchKernelGGL((k_copmem_match_sm<NW, 7>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_copmem_match_sm<NW, 0>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
 }
 
 int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
@@ -681,6 +756,7 @@ int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
     a.rc = (uint8_t *)c->d_rc.p;
     a.mism = (uint8_t *)c->d_mism.p;
     a.counters = (unsigned long long *)c->d_counters.p + 8 * strand;
+    a.work = (unsigned long long *)c->d_counters.p + 16 + strand;
     a.L = c->prm.read_len;
     a.K = (uint32_t)c->cp.K;
     a.k2 = (uint32_t)c->cp.k2;

@@ -33,6 +33,7 @@ struct DevBuf {
 struct pgrc_match_ctx {
     pgrc_match_params prm{};
     int device = 0;
+    int num_cus = 256;
     hipStream_t stream = nullptr;
     std::string err;
 
@@ -70,6 +71,7 @@ struct pgrc_match_ctx {
     pgrc_copmem_params cp{};
     uint64_t npos = 0;
     DevBuf d_ent, d_head, d_ovf_key, d_ovf_fp, d_ovf_key2, d_ovf_fp2, d_mark, d_scan_tmp;
+    DevBuf d_skey, d_sfp, d_flag, d_runidx, d_sorttmp; // overflow sort scratch (grow-only)
     uint64_t n_ovf = 0, ovf_cap_hint = 0;
     int index_strand = -1;  // which strand the buffers currently describe
 

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""In-process A/B of match-kernel tuning knobs (env vars read at every launch) on one device, interleaved rounds
+(cdna_hip_programming.md rule 24: never rank builds across processes/devices).
+usage: tools/ab_match.py [--workload C3] [--rounds 4] VAR=val,VAR=val  VAR=val ...   (each arg = one variant)"""
+import argparse, json, os, sys, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="C3")
+    ap.add_argument("--rounds", type=int, default=4)
+    ap.add_argument("variants", nargs="+")
+    a = ap.parse_args()
+    import torch, bench
+    from pgrc_amd import MatchContext, synth
+    n, L, G, seed_len, M, mode, paired = bench.WORKLOADS[a.workload]
+    g = synth.pg_params(G, seed=12345); rs = synth.reads_params(n, L, seed=12345, paired=paired)
+    nw, stride, pgw = (L + 15) // 16, (n + 63) & ~63, (G + 15) // 16
+    d_pg = torch.zeros(pgw + 64, dtype=torch.int32, device="cuda"); synth.pg_device(g, d_pg.data_ptr())
+    d_rd = torch.empty(nw * stride, dtype=torch.int32, device="cuda"); synth.reads_device(g, d_pg.data_ptr(), rs, 0, n, d_rd.data_ptr(), stride)
+    torch.cuda.synchronize()
+    ctx = MatchContext(L, seed_len, L // M, 0, mode); ctx.set_pg_packed_device(d_pg.data_ptr(), G)
+    ctx.set_reads_device(d_rd.data_ptr(), n, stride, keep=d_rd); ctx.set_profiling(True)
+    variants = [dict(kv.split("=") for kv in v.split(",") if kv) for v in a.variants]
+    keys = sorted({k for v in variants for k in v})
+    res = {i: [] for i in range(len(variants))}
+    ref = None
+    for r in range(a.rounds + 1):
+        for i, v in enumerate(variants):
+            for k in keys: os.environ.pop(k, None)
+            os.environ.update(v)
+            ctx.init_results(); ctx.run(True)
+            c = ctx.counters()
+            _, _, _, hist, matched = ctx.get_results(arrays=False)
+            if ref is None: ref = (hist.tolist(), matched)
+            assert (hist.tolist(), matched) == ref, "variants disagree on results"
+            if r: res[i].append((c["ms_match"][0], c["ms_match"][1], c["ms_index"][0] + c["ms_index"][1], c["ms_total"]))
+    for i, v in enumerate(variants):
+        med = [statistics.median(x[k] for x in res[i]) for k in range(4)]
+        print(f"{a.variants[i]:40s} match_fwd {med[0]:7.2f}  match_rc {med[1]:7.2f}  index {med[2]:7.2f}  total {med[3]:7.2f} ms")
+if __name__ == "__main__":
+    main()
