@@ -261,6 +261,8 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     // on uniform text ~6 % of the entries overflow their two inline slots; every block's region starts with
     // room for 25 % of its positions and grows to whatever a low-complexity text needs
     uint64_t region_cap = std::max<uint64_t>((c->npos / grid) / 4 + 1024, c->ovf_cap_hint);
+    if (const char *ev = getenv("PGRC_OVF_REGION_CAP")) // test knob: start tiny to exercise the grow-and-retry path
+        region_cap = std::max<uint64_t>(1, (uint64_t)atoll(ev));
     uint64_t nrec = 0;
     bool again = false;
     int e = build_once(c, strand, region_cap, &nrec, &again);

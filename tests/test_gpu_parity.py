@@ -301,3 +301,29 @@ def test_reference_adapter_drop_in(mode, seed_len, n_nset, entry):
     r = orc.ref_match(mode, pg, reads, seed_len, kmax, 0, n_nset=n_nset)
     a = orc.ref_match_via_adapter(mode, pg, reads, seed_len, kmax, 0, n_nset=n_nset, entry=entry)
     assert_same_results(a, r, f"adapter mode {mode} entry {entry}")
+
+
+def test_index_overflow_regions_grow_and_retry(monkeypatch):
+    """Low-complexity text can overflow a block's overflow region: the build must detect it, grow and redo."""
+    from pgrc_amd import MatchContext
+    rng = np.random.default_rng(11)
+    pg = rng.choice(list(b"ACGT"), size=300000).astype(np.uint8)
+    pg[20000:120000] = ord("A")                                                   # 100 kbp poly-A
+    pg[150000:200000] = np.resize(np.frombuffer(b"AC", dtype=np.uint8), 50000)    # dinucleotide tract
+    _, cumm, positions = orc.oracle_index(pg, 38)
+    monkeypatch.setenv("PGRC_OVF_REGION_CAP", "4")
+    ctx = MatchContext(100, 38, 2, 0, "c")
+    ctx.set_pg_ascii(pg)
+    c, p = ctx.export_index(0)
+    assert np.array_equal(c, cumm) and np.array_equal(p, positions)
+    # and matching over such an index
+    _, reads = make_inputs(300000, 3000, 100, seed=3)
+    for k in range(200):
+        s = 20000 + 400 * k
+        reads[k] = pg[s: s + 100]
+    o = orc.oracle_match("c", pg, reads, 38, 2, 0)
+    ctx.set_reads_ascii(reads)
+    ctx.init_results()
+    ctx.run(True)
+    pos, rc, mism, hist, matched = ctx.get_results()
+    assert_same_results({"pos": pos, "rc": rc, "mism": mism, "hist": hist, "matched": matched}, o, "low complexity")
