@@ -28,26 +28,11 @@ __device__ __forceinline__ void hash_lut_init(uint32_t *lut) {
     }
 }
 
-// Low 32 bits of the reference's u64 multiply-xor fold: the final cast to u32 only ever sees
+// Low 32 bits of the reference's u64 multiply-xor fold (Hashes.h:54-76): the final cast to u32 only ever sees
 // the low word, and xor / multiply keep the low word closed, so 32-bit arithmetic is exact.
 // t0..t3 hold the K-symbol window (2 bits/symbol, little endian); kq = K/4 steps.
-__device__ __forceinline__ uint32_t copmem_hash32(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3,
-                                                  uint32_t K, const uint32_t *lut) {
-    uint32_t h = K;
-    const uint32_t kq = K >> 2;
-    for (uint32_t j = 0; j < kq; j++) {
-        uint32_t b = t0 & 0xFFu;
-        uint32_t w = (j < 3) ? lut[b & 63u] : lut[64u + (b & 15u)];
-        h = (h ^ (w + j)) * 171717u;
-        t0 = funnel_r(t0, t1, 8);
-        t1 = funnel_r(t1, t2, 8);
-        t2 = funnel_r(t2, t3, 8);
-        t3 >>= 8;
-    }
-    return h;
-}
-
-// Same fold, additionally returning a FINGERPRINT of the window: the symbols the sparsified hash
+//
+// The fold additionally returns a FINGERPRINT of the window: the symbols the sparsified hash
 // ignores (symbol 3 of steps 0..2, symbols 2,3 of the later steps), packed 2 bits each in step
 // order, at most 24 bits.  Stored next to every indexed position, it lets the match kernel reject a
 // false candidate without touching the pseudogenome: the fingerprint symbols are ordinary window
