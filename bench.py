@@ -163,10 +163,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 (2-bit packed symbols)",
+            "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {n_per} x {L} bp {'PE' if paired else 'SE'} reads per GPU vs Pg of "
                                    f"{G} bp, mode {mode}, seed {seed_len}, -M {M} (k<={kmax}), both strands",
+                       "symbols": "2-bit packed, 16 per u32 word (integer xor/popcount work, no floating point)",
                        "reads_per_gpu": n_per, "read_len": L, "pg_len": G, "seed_len": seed_len, "max_mismatches": kmax,
                        "copmem": cp, "matched_fraction": matched / n_per,
                        "parallelism": f"reads sharded x{world}, Pg replicated" + (" (1 all-gather/step)" if world > 1 else "")},

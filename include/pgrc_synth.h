@@ -45,7 +45,8 @@ typedef struct {
     uint64_t seed;
     uint64_t n;          /* reads in the whole set (indices are global: shards pass first_read) */
     uint32_t read_len;
-    uint32_t paired;     /* 0 = SE, 1 = PE (mates interleaved: 2q, 2q+1) */
+    uint32_t paired;     /* bit 0: PE (mates interleaved: 2q, 2q+1); bit 1: experiment only -- start positions ascending
+                          * in j (a perfectly position-sorted read set, to measure what locality could buy) */
     uint64_t n_with_n;   /* the last n_with_n reads of the set carry 'N's (ASCII generator only) */
 } pgrc_synth_reads;
 
@@ -131,10 +132,14 @@ PGRC_HD pgrc_synth_read_hdr pgrc_synth_read_header(const pgrc_synth_pg *g, const
     uint32_t t = (uint32_t)(pgrc_rnd(rs->seed, PGRC_S_TYPE, j) % 100);
     h.random = t < 3;
     h.nsub = h.random ? 0 : pgrc_synth_nsub(t, pgrc_rnd(rs->seed, PGRC_S_NSUB, j));
-    uint64_t anchor = rs->paired ? (j & ~1ull) : j;
+    uint64_t anchor = (rs->paired & 1u) ? (j & ~1ull) : j;
     h.start = pgrc_rnd(rs->seed, PGRC_S_START, anchor) % span;
+    if (rs->paired & 2u) { /* anchor * span / n without 128-bit arithmetic (anchor, span % n < n < 2^32) */
+        const uint64_t nn = rs->n ? rs->n : 1;
+        h.start = anchor * (span / nn) + (anchor * (span % nn)) / nn;
+    }
     h.rc = (uint32_t)(pgrc_rnd(rs->seed, PGRC_S_RC, anchor) & 1);
-    if (rs->paired && (j & 1)) {
+    if ((rs->paired & 1u) && (j & 1)) {
         uint64_t d = 200 + pgrc_rnd(rs->seed, PGRC_S_MATE, j) % 301;
         h.start = (h.start + d < span) ? h.start + d : span - 1;
         h.rc ^= 1u;

@@ -77,3 +77,18 @@ def test_host_generators_are_deterministic_and_paired():
     r3 = synth.reads_host(g, None, rs)                  # pure-function path (no text array)
     assert np.array_equal(r1, r3)
     assert (r1[-100:] == ord("N")).any(axis=1).all() and not (r1[:-100] == ord("N")).any()
+
+
+def test_header_is_plain_c99_and_links_from_c(tmp_path):
+    """include/pgrc_match.h compiles as strict C99 and a C program links against the library (what a cgo/FFI
+    binding needs); `--dry` touches no compute entry point."""
+    import subprocess
+    from pgrc_amd import _lib
+    exe = tmp_path / "c_abi_smoke"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Werror", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "c_abi_smoke.c"), "-o", str(exe), "-L", libdir, "-lpgrc_match",
+                        f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe), "--dry"], capture_output=True, text=True)
+    assert r.returncode == 0 and "dry ok: mode c kmax 2" in r.stdout

@@ -327,3 +327,29 @@ def test_index_overflow_regions_grow_and_retry(monkeypatch):
     ctx.run(True)
     pos, rc, mism, hist, matched = ctx.get_results()
     assert_same_results({"pos": pos, "rc": rc, "mism": mism, "hist": hist, "matched": matched}, o, "low complexity")
+
+
+def test_c_consumer_of_the_abi(tmp_path):
+    """tests/c_abi_smoke.c (plain C99) drives the library end to end; its digest equals the oracle's."""
+    import os
+    import subprocess
+    from pgrc_amd import _lib, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_abi_smoke"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi_smoke.c"), "-o",
+                    str(exe), "-L", libdir, "-lpgrc_match", f"-Wl,-rpath,{libdir}"], check=True)
+    env = dict(os.environ)
+    tl = os.path.join(os.path.dirname(__import__("torch").__file__), "lib")
+    env["LD_LIBRARY_PATH"] = tl + ":" + env.get("LD_LIBRARY_PATH", "")  # same HIP runtime as the rest of the suite
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr + r.stdout
+    g = synth.SynthPg(2024, 200000, 20000, 3000, 8, 4)
+    pg = synth.pg_host(g)
+    rs = synth.SynthReads(77, 4000, 100, 0, 0)
+    reads = synth.reads_host(g, pg, rs)
+    o = orc.oracle_match("c", pg, reads, 38, 2, 0)
+    fnv = 1469598103934665603
+    for p, m, c in zip(o["pos"].tolist(), o["mism"].tolist(), o["rc"].tolist()):
+        fnv = ((fnv ^ p ^ (m << 56) ^ (c << 48)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert f"matched {o['matched']} of 4000, exact {int(o['hist'][0])}, digest {fnv:016x}" in r.stdout

@@ -9,12 +9,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--rounds", type=int, default=4)
+    ap.add_argument("--sorted-reads", action="store_true", help="experiment: position-sorted read set")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     import torch, bench
     from pgrc_amd import MatchContext, synth
     n, L, G, seed_len, M, mode, paired = bench.WORKLOADS[a.workload]
     g = synth.pg_params(G, seed=12345); rs = synth.reads_params(n, L, seed=12345, paired=paired)
+    if a.sorted_reads: rs.paired |= 2
     nw, stride, pgw = (L + 15) // 16, (n + 63) & ~63, (G + 15) // 16
     d_pg = torch.zeros(pgw + 64, dtype=torch.int32, device="cuda"); synth.pg_device(g, d_pg.data_ptr())
     d_rd = torch.empty(nw * stride, dtype=torch.int32, device="cuda"); synth.reads_device(g, d_pg.data_ptr(), rs, 0, n, d_rd.data_ptr(), stride)
