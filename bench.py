@@ -26,6 +26,7 @@ WORKLOADS = {
     "C3": (100_000_000, 150, 1_875_000_000, 38, 50, "c", False),
     "C2": (10_000_000, 100, 125_000_000, 38, 50, "c", False),
     "C3-PE": (100_000_000, 150, 1_875_000_000, 38, 50, "c", True),
+    "C5-shard": (62_500_000, 250, 3_100_000_000, 38, 50, "c", False),  # one GPU's 1/8 of configs[4]
     "tiny": (1_000_000, 150, 18_750_000, 38, 50, "c", False),
 }
 GATHER_CEILING_GPS = 51.0  # measured: tools/ubench/gather2.hip, profiles/r01_ubench_gather_width_ilp.txt
@@ -147,10 +148,10 @@ def main():
         alg_bytes = ctr["searched"][dom] * (rb + 10) + ctr["probes"][dom] * 8 + ctr["candidates"][dom] * (5 + rb)
         ms = ctr["ms_match"][dom]
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        # random lane-addresses issued by that launch: one 16-B head per probe, one 8-B entry per fetched entry,
-        # PW x 16-B per verified text window (tools/ubench: the chip sustains ~51 G of them per second)
-        pw = ((nw + 1 + 3) // 4)
-        gathers = ctr["probes"][dom] + ctr["entry_fetches"][dom] + ctr["verifies"][dom] * pw
+        # random 64-B line requests issued by that launch: one per probed bucket head, one per fetched entry pair,
+        # and per verified text window the lines a (L/4)-byte window at a random 4-B offset spans on average
+        # (tools/ubench: the chip sustains ~51 G independent random requests per second, whatever their width)
+        gathers = int(ctr["probes"][dom] + ctr["entry_fetches"][dom] + ctr["verifies"][dom] * (1.0 + max(rb - 4, 0) / 64.0))
         gather_rate = gathers / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         out = {
             "metric": "reads matched/sec (150 bp) at 1/2/4/8 MI355X; achieved HBM GB/s",
