@@ -27,6 +27,7 @@ WORKLOADS = {
     "C2": (10_000_000, 100, 125_000_000, 38, 50, "c", False),
     "C3-PE": (100_000_000, 150, 1_875_000_000, 38, 50, "c", True),
     "C5-shard": (62_500_000, 250, 3_100_000_000, 38, 50, "c", False),  # one GPU's 1/8 of configs[4]
+    "P64": (50_000_000, 150, 4_400_000_000, 38, 50, "c", False),  # Pg >= 4 Gi: the 64-bit-position kernels
     "tiny": (1_000_000, 150, 18_750_000, 38, 50, "c", False),
 }
 GATHER_CEILING_GPS = 51.0  # measured: tools/ubench/gather2.hip, profiles/r01_ubench_gather_width_ilp.txt

@@ -136,7 +136,7 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf *bufs[] = {&c->pg2[0], &c->pg2[1], &c->reads_own, &c->nread_idx, &c->nread_ascii, &c->nread_flag, &c->d_pos,
-                      &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_ent, &c->d_head, &c->d_ovf_key, &c->d_ovf_fp, &c->d_ovf_key2, &c->d_ovf_fp2, &c->d_mark, &c->d_skey, &c->d_sfp, &c->d_flag, &c->d_runidx, &c->d_sorttmp,
+                      &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_ent, &c->d_head, &c->d_ovf_h, &c->d_ovf_e, &c->d_ovf_h2, &c->d_ovf_e2, &c->d_mark, &c->d_skey, &c->d_sfp, &c->d_flag, &c->d_runidx, &c->d_sorttmp,
                       &c->d_scan_tmp, &c->s_keys, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp};
     for (DevBuf *b : bufs) pgrc_buf_free(*b);
     if (c->have_events)
@@ -166,8 +166,12 @@ int pgrc_match_set_profiling(pgrc_match_ctx *c, int enabled) {
 // ------------------------------------------------------------------ pseudogenome
 
 static int alloc_pg(pgrc_match_ctx *c, uint64_t G) {
-    if (G + 256 >= (1ull << 32)) {
-        c->err = "pseudogenome >= 4 Gi symbols needs the 64-bit index variant (not built yet)";
+    if (G + 256 >= (1ull << 40)) {
+        c->err = "pseudogenome of 2^40 symbols or more is not supported (entries keep 40 position bits)";
+        return PGRC_E_PARAM;
+    }
+    if (G + 256 >= (1ull << 32) && c->prm.mode != 'c') {
+        c->err = "modes d/i/e: pseudogenome below 4 Gi symbols only (mode c has the 64-bit-position variant)";
         return PGRC_E_PARAM;
     }
     if (G < c->prm.read_len) {

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include <cstring>
+#include <type_traits>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -35,18 +36,20 @@
 #include "devutil.h"
 
 #define HEAD_EMPTY 0xFFFFFFFFFFFFFFFFull
-#define ENT_MASK ((1ull << 56) - 1)
+#define HEAD_OVF (1ull << 63)              // w0 flag: the bucket has >= 3 entries
+#define ENT_MASK ((1ull << 62) - 1)        // entry = position << 22 | fingerprint, position < 2^40
+#define W1_BASE_MASK ((1ull << 56) - 1)
 
 // 16-B bucket head:
-//   w0 = HEAD_EMPTY                         empty bucket
-//   w0 = entry0 [| count << 56], w1 = HEAD_EMPTY            one entry
-//   w0 = entry0,                 w1 = entry1                two entries
-//   w0 = entry0 | count << 56,   w1 = base                  count = min(n, 13) >= 3: entries 1.. at ent[base + j - 1]
-// entry = position << 24 | fingerprint (56 bits), so u64 order = position order.
+//   w0 = HEAD_EMPTY                                 empty bucket
+//   w0 = entry0,            w1 = HEAD_EMPTY         one entry
+//   w0 = entry0,            w1 = entry1             two entries
+//   w0 = entry0 | HEAD_OVF, w1 = base | count << 56 count = min(n, 13) >= 3: entries 1.. at ent[base + j - 1]
+// entry = position << 22 | fingerprint (62 bits), so u64 order = position order.
 __device__ __forceinline__ uint32_t head_count(const ulonglong2 hd) {
     if (hd.x == HEAD_EMPTY) return 0u;
-    const uint32_t c = (uint32_t)(hd.x >> 56) & 15u;
-    return c ? c : (hd.y == HEAD_EMPTY ? 1u : 2u);
+    if (hd.x & HEAD_OVF) return (uint32_t)(hd.y >> 56) & 15u;
+    return hd.y == HEAD_EMPTY ? 1u : 2u;
 }
 
 // ----------------------------------------------------------------------------- index build
@@ -66,8 +69,8 @@ template <int PASS>
 __global__ void __launch_bounds__(IDX_TPB)
 k_copmem_index_build(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, uint64_t npos, uint32_t k1, uint32_t K,
                      uint32_t mask, ulonglong2 *__restrict__ head, uint8_t *__restrict__ mark,
-                     unsigned long long *__restrict__ ovf_count, uint64_t *__restrict__ ovf_key,
-                     uint32_t *__restrict__ ovf_fp, uint64_t ovf_cap) {
+                     unsigned long long *__restrict__ ovf_count, uint32_t *__restrict__ ovf_h,
+                     uint64_t *__restrict__ ovf_e, uint64_t ovf_cap) {
     __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
     __shared__ uint32_t tile[IDX_TILE_WORDS + 8];
     hash_lut_init(lut);
@@ -82,8 +85,8 @@ k_copmem_index_build(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, u
         for (uint32_t w = threadIdx.x; w < need; w += IDX_TPB) tile[w] = (w0 + w < pg_words_alloc) ? pg[w0 + w] : 0u;
         __syncthreads();
         bool push = false;     // PASS 2: this lane's entry overflows its bucket head
-        uint32_t push_h = 0, push_fp = 0;
-        uint64_t push_p = 0;
+        uint32_t push_h = 0;
+        uint64_t push_e = 0;
         if (t < npos && (PASS != 2 || mark[t])) {
             const uint64_t p = t * k1;
             const uint32_t q = (uint32_t)((p >> 4) - w0);
@@ -103,8 +106,7 @@ k_copmem_index_build(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, u
             } else {
                 push = slot[1] != e;
                 push_h = h;
-                push_fp = fp;
-                push_p = p;
+                push_e = e;
             }
         }
         if (PASS == 2) {
@@ -121,8 +123,8 @@ k_copmem_index_build(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, u
                 if (push) {
                     const unsigned long long idx = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
                     if (idx < ovf_cap) {
-                        ovf_key[(uint64_t)blockIdx.x * ovf_cap + idx] = ((uint64_t)push_h << 32) | push_p;
-                        ovf_fp[(uint64_t)blockIdx.x * ovf_cap + idx] = push_fp;
+                        ovf_h[(uint64_t)blockIdx.x * ovf_cap + idx] = push_h;
+                        ovf_e[(uint64_t)blockIdx.x * ovf_cap + idx] = push_e;
                     }
                 }
             }
@@ -169,45 +171,60 @@ __global__ void __launch_bounds__(1024) k_ovf_prefix(const unsigned long long *_
 
 __global__ void __launch_bounds__(256)
 k_ovf_compact(const unsigned long long *__restrict__ cursors, const unsigned long long *__restrict__ prefix,
-              uint64_t region_cap, const uint64_t *__restrict__ key_in, const uint32_t *__restrict__ fp_in,
-              uint64_t *__restrict__ key_out, uint32_t *__restrict__ fp_out) {
+              uint64_t region_cap, const uint32_t *__restrict__ h_in, const uint64_t *__restrict__ e_in,
+              uint32_t *__restrict__ h_out, uint64_t *__restrict__ e_out) {
     const uint64_t n = min((uint64_t)cursors[8ull * blockIdx.x], region_cap), dst = prefix[blockIdx.x];
     const uint64_t src = (uint64_t)blockIdx.x * region_cap;
     for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        key_out[dst + i] = key_in[src + i];
-        fp_out[dst + i] = fp_in[src + i];
+        h_out[dst + i] = h_in[src + i];
+        e_out[dst + i] = e_in[src + i];
     }
 }
 
-__global__ void __launch_bounds__(256) k_ovf_flags(const uint64_t *__restrict__ key, uint64_t n, uint32_t *__restrict__ flag) {
+__global__ void __launch_bounds__(256) k_ovf_flags(const uint32_t *__restrict__ sh, uint64_t n, uint32_t *__restrict__ flag) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = (i == 0 || (key[i] >> 32) != (key[i - 1] >> 32)) ? 1u : 0u;
+    if (i < n) flag[i] = (i == 0 || sh[i] != sh[i - 1]) ? 1u : 0u;
 }
 
-// sorted overflow records -> per-bucket segments [entry1, overflow entries ascending] in ent[], head fix-up
+// overflow records sorted by bucket (stable radix sort on the bucket id only: entries of one bucket arrive in
+// arbitrary order) -> per-bucket segments [entry1, the bucket's 11 smallest overflow entries ascending] in
+// ent[], head fix-up.  One thread per bucket run; runs are 1-2 records long except on low-complexity text.
 __global__ void __launch_bounds__(256)
-k_ovf_finalize(const uint64_t *__restrict__ key, const uint32_t *__restrict__ fp, const uint32_t *__restrict__ runidx,
+k_ovf_finalize(const uint32_t *__restrict__ sh, const uint64_t *__restrict__ se, const uint32_t *__restrict__ runidx,
                uint64_t n, ulonglong2 *__restrict__ head, uint64_t *__restrict__ ent) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t k = key[i];
-    const uint32_t h = (uint32_t)(k >> 32);
-    const uint64_t r = runidx[i] - 1u;                       // ordinal of this record's run
-    ent[i + r + 1] = ((k & 0xFFFFFFFFull) << PGRC_FP_BITS) | fp[i];
-    if (i == 0 || (uint32_t)(key[i - 1] >> 32) != h) {       // first record of its bucket
-        uint32_t len = 1;
-        while (len < PGRC_BUCKET_CAP - 2 && i + len < n && (uint32_t)(key[i + len] >> 32) == h) len++;
-        ulonglong2 hd = head[h];
-        ent[i + r] = hd.y;                                   // entry1 opens the segment
-        hd.x |= (uint64_t)(2u + len) << 56;                  // len is capped so that count <= 13
-        hd.y = i + r;
-        head[h] = hd;
+    const uint32_t h = sh[i];
+    if (i != 0 && sh[i - 1] == h) return;                    // not the first record of its bucket
+    constexpr int KEEP = (int)PGRC_BUCKET_CAP - 2;           // the head already holds the two smallest
+    uint64_t a[KEEP];
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) a[k] = ~0ull;
+    uint32_t len = 0;
+    for (uint64_t j = i; j < n && sh[j] == h; j++) {
+        uint64_t x = se[j];
+#pragma unroll
+        for (int k = 0; k < KEEP; k++) {
+            const uint64_t m = min(a[k], x);
+            x = max(a[k], x);
+            a[k] = m;
+        }
+        if (len < (uint32_t)KEEP) len++;
     }
+    const uint64_t base = i + (runidx[i] - 1u);              // run r starts at sorted index i: segment base i + r
+    ulonglong2 hd = head[h];
+    ent[base] = hd.y;                                        // entry1 opens the segment
+#pragma unroll
+    for (int k = 0; k < KEEP; k++)
+        if ((uint32_t)k < len) ent[base + 1 + k] = a[k];
+    hd.x |= HEAD_OVF;
+    hd.y = base | ((uint64_t)(2u + len) << 56);
+    head[h] = hd;
 }
 
 #define IDX_MAX_BLOCKS 4096u
 
-// Sweeps 0-2; leaves the overflow records compacted in d_ovf_key2 / d_ovf_fp2 and their number in *nrec_out.
+// Sweeps 0-2; leaves the overflow records compacted in d_ovf_h2 / d_ovf_e2 and their number in *nrec_out.
 // Returns PGRC_OK with *region_overflow = true when a block's region was too small (caller retries bigger).
 static int build_once(pgrc_match_ctx *c, int strand, uint64_t region_cap, uint64_t *nrec_out, bool *region_overflow) {
     const uint32_t K = (uint32_t)c->cp.K, k1 = (uint32_t)c->cp.k1;
@@ -216,8 +233,8 @@ static int build_once(pgrc_match_ctx *c, int strand, uint64_t region_cap, uint64
     const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ntiles, 1), IDX_MAX_BLOCKS);
     int e;
     if ((e = pgrc_buf_ensure(c, c->d_head, hs * 2 * sizeof(uint64_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->d_ovf_key, ((uint64_t)grid * region_cap + 16) * sizeof(uint64_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->d_ovf_fp, ((uint64_t)grid * region_cap + 16) * sizeof(uint32_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->d_ovf_h, ((uint64_t)grid * region_cap + 16) * sizeof(uint32_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->d_ovf_e, ((uint64_t)grid * region_cap + 16) * sizeof(uint64_t)))) return e;
     if ((e = pgrc_buf_ensure(c, c->d_scan_tmp, (8ull * IDX_MAX_BLOCKS + IDX_MAX_BLOCKS + 8) * sizeof(uint64_t)))) return e;
     if ((e = pgrc_buf_ensure(c, c->d_mark, c->npos + 16))) return e;
     unsigned long long *cursors = (unsigned long long *)c->d_scan_tmp.p;
@@ -230,7 +247,7 @@ static int build_once(pgrc_match_ctx *c, int strand, uint64_t region_cap, uint64
 #define LAUNCH_PASS(P)                                                                                                   \
     hipLaunchKernelGGL(k_copmem_index_build<P>, dim3(grid), dim3(IDX_TPB), 0, c->stream, (const uint32_t *)c->pg2[strand].p, \
                        c->pg_words + PGRC_PG_PAD_WORDS, c->npos, k1, K, (uint32_t)(hs - 1), (ulonglong2 *)c->d_head.p,       \
-                       (uint8_t *)c->d_mark.p, cursors, (uint64_t *)c->d_ovf_key.p, (uint32_t *)c->d_ovf_fp.p, region_cap)
+                       (uint8_t *)c->d_mark.p, cursors, (uint32_t *)c->d_ovf_h.p, (uint64_t *)c->d_ovf_e.p, region_cap)
     LAUNCH_PASS(0);
     LAUNCH_PASS(1);
     LAUNCH_PASS(2);
@@ -243,11 +260,11 @@ static int build_once(pgrc_match_ctx *c, int strand, uint64_t region_cap, uint64
     if (tail[1] > region_cap) { *region_overflow = true; *nrec_out = tail[1]; return PGRC_OK; }
     *nrec_out = tail[0];
     if (tail[0]) {
-        if ((e = pgrc_buf_ensure(c, c->d_ovf_key2, (tail[0] + 16) * sizeof(uint64_t)))) return e;
-        if ((e = pgrc_buf_ensure(c, c->d_ovf_fp2, (tail[0] + 16) * sizeof(uint32_t)))) return e;
+        if ((e = pgrc_buf_ensure(c, c->d_ovf_h2, (tail[0] + 16) * sizeof(uint32_t)))) return e;
+        if ((e = pgrc_buf_ensure(c, c->d_ovf_e2, (tail[0] + 16) * sizeof(uint64_t)))) return e;
         hipLaunchKernelGGL(k_ovf_compact, dim3(grid), dim3(256), 0, c->stream, (const unsigned long long *)cursors,
-                           (const unsigned long long *)prefix, region_cap, (const uint64_t *)c->d_ovf_key.p,
-                           (const uint32_t *)c->d_ovf_fp.p, (uint64_t *)c->d_ovf_key2.p, (uint32_t *)c->d_ovf_fp2.p);
+                           (const unsigned long long *)prefix, region_cap, (const uint32_t *)c->d_ovf_h.p,
+                           (const uint64_t *)c->d_ovf_e.p, (uint32_t *)c->d_ovf_h2.p, (uint64_t *)c->d_ovf_e2.p);
         HIP_TRY(c, hipGetLastError());
     }
     return PGRC_OK;
@@ -278,27 +295,31 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
         // scratch lives in the context (grow-only): no hipMalloc / hipFree (= device synchronisation) per build
         DevBuf &skey = c->d_skey, &sfp = c->d_sfp, &flag = c->d_flag, &runidx = c->d_runidx, &temp = c->d_sorttmp;
         auto cleanup = [&]() {};
+        if (2 * nrec + 16 >= (1ull << 32)) { c->err = "index build: overflow segments exceed 2^32 entries"; return PGRC_E_PARAM; }
+        int hbits = 0;
+        while ((1ull << hbits) < c->cp.hash_size) hbits++;
         size_t t1 = 0, t2 = 0;
-        hipError_t he = rocprim::radix_sort_pairs(nullptr, t1, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr,
-                                                  (uint32_t *)nullptr, (size_t)nrec, 0, 64, c->stream);
+        hipError_t he = rocprim::radix_sort_pairs(nullptr, t1, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr,
+                                                  (uint64_t *)nullptr, (size_t)nrec, 0, hbits, c->stream);
         if (he == hipSuccess)
             he = rocprim::inclusive_scan(nullptr, t2, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)nrec, rocprim::plus<uint32_t>(), c->stream);
         if (he != hipSuccess) { c->err = "rocprim size query failed"; return PGRC_E_NO_DEVICE; }
-        if ((e = pgrc_buf_ensure(c, skey, nrec * sizeof(uint64_t))) || (e = pgrc_buf_ensure(c, sfp, nrec * sizeof(uint32_t))) ||
+        if ((e = pgrc_buf_ensure(c, skey, nrec * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, sfp, nrec * sizeof(uint64_t))) ||
             (e = pgrc_buf_ensure(c, flag, nrec * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, runidx, nrec * sizeof(uint32_t))) ||
             (e = pgrc_buf_ensure(c, temp, std::max(t1, t2))) || (e = pgrc_buf_ensure(c, c->d_ent, (2 * nrec + 16) * sizeof(uint64_t)))) {
             cleanup();
             return e;
         }
         const uint32_t grid2 = (uint32_t)((nrec + 255) / 256);
-        he = rocprim::radix_sort_pairs(temp.p, t1, (uint64_t *)c->d_ovf_key2.p, (uint64_t *)skey.p, (uint32_t *)c->d_ovf_fp2.p,
-                                       (uint32_t *)sfp.p, (size_t)nrec, 0, 64, c->stream);
+        // stable sort on the bucket id only (its log2(hash_size) bits)
+        he = rocprim::radix_sort_pairs(temp.p, t1, (uint32_t *)c->d_ovf_h2.p, (uint32_t *)skey.p, (uint64_t *)c->d_ovf_e2.p,
+                                       (uint64_t *)sfp.p, (size_t)nrec, 0, hbits, c->stream);
         if (he == hipSuccess) {
-            hipLaunchKernelGGL(k_ovf_flags, dim3(grid2), dim3(256), 0, c->stream, (const uint64_t *)skey.p, (uint64_t)nrec, (uint32_t *)flag.p);
+            hipLaunchKernelGGL(k_ovf_flags, dim3(grid2), dim3(256), 0, c->stream, (const uint32_t *)skey.p, (uint64_t)nrec, (uint32_t *)flag.p);
             he = rocprim::inclusive_scan(temp.p, t2, (uint32_t *)flag.p, (uint32_t *)runidx.p, (size_t)nrec, rocprim::plus<uint32_t>(), c->stream);
         }
         if (he == hipSuccess) {
-            hipLaunchKernelGGL(k_ovf_finalize, dim3(grid2), dim3(256), 0, c->stream, (const uint64_t *)skey.p, (const uint32_t *)sfp.p,
+            hipLaunchKernelGGL(k_ovf_finalize, dim3(grid2), dim3(256), 0, c->stream, (const uint32_t *)skey.p, (const uint64_t *)sfp.p,
                                (const uint32_t *)runidx.p, (uint64_t)nrec, (ulonglong2 *)c->d_head.p, (uint64_t *)c->d_ent.p);
             he = hipGetLastError();
         }
@@ -329,13 +350,14 @@ k_export_positions(const ulonglong2 *__restrict__ head, const uint64_t *__restri
         const ulonglong2 hd = head[h];
         const uint32_t c = head_count(hd), lo = cumm[h];
         for (uint32_t j = 0; j < c; j++) {
-            const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (c == 2 ? hd.y : ent[(uint32_t)hd.y + j - 1]);
+            const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (c == 2 ? hd.y : ent[(hd.y & W1_BASE_MASK) + j - 1]);
             positions[lo + j] = (uint32_t)(e >> PGRC_FP_BITS);
         }
     }
 }
 
 int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_positions, uint64_t *count) {
+    if (c->G >= (1ull << 32)) { c->err = "export_index: 32-bit positions only (test helper)"; return PGRC_E_PARAM; }
     const uint64_t hs = c->cp.hash_size;
     DevBuf cnt, cumm, pos, temp;
     auto cleanup = [&]() { pgrc_buf_free(cnt); pgrc_buf_free(cumm); pgrc_buf_free(pos); pgrc_buf_free(temp); };
@@ -390,9 +412,10 @@ struct MatchArgs {
 #define MATCH_TPB 256
 
 // Per-read state of the reference's sequential query (CopMEMMatcher.cpp:483-566).
-#define POS_NONE 0xFFFFFFFFu // text positions are < 2^32 - 256 (api.hip: alloc_pg)
+template <typename pos_t>
 struct ReadState {
-    uint32_t limit, falses, cur, best;
+    uint32_t limit, falses, cur;
+    pos_t best; // all ones = none (text positions stay below 2^32 - 256, resp. 2^40 - 256: api.hip alloc_pg)
     bool done;
 };
 
@@ -445,8 +468,13 @@ __device__ __forceinline__ uint32_t hash_fp_window(const uint32_t w0, const uint
 // next one of its wave's chunk (ranks by ballot/popcount, no atomics; a wave reserves MATCH_CHUNK reads at a time
 // from one global counter), so every resident lane always has a gather in flight until the read set is
 // exhausted.  The per-read sequence of events is untouched.
-template <int NW, int KQ>
+// POS64: text positions need more than 32 bits (Pg >= 4 Gi symbols: the reference's u64 index branch,
+// CopMEMMatcher.cpp:579-586); otherwise positions are kept in one register.
+template <int NW, int KQ, bool POS64>
 __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a) {
+    typedef typename std::conditional<POS64, uint64_t, uint32_t>::type pos_t;
+    constexpr pos_t POS_NONE = (pos_t)~(pos_t)0;
+    constexpr uint32_t EPOCH_BITS = POS64 ? 13u : 16u; // POS64 keeps position bits 32..39 next to the counts
     __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
     __shared__ uint32_t fpm_tab[SM_MAX_SEEDS];
     __shared__ uint2 vcache[VC_SLOTS][MATCH_TPB]; // {position, head count | tail count << 8 | epoch << 16}
@@ -457,7 +485,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
     for (uint32_t t = threadIdx.x; t < nseeds && t < SM_MAX_SEEDS; t += blockDim.x)
         fpm_tab[t] = fp_head_mask(a.K, t * a.k2, (uint32_t)H);
 #pragma unroll
-    for (int k = 0; k < VC_SLOTS; k++) vcache[k][threadIdx.x] = make_uint2(POS_NONE, 0u);
+    for (int k = 0; k < VC_SLOTS; k++) vcache[k][threadIdx.x] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -466,7 +494,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
 #pragma unroll
     for (int k = 0; k < NW; k++) sh[k] = 0u;
 
-    ReadState st;
+    ReadState<pos_t> st;
     st.limit = 0; st.falses = 0; st.cur = 0; st.best = POS_NONE; st.done = false;
     const uint32_t budget = (a.L + 1u - a.K) / a.k2;
     const uint32_t sbits = 2u * a.k2;
@@ -477,13 +505,14 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
     uint32_t cin = 0, epoch = 0;
     uint32_t cnext = 0, cend = 0; // this wave's reserved range of reads (wave-uniform: kept in SGPRs)
     uint32_t si = 0;              // seed index: s = si * k2
-    uint32_t lo = 0, nb = 0, j = 0, fp_read = 0, cand_p = 0;
+    uint32_t lo = 0, nb = 0, j = 0, fp_read = 0;
+    pos_t cand_p = 0;
     uint64_t pend_e = 0;          // an entry already in registers (entry 1 of the head / second half of a pair)
     bool has_pend = false;
     constexpr int PWN = ((NW + 1 + 3) / 4) * 4;
 
     // judge a verified alignment (head count mh, tail count mt) exactly as CopMEMMatcher.cpp:536-560
-    auto judge = [&](uint32_t mh, uint32_t mt, uint32_t p) {
+    auto judge = [&](uint32_t mh, uint32_t mt, pos_t p) {
         const uint32_t m = mh + mt;
         if (mh > st.limit) st.falses += 1;                       // :536-539
         else if (m > st.limit) st.falses += 2;                   // :542-551 (counted twice)
@@ -527,7 +556,12 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                         st.done = false;
                         si = 0;
                         has_pend = false;
-                        epoch = (epoch + 1u) & 0xFFFFu;              // invalidates this lane's verify-cache entries
+                        epoch = (epoch + 1u) & ((1u << EPOCH_BITS) - 1u); // invalidates this lane's verify-cache entries
+                        if (epoch == 0) {                            // wrapped: really clear them
+#pragma unroll
+                            for (int k = 0; k < VC_SLOTS; k++) vcache[k][threadIdx.x] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+                            epoch = 1;
+                        }
                         started = true;
                         mode = M_PROBE;
                     }
@@ -565,7 +599,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
         uint32_t next = m0;
         if (m0 == M_VERIFY) {
             uint32_t pw[PWN];
-            const uint32_t b = (cand_p & 15u) * 2u;
+            const uint32_t b = ((uint32_t)cand_p & 15u) * 2u;
             const uint32_t *src = a.pg + (cand_p >> 4); // the text is padded: PWN words are always in bounds
 #pragma unroll
             for (int k = 0; k < PWN; k += 4) {
@@ -580,7 +614,9 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                 mh += mism2(tw, rw, sym_mask(k, 0, H));
                 mt += mism2(tw, rw, sym_mask(k, H, (int)a.L));
             }
-            vcache[(cand_p * 0x9E3779B1u) >> 30][threadIdx.x] = make_uint2(cand_p, mh | (mt << 8) | (epoch << 16));
+            vcache[((uint32_t)cand_p * 0x9E3779B1u) >> 30][threadIdx.x] =
+                make_uint2((uint32_t)cand_p, POS64 ? (mh | (mt << 8) | ((uint32_t)((uint64_t)cand_p >> 32) << 11) | (epoch << 19))
+                                                   : (mh | (mt << 8) | (epoch << 16)));
             judge(mh, mt, cand_p);
             next = st.done ? M_NEED : (j < nb ? M_ENTRY : M_ADV);
         } else if (m0 <= M_ENTRY) {
@@ -593,7 +629,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                     if (st.falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET); // :510-514
                     has_pend = cnt == 2 && nb > 1; // entry 1 of a two-entry bucket sits in the head
                     pend_e = hd.y;
-                    lo = (uint32_t)hd.y;            // count >= 3: entries 1.. live at ent[lo + j - 1]
+                    lo = (uint32_t)(hd.y & W1_BASE_MASK); // count >= 3: entries 1.. live at ent[lo + j - 1] (< 2^32 entries)
                     e = hd.x & ENT_MASK;
                     have = true;
                     j = 1;
@@ -610,14 +646,17 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                 const uint64_t sp = e >> PGRC_FP_BITS;
                 if ((uint64_t)s <= sp && sp - s + a.L <= a.G) {      // :517-520
                     counted_cand = true;
-                    const uint32_t p = (uint32_t)(sp - s);
+                    const pos_t p = (pos_t)(sp - s);
                     const uint32_t x = ((uint32_t)e ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
                     if ((uint32_t)__popc((x | (x >> 1)) & fpm_tab[si]) > st.limit) {
                         st.falses += 1;                              // certain head reject
                     } else {
-                        const uint2 cv = vcache[(p * 0x9E3779B1u) >> 30][threadIdx.x];
-                        if (cv.x == p && (cv.y >> 16) == epoch) {
-                            judge(cv.y & 0xFFu, (cv.y >> 8) & 0xFFu, p);
+                        const uint2 cv = vcache[((uint32_t)p * 0x9E3779B1u) >> 30][threadIdx.x];
+                        const bool hit = POS64 ? (cv.x == (uint32_t)p && (cv.y >> 19) == epoch &&
+                                                  ((cv.y >> 11) & 0xFFu) == (uint32_t)((uint64_t)p >> 32))
+                                               : (cv.x == (uint32_t)p && (cv.y >> 16) == epoch);
+                        if (hit) {
+                            judge(cv.y & 0xFFu, (cv.y >> 8) & (POS64 ? 0x7u : 0xFFu), p);
                             if (st.done) next = M_NEED;
                         } else {
                             cand_p = p;
@@ -695,7 +734,7 @@ k_copmem_match_ascii(const MatchArgs a, const uint32_t *__restrict__ nidx, const
             uint32_t nb = cnt;
             if (falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET);
             for (uint32_t j = 0; j < nb; j++) {
-                const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (cnt == 2 ? hd.y : a.ent[(uint32_t)hd.y + j - 1]);
+                const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (cnt == 2 ? hd.y : a.ent[(hd.y & W1_BASE_MASK) + j - 1]);
                 const uint64_t sp = e >> PGRC_FP_BITS;
                 if ((uint64_t)s > sp) continue;
                 const uint64_t p = sp - s;
@@ -738,9 +777,16 @@ static void launch_match(pgrc_match_ctx *c, const MatchArgs &a) {
     // persistent grid: what the chip can hold (8 blocks of 4 waves per CU is the register/LDS limit at most)
     const uint64_t want = (a.n + MATCH_TPB - 1) / MATCH_TPB;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)c->num_cus * 8u);
-    const char *hs = getenv("PGRC_HASH_STATIC"); // tuning knob (A/B): 0 = always the run-time K loop
-    if (a.K == 28 && !(hs && hs[0] == '0')) hipLaunchKernelGGL((k_copmem_match_sm<NW, 7>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_copmem_match_sm<NW, 0>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+    const char *f64 = getenv("PGRC_FORCE_POS64"); // test knob: run the 64-bit-position kernel on a small text
+    const bool pos64 = c->G + 256 >= (1ull << 32) || (f64 && f64[0] == '1');
+    const bool k28 = a.K == 28;                   // the default seed: compile-time hash loop
+    if (pos64) {
+        if (k28) hipLaunchKernelGGL((k_copmem_match_sm<NW, 7, true>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_copmem_match_sm<NW, 0, true>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+    } else {
+        if (k28) hipLaunchKernelGGL((k_copmem_match_sm<NW, 7, false>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_copmem_match_sm<NW, 0, false>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+    }
 }
 
 int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {

@@ -70,7 +70,7 @@ struct pgrc_match_ctx {
     // copMEM index (rebuilt per pass, buffers reused)
     pgrc_copmem_params cp{};
     uint64_t npos = 0;
-    DevBuf d_ent, d_head, d_ovf_key, d_ovf_fp, d_ovf_key2, d_ovf_fp2, d_mark, d_scan_tmp;
+    DevBuf d_ent, d_head, d_ovf_h, d_ovf_e, d_ovf_h2, d_ovf_e2, d_mark, d_scan_tmp;
     DevBuf d_skey, d_sfp, d_flag, d_runidx, d_sorttmp; // overflow sort scratch (grow-only)
     uint64_t n_ovf = 0, ovf_cap_hint = 0;
     int index_strand = -1;  // which strand the buffers currently describe

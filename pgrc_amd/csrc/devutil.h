@@ -34,10 +34,10 @@ __device__ __forceinline__ void hash_lut_init(uint32_t *lut) {
 //
 // The fold additionally returns a FINGERPRINT of the window: the symbols the sparsified hash
 // ignores (symbol 3 of steps 0..2, symbols 2,3 of the later steps), packed 2 bits each in step
-// order, at most 24 bits.  Stored next to every indexed position, it lets the match kernel reject a
+// order, at most 22 bits (exactly what K = 28 yields; entries keep 40 bits for the position).  Stored next to every indexed position, it lets the match kernel reject a
 // false candidate without touching the pseudogenome: the fingerprint symbols are ordinary window
 // symbols, so their mismatches are a lower bound of the Hamming distance.
-#define PGRC_FP_BITS 24u
+#define PGRC_FP_BITS 22u
 __device__ __forceinline__ uint32_t copmem_hash32_fp(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3,
                                                      uint32_t K, const uint32_t *lut, uint32_t *fp_out) {
     uint32_t h = K, fp = 0, fb = 0;

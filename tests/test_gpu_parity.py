@@ -353,3 +353,17 @@ def test_c_consumer_of_the_abi(tmp_path):
     for p, m, c in zip(o["pos"].tolist(), o["mism"].tolist(), o["rc"].tolist()):
         fnv = ((fnv ^ p ^ (m << 56) ^ (c << 48)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert f"matched {o['matched']} of 4000, exact {int(o['hist'][0])}, digest {fnv:016x}" in r.stdout
+
+
+@pytest.mark.parametrize("L,seed_len,M,shortcut", [(100, 38, 50, False), (150, 38, 3, False), (250, 45, 20, True), (64, 32, 10, False)])
+def test_copmem_64bit_position_kernels_on_small_text(monkeypatch, L, seed_len, M, shortcut):
+    """PGRC_FORCE_POS64 selects the kernels that a pseudogenome >= 4 Gi symbols needs (the reference's u64 index
+    branch, CopMEMMatcher.cpp:579-586) on a small text; results must not change.  (The real thing is exercised by
+    tools/fullscale_parity.py --workload P64, profiles/r01_fullscale_parity_P64.json.)"""
+    monkeypatch.setenv("PGRC_FORCE_POS64", "1")
+    pg, reads = make_inputs(300000, 12000, L, seed=4000 + L, n_with_n=300)
+    kmax = L // M
+    kmin = kmax if shortcut else 0
+    o = orc.oracle_match("c", pg, reads, seed_len, kmax, kmin)
+    g = gpu_match("c", pg, reads, seed_len, kmax, kmin)
+    assert_same_results(g, o, f"pos64 L={L}")
