@@ -154,6 +154,17 @@ def main():
         # (tools/ubench: the chip sustains ~51 G independent random requests per second, whatever their width)
         gathers = int(ctr["probes"][dom] + ctr["entry_fetches"][dom] + ctr["verifies"][dom] * (1.0 + max(rb - 4, 0) / 64.0))
         gather_rate = gathers / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        # HBM traffic of that launch from the PMC counters (FETCH_SIZE + WRITE_SIZE): they cannot be read from inside
+        # this process, so the value comes from the committed separate `rocprofv3 --pmc` passes of this very command
+        # (tools/pmc_groups.sh + tools/pmc_traffic.py -> profiles/); null for workloads that were not profiled.
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", f"r01_final_{args.workload.lower()}_traffic.json")
+        if world == 1 and os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp))["dispatches"][dom]["hbm_bytes"]
+                traffic_src = os.path.relpath(tp, ROOT)
+            except Exception:
+                traffic = None
         out = {
             "metric": "reads matched/sec (150 bp) at 1/2/4/8 MI355X; achieved HBM GB/s",
             "value": value,
@@ -174,7 +185,7 @@ def main():
                        "copmem": cp, "matched_fraction": matched / n_per,
                        "parallelism": f"reads sharded x{world}, Pg replicated" + (" (1 all-gather/step)" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_copmem_match" + ("(fwd)" if dom == 0 else "(rc)"),
                          "kernel_ms": ms, "algorithmic_bytes": alg_bytes,
                          "random_gathers": gathers, "gather_rate_G_per_s": gather_rate,
