@@ -195,7 +195,10 @@ def main():
             "counters": {k: ctr[k] for k in ("searched", "candidates", "probes", "entry_fetches", "verifies", "index_entries")},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax)
+            except Exception as e:  # the GPU measurement must not be lost to a host-side problem
+                out["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
