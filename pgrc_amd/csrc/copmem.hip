@@ -777,15 +777,17 @@ static void launch_match(pgrc_match_ctx *c, const MatchArgs &a) {
     // persistent grid: what the chip can hold (8 blocks of 4 waves per CU is the register/LDS limit at most)
     const uint64_t want = (a.n + MATCH_TPB - 1) / MATCH_TPB;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)c->num_cus * 8u);
+    const char *xl = getenv("PGRC_EXTRA_LDS");    // experiment knob: extra dynamic LDS per block lowers the occupancy
+    const uint32_t dyn_lds = xl ? (uint32_t)atoi(xl) : 0u;
     const char *f64 = getenv("PGRC_FORCE_POS64"); // test knob: run the 64-bit-position kernel on a small text
     const bool pos64 = c->G + 256 >= (1ull << 32) || (f64 && f64[0] == '1');
     const bool k28 = a.K == 28;                   // the default seed: compile-time hash loop
     if (pos64) {
-        if (k28) hipLaunchKernelGGL((k_copmem_match_sm<NW, 7, true>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_copmem_match_sm<NW, 0, true>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+        if (k28) hipLaunchKernelGGL((k_copmem_match_sm<NW, 7, true>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
+        else hipLaunchKernelGGL((k_copmem_match_sm<NW, 0, true>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
     } else {
-        if (k28) hipLaunchKernelGGL((k_copmem_match_sm<NW, 7, false>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_copmem_match_sm<NW, 0, false>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+        if (k28) hipLaunchKernelGGL((k_copmem_match_sm<NW, 7, false>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
+        else hipLaunchKernelGGL((k_copmem_match_sm<NW, 0, false>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
     }
 }
 
