@@ -69,7 +69,7 @@ template <int PASS>
 __global__ void __launch_bounds__(IDX_TPB)
 k_copmem_index_build(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, uint64_t npos, uint32_t k1, uint32_t K,
                      uint32_t mask, ulonglong2 *__restrict__ head, uint8_t *__restrict__ mark,
-                     unsigned long long *__restrict__ ovf_count, uint32_t *__restrict__ ovf_h,
+                     unsigned long long *__restrict__ ovf_count, uint64_t *__restrict__ ovf_k,
                      uint64_t *__restrict__ ovf_e, uint64_t ovf_cap) {
     __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
     __shared__ uint32_t tile[IDX_TILE_WORDS + 8];
@@ -123,7 +123,8 @@ k_copmem_index_build(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, u
                 if (push) {
                     const unsigned long long idx = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
                     if (idx < ovf_cap) {
-                        ovf_h[(uint64_t)blockIdx.x * ovf_cap + idx] = push_h;
+                        // sort key: bucket, then the position in units of 128 symbols (31 + 33 bits)
+                        ovf_k[(uint64_t)blockIdx.x * ovf_cap + idx] = ((uint64_t)push_h << 33) | (push_e >> (PGRC_FP_BITS + 7));
                         ovf_e[(uint64_t)blockIdx.x * ovf_cap + idx] = push_e;
                     }
                 }
@@ -171,37 +172,39 @@ __global__ void __launch_bounds__(1024) k_ovf_prefix(const unsigned long long *_
 
 __global__ void __launch_bounds__(256)
 k_ovf_compact(const unsigned long long *__restrict__ cursors, const unsigned long long *__restrict__ prefix,
-              uint64_t region_cap, const uint32_t *__restrict__ h_in, const uint64_t *__restrict__ e_in,
-              uint32_t *__restrict__ h_out, uint64_t *__restrict__ e_out) {
+              uint64_t region_cap, const uint64_t *__restrict__ k_in, const uint64_t *__restrict__ e_in,
+              uint64_t *__restrict__ k_out, uint64_t *__restrict__ e_out) {
     const uint64_t n = min((uint64_t)cursors[8ull * blockIdx.x], region_cap), dst = prefix[blockIdx.x];
     const uint64_t src = (uint64_t)blockIdx.x * region_cap;
     for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        h_out[dst + i] = h_in[src + i];
+        k_out[dst + i] = k_in[src + i];
         e_out[dst + i] = e_in[src + i];
     }
 }
 
-__global__ void __launch_bounds__(256) k_ovf_flags(const uint32_t *__restrict__ sh, uint64_t n, uint32_t *__restrict__ flag) {
+__global__ void __launch_bounds__(256) k_ovf_flags(const uint64_t *__restrict__ sk, uint64_t n, uint32_t *__restrict__ flag) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = (i == 0 || sh[i] != sh[i - 1]) ? 1u : 0u;
+    if (i < n) flag[i] = (i == 0 || (sk[i] >> 33) != (sk[i - 1] >> 33)) ? 1u : 0u;
 }
 
-// overflow records sorted by bucket (stable radix sort on the bucket id only: entries of one bucket arrive in
-// arbitrary order) -> per-bucket segments [entry1, the bucket's 11 smallest overflow entries ascending] in
-// ent[], head fix-up.  One thread per bucket run; runs are 1-2 records long except on low-complexity text.
+// Overflow records sorted by (bucket, position / 128) -> per-bucket segments [entry1, the bucket's 11 smallest
+// overflow entries ascending] in ent[], head fix-up.  One thread per bucket run.  The run is ordered by
+// 128-symbol blocks, a block holds at most ceil(128 / k1) <= 43 sampled positions (k1 >= 3), so the 11 smallest
+// entries are among the run's first 10 + 43 records: the scan is bounded whatever the run length (poly-A...).
+#define OVF_SCAN_MAX 54u
 __global__ void __launch_bounds__(256)
-k_ovf_finalize(const uint32_t *__restrict__ sh, const uint64_t *__restrict__ se, const uint32_t *__restrict__ runidx,
+k_ovf_finalize(const uint64_t *__restrict__ sk, const uint64_t *__restrict__ se, const uint32_t *__restrict__ runidx,
                uint64_t n, ulonglong2 *__restrict__ head, uint64_t *__restrict__ ent) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t h = sh[i];
-    if (i != 0 && sh[i - 1] == h) return;                    // not the first record of its bucket
+    const uint64_t hk = sk[i] >> 33;
+    if (i != 0 && (sk[i - 1] >> 33) == hk) return;           // not the first record of its bucket
     constexpr int KEEP = (int)PGRC_BUCKET_CAP - 2;           // the head already holds the two smallest
     uint64_t a[KEEP];
 #pragma unroll
     for (int k = 0; k < KEEP; k++) a[k] = ~0ull;
     uint32_t len = 0;
-    for (uint64_t j = i; j < n && sh[j] == h; j++) {
+    for (uint64_t j = i; j < n && j < i + OVF_SCAN_MAX && (sk[j] >> 33) == hk; j++) {
         uint64_t x = se[j];
 #pragma unroll
         for (int k = 0; k < KEEP; k++) {
@@ -212,6 +215,7 @@ k_ovf_finalize(const uint32_t *__restrict__ sh, const uint64_t *__restrict__ se,
         if (len < (uint32_t)KEEP) len++;
     }
     const uint64_t base = i + (runidx[i] - 1u);              // run r starts at sorted index i: segment base i + r
+    const uint32_t h = (uint32_t)hk;
     ulonglong2 hd = head[h];
     ent[base] = hd.y;                                        // entry1 opens the segment
 #pragma unroll
@@ -233,7 +237,7 @@ static int build_once(pgrc_match_ctx *c, int strand, uint64_t region_cap, uint64
     const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ntiles, 1), IDX_MAX_BLOCKS);
     int e;
     if ((e = pgrc_buf_ensure(c, c->d_head, hs * 2 * sizeof(uint64_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->d_ovf_h, ((uint64_t)grid * region_cap + 16) * sizeof(uint32_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->d_ovf_h, ((uint64_t)grid * region_cap + 16) * sizeof(uint64_t)))) return e;
     if ((e = pgrc_buf_ensure(c, c->d_ovf_e, ((uint64_t)grid * region_cap + 16) * sizeof(uint64_t)))) return e;
     if ((e = pgrc_buf_ensure(c, c->d_scan_tmp, (8ull * IDX_MAX_BLOCKS + IDX_MAX_BLOCKS + 8) * sizeof(uint64_t)))) return e;
     if ((e = pgrc_buf_ensure(c, c->d_mark, c->npos + 16))) return e;
@@ -247,7 +251,7 @@ static int build_once(pgrc_match_ctx *c, int strand, uint64_t region_cap, uint64
 #define LAUNCH_PASS(P)                                                                                                   \
     hipLaunchKernelGGL(k_copmem_index_build<P>, dim3(grid), dim3(IDX_TPB), 0, c->stream, (const uint32_t *)c->pg2[strand].p, \
                        c->pg_words + PGRC_PG_PAD_WORDS, c->npos, k1, K, (uint32_t)(hs - 1), (ulonglong2 *)c->d_head.p,       \
-                       (uint8_t *)c->d_mark.p, cursors, (uint32_t *)c->d_ovf_h.p, (uint64_t *)c->d_ovf_e.p, region_cap)
+                       (uint8_t *)c->d_mark.p, cursors, (uint64_t *)c->d_ovf_h.p, (uint64_t *)c->d_ovf_e.p, region_cap)
     LAUNCH_PASS(0);
     LAUNCH_PASS(1);
     LAUNCH_PASS(2);
@@ -260,11 +264,11 @@ static int build_once(pgrc_match_ctx *c, int strand, uint64_t region_cap, uint64
     if (tail[1] > region_cap) { *region_overflow = true; *nrec_out = tail[1]; return PGRC_OK; }
     *nrec_out = tail[0];
     if (tail[0]) {
-        if ((e = pgrc_buf_ensure(c, c->d_ovf_h2, (tail[0] + 16) * sizeof(uint32_t)))) return e;
+        if ((e = pgrc_buf_ensure(c, c->d_ovf_h2, (tail[0] + 16) * sizeof(uint64_t)))) return e;
         if ((e = pgrc_buf_ensure(c, c->d_ovf_e2, (tail[0] + 16) * sizeof(uint64_t)))) return e;
         hipLaunchKernelGGL(k_ovf_compact, dim3(grid), dim3(256), 0, c->stream, (const unsigned long long *)cursors,
-                           (const unsigned long long *)prefix, region_cap, (const uint32_t *)c->d_ovf_h.p,
-                           (const uint64_t *)c->d_ovf_e.p, (uint32_t *)c->d_ovf_h2.p, (uint64_t *)c->d_ovf_e2.p);
+                           (const unsigned long long *)prefix, region_cap, (const uint64_t *)c->d_ovf_h.p,
+                           (const uint64_t *)c->d_ovf_e.p, (uint64_t *)c->d_ovf_h2.p, (uint64_t *)c->d_ovf_e2.p);
         HIP_TRY(c, hipGetLastError());
     }
     return PGRC_OK;
@@ -298,28 +302,34 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
         if (2 * nrec + 16 >= (1ull << 32)) { c->err = "index build: overflow segments exceed 2^32 entries"; return PGRC_E_PARAM; }
         int hbits = 0;
         while ((1ull << hbits) < c->cp.hash_size) hbits++;
+        int pbits = 1; // bits of (position >> 7)
+        while ((1ull << (pbits + 7)) < c->G) pbits++;
         size_t t1 = 0, t2 = 0;
-        hipError_t he = rocprim::radix_sort_pairs(nullptr, t1, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr,
-                                                  (uint64_t *)nullptr, (size_t)nrec, 0, hbits, c->stream);
+        // key = bucket << 33 | position >> 7: only the bits that can be set take part in the sort
+        hipError_t he = rocprim::radix_sort_pairs(nullptr, t1, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr,
+                                                  (uint64_t *)nullptr, (size_t)nrec, 0, 33 + hbits, c->stream);
         if (he == hipSuccess)
             he = rocprim::inclusive_scan(nullptr, t2, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)nrec, rocprim::plus<uint32_t>(), c->stream);
         if (he != hipSuccess) { c->err = "rocprim size query failed"; return PGRC_E_NO_DEVICE; }
-        if ((e = pgrc_buf_ensure(c, skey, nrec * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, sfp, nrec * sizeof(uint64_t))) ||
+        if ((e = pgrc_buf_ensure(c, skey, nrec * sizeof(uint64_t))) || (e = pgrc_buf_ensure(c, sfp, nrec * sizeof(uint64_t))) ||
             (e = pgrc_buf_ensure(c, flag, nrec * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, runidx, nrec * sizeof(uint32_t))) ||
             (e = pgrc_buf_ensure(c, temp, std::max(t1, t2))) || (e = pgrc_buf_ensure(c, c->d_ent, (2 * nrec + 16) * sizeof(uint64_t)))) {
             cleanup();
             return e;
         }
         const uint32_t grid2 = (uint32_t)((nrec + 255) / 256);
-        // stable sort on the bucket id only (its log2(hash_size) bits)
-        he = rocprim::radix_sort_pairs(temp.p, t1, (uint32_t *)c->d_ovf_h2.p, (uint32_t *)skey.p, (uint64_t *)c->d_ovf_e2.p,
-                                       (uint64_t *)sfp.p, (size_t)nrec, 0, hbits, c->stream);
+        // two sorts on disjoint bit ranges = one stable sort on (bucket, position / 128), skipping the unused key bits
+        he = rocprim::radix_sort_pairs(temp.p, t1, (uint64_t *)c->d_ovf_h2.p, (uint64_t *)skey.p, (uint64_t *)c->d_ovf_e2.p,
+                                       (uint64_t *)sfp.p, (size_t)nrec, 0, pbits, c->stream);
+        if (he == hipSuccess)
+            he = rocprim::radix_sort_pairs(temp.p, t1, (uint64_t *)skey.p, (uint64_t *)c->d_ovf_h2.p, (uint64_t *)sfp.p,
+                                           (uint64_t *)c->d_ovf_e2.p, (size_t)nrec, 33, 33 + hbits, c->stream);
         if (he == hipSuccess) {
-            hipLaunchKernelGGL(k_ovf_flags, dim3(grid2), dim3(256), 0, c->stream, (const uint32_t *)skey.p, (uint64_t)nrec, (uint32_t *)flag.p);
+            hipLaunchKernelGGL(k_ovf_flags, dim3(grid2), dim3(256), 0, c->stream, (const uint64_t *)c->d_ovf_h2.p, (uint64_t)nrec, (uint32_t *)flag.p);
             he = rocprim::inclusive_scan(temp.p, t2, (uint32_t *)flag.p, (uint32_t *)runidx.p, (size_t)nrec, rocprim::plus<uint32_t>(), c->stream);
         }
         if (he == hipSuccess) {
-            hipLaunchKernelGGL(k_ovf_finalize, dim3(grid2), dim3(256), 0, c->stream, (const uint32_t *)skey.p, (const uint64_t *)sfp.p,
+            hipLaunchKernelGGL(k_ovf_finalize, dim3(grid2), dim3(256), 0, c->stream, (const uint64_t *)c->d_ovf_h2.p, (const uint64_t *)c->d_ovf_e2.p,
                                (const uint32_t *)runidx.p, (uint64_t)nrec, (ulonglong2 *)c->d_head.p, (uint64_t *)c->d_ent.p);
             he = hipGetLastError();
         }
