@@ -42,6 +42,19 @@ namespace PgTools {
 
     void HipReadsMatcher::upload() {
         if (uploaded) return;
+        uploaded = true;
+        // Modes d/i/e index the reads the way DefaultConstantLengthPatternsOnTextHashMatcher::addReadsSetOfPatterns does
+        // (matching/ConstantLengthPatternsOnTextHashMatcher.cpp:30): the first getReadsSetProperties()->readsCount
+        // reads.  For a PackedConstantLengthReadsSet that is every read; the LQ + N SumOfConstantLengthReadsSets of
+        // pgrc-encoder.cpp:349-352 never fills its properties, so the reference indexes -- and matches -- nothing there.
+        // Kept bit for bit: only the indexed reads go to the device, the others keep their state.
+        deviceReads = readsCount;
+        if (hipMode != 'c') {
+            const uint_reads_cnt_max indexed = readsSet->getReadsSetProperties()->readsCount;
+            if (indexed < deviceReads) deviceReads = indexed;
+        }
+        if (deviceReads == 0) return;
+        const uint_reads_cnt_max readsCount = deviceReads;   // shadows the member for the rest of this function
         failOn(pgrc_match_set_pg_ascii(ctx, pgPtr, pgLength), "set_pg_ascii");
         auto *packed = dynamic_cast<PackedConstantLengthReadsSet *>(readsSet);
         if (packed && packed->getReadsSetProperties()->symbolsCount == 4 &&
@@ -64,20 +77,25 @@ namespace PgTools {
             }
             failOn(pgrc_match_end_reads(ctx), "end_reads");
         }
-        uploaded = true;
     }
 
     void HipReadsMatcher::fetchResults() {
         readMatchPos.resize(readsCount);
         readMismatchesCount.resize(readsCount);
-        std::vector<uint8_t> rc(readsCount);
-        uint64_t hist[NOT_MATCHED_COUNT + 1];
+        readMatchRC.resize(readsCount, false);
+        uint64_t hist[NOT_MATCHED_COUNT + 1] = {0};
         uint64_t matched = 0;
-        failOn(pgrc_match_get_results(ctx, readMatchPos.data(), rc.data(), readMismatchesCount.data(), hist, &matched),
-               "get_results");
-        readMatchRC.assign(readsCount, false);
-        for (uint_reads_cnt_max i = 0; i < readsCount; i++)
-            readMatchRC[i] = rc[i] != 0;
+        if (deviceReads) {
+            std::vector<uint8_t> rc(deviceReads);
+            failOn(pgrc_match_get_results(ctx, readMatchPos.data(), rc.data(), readMismatchesCount.data(), hist,
+                                          &matched), "get_results");
+            for (uint_reads_cnt_max i = 0; i < deviceReads; i++)
+                readMatchRC[i] = rc[i] != 0;
+        }
+        for (uint_reads_cnt_max i = deviceReads; i < readsCount; i++) {   // reads that never went to the device
+            hist[readMismatchesCount[i]]++;
+            matched += readMismatchesCount[i] != NOT_MATCHED_COUNT;
+        }
         matchedReadsCount = matched;
         for (int k = 0; k <= NOT_MATCHED_COUNT; k++)
             matchedCountPerMismatches[k] = hist[k];
@@ -88,32 +106,33 @@ namespace PgTools {
         readMismatchesCount.clear();
         readMismatchesCount.insert(readMismatchesCount.end(), readsCount, NOT_MATCHED_COUNT);
         upload();
-        failOn(pgrc_match_init_results(ctx), "init_results");
+        if (deviceReads) failOn(pgrc_match_init_results(ctx), "init_results");
     }
 
     void HipReadsMatcher::initMatchingContinuation(DefaultReadsMatcher *pMatcher) {
         AbstractReadsApproxMatcher::initMatchingContinuation(pMatcher); // takes the result vectors over (:111-133)
         upload();
-        std::vector<uint8_t> rc(readsCount);
-        for (uint_reads_cnt_max i = 0; i < readsCount; i++)
+        if (!deviceReads) return;
+        std::vector<uint8_t> rc(deviceReads);
+        for (uint_reads_cnt_max i = 0; i < deviceReads; i++)
             rc[i] = readMatchRC[i] ? 1 : 0;
         failOn(pgrc_match_set_results(ctx, readMatchPos.data(), rc.data(), readMismatchesCount.data()), "set_results");
     }
 
     void HipReadsMatcher::executeMatching(bool revCompMode) {
-        failOn(pgrc_match_run_pass(ctx, revCompMode ? 1 : 0), "run_pass");
+        if (deviceReads) failOn(pgrc_match_run_pass(ctx, revCompMode ? 1 : 0), "run_pass");
         fetchResults();
     }
 
     void HipReadsMatcher::matchConstantLengthReadsOnDevice() {
         initMatching();
-        failOn(pgrc_match_run(ctx, revComplPg ? 1 : 0), "run");
+        if (deviceReads) failOn(pgrc_match_run(ctx, revComplPg ? 1 : 0), "run");
         fetchResults();
     }
 
     void HipReadsMatcher::continueMatchingConstantLengthReadsOnDevice(DefaultReadsMatcher *pMatcher) {
         initMatchingContinuation(pMatcher);
-        failOn(pgrc_match_run(ctx, revComplPg ? 1 : 0), "run");
+        if (deviceReads) failOn(pgrc_match_run(ctx, revComplPg ? 1 : 0), "run");
         fetchResults();
     }
 }

@@ -21,6 +21,7 @@ namespace PgTools {
         const char hipMode;                  // 'c', 'd', 'i' or 'e' (the matcher the reference would have built)
         const uint16_t seedChars;
         bool uploaded = false;
+        uint_reads_cnt_max deviceReads = 0;  // reads that take part (all in mode c; see upload() for modes d/i/e)
 
         void failOn(int code, const char *what);
         void upload();

@@ -21,6 +21,8 @@
 #include "utils/helper.h"
 #ifdef PGRC_WITH_HIP_ADAPTER
 #include "HipReadsMatcher.h"
+#include "pgrc/pgrc-decoder.h"
+#include "pgrc/pgrc-encoder.h"
 #endif
 
 using namespace PgTools;
@@ -53,6 +55,7 @@ struct Silence {
     std::ostream *old_log;
     std::ios::iostate old_state;
     Silence() : old_log(PgHelpers::logout), old_state(std::cout.rdstate()) {
+        if (getenv("PGRC_REF_VERBOSE")) return;   // debugging aid: keep the reference's own log
         PgHelpers::logout = &null_stream;
         std::cout.setstate(std::ios::failbit);
     }
@@ -168,6 +171,128 @@ int pgrc_ref_match(char mode, const char *pg, uint64_t G, const char *reads, uin
 }
 
 #ifdef PGRC_WITH_HIP_ADAPTER
+} // extern "C" (the C++ definition of PgTools::mapReadsIntoPg below cannot live in a C-linkage block)
+// ---------------------------------------------------------------------------------------------------------------
+// End-to-end drop-in.  The reference's encoder (pgrc-encoder.cpp:359-366) calls PgTools::mapReadsIntoPg.  The
+// definition below REPLACES the reference's (whose object code is kept under the name
+// pgrc_ref_mapReadsIntoPg_original by oracle/Makefile): with g_gpu_matching off it forwards to the untouched
+// original, with it on it is the patched function of INTEGRATION.md section 1 -- same parameter derivation
+// (ReadsMatchers.cpp:699-713), HipReadsMatcher in the matcher seam, the reference's own export afterwards
+// (:783-792).  New code written against the reference's public interfaces.
+static bool g_gpu_matching = false;
+static int g_gpu_calls = 0;
+
+extern "C" const std::vector<bool> pgrc_ref_mapReadsIntoPg_original(
+        SeparatedPseudoGenome *sPg, bool revComplPg, bool preserveOrderMode, ConstantLengthReadsSetInterface *readsSet,
+        bool pairFileMode, bool revComplPairFile, uint_read_len_max matchPrefixLength, uint16_t preReadsExactMatchingChars,
+        uint16_t readsExactMatchingChars, uint16_t minCharsPerMismatch, char preMatchingMode, char matchingMode,
+        bool dumpInfo, ostream &pgrcOut, uint8_t compressionLevel, const string &pgDestFilePrefix,
+        IndexesMapping *orgIndexesMapping);
+
+namespace PgTools {
+    const vector<bool> mapReadsIntoPg(SeparatedPseudoGenome *sPg, bool revComplPg, bool preserveOrderMode,
+                                      ConstantLengthReadsSetInterface *readsSet, bool pairFileMode, bool revComplPairFile,
+                                      uint_read_len_max matchPrefixLength, uint16_t preReadsExactMatchingChars,
+                                      uint16_t readsExactMatchingChars, uint16_t minCharsPerMismatch, char preMatchingMode,
+                                      char matchingMode, bool dumpInfo, ostream &pgrcOut, uint8_t compressionLevel,
+                                      const string &pgDestFilePrefix, IndexesMapping *orgIndexesMapping) {
+        if (!g_gpu_matching)
+            return pgrc_ref_mapReadsIntoPg_original(sPg, revComplPg, preserveOrderMode, readsSet, pairFileMode,
+                                                    revComplPairFile, matchPrefixLength, preReadsExactMatchingChars,
+                                                    readsExactMatchingChars, minCharsPerMismatch, preMatchingMode,
+                                                    matchingMode, dumpInfo, pgrcOut, compressionLevel, pgDestFilePrefix,
+                                                    orgIndexesMapping);
+        g_gpu_calls++;
+        const uint_read_len_max readLength = readsSet->maxReadLength();
+        const uint8_t maxMismatches = readLength / minCharsPerMismatch;
+        if (readsExactMatchingChars > readLength) readsExactMatchingChars = readLength;
+        if (preReadsExactMatchingChars > readLength) preReadsExactMatchingChars = readLength;
+        auto kindOf = [&](char mode, uint16_t seed) -> char {
+            const char low = (char) tolower(mode);
+            if (readLength == seed) return low == 'c' ? 'c' : 'e';
+            if (low != 'c' && low != 'd' && low != 'i') {
+                fprintf(stderr, "Unknown matching mode: %c.\n", mode);
+                exit(EXIT_FAILURE);
+            }
+            return low;
+        };
+        const uint16_t firstSeed = preReadsExactMatchingChars > 0 ? preReadsExactMatchingChars : readsExactMatchingChars;
+        const char firstMode = preReadsExactMatchingChars > 0 ? preMatchingMode : matchingMode;
+        const uint8_t firstMin = (toupper(firstMode) == firstMode) ? maxMismatches : 0;
+        char *pg = (char *) sPg->getPgSequence().data();
+        const uint_pg_len_max pgLen = sPg->getPgSequence().length();
+        HipReadsMatcher *matcher = new HipReadsMatcher(pg, pgLen, revComplPg, readsSet, matchPrefixLength, firstSeed,
+                                                       maxMismatches, firstMin, kindOf(firstMode, firstSeed));
+        matcher->matchConstantLengthReadsOnDevice();
+        if (preReadsExactMatchingChars > 0) {
+            // :713 -- the value the reference uses at :752 is still the FIRST phase's (it is recomputed only at :770)
+            const uint8_t targetMismatches = readLength / firstSeed - 1;
+            const uint8_t secondMin = (toupper(matchingMode) == matchingMode) ? maxMismatches : targetMismatches + 1;
+            HipReadsMatcher *second = new HipReadsMatcher(pg, pgLen, revComplPg, readsSet, matchPrefixLength,
+                                                          readsExactMatchingChars, maxMismatches, secondMin,
+                                                          kindOf(matchingMode, readsExactMatchingChars));
+            second->continueMatchingConstantLengthReadsOnDevice(matcher);
+            delete matcher;
+            matcher = second;
+        }
+        const vector<bool> res = matcher->getMatchedReadsBitmap();
+        if (matchPrefixLength == DefaultReadsMatcher::DISABLED_PREFIX_MODE) {
+            if (preserveOrderMode)
+                matcher->exportMatchesInOriginalOrder(sPg, pgrcOut, compressionLevel, pgDestFilePrefix, orgIndexesMapping,
+                                                      pairFileMode, revComplPairFile);
+            else
+                matcher->exportMatchesInPgOrder(sPg, pgrcOut, compressionLevel, pgDestFilePrefix, orgIndexesMapping,
+                                                pairFileMode, revComplPairFile);
+        }
+        delete matcher;
+        return res;
+    }
+}
+
+// Runs the reference's whole encoder (PgRC.cpp:244-262) on a FASTQ file with the CPU or the GPU matcher.
+// Returns the number of times the GPU mapReadsIntoPg ran (>= 0), or a negative error.
+extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const char *archive, int threads, int use_gpu,
+                               int preserve_order, char mode, int seed_len, int min_chars_per_mismatch, char pre_mode,
+                               int pre_seed_len) {
+    Silence quiet;
+    PgHelpers::numberOfThreads = threads;
+    omp_set_num_threads(threads);
+    g_gpu_matching = use_gpu != 0;
+    g_gpu_calls = 0;
+    PgRCParams *params = new PgRCParams();
+    params->setSrcFastqFile(fastq);
+    if (pair_fastq && pair_fastq[0]) params->setPairFastqFile(pair_fastq);
+    if (preserve_order) params->setPreserveOrderMode();
+    if (mode) params->setMatchingMode(mode);
+    if (seed_len > 0) params->setReadSeedLength((uint16_t) seed_len);
+    if (min_chars_per_mismatch > 0) params->setMinCharsPerMismatch((uint16_t) min_chars_per_mismatch);
+    if (pre_mode) params->setPreMatchingMode(pre_mode);
+    if (pre_seed_len > 0) params->setPreReadsExactMatchingChars((uint16_t) pre_seed_len);
+    params->setPgRCFileName(archive);
+    {
+        PgRCEncoder encoder(params);
+        encoder.executePgRCChain();
+    }
+    delete params;
+    g_gpu_matching = false;
+    return g_gpu_calls;
+}
+
+extern "C" int pgrc_ref_decode(const char *archive, int threads) {
+    Silence quiet;
+    PgHelpers::numberOfThreads = threads;
+    omp_set_num_threads(threads);
+    PgRCParams *params = new PgRCParams();
+    params->setPgRCFileName(archive);
+    {
+        PgRCDecoder decoder(params);
+        decoder.decompressPgRC();
+    }
+    delete params;
+    return 0;
+}
+
+extern "C" {
 // The drop-in itself: the reference's own flow with integration/HipReadsMatcher in the matcher seam.
 // entry 0 = DefaultReadsMatcher::matchConstantLengthReads() (base-class driver: initMatching, executeMatching(false),
 // in-place RC of the host text, executeMatching(true), RC back); entry 1 = matchConstantLengthReadsOnDevice().

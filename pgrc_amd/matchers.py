@@ -316,10 +316,11 @@ def mapReadsIntoPg(pg, revComplPg: bool, readsSet, readsExactMatchingChars: int,
     matcher = build(seed, kmax, kmin, kind)
     matcher.matchConstantLengthReads()
     if preReadsExactMatchingChars > 0:
-        # 2nd phase, ReadsMatchers.cpp:749-779: minMismatches = shortcut ? max : targetMismatches+1
+        # 2nd phase, ReadsMatchers.cpp:749-779: minMismatches = shortcut ? max : targetMismatches+1, where
+        # targetMismatches is still the FIRST phase's value (:713; it is only recomputed at :770, after its use)
         seed2 = min(readsExactMatchingChars, readLength)
         shortcut = matchingMode.upper() == matchingMode
-        target = readLength // seed2 - 1
+        target = readLength // seed - 1
         kmin2 = kmax if shortcut else target + 1
         kind2 = matchingMode.lower()
         if kind2 not in "cdi":

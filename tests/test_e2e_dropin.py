@@ -1,0 +1,49 @@
+"""End-to-end drop-in: the reference's whole encoder with HipReadsMatcher in its matcher seam must write the same
+archive, byte for byte, as the untouched reference at -t 1, and that archive must decode to the input reads
+(tests/e2e_dropin.py does the work in a child process; oracle/Makefile explains the mapReadsIntoPg interposition)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _have_e2e():
+    return orc.have_ref() and hasattr(orc.ref(), "pgrc_ref_encode")
+
+
+def _run(tmp_path, case, cpu_only):
+    env = dict(os.environ)
+    env.pop("PGRC_REF_VERBOSE", None)
+    if cpu_only:
+        env["PGRC_E2E_CPU_ONLY"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(HERE, "e2e_dropin.py"), str(tmp_path), case], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, f"e2e child failed ({p.returncode}):\n{p.stdout[-2000:]}\n{p.stderr[-2000:]}"
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("case", ["se", "pe_order"])
+def test_reference_encoder_harness_cpu(tmp_path, case):
+    """The harness itself, no GPU: the compiled reference encoder is deterministic at -t 1 and round-trips."""
+    if not _have_e2e():
+        pytest.skip("oracle/_ref was built without the encoder harness")
+    r = _run(tmp_path, case, cpu_only=True)
+    assert r["identical"] and r["roundtrip"], r
+    assert r["cpu_gpu_calls"] == 0 and r["gpu_gpu_calls"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["se", "se_order", "pe", "pe_order", "se_pre", "se_modeD", "se_modeI"])
+def test_archive_identical_with_gpu_matcher(tmp_path, case):
+    if not _have_e2e():
+        pytest.skip("oracle/_ref was built without the encoder harness")
+    r = _run(tmp_path, case, cpu_only=False)
+    assert r["cpu_gpu_calls"] == 0 and r["gpu_gpu_calls"] >= 1, r     # the GPU leg really went through HipReadsMatcher
+    assert r["identical"], r
+    assert r["roundtrip"], r

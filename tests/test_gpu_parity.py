@@ -176,7 +176,8 @@ def test_two_phase_continuation():
     pg, reads = make_inputs(200000, 5000, 100, seed=91)
     bitmap, m = mapReadsIntoPg(pg, True, reads, 38, 50, "c", preReadsExactMatchingChars=100, preMatchingMode="c")
     o1 = orc.oracle_match("c", pg, reads, 100, 2, 0)
-    o2 = orc.oracle_match("c", pg, reads, 38, 2, 100 // 38 - 1 + 1, state=(o1["pos"], o1["rc"], o1["mism"]))
+    # 2nd-phase minMismatches = targetMismatches(1st phase seed) + 1 = 100 // 100 - 1 + 1 (ReadsMatchers.cpp:713, :752)
+    o2 = orc.oracle_match("c", pg, reads, 38, 2, 100 // 100 - 1 + 1, state=(o1["pos"], o1["rc"], o1["mism"]))
     assert np.array_equal(m.readMatchPos, o2["pos"])
     assert np.array_equal(m.readMismatchesCount, o2["mism"])
     assert np.array_equal(m.readMatchRC.astype(np.uint8), o2["rc"])
@@ -289,7 +290,12 @@ def test_map_reads_into_pg_factory():
 
 
 @pytest.mark.skipif(not orc.have_ref(), reason="needs oracle/_ref (the compiled reference)")
-@pytest.mark.parametrize("mode,seed_len,n_nset", [("c", 38, 0), ("c", 38, 500), ("d", 38, 0), ("i", 38, 0), ("e", 100, 0)])
+@pytest.mark.parametrize("mode,seed_len,n_nset", [("c", 38, 0), ("c", 38, 500), ("d", 38, 0), ("i", 38, 0), ("e", 100, 0),
+                                                  # LQ + N sum set in modes d/i/e: the reference indexes no read
+                                                  # (reference quirk 4) and the adapter keeps that
+                                                  ("d", 38, 500), ("i", 38, 500), ("e", 100, 500),
+                                                  # one ACGNT set holding every read: all of them are indexed
+                                                  ("d", 38, 5000), ("i", 38, 5000)])
 @pytest.mark.parametrize("entry", [0, 1])
 def test_reference_adapter_drop_in(mode, seed_len, n_nset, entry):
     """integration/HipReadsMatcher inside the REFERENCE's matcher hierarchy (compiled against its headers, its own
