@@ -5,6 +5,8 @@
 
 namespace PgTools {
 
+    uint64_t HipReadsMatcher::bulkUpdatesServed = 0;
+
     HipReadsMatcher::HipReadsMatcher(char *pgPtr, const uint_pg_len_max pgLength, bool revComplPg,
                                      ConstantLengthReadsSetInterface *readsSet, uint32_t matchPrefixLength,
                                      uint16_t readsExactMatchingChars, uint8_t maxMismatches, uint8_t minMismatches,
@@ -117,6 +119,55 @@ namespace PgTools {
         for (uint_reads_cnt_max i = 0; i < deviceReads; i++)
             rc[i] = readMatchRC[i] ? 1 : 0;
         failOn(pgrc_match_set_results(ctx, readMatchPos.data(), rc.data(), readMismatchesCount.data()), "set_results");
+    }
+
+    // ---- export support: mismatch lists of all matched reads in one device pass (replaces the per-read
+    //      getRead + reverseComplementInPlace + fillEntryWith(Reversed)Mismatches of ReadsMatchers.cpp:548-559) ----
+    void HipReadsMatcher::initEntryUpdating() {
+        bulkMismatches = false;
+        if (!uploaded || deviceReads != readsCount || readsCount == 0) return;   // inherited per-read path
+        mmCum.resize((size_t) readsCount + 1);
+        failOn(pgrc_match_extract_mismatches(ctx, nullptr, mmCum.data(), nullptr, nullptr), "extract_mismatches");
+        const uint64_t total = mmCum[readsCount];
+        mmCodes.resize(total);
+        mmOffsets.resize(total);
+        if (total)
+            failOn(pgrc_match_extract_mismatches(ctx, nullptr, mmCum.data(), mmCodes.data(), mmOffsets.data()),
+                   "extract_mismatches");
+        bulkMismatches = true;
+    }
+
+    static inline uint8_t complementValue(uint8_t v) { return v < 4 ? 3 - v : v; }   // A<->T, C<->G, N stays
+
+    void HipReadsMatcher::updateEntry(DefaultReadsListEntry &entry, uint_reads_cnt_max matchIdx, bool revComplPairFile) {
+        if (!bulkMismatches) {
+            AbstractReadsApproxMatcher::updateEntry(entry, matchIdx, revComplPairFile);
+            return;
+        }
+        // the device lists are in the SE form: "reversed" (original read orientation) iff the read matched the RC
+        // strand.  With revComplPairFile the reference wants the reversed form iff rc != (orgIdx odd) (:553); the
+        // other form of the same list is its mirror image: reverse order, offset -> L-1-offset, symbols complemented.
+        bulkUpdatesServed++;
+        const bool rc = readMatchRC[matchIdx];
+        const bool wantReversed = revComplPairFile ? (rc != (bool) (entry.idx % 2)) : rc;
+        const uint64_t first = mmCum[matchIdx], last = mmCum[matchIdx + 1];
+        if (wantReversed == rc) {
+            for (uint64_t k = first; k < last; k++)
+                entry.addMismatch(mmCodes[k], mmOffsets[k]);
+        } else {
+            for (uint64_t k = last; k-- > first;) {
+                const uint8_t code = mmCodes[k];
+                entry.addMismatch((uint8_t) ((complementValue(code >> 4) << 4) + complementValue(code & 15)),
+                                  (uint_read_len_max) (readLength - 1 - mmOffsets[k]));
+            }
+        }
+    }
+
+    void HipReadsMatcher::closeEntryUpdating() {
+        std::vector<uint64_t>().swap(mmCum);
+        std::vector<uint8_t>().swap(mmCodes);
+        std::vector<uint16_t>().swap(mmOffsets);
+        bulkMismatches = false;
     }
 
     void HipReadsMatcher::executeMatching(bool revCompMode) {

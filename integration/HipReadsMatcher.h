@@ -23,6 +23,12 @@ namespace PgTools {
         bool uploaded = false;
         uint_reads_cnt_max deviceReads = 0;  // reads that take part (all in mode c; see upload() for modes d/i/e)
 
+        // mismatch lists of all matched reads, filled by initEntryUpdating() (CSR: mmCum[i] .. mmCum[i+1])
+        bool bulkMismatches = false;
+        std::vector<uint64_t> mmCum;
+        std::vector<uint8_t> mmCodes;
+        std::vector<uint16_t> mmOffsets;
+
         void failOn(int code, const char *what);
         void upload();
         void fetchResults();
@@ -33,6 +39,12 @@ namespace PgTools {
         // one pass on the device; the text handed to the library at initMatching() is the forward one, the
         // reverse complement is derived on the GPU (the in-place RC of pgPtr by the caller is not needed).
         void executeMatching(bool revCompMode = false) override;
+
+        // export hooks (ReadsMatchers.h:52-54): the mismatch lists come from one device pass over all matched reads
+        // (pgrc_match_extract_mismatches) instead of one getRead + compare per read on the host
+        void initEntryUpdating() override;
+        void updateEntry(DefaultReadsListEntry &entry, uint_reads_cnt_max matchIdx, bool revComplPairFile) override;
+        void closeEntryUpdating() override;
 
     public:
         HipReadsMatcher(char *pgPtr, const uint_pg_len_max pgLength, bool revComplPg,
@@ -48,6 +60,9 @@ namespace PgTools {
 
         // Same contract as continueMatchingConstantLengthReads (ReadsMatchers.cpp:174-184).
         void continueMatchingConstantLengthReadsOnDevice(DefaultReadsMatcher *pMatcher);
+
+        // entries whose mismatch list was served from the device extraction (diagnostics / tests)
+        static uint64_t bulkUpdatesServed;
     };
 }
 

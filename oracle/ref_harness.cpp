@@ -278,6 +278,8 @@ extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const 
     return g_gpu_calls;
 }
 
+extern "C" uint64_t pgrc_ref_bulk_updates() { return HipReadsMatcher::bulkUpdatesServed; }
+
 extern "C" int pgrc_ref_decode(const char *archive, int threads) {
     Silence quiet;
     PgHelpers::numberOfThreads = threads;

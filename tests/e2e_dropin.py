@@ -82,6 +82,7 @@ def main():
     lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libpgrc_ref.so"))
     lib.pgrc_ref_encode.argtypes = [C.c_char_p] * 3 + [C.c_int] * 3 + [C.c_char, C.c_int, C.c_int, C.c_char, C.c_int]
     lib.pgrc_ref_decode.argtypes = [C.c_char_p, C.c_int]
+    lib.pgrc_ref_bulk_updates.restype = C.c_uint64
 
     G, L, n = 300000, 100, 60000
     reads = make_reads(11, G, L, n, paired)
@@ -108,6 +109,7 @@ def main():
         digests[leg] = hashlib.sha256(blob).hexdigest()
         out[leg + "_bytes"] = len(blob)
         out[leg + "_gpu_calls"] = calls
+        out[leg + "_bulk_updates"] = int(lib.pgrc_ref_bulk_updates())   # entries served by the device extraction
     out["identical"] = digests["cpu"] == digests["gpu"]
     out["sha256"] = digests
 

@@ -47,3 +47,5 @@ def test_archive_identical_with_gpu_matcher(tmp_path, case):
     assert r["cpu_gpu_calls"] == 0 and r["gpu_gpu_calls"] >= 1, r     # the GPU leg really went through HipReadsMatcher
     assert r["identical"], r
     assert r["roundtrip"], r
+    if case not in ("se_modeD", "se_modeI"):     # (those match nothing: the sum-set quirk)
+        assert r["gpu_bulk_updates"] > 1000 and r["cpu_bulk_updates"] == 0, r   # export used the device mismatch lists
