@@ -16,11 +16,9 @@
 //     two smallest entries; every entry carries a 24-bit fingerprint of the window symbols the
 //     sparsified hash ignores, so a false candidate is rejected -- with exactly the reference's
 //     head-reject accounting -- without fetching its text window.
-//   * index build in ONE pass over the text: each sampled position cascades through its bucket head
-//     with two 64-bit atomicMin (the loser of slot 0 tries slot 1, the loser of slot 1 is appended to
-//     an overflow list); only the ~6 % of entries that overflow are sorted (rocPRIM radix sort) and
-//     laid out per bucket.  Minimum selection makes the result independent of execution order: it
-//     is the reference's SERIAL index (ascending positions, the 13 smallest kept), bit for bit.
+//   * index build without atomics: (bucket, entry) records in position order, one STABLE rocPRIM radix sort by
+//     bucket, one streaming pass that writes the heads; the sorted entries are ent[].  Stability makes the result
+//     the reference's SERIAL index (ascending positions, the 13 smallest kept), bit for bit.
 //   * match = one read per lane, as a per-lane state machine; the reference's sequential per-read
 //     semantics (limit tightening, false-candidate budget, early exit) are kept exactly.
 //   * all of it is random-access bound integer work: no MFMA.
@@ -57,20 +55,22 @@ __device__ __forceinline__ uint32_t head_count(const ulonglong2 hd) {
 #define IDX_TPB 256
 #define IDX_TILE_WORDS (IDX_TPB + 16) // 256 positions * k1(<=16) symbols / 16 + K/16 + slack
 
+// Sort-based build, no atomics (the earlier build cascaded every sampled position through its bucket head with
+// random 64-bit atomicMin -- three sweeps at ~18 G atomics/s, 44 ms per strand at C3; rocPRIM's radix sort moves the
+// same 375 M records at 32 G/s, tools/ubench/sortrate.hip):
+//   1. k_copmem_index_gen   : sampled position t -> (bucket, entry), written in ascending position order (streaming)
+//   2. rocprim radix sort   : STABLE sort of the pairs by bucket => every bucket's entries are contiguous and in
+//                             ascending position order, i.e. exactly the order the reference's serial build appends them
+//   3. k_copmem_index_heads : one streaming pass over the sorted runs writes the 16-byte bucket heads; the sorted
+//                             entry array itself serves as ent[] (entry j >= 1 of a bucket whose run starts at i is
+//                             ent[i + j]; entries beyond the 13th are simply never addressed = the bucket cap)
+// The result is the reference's SERIAL index bit for bit, whatever the execution order.
+
 // One block walks tiles of IDX_TPB consecutive sampled positions; the tile's text words are loaded once,
-// coalesced, into LDS; every thread hashes its K-symbol window from LDS.  Three sweeps, because on gfx950 a
-// random atomic WITHOUT return value runs ~2.5x faster than one whose result is used (measured: 375 M
-// returning 64-bit atomicMin cascades took 63 ms, the three sweeps below 36 ms):
-//   PASS 0  atomicMin(slot0, entry)                              -> slot0 = the bucket's smallest entry
-//   PASS 1  entry != slot0 ?  atomicMin(slot1, entry), mark it   -> slot1 = the second smallest
-//   PASS 2  marked and entry != slot1 ?  append to the overflow list
-// Minimum selection makes the outcome independent of execution order.
-template <int PASS>
+// coalesced, into LDS; every thread hashes its K-symbol window from LDS.
 __global__ void __launch_bounds__(IDX_TPB)
-k_copmem_index_build(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, uint64_t npos, uint32_t k1, uint32_t K,
-                     uint32_t mask, ulonglong2 *__restrict__ head, uint8_t *__restrict__ mark,
-                     unsigned long long *__restrict__ ovf_count, uint64_t *__restrict__ ovf_k,
-                     uint64_t *__restrict__ ovf_e, uint64_t ovf_cap) {
+k_copmem_index_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, uint64_t npos, uint32_t k1, uint32_t K,
+                   uint32_t mask, uint32_t *__restrict__ keys, uint64_t *__restrict__ vals) {
     __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
     __shared__ uint32_t tile[IDX_TILE_WORDS + 8];
     hash_lut_init(lut);
@@ -84,10 +84,7 @@ k_copmem_index_build(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, u
         __syncthreads();
         for (uint32_t w = threadIdx.x; w < need; w += IDX_TPB) tile[w] = (w0 + w < pg_words_alloc) ? pg[w0 + w] : 0u;
         __syncthreads();
-        bool push = false;     // PASS 2: this lane's entry overflows its bucket head
-        uint32_t push_h = 0;
-        uint64_t push_e = 0;
-        if (t < npos && (PASS != 2 || mark[t])) {
+        if (t < npos) {
             const uint64_t p = t * k1;
             const uint32_t q = (uint32_t)((p >> 4) - w0);
             const uint32_t sh = ((uint32_t)p & 15u) * 2u;
@@ -95,251 +92,78 @@ k_copmem_index_build(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, u
             uint32_t fp;
             const uint32_t h = copmem_hash32_fp(funnel_r(a0, a1, sh), funnel_r(a1, a2, sh), funnel_r(a2, a3, sh),
                                                 funnel_r(a3, a4, sh), K, lut, &fp) & mask;
-            unsigned long long *slot = reinterpret_cast<unsigned long long *>(head + h);
-            const unsigned long long e = (p << PGRC_FP_BITS) | fp;
-            if (PASS == 0) {
-                atomicMin(slot, e);
-            } else if (PASS == 1) {
-                const bool loser = slot[0] != e;
-                if (loser) atomicMin(slot + 1, e);
-                mark[t] = loser ? 1 : 0;
-            } else {
-                push = slot[1] != e;
-                push_h = h;
-                push_e = e;
-            }
-        }
-        if (PASS == 2) {
-            // wave-aggregated append into THIS BLOCK's region: every block owns a cursor (64 B apart) and a slice
-            // of the overflow arrays, so no two blocks ever contend for an address (a single shared cursor
-            // serialises ~5 M same-address atomics: measured 57 ms instead of 3)
-            const unsigned long long m = __ballot(push);
-            if (m) {
-                const uint32_t lane = threadIdx.x & 63u;
-                const int leader = __ffsll((long long)m) - 1;
-                unsigned long long base = 0;
-                if ((int)lane == leader) base = atomicAdd(ovf_count + 8ull * blockIdx.x, (unsigned long long)__popcll(m));
-                base = __shfl(base, leader, 64);
-                if (push) {
-                    const unsigned long long idx = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-                    if (idx < ovf_cap) {
-                        // sort key: bucket, then the position in units of 128 symbols (31 + 33 bits)
-                        ovf_k[(uint64_t)blockIdx.x * ovf_cap + idx] = ((uint64_t)push_h << 33) | (push_e >> (PGRC_FP_BITS + 7));
-                        ovf_e[(uint64_t)blockIdx.x * ovf_cap + idx] = push_e;
-                    }
-                }
-            }
+            keys[t] = h;
+            vals[t] = (p << PGRC_FP_BITS) | fp;
         }
     }
 }
 
-// exclusive prefix of the per-block overflow counts (nblk <= 4096), total and the largest count
-__global__ void __launch_bounds__(1024) k_ovf_prefix(const unsigned long long *__restrict__ cursors, uint32_t nblk,
-                                                     unsigned long long *__restrict__ prefix /*[nblk+2]*/) {
-    __shared__ unsigned long long sh[1024];
-    unsigned long long v[4], s = 0, mx = 0;
-    for (int k = 0; k < 4; k++) {
-        const uint32_t b = threadIdx.x * 4 + k;
-        v[k] = b < nblk ? cursors[8ull * b] : 0ull;
-        s += v[k];
-        mx = max(mx, v[k]);
-    }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        unsigned long long u = threadIdx.x >= (uint32_t)o ? sh[threadIdx.x - o] : 0ull;
-        __syncthreads();
-        sh[threadIdx.x] += u;
-        __syncthreads();
-    }
-    unsigned long long run = sh[threadIdx.x] - s;
-    for (int k = 0; k < 4; k++) {
-        const uint32_t b = threadIdx.x * 4 + k;
-        if (b < nblk) prefix[b] = run;
-        run += v[k];
-    }
-    if (threadIdx.x == 1023) prefix[nblk] = sh[1023];
-    // largest per-block count (regions must not overflow): reduce through the now free shared array
-    __syncthreads();
-    sh[threadIdx.x] = mx;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if (threadIdx.x < (uint32_t)o) sh[threadIdx.x] = max(sh[threadIdx.x], sh[threadIdx.x + o]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) prefix[nblk + 1] = sh[0];
-}
-
+// sorted (bucket, entry) records -> bucket heads.  One thread per record; the first record of a run writes its head.
+// The table was filled with HEAD_EMPTY before (buckets without a run stay empty).
 __global__ void __launch_bounds__(256)
-k_ovf_compact(const unsigned long long *__restrict__ cursors, const unsigned long long *__restrict__ prefix,
-              uint64_t region_cap, const uint64_t *__restrict__ k_in, const uint64_t *__restrict__ e_in,
-              uint64_t *__restrict__ k_out, uint64_t *__restrict__ e_out) {
-    const uint64_t n = min((uint64_t)cursors[8ull * blockIdx.x], region_cap), dst = prefix[blockIdx.x];
-    const uint64_t src = (uint64_t)blockIdx.x * region_cap;
-    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        k_out[dst + i] = k_in[src + i];
-        e_out[dst + i] = e_in[src + i];
-    }
-}
-
-__global__ void __launch_bounds__(256) k_ovf_flags(const uint64_t *__restrict__ sk, uint64_t n, uint32_t *__restrict__ flag) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = (i == 0 || (sk[i] >> 33) != (sk[i - 1] >> 33)) ? 1u : 0u;
-}
-
-// Overflow records sorted by (bucket, position / 128) -> per-bucket segments [entry1, the bucket's 11 smallest
-// overflow entries ascending] in ent[], head fix-up.  One thread per bucket run.  The run is ordered by
-// 128-symbol blocks, a block holds at most ceil(128 / k1) <= 43 sampled positions (k1 >= 3), so the 11 smallest
-// entries are among the run's first 10 + 43 records: the scan is bounded whatever the run length (poly-A...).
-#define OVF_SCAN_MAX 54u
-__global__ void __launch_bounds__(256)
-k_ovf_finalize(const uint64_t *__restrict__ sk, const uint64_t *__restrict__ se, const uint32_t *__restrict__ runidx,
-               uint64_t n, ulonglong2 *__restrict__ head, uint64_t *__restrict__ ent) {
+k_copmem_index_heads(const uint32_t *__restrict__ sk, const uint64_t *__restrict__ se, uint64_t n,
+                     ulonglong2 *__restrict__ head) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t hk = sk[i] >> 33;
-    if (i != 0 && (sk[i - 1] >> 33) == hk) return;           // not the first record of its bucket
-    constexpr int KEEP = (int)PGRC_BUCKET_CAP - 2;           // the head already holds the two smallest
-    uint64_t a[KEEP];
-#pragma unroll
-    for (int k = 0; k < KEEP; k++) a[k] = ~0ull;
-    uint32_t len = 0;
-    for (uint64_t j = i; j < n && j < i + OVF_SCAN_MAX && (sk[j] >> 33) == hk; j++) {
-        uint64_t x = se[j];
-#pragma unroll
-        for (int k = 0; k < KEEP; k++) {
-            const uint64_t m = min(a[k], x);
-            x = max(a[k], x);
-            a[k] = m;
-        }
-        if (len < (uint32_t)KEEP) len++;
+    const uint32_t b = sk[i];
+    if (i != 0 && sk[i - 1] == b) return;                    // not the first record of its bucket
+    uint32_t cnt = 1;
+    while (cnt < PGRC_BUCKET_CAP && i + cnt < n && sk[i + cnt] == b) cnt++;
+    ulonglong2 hd;
+    hd.x = se[i];
+    if (cnt == 1) hd.y = HEAD_EMPTY;
+    else if (cnt == 2) hd.y = se[i + 1];
+    else {
+        hd.x |= HEAD_OVF;
+        hd.y = (i + 1) | ((uint64_t)cnt << 56);              // entries 1.. at ent[(i + 1) + j - 1]
     }
-    const uint64_t base = i + (runidx[i] - 1u);              // run r starts at sorted index i: segment base i + r
-    const uint32_t h = (uint32_t)hk;
-    ulonglong2 hd = head[h];
-    ent[base] = hd.y;                                        // entry1 opens the segment
-#pragma unroll
-    for (int k = 0; k < KEEP; k++)
-        if ((uint32_t)k < len) ent[base + 1 + k] = a[k];
-    hd.x |= HEAD_OVF;
-    hd.y = base | ((uint64_t)(2u + len) << 56);
-    head[h] = hd;
+    head[b] = hd;
 }
 
 #define IDX_MAX_BLOCKS 4096u
 
-// Sweeps 0-2; leaves the overflow records compacted in d_ovf_h2 / d_ovf_e2 and their number in *nrec_out.
-// Returns PGRC_OK with *region_overflow = true when a block's region was too small (caller retries bigger).
-static int build_once(pgrc_match_ctx *c, int strand, uint64_t region_cap, uint64_t *nrec_out, bool *region_overflow) {
-    const uint32_t K = (uint32_t)c->cp.K, k1 = (uint32_t)c->cp.k1;
-    const uint64_t hs = c->cp.hash_size;
-    const uint64_t ntiles = (c->npos + IDX_TPB - 1) / IDX_TPB;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ntiles, 1), IDX_MAX_BLOCKS);
-    int e;
-    if ((e = pgrc_buf_ensure(c, c->d_head, hs * 2 * sizeof(uint64_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->d_ovf_h, ((uint64_t)grid * region_cap + 16) * sizeof(uint64_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->d_ovf_e, ((uint64_t)grid * region_cap + 16) * sizeof(uint64_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->d_scan_tmp, (8ull * IDX_MAX_BLOCKS + IDX_MAX_BLOCKS + 8) * sizeof(uint64_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->d_mark, c->npos + 16))) return e;
-    unsigned long long *cursors = (unsigned long long *)c->d_scan_tmp.p;
-    unsigned long long *prefix = cursors + 8ull * IDX_MAX_BLOCKS;
-    HIP_TRY(c, hipMemsetAsync(c->d_head.p, 0xFF, hs * 2 * sizeof(uint64_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(cursors, 0, (8ull * IDX_MAX_BLOCKS + IDX_MAX_BLOCKS + 8) * sizeof(uint64_t), c->stream));
-    *nrec_out = 0;
-    *region_overflow = false;
-    if (!c->npos) return PGRC_OK;
-#define LAUNCH_PASS(P)                                                                                                   \
-    hipLaunchKernelGGL(k_copmem_index_build<P>, dim3(grid), dim3(IDX_TPB), 0, c->stream, (const uint32_t *)c->pg2[strand].p, \
-                       c->pg_words + PGRC_PG_PAD_WORDS, c->npos, k1, K, (uint32_t)(hs - 1), (ulonglong2 *)c->d_head.p,       \
-                       (uint8_t *)c->d_mark.p, cursors, (uint64_t *)c->d_ovf_h.p, (uint64_t *)c->d_ovf_e.p, region_cap)
-    LAUNCH_PASS(0);
-    LAUNCH_PASS(1);
-    LAUNCH_PASS(2);
-#undef LAUNCH_PASS
-    hipLaunchKernelGGL(k_ovf_prefix, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long *)cursors, grid, prefix);
-    HIP_TRY(c, hipGetLastError());
-    unsigned long long tail[2] = {0, 0}; // total, largest region count
-    HIP_TRY(c, hipMemcpyAsync(tail, prefix + grid, sizeof tail, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (tail[1] > region_cap) { *region_overflow = true; *nrec_out = tail[1]; return PGRC_OK; }
-    *nrec_out = tail[0];
-    if (tail[0]) {
-        if ((e = pgrc_buf_ensure(c, c->d_ovf_h2, (tail[0] + 16) * sizeof(uint64_t)))) return e;
-        if ((e = pgrc_buf_ensure(c, c->d_ovf_e2, (tail[0] + 16) * sizeof(uint64_t)))) return e;
-        hipLaunchKernelGGL(k_ovf_compact, dim3(grid), dim3(256), 0, c->stream, (const unsigned long long *)cursors,
-                           (const unsigned long long *)prefix, region_cap, (const uint64_t *)c->d_ovf_h.p,
-                           (const uint64_t *)c->d_ovf_e.p, (uint64_t *)c->d_ovf_h2.p, (uint64_t *)c->d_ovf_e2.p);
-        HIP_TRY(c, hipGetLastError());
-    }
-    return PGRC_OK;
-}
-
 int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     const uint32_t K = (uint32_t)c->cp.K, k1 = (uint32_t)c->cp.k1;
+    const uint64_t hs = c->cp.hash_size;
     c->npos = (c->G >= K) ? (c->G - K) / k1 + 1 : 0;
-    const uint64_t ntiles = (c->npos + IDX_TPB - 1) / IDX_TPB;
-    const uint64_t grid = std::min<uint64_t>(std::max<uint64_t>(ntiles, 1), IDX_MAX_BLOCKS);
-    // on uniform text ~6 % of the entries overflow their two inline slots; every block's region starts with
-    // room for 25 % of its positions and grows to whatever a low-complexity text needs
-    uint64_t region_cap = std::max<uint64_t>((c->npos / grid) / 4 + 1024, c->ovf_cap_hint);
-    if (const char *ev = getenv("PGRC_OVF_REGION_CAP")) // test knob: start tiny to exercise the grow-and-retry path
-        region_cap = std::max<uint64_t>(1, (uint64_t)atoll(ev));
-    uint64_t nrec = 0;
-    bool again = false;
-    int e = build_once(c, strand, region_cap, &nrec, &again);
-    if (e) return e;
-    if (again) {
-        region_cap = nrec + 1024; // nrec = the largest per-block count seen
-        c->ovf_cap_hint = region_cap;
-        if ((e = build_once(c, strand, region_cap, &nrec, &again))) return e;
-        if (again) { c->err = "index build: overflow regions did not converge"; return PGRC_E_ALLOC; }
-    }
-    c->n_ovf = nrec;
-    if (nrec) {
-        // scratch lives in the context (grow-only): no hipMalloc / hipFree (= device synchronisation) per build
-        DevBuf &skey = c->d_skey, &sfp = c->d_sfp, &flag = c->d_flag, &runidx = c->d_runidx, &temp = c->d_sorttmp;
-        auto cleanup = [&]() {};
-        if (2 * nrec + 16 >= (1ull << 32)) { c->err = "index build: overflow segments exceed 2^32 entries"; return PGRC_E_PARAM; }
-        int hbits = 0;
-        while ((1ull << hbits) < c->cp.hash_size) hbits++;
-        int pbits = 1; // bits of (position >> 7)
-        while ((1ull << (pbits + 7)) < c->G) pbits++;
-        size_t t1 = 0, t2 = 0;
-        // key = bucket << 33 | position >> 7: only the bits that can be set take part in the sort
-        hipError_t he = rocprim::radix_sort_pairs(nullptr, t1, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr,
-                                                  (uint64_t *)nullptr, (size_t)nrec, 0, 33 + hbits, c->stream);
-        if (he == hipSuccess)
-            he = rocprim::inclusive_scan(nullptr, t2, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)nrec, rocprim::plus<uint32_t>(), c->stream);
-        if (he != hipSuccess) { c->err = "rocprim size query failed"; return PGRC_E_NO_DEVICE; }
-        if ((e = pgrc_buf_ensure(c, skey, nrec * sizeof(uint64_t))) || (e = pgrc_buf_ensure(c, sfp, nrec * sizeof(uint64_t))) ||
-            (e = pgrc_buf_ensure(c, flag, nrec * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, runidx, nrec * sizeof(uint32_t))) ||
-            (e = pgrc_buf_ensure(c, temp, std::max(t1, t2))) || (e = pgrc_buf_ensure(c, c->d_ent, (2 * nrec + 16) * sizeof(uint64_t)))) {
-            cleanup();
-            return e;
-        }
-        const uint32_t grid2 = (uint32_t)((nrec + 255) / 256);
-        // two sorts on disjoint bit ranges = one stable sort on (bucket, position / 128), skipping the unused key bits
-        he = rocprim::radix_sort_pairs(temp.p, t1, (uint64_t *)c->d_ovf_h2.p, (uint64_t *)skey.p, (uint64_t *)c->d_ovf_e2.p,
-                                       (uint64_t *)sfp.p, (size_t)nrec, 0, pbits, c->stream);
-        if (he == hipSuccess)
-            he = rocprim::radix_sort_pairs(temp.p, t1, (uint64_t *)skey.p, (uint64_t *)c->d_ovf_h2.p, (uint64_t *)sfp.p,
-                                           (uint64_t *)c->d_ovf_e2.p, (size_t)nrec, 33, 33 + hbits, c->stream);
-        if (he == hipSuccess) {
-            hipLaunchKernelGGL(k_ovf_flags, dim3(grid2), dim3(256), 0, c->stream, (const uint64_t *)c->d_ovf_h2.p, (uint64_t)nrec, (uint32_t *)flag.p);
-            he = rocprim::inclusive_scan(temp.p, t2, (uint32_t *)flag.p, (uint32_t *)runidx.p, (size_t)nrec, rocprim::plus<uint32_t>(), c->stream);
-        }
-        if (he == hipSuccess) {
-            hipLaunchKernelGGL(k_ovf_finalize, dim3(grid2), dim3(256), 0, c->stream, (const uint64_t *)c->d_ovf_h2.p, (const uint64_t *)c->d_ovf_e2.p,
-                               (const uint32_t *)runidx.p, (uint64_t)nrec, (ulonglong2 *)c->d_head.p, (uint64_t *)c->d_ent.p);
-            he = hipGetLastError();
-        }
-        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-        cleanup();
-        if (he != hipSuccess) { c->err = std::string("index overflow pass: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
-    } else if ((e = pgrc_buf_ensure(c, c->d_ent, 64))) {
-        return e;
-    }
+    const uint64_t npos = c->npos;
+    // the match kernel addresses ent[] with 32-bit indices
+    if (npos + PGRC_BUCKET_CAP >= (1ull << 32)) { c->err = "index build: more than 2^32 sampled positions"; return PGRC_E_PARAM; }
+    int e;
+    if ((e = pgrc_buf_ensure(c, c->d_head, hs * 2 * sizeof(uint64_t)))) return e;
+    HIP_TRY(c, hipMemsetAsync(c->d_head.p, 0xFF, hs * 2 * sizeof(uint64_t), c->stream));
+    c->ent_ptr = nullptr;
     c->index_strand = strand;
+    if (!npos) {
+        if ((e = pgrc_buf_ensure(c, c->d_sval[0], 64))) return e;
+        c->ent_ptr = (const uint64_t *)c->d_sval[0].p;
+        return PGRC_OK;
+    }
+    int hbits = 0;
+    while ((1ull << hbits) < hs) hbits++;
+    // scratch lives in the context (grow-only): no hipMalloc / hipFree (= device synchronisation) per build
+    for (int k = 0; k < 2; k++) {
+        if ((e = pgrc_buf_ensure(c, c->d_skey[k], (npos + 16) * sizeof(uint32_t)))) return e;
+        if ((e = pgrc_buf_ensure(c, c->d_sval[k], (npos + 16) * sizeof(uint64_t)))) return e;
+    }
+    rocprim::double_buffer<uint32_t> keys((uint32_t *)c->d_skey[0].p, (uint32_t *)c->d_skey[1].p);
+    rocprim::double_buffer<uint64_t> vals((uint64_t *)c->d_sval[0].p, (uint64_t *)c->d_sval[1].p);
+    size_t tbytes = 0;
+    hipError_t he = rocprim::radix_sort_pairs(nullptr, tbytes, keys, vals, (size_t)npos, 0, hbits, c->stream);
+    if (he != hipSuccess) { c->err = "rocprim size query failed"; return PGRC_E_NO_DEVICE; }
+    if ((e = pgrc_buf_ensure(c, c->d_sorttmp, tbytes + 16))) return e;
+
+    const uint64_t ntiles = (npos + IDX_TPB - 1) / IDX_TPB;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ntiles, 1), IDX_MAX_BLOCKS);
+    hipLaunchKernelGGL(k_copmem_index_gen, dim3(grid), dim3(IDX_TPB), 0, c->stream, (const uint32_t *)c->pg2[strand].p,
+                       c->pg_words + PGRC_PG_PAD_WORDS, npos, k1, K, (uint32_t)(hs - 1), keys.current(), vals.current());
+    HIP_TRY(c, hipGetLastError());
+    he = rocprim::radix_sort_pairs(c->d_sorttmp.p, tbytes, keys, vals, (size_t)npos, 0, hbits, c->stream);
+    if (he != hipSuccess) { c->err = std::string("index sort: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
+    hipLaunchKernelGGL(k_copmem_index_heads, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, c->stream,
+                       (const uint32_t *)keys.current(), (const uint64_t *)vals.current(), npos, (ulonglong2 *)c->d_head.p);
+    HIP_TRY(c, hipGetLastError());
+    c->ent_ptr = vals.current();
     return PGRC_OK;
 }
 
@@ -390,7 +214,7 @@ int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_po
     if (h_positions && total) {
         if ((e = pgrc_buf_ensure(c, pos, (size_t)total * sizeof(uint32_t)))) { cleanup(); return e; }
         hipLaunchKernelGGL(k_export_positions, dim3(sgrid), dim3(256), 0, c->stream, (const ulonglong2 *)c->d_head.p,
-                           (const uint64_t *)c->d_ent.p, (const uint32_t *)cumm.p, hs, (uint32_t *)pos.p);
+                           c->ent_ptr, (const uint32_t *)cumm.p, hs, (uint32_t *)pos.p);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
             hipMemcpy(h_positions, pos.p, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
             cleanup();
@@ -811,7 +635,7 @@ int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
     a.stride = c->stride;
     a.nflag = c->n_nreads ? (const uint8_t *)c->nread_flag.p : nullptr;
     a.head = (const ulonglong2 *)c->d_head.p;
-    a.ent = (const uint64_t *)c->d_ent.p;
+    a.ent = c->ent_ptr;
     a.pos = (uint64_t *)c->d_pos.p;
     a.rc = (uint8_t *)c->d_rc.p;
     a.mism = (uint8_t *)c->d_mism.p;

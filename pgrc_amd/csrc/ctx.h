@@ -70,9 +70,9 @@ struct pgrc_match_ctx {
     // copMEM index (rebuilt per pass, buffers reused)
     pgrc_copmem_params cp{};
     uint64_t npos = 0;
-    DevBuf d_ent, d_head, d_ovf_h, d_ovf_e, d_ovf_h2, d_ovf_e2, d_mark, d_scan_tmp;
-    DevBuf d_skey, d_sfp, d_flag, d_runidx, d_sorttmp; // overflow sort scratch (grow-only)
-    uint64_t n_ovf = 0, ovf_cap_hint = 0;
+    DevBuf d_head;                      // ulonglong2[hash_size] bucket heads
+    DevBuf d_skey[2], d_sval[2], d_sorttmp; // (bucket, entry) records: radix sort ping-pong + rocPRIM scratch (grow-only)
+    const uint64_t *ent_ptr = nullptr;  // the sorted entries (one of d_sval[]): ent[] of the match kernel
     int index_strand = -1;  // which strand the buffers currently describe
 
     // read-side seed index (modes d / i / e)

@@ -309,15 +309,14 @@ def test_reference_adapter_drop_in(mode, seed_len, n_nset, entry):
     assert_same_results(a, r, f"adapter mode {mode} entry {entry}")
 
 
-def test_index_overflow_regions_grow_and_retry(monkeypatch):
-    """Low-complexity text can overflow a block's overflow region: the build must detect it, grow and redo."""
+def test_index_of_low_complexity_text():
+    """Poly-A / dinucleotide tracts: buckets with tens of thousands of candidates keep exactly their 13 smallest."""
     from pgrc_amd import MatchContext
     rng = np.random.default_rng(11)
     pg = rng.choice(list(b"ACGT"), size=300000).astype(np.uint8)
     pg[20000:120000] = ord("A")                                                   # 100 kbp poly-A
     pg[150000:200000] = np.resize(np.frombuffer(b"AC", dtype=np.uint8), 50000)    # dinucleotide tract
     _, cumm, positions = orc.oracle_index(pg, 38)
-    monkeypatch.setenv("PGRC_OVF_REGION_CAP", "4")
     ctx = MatchContext(100, 38, 2, 0, "c")
     ctx.set_pg_ascii(pg)
     c, p = ctx.export_index(0)
