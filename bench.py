@@ -253,7 +253,7 @@ def cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax):
     # reference builds its copMEM index with its racy multithreaded code (CopMEMMatcher.cpp:238-254, :284-305;
     # which of a crowded bucket's entries survive the 13-entry cap varies from run to run), so a small number
     # of reads in repeats legitimately differ; bit-parity is pinned against the SERIAL index build
-    # (tools/fullscale_parity.py, tests/).
+    # (tests/fullscale_parity.py, tests/).
     pos, rc, mism, _, _ = ctx.get_results()
     diff = int((mism[:ns] != r["mism"]).sum())
     return {"value": value, "unit": "reads/s", "cores": threads, "kind": kind,

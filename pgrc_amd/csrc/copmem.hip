@@ -98,26 +98,65 @@ k_copmem_index_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, uin
     }
 }
 
-// sorted (bucket, entry) records -> bucket heads.  One thread per record; the first record of a run writes its head.
-// The table was filled with HEAD_EMPTY before (buckets without a run stay empty).
-__global__ void __launch_bounds__(256)
-k_copmem_index_heads(const uint32_t *__restrict__ sk, const uint64_t *__restrict__ se, uint64_t n,
+// sorted (bucket, entry) records -> bucket heads, written ONCE and in whole lines.  A block takes HEADS_REC consecutive
+// records and owns the buckets after the previous block's last bucket up to its own last bucket (the last block: up to
+// the end of the table); it stages them in LDS -- empty heads for buckets without a run, the head of every run that
+// starts in the block -- and streams the tile out, so no memset of the table and no partial-line scatter is needed.
+// A bucket range larger than the tile (sparse or degenerate text) is walked in tile-sized chunks.
+#define HEADS_TPB 256
+#define HEADS_RPT 4
+#define HEADS_REC (HEADS_TPB * HEADS_RPT)
+#define HEADS_CAP 2048u
+__global__ void __launch_bounds__(HEADS_TPB)
+k_copmem_index_heads(const uint32_t *__restrict__ sk, const uint64_t *__restrict__ se, uint64_t n, uint64_t hs,
                      ulonglong2 *__restrict__ head) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t b = sk[i];
-    if (i != 0 && sk[i - 1] == b) return;                    // not the first record of its bucket
-    uint32_t cnt = 1;
-    while (cnt < PGRC_BUCKET_CAP && i + cnt < n && sk[i + cnt] == b) cnt++;
-    ulonglong2 hd;
-    hd.x = se[i];
-    if (cnt == 1) hd.y = HEAD_EMPTY;
-    else if (cnt == 2) hd.y = se[i + 1];
-    else {
-        hd.x |= HEAD_OVF;
-        hd.y = (i + 1) | ((uint64_t)cnt << 56);              // entries 1.. at ent[(i + 1) + j - 1]
+    __shared__ ulonglong2 tile[HEADS_CAP];
+    __shared__ uint32_t skey[HEADS_REC + 16];        // keys i0-1 .. i1+12 (0xFFFFFFFF beyond the end: never a bucket)
+    const uint64_t i0 = (uint64_t)blockIdx.x * HEADS_REC;
+    const uint64_t i1 = min(n, i0 + HEADS_REC);
+    // all loads of the block are issued up front: keys into LDS, this thread's 4 consecutive entries (+1) in registers
+    for (uint32_t x = threadIdx.x; x < HEADS_REC + 14; x += HEADS_TPB) {
+        const uint64_t i = i0 + x;                   // skey[x] = sk[i - 1]
+        skey[x] = (i >= 1 && i - 1 < n) ? sk[i - 1] : 0xFFFFFFFFu;
     }
-    head[b] = hd;
+    const uint64_t f = i0 + (uint64_t)threadIdx.x * HEADS_RPT;
+    uint64_t ev[HEADS_RPT + 1];
+#pragma unroll
+    for (int k = 0; k <= HEADS_RPT; k++) ev[k] = (f + k < n) ? se[f + k] : 0ull;
+    __syncthreads();
+    const uint64_t lo = i0 ? (uint64_t)skey[0] + 1 : 0;                       // first owned bucket
+    const uint64_t hi = (i1 == n) ? hs : (uint64_t)skey[i1 - i0] + 1;         // one past the last owned bucket
+    bool st[HEADS_RPT];
+    uint32_t bk[HEADS_RPT];
+    ulonglong2 hv[HEADS_RPT];
+#pragma unroll
+    for (int k = 0; k < HEADS_RPT; k++) {
+        const uint32_t x = threadIdx.x * HEADS_RPT + k + 1;                   // skey index of record f + k
+        const uint32_t b = skey[x];
+        st[k] = (f + k < i1) && (f + k == 0 || skey[x - 1] != b);             // first record of its bucket
+        bk[k] = b;
+        hv[k] = make_ulonglong2(ev[k], HEAD_EMPTY);
+        if (st[k]) {
+            uint32_t cnt = 1;
+            while (cnt < PGRC_BUCKET_CAP && skey[x + cnt] == b) cnt++;       // x + cnt <= HEADS_REC + 13
+            if (cnt == 2) hv[k].y = ev[k + 1];
+            else if (cnt > 2) {
+                hv[k].x |= HEAD_OVF;
+                hv[k].y = (f + k + 1) | ((uint64_t)cnt << 56);               // entries 1.. at ent[(i + 1) + j - 1]
+            }
+        }
+    }
+    for (uint64_t base = lo; base < hi; base += HEADS_CAP) {
+        const uint32_t m = (uint32_t)min((uint64_t)HEADS_CAP, hi - base);
+        for (uint32_t x = threadIdx.x; x < m; x += HEADS_TPB) tile[x] = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < HEADS_RPT; k++)
+            if (st[k] && bk[k] >= base && bk[k] - base < m) tile[bk[k] - base] = hv[k];
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < m; x += HEADS_TPB) head[base + x] = tile[x];
+        __syncthreads();
+    }
 }
 
 #define IDX_MAX_BLOCKS 4096u
@@ -131,10 +170,10 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     if (npos + PGRC_BUCKET_CAP >= (1ull << 32)) { c->err = "index build: more than 2^32 sampled positions"; return PGRC_E_PARAM; }
     int e;
     if ((e = pgrc_buf_ensure(c, c->d_head, hs * 2 * sizeof(uint64_t)))) return e;
-    HIP_TRY(c, hipMemsetAsync(c->d_head.p, 0xFF, hs * 2 * sizeof(uint64_t), c->stream));
     c->ent_ptr = nullptr;
     c->index_strand = strand;
     if (!npos) {
+        HIP_TRY(c, hipMemsetAsync(c->d_head.p, 0xFF, hs * 2 * sizeof(uint64_t), c->stream));
         if ((e = pgrc_buf_ensure(c, c->d_sval[0], 64))) return e;
         c->ent_ptr = (const uint64_t *)c->d_sval[0].p;
         return PGRC_OK;
@@ -160,8 +199,8 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     HIP_TRY(c, hipGetLastError());
     he = rocprim::radix_sort_pairs(c->d_sorttmp.p, tbytes, keys, vals, (size_t)npos, 0, hbits, c->stream);
     if (he != hipSuccess) { c->err = std::string("index sort: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
-    hipLaunchKernelGGL(k_copmem_index_heads, dim3((uint32_t)((npos + 255) / 256)), dim3(256), 0, c->stream,
-                       (const uint32_t *)keys.current(), (const uint64_t *)vals.current(), npos, (ulonglong2 *)c->d_head.p);
+    hipLaunchKernelGGL(k_copmem_index_heads, dim3((uint32_t)((npos + HEADS_REC - 1) / HEADS_REC)), dim3(HEADS_TPB), 0, c->stream,
+                       (const uint32_t *)keys.current(), (const uint64_t *)vals.current(), npos, hs, (ulonglong2 *)c->d_head.p);
     HIP_TRY(c, hipGetLastError());
     c->ent_ptr = vals.current();
     return PGRC_OK;

@@ -10,7 +10,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # this directory
 
 
 def main():
@@ -18,7 +18,9 @@ def main():
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--sample", type=int, default=200000)
     ap.add_argument("--gpu-reads", type=int, default=0, help="reads matched on the GPU (0 = the sample only)")
-    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--threads", type=int, default=1,
+                    help="threads of the reference's per-read loop; >1 exposes the reference's vector<bool> race "
+                         "(DESIGN.md, reference quirk 7), so parity runs use 1")
     ap.add_argument("--checker", default="auto", choices=["auto", "reference", "port"])
     ap.add_argument("--out", default="gpurun_out/fullscale_parity.json")
     a = ap.parse_args()

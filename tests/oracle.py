@@ -167,7 +167,11 @@ def oracle_extract(pg, pos, read, rc, reversed_, cnt):
     return codes[:cnt], offs[:cnt]
 
 
-def ref_match(mode, pg, reads, seed_len, kmax, kmin, rev_compl=True, n_nset=0, index_threads=1, omp_threads=8):
+def ref_match(mode, pg, reads, seed_len, kmax, kmin, rev_compl=True, n_nset=0, index_threads=1, omp_threads=1):
+    """The compiled reference.  index_threads=1 selects its serial (deterministic) copMEM index build.  omp_threads is
+    the width of its per-read loop: it defaults to 1 because that loop stores readMatchRC -- a vector<bool> -- from
+    several threads (ReadsMatchers.cpp:426-446), so reads whose flags share a 64-bit word across two threads' chunks
+    occasionally lose an update (seen once: one RC flag of 10 000 reads; DESIGN.md, reference quirk 7)."""
     pg = np.ascontiguousarray(pg, dtype=np.uint8)
     reads = np.ascontiguousarray(reads, dtype=np.uint8)
     n, L = reads.shape

@@ -364,7 +364,7 @@ def test_c_consumer_of_the_abi(tmp_path):
 def test_copmem_64bit_position_kernels_on_small_text(monkeypatch, L, seed_len, M, shortcut):
     """PGRC_FORCE_POS64 selects the kernels that a pseudogenome >= 4 Gi symbols needs (the reference's u64 index
     branch, CopMEMMatcher.cpp:579-586) on a small text; results must not change.  (The real thing is exercised by
-    tools/fullscale_parity.py --workload P64, profiles/r01_fullscale_parity_P64.json.)"""
+    tests/fullscale_parity.py --workload P64, profiles/r01_fullscale_parity_P64.json.)"""
     monkeypatch.setenv("PGRC_FORCE_POS64", "1")
     pg, reads = make_inputs(300000, 12000, L, seed=4000 + L, n_with_n=300)
     kmax = L // M
