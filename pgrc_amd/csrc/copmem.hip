@@ -166,8 +166,8 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     const uint64_t hs = c->cp.hash_size;
     c->npos = (c->G >= K) ? (c->G - K) / k1 + 1 : 0;
     const uint64_t npos = c->npos;
-    // the match kernel addresses ent[] with 32-bit indices
-    if (npos + PGRC_BUCKET_CAP >= (1ull << 32)) { c->err = "index build: more than 2^32 sampled positions"; return PGRC_E_PARAM; }
+    // (the match kernel addresses ent[] with 32-bit indices unless it runs its 64-bit-position variant, which a text
+    //  with 2^32 or more sampled positions always does)
     int e;
     if ((e = pgrc_buf_ensure(c, c->d_head, hs * 2 * sizeof(uint64_t)))) return e;
     c->ent_ptr = nullptr;
@@ -378,7 +378,8 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
     uint32_t cin = 0, epoch = 0;
     uint32_t cnext = 0, cend = 0; // this wave's reserved range of reads (wave-uniform: kept in SGPRs)
     uint32_t si = 0;              // seed index: s = si * k2
-    uint32_t lo = 0, nb = 0, j = 0, fp_read = 0;
+    pos_t lo = 0;          // index into ent[] (as many entries as sampled positions: 32 bits unless POS64)
+    uint32_t nb = 0, j = 0, fp_read = 0;
     pos_t cand_p = 0;
     uint64_t pend_e = 0;          // an entry already in registers (entry 1 of the head / second half of a pair)
     bool has_pend = false;
@@ -502,7 +503,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                     if (st.falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET); // :510-514
                     has_pend = cnt == 2 && nb > 1; // entry 1 of a two-entry bucket sits in the head
                     pend_e = hd.y;
-                    lo = (uint32_t)(hd.y & W1_BASE_MASK); // count >= 3: entries 1.. live at ent[lo + j - 1] (< 2^32 entries)
+                    lo = (pos_t)(hd.y & W1_BASE_MASK); // count >= 3: entries 1.. live at ent[lo + j - 1]
                     e = hd.x & ENT_MASK;
                     have = true;
                     j = 1;

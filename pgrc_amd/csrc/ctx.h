@@ -5,10 +5,10 @@
 //   reads2        u32[NW][stride]          word-major ("transposed") reads: thread i of a wave
 //                                          reads word w of read i at reads2[w*stride+i] => every
 //                                          wave-level load is one coalesced 256-B line
-//   head          2 x u64[hash_size]       the bucket's two smallest entries (pos << 24 | 24-bit fingerprint); for
-//                                          buckets with >= 3 entries w0 also carries the count, w1 the segment base
-//                                          in ent[]: one 16-B gather per probe (copmem.hip)
-//   ent           u64[<= 2 * overflow]     per overflowing bucket: [entry1, entries 2..12 ascending]
+//   head          2 x u64[hash_size]       the bucket's two smallest entries (pos << 22 | 22-bit fingerprint); for
+//                                          buckets with >= 3 entries w0 carries a flag, w1 the count and the index
+//                                          of entry 1 in ent[]: one 16-B gather per probe (copmem.hip)
+//   ent           u64[sampled positions]   all entries sorted by (bucket, position): the build's radix-sort output
 //   pos/rc/mism   u64[n] / u8[n] / u8[n]   per-read results (ReadsMatchers.h:32-35,115)
 #pragma once
 
