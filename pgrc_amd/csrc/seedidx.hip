@@ -119,35 +119,108 @@ __global__ void __launch_bounds__(256) k_seed_insert_ascii(const SeedArgs a) {
     table_insert(a, key_fix(h0, h1), (uint32_t)(i * a.P + j));
 }
 
-// ---- 2. stream the text: one thread per window start; COUNT pass sizes the hit buffer, FILL pass writes it
-template <bool FILL>
-__global__ void __launch_bounds__(256) k_seed_scan(const SeedArgs a, uint64_t nwin, unsigned long long *cursor, uint64_t *hits) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nwin) return;
+// ---- 2. stream the text past the table.  A block stages its stretch of the text in LDS; a thread walks SCAN_R window
+// starts that are cstride apart with the O(1) rolling update of the cyclic polynomial (the reference's own scan,
+// cyclichash.h:110-118) and probes the table for each; hits are appended with ONE atomic per wave and iteration
+// into a block-local LDS buffer that is flushed with one global atomic per block (same-address returning atomics
+// serialise at ~90 M/s: one per hit, or even one per wave and iteration -- 4 M at C2 -- made the cursor the whole
+// cost of this kernel).  Single pass: the hit buffer is sized by a guess, the cursor keeps counting past its end, and
+// the host reruns the pass with the exact size if it overflowed.
+#define SCAN_TPB 256
+#define SCAN_R 16
+#define SCAN_TILE_WORDS (SCAN_TPB * SCAN_R / 16 + 24)
+#define SCAN_LCAP 2048u
+__global__ void __launch_bounds__(SCAN_TPB)
+k_seed_scan(const SeedArgs a, uint64_t nwin, uint64_t pg_words_alloc, unsigned long long *cursor, uint64_t *hits, uint64_t cap) {
+    __shared__ uint32_t tile[SCAN_TILE_WORDS];
+    __shared__ uint64_t lbuf[SCAN_LCAP];
+    __shared__ uint32_t lcount;
+    __shared__ unsigned long long gbase;
+    if (threadIdx.x == 0) lcount = 0;
+    const uint32_t cs = a.cstride, m = a.m;
+    const uint32_t groups = SCAN_TPB / cs;               // runs of SCAN_R * cs consecutive starts, one thread per phase
+    const uint32_t per_block = groups * cs * SCAN_R;
+    const uint64_t b0 = (uint64_t)blockIdx.x * per_block;
+    const uint64_t w0 = b0 >> 4;
+    const uint32_t need = (uint32_t)(((b0 & 15) + per_block + (uint64_t)m * cs + 15) >> 4) + 1;   // <= SCAN_TILE_WORDS
+    for (uint32_t w = threadIdx.x; w < need; w += SCAN_TPB) tile[w] = (w0 + w < pg_words_alloc) ? a.pg[w0 + w] : 0u;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool worker = threadIdx.x < groups * cs;
+    const uint32_t g = threadIdx.x / cs, phase = threadIdx.x % cs;
+    const uint64_t s0 = b0 + (uint64_t)g * cs * SCAN_R + phase;
+    const uint32_t x0 = (uint32_t)(s0 - (w0 << 4));       // tile-relative symbol index of s0
+    auto sym = [&](uint32_t x) -> uint32_t { return (tile[x >> 4] >> (2u * (x & 15u))) & 3u; };
     uint32_t h0 = 0, h1 = 0;
-    for (uint32_t k = 0; k < a.m; k++) {
-        const uint64_t x = t + (uint64_t)k * a.cstride;
-        const uint32_t c = (a.pg[x >> 4] >> (2u * ((uint32_t)x & 15u))) & 3u;
-        h0 = rotl1(h0) ^ cyc_t0(c);
-        h1 = rotl1(h1) ^ cyc_t1(c);
+    if (worker)
+        for (uint32_t k = 0; k < m; k++) {
+            const uint32_t c = sym(x0 + k * cs);
+            h0 = rotl1(h0) ^ cyc_t0(c);
+            h1 = rotl1(h1) ^ cyc_t1(c);
+        }
+    const uint32_t mr = m & 31u;
+    for (uint32_t r = 0; r < SCAN_R; r++) {
+        const uint64_t t = s0 + (uint64_t)r * cs;
+        const bool active = worker && t < nwin;
+        const uint64_t key = key_fix(h0, h1);
+        uint64_t slot = mix64d(key) & a.tmask;
+        bool searching = active, found = false;
+        while (__any(searching)) {
+            if (searching) {
+                const uint64_t k = a.tkeys[slot];
+                if (k == SX_EMPTY) searching = false;
+                else if (k == key) { found = true; searching = false; }
+                else slot = (slot + 1) & a.tmask;
+            }
+        }
+        uint32_t e = found ? a.theads[slot] : SX_NIL;
+        while (__any(e != SX_NIL)) {
+            bool emit = false;
+            uint64_t rec = 0;
+            if (e != SX_NIL) {
+                const uint64_t i = e / a.P;
+                const uint32_t j = e % a.P;
+                const uint64_t shift = part_offset(a, j);
+                // ReadsMatchers.cpp:308-309 / :375-376 and :311-312 / :378-379
+                if (shift <= t && t - shift + a.L <= a.G) { emit = true; rec = (i << 36) | (t << 4) | (15u - j); }
+                e = a.next[e];
+            }
+            const unsigned long long mk = __ballot(emit);
+            if (mk) {
+                const int leader = __ffsll((long long)mk) - 1;
+                uint32_t lb = 0;
+                if ((int)lane == leader) lb = atomicAdd(&lcount, (uint32_t)__popcll(mk));
+                lb = __shfl(lb, leader, 64);
+                const uint32_t li = lb + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+                const bool spill = emit && li >= SCAN_LCAP;      // LDS buffer full (repeats): straight to HBM
+                if (emit && !spill) lbuf[li] = rec;
+                const unsigned long long sk = __ballot(spill);
+                if (sk) {
+                    const int sl = __ffsll((long long)sk) - 1;
+                    unsigned long long base = 0;
+                    if ((int)lane == sl) base = atomicAdd(cursor, (unsigned long long)__popcll(sk));
+                    base = __shfl(base, sl, 64);
+                    if (spill) {
+                        const unsigned long long idx = base + (unsigned long long)__popcll(sk & ((1ull << lane) - 1ull));
+                        if (idx < cap) hits[idx] = rec;
+                    }
+                }
+            }
+        }
+        if (worker && r + 1 < SCAN_R) {                      // roll to t + cs (cyclichash.h:110-118)
+            const uint32_t xo = x0 + r * cs;
+            const uint32_t co = sym(xo), cn = sym(xo + m * cs);
+            const uint32_t o0 = cyc_t0(co), o1 = cyc_t1(co);
+            h0 = rotl1(h0) ^ ((o0 << mr) | (mr ? o0 >> (32u - mr) : 0u)) ^ cyc_t0(cn);
+            h1 = rotl1(h1) ^ ((o1 << mr) | (mr ? o1 >> (32u - mr) : 0u)) ^ cyc_t1(cn);
+        }
     }
-    const uint64_t key = key_fix(h0, h1);
-    uint64_t slot = mix64d(key) & a.tmask;
-    for (;;) {
-        const uint64_t k = a.tkeys[slot];
-        if (k == SX_EMPTY) return;
-        if (k == key) break;
-        slot = (slot + 1) & a.tmask;
-    }
-    for (uint32_t e = a.theads[slot]; e != SX_NIL; e = a.next[e]) {
-        const uint64_t i = e / a.P;
-        const uint32_t j = e % a.P;
-        const uint64_t shift = part_offset(a, j);
-        if (shift > t) continue;                    // ReadsMatchers.cpp:308-309 / :375-376
-        if (t - shift + a.L > a.G) continue;        // :311-312 / :378-379
-        const unsigned long long o = atomicAdd(cursor, 1ull);
-        if (FILL) hits[o] = (i << 36) | (t << 4) | (15u - j);
-    }
+    __syncthreads();
+    const uint32_t nl = min(lcount, SCAN_LCAP);
+    if (threadIdx.x == 0 && nl) gbase = atomicAdd(cursor, (unsigned long long)nl);
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < nl; x += SCAN_TPB)
+        if (gbase + x < cap) hits[gbase + x] = lbuf[x];
 }
 
 // ---- 3. per-read sequential replay over its sorted candidates
@@ -302,24 +375,34 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
         a.strand = (uint32_t)pass;
         if (c->G < span) continue; // no window fits (the reference's scan loops are empty / undefined there)
         const uint64_t nwin = c->G - span + 1;
-        const uint32_t grid = (uint32_t)((nwin + 255) / 256);
-        HIP_TRY(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
-        hipLaunchKernelGGL(k_seed_scan<false>, dim3(grid), dim3(256), 0, c->stream, a, nwin, cursor, (uint64_t *)nullptr);
+        const uint32_t per_block = (SCAN_TPB / a.cstride) * a.cstride * SCAN_R;
+        const uint32_t grid = (uint32_t)((nwin + per_block - 1) / per_block);
+        // hit buffer: a guess (two hits per indexed part, or whatever an earlier pass needed); exact size on overflow
+        uint64_t cap = std::max<uint64_t>(2 * nent + 4096, c->s_hits.bytes / sizeof(uint64_t));
         unsigned long long nhits = 0;
-        HIP_TRY(c, hipMemcpyAsync(&nhits, cursor, sizeof nhits, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (int attempt = 0; attempt < 2; attempt++) {
+            if ((e = pgrc_buf_ensure(c, c->s_hits, cap * sizeof(uint64_t)))) return e;
+            HIP_TRY(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
+            hipLaunchKernelGGL(k_seed_scan, dim3(grid), dim3(SCAN_TPB), 0, c->stream, a, nwin, c->pg_words + PGRC_PG_PAD_WORDS,
+                               cursor, (uint64_t *)c->s_hits.p, cap);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(&nhits, cursor, sizeof nhits, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (nhits <= cap) break;
+            cap = nhits;                                    // the guess was too small: once more with the exact size
+        }
         if (nhits == 0) continue;
+        int ibits = 1, tbits = 1;                           // only the key bits that can be set take part in the sort
+        while ((1ull << ibits) < c->n) ibits++;
+        while ((1ull << tbits) < c->G) tbits++;
+        const int end_bit = 36 + ibits;
+        (void)tbits;
         size_t temp_bytes = 0;
-        HIP_TRY(c, rocprim::radix_sort_keys(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)nhits, 0, 64, c->stream));
+        HIP_TRY(c, rocprim::radix_sort_keys(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)nhits, 0, end_bit, c->stream));
         DevBuf sorted, temp;
-        if ((e = pgrc_buf_ensure(c, c->s_hits, nhits * sizeof(uint64_t)))) return e;
         if ((e = pgrc_buf_ensure(c, sorted, nhits * sizeof(uint64_t)))) return e;
         if ((e = pgrc_buf_ensure(c, temp, temp_bytes))) { pgrc_buf_free(sorted); return e; }
-        hipError_t he = hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream);
-        hipLaunchKernelGGL(k_seed_scan<true>, dim3(grid), dim3(256), 0, c->stream, a, nwin, cursor, (uint64_t *)c->s_hits.p);
-        if (he == hipSuccess) he = hipGetLastError();
-        if (he == hipSuccess)
-            he = rocprim::radix_sort_keys(temp.p, temp_bytes, (uint64_t *)c->s_hits.p, (uint64_t *)sorted.p, (size_t)nhits, 0, 64, c->stream);
+        hipError_t he = rocprim::radix_sort_keys(temp.p, temp_bytes, (uint64_t *)c->s_hits.p, (uint64_t *)sorted.p, (size_t)nhits, 0, end_bit, c->stream);
         if (he == hipSuccess) {
             hipLaunchKernelGGL(k_seed_replay<false>, dim3((uint32_t)((c->n + 255) / 256)), dim3(256), 0, c->stream, a,
                                (const uint64_t *)sorted.p, (uint64_t)nhits);
