@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(256) k_seed_insert_ascii(const SeedArgs a) {
 #define SCAN_R 16
 #define SCAN_TILE_WORDS (SCAN_TPB * SCAN_R / 16 + 24)
 #define SCAN_LCAP 2048u
+#define SCAN_B 8
 __global__ void __launch_bounds__(SCAN_TPB)
 k_seed_scan(const SeedArgs a, uint64_t nwin, uint64_t pg_words_alloc, unsigned long long *cursor, uint64_t *hits, uint64_t cap) {
     __shared__ uint32_t tile[SCAN_TILE_WORDS];
@@ -159,60 +160,81 @@ k_seed_scan(const SeedArgs a, uint64_t nwin, uint64_t pg_words_alloc, unsigned l
             h1 = rotl1(h1) ^ cyc_t1(c);
         }
     const uint32_t mr = m & 31u;
-    for (uint32_t r = 0; r < SCAN_R; r++) {
-        const uint64_t t = s0 + (uint64_t)r * cs;
-        const bool active = worker && t < nwin;
-        const uint64_t key = key_fix(h0, h1);
-        uint64_t slot = mix64d(key) & a.tmask;
-        bool searching = active, found = false;
-        while (__any(searching)) {
-            if (searching) {
-                const uint64_t k = a.tkeys[slot];
-                if (k == SX_EMPTY) searching = false;
-                else if (k == key) { found = true; searching = false; }
-                else slot = (slot + 1) & a.tmask;
+    // batches of SCAN_B window starts: all keys of a batch first (rolling), then their table probes as independent
+    // loads, then the heads of the keys found -- a dependent round trip per batch instead of one per start
+    for (uint32_t r0 = 0; r0 < SCAN_R; r0 += SCAN_B) {
+        uint64_t keyv[SCAN_B], slotv[SCAN_B], kv[SCAN_B];
+        uint32_t ev[SCAN_B];
+#pragma unroll
+        for (int b = 0; b < SCAN_B; b++) {
+            keyv[b] = key_fix(h0, h1);
+            slotv[b] = mix64d(keyv[b]) & a.tmask;
+            if (worker) {                                     // roll to the next start (cyclichash.h:110-118)
+                const uint32_t xo = x0 + (r0 + b) * cs;
+                const uint32_t co = sym(xo), cn = sym(xo + m * cs);
+                const uint32_t o0 = cyc_t0(co), o1 = cyc_t1(co);
+                h0 = rotl1(h0) ^ ((o0 << mr) | (mr ? o0 >> (32u - mr) : 0u)) ^ cyc_t0(cn);
+                h1 = rotl1(h1) ^ ((o1 << mr) | (mr ? o1 >> (32u - mr) : 0u)) ^ cyc_t1(cn);
             }
         }
-        uint32_t e = found ? a.theads[slot] : SX_NIL;
-        while (__any(e != SX_NIL)) {
-            bool emit = false;
-            uint64_t rec = 0;
-            if (e != SX_NIL) {
-                const uint64_t i = e / a.P;
-                const uint32_t j = e % a.P;
-                const uint64_t shift = part_offset(a, j);
-                // ReadsMatchers.cpp:308-309 / :375-376 and :311-312 / :378-379
-                if (shift <= t && t - shift + a.L <= a.G) { emit = true; rec = (i << 36) | (t << 4) | (15u - j); }
-                e = a.next[e];
+#pragma unroll
+        for (int b = 0; b < SCAN_B; b++) {
+            const uint64_t t = s0 + (uint64_t)(r0 + b) * cs;
+            kv[b] = (worker && t < nwin) ? a.tkeys[slotv[b]] : SX_EMPTY;
+        }
+#pragma unroll
+        for (int b = 0; b < SCAN_B; b++) {
+            bool searching = kv[b] != SX_EMPTY && kv[b] != keyv[b];     // rare: the slot holds another key
+            bool found = kv[b] == keyv[b];
+            while (__any(searching)) {
+                if (searching) {
+                    slotv[b] = (slotv[b] + 1) & a.tmask;
+                    const uint64_t k = a.tkeys[slotv[b]];
+                    if (k == SX_EMPTY) searching = false;
+                    else if (k == keyv[b]) { found = true; searching = false; }
+                }
             }
-            const unsigned long long mk = __ballot(emit);
-            if (mk) {
-                const int leader = __ffsll((long long)mk) - 1;
-                uint32_t lb = 0;
-                if ((int)lane == leader) lb = atomicAdd(&lcount, (uint32_t)__popcll(mk));
-                lb = __shfl(lb, leader, 64);
-                const uint32_t li = lb + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
-                const bool spill = emit && li >= SCAN_LCAP;      // LDS buffer full (repeats): straight to HBM
-                if (emit && !spill) lbuf[li] = rec;
-                const unsigned long long sk = __ballot(spill);
-                if (sk) {
-                    const int sl = __ffsll((long long)sk) - 1;
-                    unsigned long long base = 0;
-                    if ((int)lane == sl) base = atomicAdd(cursor, (unsigned long long)__popcll(sk));
-                    base = __shfl(base, sl, 64);
-                    if (spill) {
-                        const unsigned long long idx = base + (unsigned long long)__popcll(sk & ((1ull << lane) - 1ull));
-                        if (idx < cap) hits[idx] = rec;
+            kv[b] = found ? 1ull : 0ull;
+        }
+#pragma unroll
+        for (int b = 0; b < SCAN_B; b++) ev[b] = kv[b] ? a.theads[slotv[b]] : SX_NIL;
+#pragma unroll
+        for (int b = 0; b < SCAN_B; b++) {
+            const uint64_t t = s0 + (uint64_t)(r0 + b) * cs;
+            uint32_t e = ev[b];
+            while (__any(e != SX_NIL)) {
+                bool emit = false;
+                uint64_t rec = 0;
+                if (e != SX_NIL) {
+                    const uint64_t i = e / a.P;
+                    const uint32_t j = e % a.P;
+                    const uint64_t shift = part_offset(a, j);
+                    // ReadsMatchers.cpp:308-309 / :375-376 and :311-312 / :378-379
+                    if (shift <= t && t - shift + a.L <= a.G) { emit = true; rec = (i << 36) | (t << 4) | (15u - j); }
+                    e = a.next[e];
+                }
+                const unsigned long long mk = __ballot(emit);
+                if (mk) {
+                    const int leader = __ffsll((long long)mk) - 1;
+                    uint32_t lb = 0;
+                    if ((int)lane == leader) lb = atomicAdd(&lcount, (uint32_t)__popcll(mk));
+                    lb = __shfl(lb, leader, 64);
+                    const uint32_t li = lb + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+                    const bool spill = emit && li >= SCAN_LCAP;      // LDS buffer full (repeats): straight to HBM
+                    if (emit && !spill) lbuf[li] = rec;
+                    const unsigned long long sk = __ballot(spill);
+                    if (sk) {
+                        const int sl = __ffsll((long long)sk) - 1;
+                        unsigned long long base = 0;
+                        if ((int)lane == sl) base = atomicAdd(cursor, (unsigned long long)__popcll(sk));
+                        base = __shfl(base, sl, 64);
+                        if (spill) {
+                            const unsigned long long idx = base + (unsigned long long)__popcll(sk & ((1ull << lane) - 1ull));
+                            if (idx < cap) hits[idx] = rec;
+                        }
                     }
                 }
             }
-        }
-        if (worker && r + 1 < SCAN_R) {                      // roll to t + cs (cyclichash.h:110-118)
-            const uint32_t xo = x0 + r * cs;
-            const uint32_t co = sym(xo), cn = sym(xo + m * cs);
-            const uint32_t o0 = cyc_t0(co), o1 = cyc_t1(co);
-            h0 = rotl1(h0) ^ ((o0 << mr) | (mr ? o0 >> (32u - mr) : 0u)) ^ cyc_t0(cn);
-            h1 = rotl1(h1) ^ ((o1 << mr) | (mr ? o1 >> (32u - mr) : 0u)) ^ cyc_t1(cn);
         }
     }
     __syncthreads();
@@ -250,17 +272,26 @@ __device__ __forceinline__ uint32_t hamming_vs_text(const SeedArgs &a, uint64_t 
     return mm;
 }
 
-__device__ __forceinline__ uint64_t lower_bound_u64(const uint64_t *v, uint64_t n, uint64_t x) {
-    uint64_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (v[mid] < x) lo = mid + 1; else hi = mid;
-    }
-    return lo;
+// Hamming count of EVERY hit, one thread per hit (the replay below only compares counts with the read's current limit,
+// ReadsMatchers.cpp:315-319, so the full count serves every limit), and the first hit of every read.
+__global__ void __launch_bounds__(256)
+k_seed_hamming(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhits, uint8_t *__restrict__ mmv,
+               uint64_t *__restrict__ rstart) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nhits) return;
+    const uint64_t hkey = hits[x];
+    const uint64_t i = hkey >> 36;
+    if (x == 0 || (hits[x - 1] >> 36) != i) rstart[i] = x;
+    if (a.nflag && a.nflag[i]) return;                     // byte-path read: k_seed_replay<true> compares itself
+    const uint64_t tp = (hkey >> 4) & 0xFFFFFFFFull;
+    const uint32_t j = 15u - (uint32_t)(hkey & 15u);
+    mmv[x] = (uint8_t)min(hamming_vs_text<false>(a, i, 0, tp - part_offset(a, j)), 255u);
 }
 
 template <bool ASCII>
-__global__ void __launch_bounds__(256) k_seed_replay(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhits) {
+__global__ void __launch_bounds__(256)
+k_seed_replay(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhits, const uint8_t *__restrict__ mmv,
+              const uint64_t *__restrict__ rstart) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t i, trow = 0;
     if (ASCII) {
@@ -277,16 +308,16 @@ __global__ void __launch_bounds__(256) k_seed_replay(const SeedArgs a, const uin
     uint32_t rcflag = a.rc[i];
     const bool exact = a.mode == 'e';
     if (exact ? (stored != PGRC_NOT_MATCHED_POS) : (c <= a.kmin)) return;
-    const uint64_t lo = lower_bound_u64(hits, nhits, i << 36), hi = lower_bound_u64(hits, nhits, (i + 1) << 36);
     bool changed = false;
-    for (uint64_t x = lo; x < hi; x++) {
+    for (uint64_t x = rstart[i]; x < nhits; x++) {             // rstart = all ones for a read without hits
         const uint64_t hkey = hits[x];
+        if ((hkey >> 36) != i) break;
         const uint64_t tp = (hkey >> 4) & 0xFFFFFFFFull;
         const uint32_t j = 15u - (uint32_t)(hkey & 15u);
         const uint64_t p = tp - part_offset(a, j);
         const uint64_t cand = a.strand ? a.G - (p + a.L) : p;
         if (exact) {
-            if (hamming_vs_text<ASCII>(a, i, trow, p) != 0) continue; // compareReadWithPattern == 0, :207
+            if ((ASCII ? hamming_vs_text<true>(a, i, trow, p) : (uint32_t)mmv[x]) != 0) continue; // compareReadWithPattern == 0, :207
             stored = cand;                                              // first hit in scan order wins, :209-212
             rcflag = a.strand;
             c = 0;
@@ -296,7 +327,7 @@ __global__ void __launch_bounds__(256) k_seed_replay(const SeedArgs a, const uin
         if (c <= a.kmin) break;                                         // :304-305 (every later hit is skipped too)
         if (stored == cand) continue;                                   // :313-314
         const uint32_t limit = (c == PGRC_NOT_MATCHED_CNT) ? a.kmax : c - 1u; // :315-316
-        const uint32_t mm = hamming_vs_text<ASCII>(a, i, trow, p);
+        const uint32_t mm = ASCII ? hamming_vs_text<true>(a, i, trow, p) : (uint32_t)mmv[x];
         if (mm <= limit) {                                              // got < count  (:319-328)
             c = mm;
             stored = cand;
@@ -399,21 +430,25 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
         (void)tbits;
         size_t temp_bytes = 0;
         HIP_TRY(c, rocprim::radix_sort_keys(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)nhits, 0, end_bit, c->stream));
-        DevBuf sorted, temp;
+        // scratch lives in the context (grow-only): no hipMalloc / hipFree (= device synchronisation) per pass
+        DevBuf &sorted = c->s_sorted, &temp = c->s_sorttmp;
         if ((e = pgrc_buf_ensure(c, sorted, nhits * sizeof(uint64_t)))) return e;
-        if ((e = pgrc_buf_ensure(c, temp, temp_bytes))) { pgrc_buf_free(sorted); return e; }
+        if ((e = pgrc_buf_ensure(c, temp, temp_bytes))) return e;
+        if ((e = pgrc_buf_ensure(c, c->s_mm, nhits))) return e;
+        if ((e = pgrc_buf_ensure(c, c->s_rstart, c->n * sizeof(uint64_t)))) return e;
         hipError_t he = rocprim::radix_sort_keys(temp.p, temp_bytes, (uint64_t *)c->s_hits.p, (uint64_t *)sorted.p, (size_t)nhits, 0, end_bit, c->stream);
+        if (he == hipSuccess) he = hipMemsetAsync(c->s_rstart.p, 0xFF, c->n * sizeof(uint64_t), c->stream);
         if (he == hipSuccess) {
+            hipLaunchKernelGGL(k_seed_hamming, dim3((uint32_t)((nhits + 255) / 256)), dim3(256), 0, c->stream, a,
+                               (const uint64_t *)sorted.p, (uint64_t)nhits, (uint8_t *)c->s_mm.p, (uint64_t *)c->s_rstart.p);
             hipLaunchKernelGGL(k_seed_replay<false>, dim3((uint32_t)((c->n + 255) / 256)), dim3(256), 0, c->stream, a,
-                               (const uint64_t *)sorted.p, (uint64_t)nhits);
+                               (const uint64_t *)sorted.p, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p);
             if (c->n_nreads)
                 hipLaunchKernelGGL(k_seed_replay<true>, dim3((uint32_t)((c->n_nreads + 255) / 256)), dim3(256), 0, c->stream, a,
-                                   (const uint64_t *)sorted.p, (uint64_t)nhits);
+                                   (const uint64_t *)sorted.p, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p);
             he = hipGetLastError();
         }
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-        pgrc_buf_free(sorted);
-        pgrc_buf_free(temp);
         if (he != hipSuccess) { c->err = std::string("seed-index pass: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
         c->ctr.searched[pass] = c->n;
         c->ctr.candidates[pass] = nhits;
