@@ -444,6 +444,7 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
     int e;
     if (!c->have_results && (e = pgrc_match_init_results(c))) return e;
     HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, 32 * sizeof(uint64_t), c->stream));
+    memset(&c->ctr, 0, sizeof c->ctr);
     const bool prof = c->profiling && c->have_events;
     int evi = 0;
     auto mark = [&]() { if (prof) (void)hipEventRecord(c->ev[evi], c->stream); evi++; };
@@ -468,8 +469,7 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
     mark();
     uint64_t ctr[16];
     HIP_TRY(c, hipMemcpy(ctr, c->d_counters.p, sizeof ctr, hipMemcpyDeviceToHost));
-    memset(&c->ctr, 0, sizeof c->ctr);
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < 2 && c->prm.mode == 'c'; s++) {      // (modes d/i/e: pgrc_seedidx_run filled searched / candidates)
         c->ctr.searched[s] = ctr[8 * s + 0];
         c->ctr.candidates[s] = ctr[8 * s + 1];
         c->ctr.probes[s] = ctr[8 * s + 2];

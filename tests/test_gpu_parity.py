@@ -251,6 +251,31 @@ def test_seedindex_modes_parity(mode, L, seed_len, M, shortcut, G, n, n_with_n):
         assert_same_results(g, r, "vs real reference")
 
 
+@pytest.mark.parametrize("mode", ["d", "i", "e"])
+def test_seedindex_hit_floods_on_low_complexity_text(mode):
+    """A poly-A tract and reads taken from it: every window of the tract hits every part of those reads (~1.4 M hits
+    from 8 kbp of text), which overflows the scan kernel's block-local hit buffer and the first guess of the hit
+    array -- both slow paths must give the reference's result."""
+    L = 100
+    seed_len = L if mode == "e" else 38
+    pg, reads = make_inputs(120000, 3000, L, seed=4242)
+    pg[30000:38000] = ord("A")
+    pg[60000:64000] = np.resize(np.frombuffer(b"AC", dtype=np.uint8), 4000)
+    for k in range(90):
+        reads[k] = ord("A")
+        if mode != "e" and k % 3:
+            reads[k, 5 + k % 50] = ord("C")          # approximate matches inside the tract
+    for k in range(90, 130):
+        reads[k] = np.resize(np.frombuffer(b"AC" if k % 2 else b"CA", dtype=np.uint8), L)
+    kmax = 0 if mode == "e" else 2
+    o = orc.oracle_match(mode, pg, reads, seed_len, kmax, 0)
+    g = gpu_match(mode, pg, reads, seed_len, kmax, 0)
+    assert_same_results(g, o, f"hit flood, mode {mode}")
+    assert g["ctx"].counters()["candidates"][0] > 3 * 3000 * (L // seed_len) + 4096     # the guess was exceeded
+    if orc.have_ref():
+        assert_same_results(g, orc.ref_match(mode, pg, reads, seed_len, kmax, 0), "hit flood vs real reference")
+
+
 def test_seedindex_cyclic_equivalence_candidates():
     """seeds longer than 32: the reference's CyclicHash collides deterministically for symbol swaps 32 apart;
     the GPU key must yield the same candidates (see tests/test_oracle_vs_ref.py)."""
