@@ -574,3 +574,115 @@ void pgrc_or_extract_mismatches(const char *pg, uint64_t pos, const char *read, 
             }
     }
 }
+
+/* ------------------------------------------------------ Pg-vs-Pg exact matches */
+
+/* CopMEMMatcher::matchTexts -> processExactMatchQueryTight, matching/copmem/CopMEMMatcher.cpp:333-481, :604-622,
+ * over the same serial seed index as the read matcher.  The destination text is scanned left to right in steps of
+ * k2; the scan is SEQUENTIAL by nature (what a probe does depends on the last match found), and four 32-bit "side
+ * context" registers l1/r1/l2/r2 are only refreshed when their 4 bytes lie inside the text, i.e. they keep a stale
+ * value near the text ends (:381-382, :401-402).  All of that is restated here as it behaves. */
+typedef struct {
+    const pgrc_or_index *idx;
+    const char *src, *dest;
+    uint64_t N, N2;
+    int dest_is_src, rev_compl;
+    uint32_t min_len;
+    int K, LK2, KLK24;
+    uint32_t l1, l2, r1, r2;
+    pgrc_or_text_match *out;
+    uint64_t n_out, cap;
+} mem_scan;
+
+static uint32_t le32_at(const char *p) {
+    uint32_t v;
+    memcpy(&v, p, 4);
+    return v;
+}
+
+/* one probe of the destination at q; returns 1 when the scan must jump ahead (a match was pushed, or the window
+ * lies inside the previous match on its diagonal) */
+static int mem_visit(mem_scan *s, uint64_t q, int tail_loop) {
+    const char *c2 = s->dest + q;
+    const uint32_t h = pgrc_or_copmem_hash(s->K, c2) & (s->idx->p.hash_size - 1);
+    const uint32_t lo = s->idx->cumm[h], hi = s->idx->cumm[h + 1];
+    if (lo == hi) return 0;
+    if (q >= (uint64_t)s->LK2) s->l2 = le32_at(c2 - s->LK2);                         /* :381 / :436 */
+    if (q + (uint64_t)s->KLK24 + 4 <= s->N2) s->r2 = le32_at(c2 + s->KLK24);          /* :382 / :437 */
+    for (uint32_t j = lo; j < hi; j++) {
+        const uint64_t p = s->idx->positions[j];
+        const char *c1 = s->src + p;
+        if (s->dest_is_src && (s->rev_compl ? s->N2 - p < q : q >= p)) continue;      /* :389-392 */
+        if (s->n_out) {                                                              /* :393-399 */
+            const pgrc_or_text_match *b = &s->out[s->n_out - 1];
+            if (q - p == b->pos_dest - b->pos_src && q + (uint64_t)s->K < b->pos_dest + b->length) return 1;
+        }
+        /* the tail loop reads these unconditionally (:456-457), which is out of bounds for the same positions;
+         * treated like the main loop here (the value is unspecified in the reference) */
+        (void)tail_loop;
+        if (p >= (uint64_t)s->LK2) s->l1 = le32_at(c1 - s->LK2);                      /* :401 */
+        if (p + (uint64_t)s->KLK24 + 4 <= s->N) s->r1 = le32_at(c1 + s->KLK24);       /* :402 */
+        if (s->r1 != s->r2 && s->l1 != s->l2) continue;                              /* :404 */
+        /* right extension: from the last symbol of the K-mer, pre-incrementing (:405-407) */
+        uint64_t a = p + (uint64_t)s->K - 1, b2 = q + (uint64_t)s->K - 1;
+        for (;;) {
+            if (++a == s->N) break;
+            if (++b2 == s->N2) break;
+            if (s->src[a] != s->dest[b2]) break;
+        }
+        const uint64_t right = a;
+        /* left extension: stops ON the first text symbol without stepping over it (:409-411) */
+        uint64_t x = p, y = q;
+        while (x != 0 && y != 0) {
+            --x; --y;
+            if (s->src[x] != s->dest[y]) break;
+        }
+        /* x, y now name the symbol BEFORE the match (or symbol 0, which is then left out of the match: the
+         * reference's off-by-one at the text start) */
+        if (right - x > (uint64_t)s->min_len && memcmp(c1, c2, (size_t)s->K) == 0) {   /* :413 */
+            if (s->n_out == s->cap) {
+                s->cap = s->cap ? 2 * s->cap : 1024;
+                s->out = (pgrc_or_text_match *)realloc(s->out, s->cap * sizeof *s->out);
+            }
+            s->out[s->n_out].pos_src = x + 1;
+            s->out[s->n_out].length = right - x - 1;
+            s->out[s->n_out].pos_dest = y + 1;
+            s->n_out++;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+int pgrc_or_mem_match(const char *src, uint64_t N, const char *dest, uint64_t N2, int dest_is_src, int rev_compl,
+                      uint32_t target_len, uint32_t min_match_len, pgrc_or_text_match **out, uint64_t *count) {
+    pgrc_or_index idx;
+    *out = NULL;
+    *count = 0;
+    int e = pgrc_or_index_build(src, N, target_len, &idx);
+    if (e) return e;
+    if ((int)min_match_len < idx.p.K) { pgrc_or_index_free(&idx); return 4; }         /* :606-609 */
+    mem_scan s;
+    memset(&s, 0, sizeof s);
+    s.idx = &idx; s.src = src; s.dest = dest; s.N = N; s.N2 = N2;
+    s.dest_is_src = dest_is_src; s.rev_compl = rev_compl; s.min_len = min_match_len;
+    s.K = idx.p.K;
+    s.LK2 = (idx.p.L - idx.p.K) / 2;                                                  /* :87-89 */
+    s.KLK24 = idx.p.K + s.LK2 - 4;
+    const uint64_t k2 = (uint64_t)idx.p.k2, block = 256 * k2;
+    const uint64_t skip = (uint64_t)(idx.p.K / idx.p.k1 - 1);                         /* :352 */
+    uint64_t i1 = 0;
+    /* blocks of 256 probes: a jump ahead never leaves its block (:365-424) */
+    for (; i1 + (uint64_t)s.K + block < N2 + 1; i1 += block)
+        for (uint64_t i2 = 0; i2 < 256; i2++)
+            if (mem_visit(&s, i1 + i2 * k2, 0)) i2 += skip;
+    /* the remaining probes, one by one; here a jump carries through (:428-476) */
+    for (; i1 + (uint64_t)s.K < N2 + 1; i1 += k2)
+        if (mem_visit(&s, i1, 1)) i1 += skip * k2;
+    pgrc_or_index_free(&idx);
+    *out = s.out;
+    *count = s.n_out;
+    return 0;
+}
+
+void pgrc_or_mem_free(pgrc_or_text_match *m) { free(m); }

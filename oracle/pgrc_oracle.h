@@ -126,6 +126,17 @@ void pgrc_or_extract_mismatches(const char *pg, uint64_t pos, const char *read, 
                                 int rc, int reversed, uint8_t cnt, uint8_t *codes,
                                 uint16_t *offsets);
 
+/* Pg-vs-Pg exact matching: CopMEMMatcher::matchTexts (matching/copmem/CopMEMMatcher.cpp:604-622 ->
+ * processExactMatchQueryTight :333-481) with a matcher built by CopMEMMatcher(src, N, target_len) (:571-591).
+ * dest is the text as handed to matchTexts (the caller reverse-complements it, SimplePgMatcher.cpp:31-41).
+ * Matches come out in discovery order.  Returns non-zero where the reference would exit (min_match_len < K). */
+typedef struct {
+    uint64_t pos_src, length, pos_dest;   /* TextMatch, matching/TextMatchers.h:10-16 */
+} pgrc_or_text_match;
+int pgrc_or_mem_match(const char *src, uint64_t N, const char *dest, uint64_t N2, int dest_is_src, int rev_compl,
+                      uint32_t target_len, uint32_t min_match_len, pgrc_or_text_match **out, uint64_t *count);
+void pgrc_or_mem_free(pgrc_or_text_match *m);
+
 /* helpers */
 void pgrc_or_revcomp(char *seq, uint64_t n);                 /* helper.cpp:383-393 */
 uint8_t pgrc_or_sym2val(char c);                             /* helper.cpp:277-283: A0 C1 G2 T3 N4 */

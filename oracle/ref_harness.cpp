@@ -170,6 +170,28 @@ int pgrc_ref_match(char mode, const char *pg, uint64_t G, const char *reads, uin
     return 0;
 }
 
+// Pg-vs-Pg exact matching: CopMEMMatcher(src, N, target_len, ctor_min_len).matchTexts(...).  out receives count
+// triples (posSrcText, length, posDestText) in discovery order; free with pgrc_ref_free.
+int pgrc_ref_mem_match(const char *src, uint64_t N, const char *dest, uint64_t N2, int dest_is_src, int rev_compl,
+                       uint32_t target_len, uint32_t ctor_min_len, uint32_t min_match_len, int threads,
+                       uint64_t **out, uint64_t *count) {
+    Silence quiet;
+    PgHelpers::numberOfThreads = threads;
+    omp_set_num_threads(threads);
+    CopMEMMatcher matcher(src, (size_t) N, target_len, ctor_min_len);
+    std::vector<TextMatch> res;
+    const std::string d(dest, (size_t) N2);
+    matcher.matchTexts(res, d, dest_is_src != 0, rev_compl != 0, min_match_len);
+    *count = res.size();
+    *out = (uint64_t *) malloc((res.size() * 3 + 1) * sizeof(uint64_t));
+    for (size_t i = 0; i < res.size(); i++) {
+        (*out)[3 * i] = res[i].posSrcText;
+        (*out)[3 * i + 1] = res[i].length;
+        (*out)[3 * i + 2] = res[i].posDestText;
+    }
+    return 0;
+}
+
 #ifdef PGRC_WITH_HIP_ADAPTER
 } // extern "C" (the C++ definition of PgTools::mapReadsIntoPg below cannot live in a C-linkage block)
 // ---------------------------------------------------------------------------------------------------------------

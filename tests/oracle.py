@@ -98,6 +98,9 @@ def ref():
         lib.pgrc_ref_pack_read.argtypes = [_P, C.c_uint32, C.c_char_p, _P]
         lib.pgrc_ref_revcomp.argtypes = [_P, C.c_uint64]
         lib.pgrc_ref_free.argtypes = [_P]
+        if hasattr(lib, "pgrc_ref_mem_match"):
+            lib.pgrc_ref_mem_match.argtypes = [_P, C.c_uint64, _P, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                               C.c_uint32, C.c_int, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
         _ref = lib
     return _ref
 
@@ -238,3 +241,51 @@ def ref_match_via_adapter(mode, pg, reads, seed_len, kmax, kmin, rev_compl=True,
     if e:
         raise RuntimeError(f"adapter returned {e}")
     return {"pos": pos, "rc": rc, "mism": mism, "hist": hist, "matched": int(matched.value)}
+
+
+# ---- Pg-vs-Pg exact matching
+
+def revcomp_ascii(a):
+    """reverse complement of an ASCII uint8 array (N stays N)"""
+    lut = np.arange(256, dtype=np.uint8)
+    for x, y in (b"AT", b"TA", b"CG", b"GC"):
+        lut[x] = y
+    return lut[np.ascontiguousarray(a, dtype=np.uint8)[::-1]].copy()
+
+
+def mem_dest(src, dest, dest_is_src, rev_compl):
+    """the text SimplePgMatcher::exactMatchPg hands to matchTexts (SimplePgMatcher.cpp:31-43)"""
+    base = src if dest_is_src else dest
+    return revcomp_ascii(base) if rev_compl else np.ascontiguousarray(base, dtype=np.uint8)
+
+
+def oracle_mem_match(src, dest_text, dest_is_src, rev_compl, target_len=45, min_len=None):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    d = np.ascontiguousarray(dest_text, dtype=np.uint8)
+    lib = oracle()
+    lib.pgrc_or_mem_match.argtypes = [_P, C.c_uint64, _P, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                      C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
+    lib.pgrc_or_mem_free.argtypes = [C.POINTER(C.c_uint64)]
+    out = C.POINTER(C.c_uint64)()
+    cnt = C.c_uint64(0)
+    e = lib.pgrc_or_mem_match(_ptr(src), src.size, _ptr(d), d.size, int(dest_is_src), int(rev_compl), target_len,
+                              target_len if min_len is None else min_len, C.byref(out), C.byref(cnt))
+    if e:
+        raise RuntimeError(f"oracle mem_match returned {e}")
+    res = np.ctypeslib.as_array(out, shape=(cnt.value * 3,)).reshape(-1, 3).copy() if cnt.value else np.zeros((0, 3), np.uint64)
+    lib.pgrc_or_mem_free(out)
+    return res
+
+
+def ref_mem_match(src, dest_text, dest_is_src, rev_compl, target_len=45, min_len=None, threads=1):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    d = np.ascontiguousarray(dest_text, dtype=np.uint8)
+    out = C.POINTER(C.c_uint64)()
+    cnt = C.c_uint64(0)
+    e = ref().pgrc_ref_mem_match(_ptr(src), src.size, _ptr(d), d.size, int(dest_is_src), int(rev_compl), target_len,
+                                 0xFFFFFFFF, target_len if min_len is None else min_len, threads, C.byref(out), C.byref(cnt))
+    if e:
+        raise RuntimeError(f"ref mem_match returned {e}")
+    res = np.ctypeslib.as_array(out, shape=(cnt.value * 3,)).reshape(-1, 3).copy() if cnt.value else np.zeros((0, 3), np.uint64)
+    ref().pgrc_ref_free(C.cast(out, _P))
+    return res
