@@ -16,4 +16,5 @@ from .matchers import (  # noqa: F401
     copmem_params,
     mapReadsIntoPg,
 )
+from .textmatch import CopMEMMatcher  # noqa: F401
 from . import synth  # noqa: F401

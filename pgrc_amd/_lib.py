@@ -50,7 +50,16 @@ class SynthReads(C.Structure):
                 ("n_with_n", C.c_uint64)]
 
 
-# every symbol include/pgrc_match.h declares: (name, restype, argtypes)
+class TextMatch(C.Structure):     # pgrc_text_match (include/pgrc_mem.h) = TextMatch, matching/TextMatchers.h:10-16
+    _fields_ = [("pos_src", C.c_uint64), ("length", C.c_uint64), ("pos_dest", C.c_uint64)]
+
+
+class MemCounters(C.Structure):
+    _fields_ = [("probes", C.c_uint64), ("events", C.c_uint64), ("stale_lookups", C.c_uint64), ("ms_index", C.c_float),
+                ("ms_probe", C.c_float), ("ms_sort", C.c_float), ("ms_extend", C.c_float), ("ms_host", C.c_float)]
+
+
+# every symbol include/pgrc_match.h and include/pgrc_mem.h declare: (name, restype, argtypes)
 _P = C.c_void_p
 _PROTOS = [
     ("pgrc_match_version", C.c_char_p, []),
@@ -86,6 +95,15 @@ _PROTOS = [
     ("pgrc_synth_pg_device", C.c_int, [C.POINTER(SynthPg), _P, _P]),
     ("pgrc_synth_reads_device", C.c_int, [C.POINTER(SynthPg), _P, C.POINTER(SynthReads), C.c_uint64, C.c_uint64,
                                           _P, C.c_uint64, _P]),
+    # include/pgrc_mem.h
+    ("pgrc_mem_create", C.c_int, [C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(_P)]),
+    ("pgrc_mem_destroy", None, [_P]),
+    ("pgrc_mem_last_error", C.c_char_p, [_P]),
+    ("pgrc_mem_set_src_ascii", C.c_int, [_P, _P, C.c_uint64]),
+    ("pgrc_mem_match_texts", C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.POINTER(TextMatch)),
+                                       C.POINTER(C.c_uint64)]),
+    ("pgrc_mem_free_matches", None, [C.POINTER(TextMatch)]),
+    ("pgrc_mem_get_counters", C.c_int, [_P, C.POINTER(MemCounters)]),
 ]
 
 EXPORTED_SYMBOLS = [p[0] for p in _PROTOS]

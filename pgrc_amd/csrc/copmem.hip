@@ -32,23 +32,7 @@
 
 #include "ctx.h"
 #include "devutil.h"
-
-#define HEAD_EMPTY 0xFFFFFFFFFFFFFFFFull
-#define HEAD_OVF (1ull << 63)              // w0 flag: the bucket has >= 3 entries
-#define ENT_MASK ((1ull << 62) - 1)        // entry = position << 22 | fingerprint, position < 2^40
-#define W1_BASE_MASK ((1ull << 56) - 1)
-
-// 16-B bucket head:
-//   w0 = HEAD_EMPTY                                 empty bucket
-//   w0 = entry0,            w1 = HEAD_EMPTY         one entry
-//   w0 = entry0,            w1 = entry1             two entries
-//   w0 = entry0 | HEAD_OVF, w1 = base | count << 56 count = min(n, 13) >= 3: entries 1.. at ent[base + j - 1]
-// entry = position << 22 | fingerprint (62 bits), so u64 order = position order.
-__device__ __forceinline__ uint32_t head_count(const ulonglong2 hd) {
-    if (hd.x == HEAD_EMPTY) return 0u;
-    if (hd.x & HEAD_OVF) return (uint32_t)(hd.y >> 56) & 15u;
-    return hd.y == HEAD_EMPTY ? 1u : 2u;
-}
+#include "headfmt.h"
 
 // ----------------------------------------------------------------------------- index build
 

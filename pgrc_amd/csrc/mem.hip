@@ -1,0 +1,609 @@
+// mem.hip -- pseudogenome-vs-pseudogenome exact matching on gfx950.
+//
+// Reference behaviour restated (not translated):
+//   CopMEMMatcher::matchTexts -> processExactMatchQueryTight, matching/copmem/CopMEMMatcher.cpp:333-481, :604-622,
+//   driven by SimplePgMatcher::exactMatchPg, matching/SimplePgMatcher.cpp:24-55.
+//
+// The reference scans the destination text left to right in steps of k2; for every window whose bucket is not
+// empty it walks the bucket and (a) drops self matches, (b) jumps ahead when the window lies inside the previous
+// match on the same diagonal, (c) pre-filters on two 4-symbol side contexts, (d) extends and, if long enough, records
+// a match and jumps ahead.  (b) and the jumps make the scan sequential -- but only (window, entry) pairs whose K-mers
+// are EQUAL can record a match or trigger (b) (a window inside a match on its diagonal equals the source there),
+// and those pairs are rare.  So:
+//   1. k_mem_probe   : every destination window in parallel -- hash, ONE 16-byte head gather, fingerprint reject,
+//                      exact K-mer compare -- emits the equal pairs ("events") after filter (a);
+//   2. rocPRIM sort  : events by (window, bucket order) = the order the reference meets them;
+//   3. k_mem_extend  : per event the side-context test (c) and the maximal extension (d), word-parallel on 2-bit text;
+//   4. host          : one pass over the events replays (b), the jumps (which never leave a block of 256 windows in
+//                      the main loop, :365-424, but carry through in the tail loop, :428-476) and the acceptance.
+// The side-context registers l1/r1/l2/r2 are refreshed only when their 4 bytes lie inside the text (:381-382,
+// :401-402): for the handful of events at the text ends the host re-creates the stale value the reference would
+// hold by walking back through the windows actually examined (bucket lookups from the device on demand).
+//
+// All integer work, bound by the random head gathers (one per window): no MFMA.
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "ctx.h"
+#include "devutil.h"
+#include "headfmt.h"
+#include "pgrc_mem.h"
+
+struct pgrc_mem_ctx {
+    pgrc_match_ctx *base = nullptr;   // owns the packed source, its reverse complement and the seed index
+    uint32_t L = 0;
+    int K = 0, k1 = 0, k2 = 0, LK2 = 0, KLK24 = 0;
+    const char *src = nullptr;        // borrowed host text
+    uint64_t N = 0;
+    bool have_src = false;
+    DevBuf d_dest, d_nmap, d_stage, d_flag, d_cursor, d_evk[2], d_evv[2], d_tmp, d_ostart, d_olen, d_oflag;
+    pgrc_mem_counters ctr{};
+    std::string err;
+};
+
+static std::string g_mem_create_err;
+
+// ------------------------------------------------------------------------------------------------ device side
+
+// 16 ASCII symbols -> one 2-bit word + a 16-bit mask of the 'N's among them (N packs as code 0)
+__global__ void __launch_bounds__(256)
+k_mem_pack(const uint8_t *__restrict__ ascii, uint64_t count, uint32_t *__restrict__ words, uint16_t *__restrict__ nmap,
+           uint32_t *flags) {
+    const uint64_t nwords = (count + 15) / 16;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t out = 0, nb = 0, fl = 0;
+        for (uint32_t k = 0; k < 16 && w * 16 + k < count; k++) {
+            const uint32_t c = ascii[w * 16 + k];
+            uint32_t x = (c >> 1) & 3u;
+            x ^= x >> 1;                                   // A0 C1 G2 T3
+            if (c == 'N') { nb |= 1u << k; x = 0; fl |= 2u; }
+            else if (c != 'A' && c != 'C' && c != 'G' && c != 'T') fl |= 1u;
+            out |= x << (2 * k);
+        }
+        words[w] = out;
+        nmap[w] = (uint16_t)nb;
+        if (fl) atomicOr(flags, fl);
+    }
+}
+
+struct MemArgs {
+    const uint32_t *src;
+    const uint32_t *dest;
+    const uint16_t *nmap;        // nullptr: the destination holds no 'N'
+    uint64_t N, N2;
+    uint64_t dest_words_alloc;
+    const ulonglong2 *head;
+    const uint64_t *ent;
+    uint32_t mask, K, k2;
+    uint32_t LK2, KLK24;
+    uint64_t nprobes;
+    int dest_is_src, rev_compl;
+};
+
+__device__ __forceinline__ uint32_t sym16(const uint32_t *t, uint64_t pos) {   // 16 symbols from an arbitrary position
+    const uint32_t *p = t + (pos >> 4);
+    return funnel_r(p[0], p[1], ((uint32_t)pos & 15u) * 2u);
+}
+__device__ __forceinline__ uint32_t nbits16(const uint16_t *nm, uint64_t pos) { // the N flags of the same 16 symbols
+    const uint64_t w = pos >> 4;
+    const uint32_t v = (uint32_t)nm[w] | ((uint32_t)nm[w + 1] << 16);
+    return (v >> ((uint32_t)pos & 15u)) & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {                      // bit i -> bit 2i
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+// per-symbol difference mask (bits at even positions) of 16 source symbols at ps and 16 destination symbols at pd
+__device__ __forceinline__ uint32_t diff16(const MemArgs &a, uint64_t ps, uint64_t pd) {
+    const uint32_t x = sym16(a.src, ps) ^ sym16(a.dest, pd);
+    uint32_t d = (x | (x >> 1)) & 0x55555555u;
+    if (a.nmap) d |= spread16(nbits16(a.nmap, pd));
+    return d;
+}
+
+#define MEM_TPB 256
+#define MEM_TILE_WORDS 272   // 255 * k2 (k2 <= 15) + K (<= 56) symbols, + slack
+#define MEM_LCAP 2048u
+
+// 1. one thread per destination window
+__global__ void __launch_bounds__(MEM_TPB)
+k_mem_probe(const MemArgs a, unsigned long long *cursor, uint64_t *__restrict__ evk, uint64_t *__restrict__ evv, uint64_t cap) {
+    __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
+    __shared__ uint32_t tile[MEM_TILE_WORDS];
+    __shared__ uint64_t lk[MEM_LCAP], lv[MEM_LCAP];
+    __shared__ uint32_t lcount;
+    __shared__ unsigned long long gbase;
+    hash_lut_init(lut);
+    if (threadIdx.x == 0) lcount = 0;
+    const uint64_t t0 = (uint64_t)blockIdx.x * MEM_TPB;
+    const uint64_t q0 = t0 * a.k2;
+    const uint64_t w0 = q0 >> 4;
+    const uint32_t need = (uint32_t)((((q0 & 15) + (uint64_t)(MEM_TPB - 1) * a.k2 + a.K + 15) >> 4) + 5);
+    for (uint32_t w = threadIdx.x; w < need; w += MEM_TPB) tile[w] = (w0 + w < a.dest_words_alloc) ? a.dest[w0 + w] : 0u;
+    __syncthreads();
+    const uint64_t t = t0 + threadIdx.x;
+    if (t < a.nprobes) {
+        const uint64_t q = t * a.k2;
+        const uint32_t x = (uint32_t)((q >> 4) - w0);
+        const uint32_t sh = ((uint32_t)q & 15u) * 2u;
+        const uint32_t d0 = funnel_r(tile[x], tile[x + 1], sh), d1 = funnel_r(tile[x + 1], tile[x + 2], sh),
+                       d2 = funnel_r(tile[x + 2], tile[x + 3], sh), d3 = funnel_r(tile[x + 3], tile[x + 4], sh);
+        bool has_n = false;
+        if (a.nmap)
+            for (uint32_t k = 0; k < a.K; k += 16) {
+                const uint32_t nb = nbits16(a.nmap, q + k);
+                has_n |= (nb & (a.K - k >= 16 ? 0xFFFFu : ((1u << (a.K - k)) - 1u))) != 0;
+            }
+        if (!has_n) {       // a window with an 'N' equals no source K-mer: it can produce no event
+            uint32_t fp;
+            const uint32_t h = copmem_hash32_fp(d0, d1, d2, d3, a.K, lut, &fp) & a.mask;
+            const ulonglong2 hd = a.head[h];
+            const uint32_t cnt = head_count(hd);
+            const uint64_t base = hd.y & W1_BASE_MASK;
+            const uint32_t dw[4] = {d0, d1, d2, d3};
+            for (uint32_t j = 0; j < cnt; j++) {
+                const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (cnt == 2 ? hd.y : a.ent[base + j - 1]);
+                const uint64_t p = e >> PGRC_FP_BITS;
+                if (a.dest_is_src && (a.rev_compl ? a.N2 - p < q : q >= p)) continue;              // :389-392
+                if (((uint32_t)e ^ fp) & ((1u << PGRC_FP_BITS) - 1u)) continue;                     // K-mers differ
+                bool equal = true;
+                for (uint32_t k = 0; k < a.K; k += 16) {
+                    uint32_t dx = sym16(a.src, p + k) ^ dw[k >> 4];
+                    if (a.K - k < 16) dx &= (1u << (2 * (a.K - k))) - 1u;
+                    equal &= dx == 0;
+                }
+                if (!equal) continue;
+                const uint32_t li = atomicAdd(&lcount, 1u);
+                if (li < MEM_LCAP) {
+                    lk[li] = (t << 4) | j;
+                    lv[li] = p;
+                } else {                                  // buffer full (low-complexity text): straight to HBM
+                    const unsigned long long idx = atomicAdd(cursor, 1ull);
+                    if (idx < cap) { evk[idx] = (t << 4) | j; evv[idx] = p; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nl = min(lcount, MEM_LCAP);
+    if (threadIdx.x == 0 && nl) gbase = atomicAdd(cursor, (unsigned long long)nl);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nl; i += MEM_TPB)
+        if (gbase + i < cap) { evk[gbase + i] = lk[i]; evv[gbase + i] = lv[i]; }
+}
+
+// flags of an event
+#define MF_L1_OK 1u    // the source side context lies inside the source text (else the register is stale, :401-402)
+#define MF_R1_OK 2u
+#define MF_L2_OK 4u    // the same for the destination (:381-382)
+#define MF_R2_OK 8u
+#define MF_L_EQ 16u    // both left contexts fresh and equal
+#define MF_R_EQ 32u
+
+// 3. one thread per event: side-context test and maximal extension
+__global__ void __launch_bounds__(256)
+k_mem_extend(const MemArgs a, const uint64_t *__restrict__ evk, const uint64_t *__restrict__ evv, uint64_t nev,
+             uint64_t *__restrict__ ostart, uint64_t *__restrict__ olen, uint8_t *__restrict__ oflag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nev) return;
+    const uint64_t q = (evk[i] >> 4) * a.k2, p = evv[i];
+    uint32_t fl = 0;
+    if (p >= a.LK2) fl |= MF_L1_OK;
+    if (p + a.KLK24 + 4 <= a.N) fl |= MF_R1_OK;
+    if (q >= a.LK2) fl |= MF_L2_OK;
+    if (q + a.KLK24 + 4 <= a.N2) fl |= MF_R2_OK;
+    if ((fl & (MF_L1_OK | MF_L2_OK)) == (MF_L1_OK | MF_L2_OK) && (diff16(a, p - a.LK2, q - a.LK2) & 0xFFu) == 0) fl |= MF_L_EQ;
+    if ((fl & (MF_R1_OK | MF_R2_OK)) == (MF_R1_OK | MF_R2_OK) && (diff16(a, p + a.KLK24, q + a.KLK24) & 0xFFu) == 0) fl |= MF_R_EQ;
+    // right: symbols after the K-mer, up to the first difference or either text end (:405-407)
+    const uint64_t rlim = min(a.N - (p + a.K), a.N2 - (q + a.K));
+    uint64_t r = 0;
+    while (r < rlim) {
+        const uint32_t d = diff16(a, p + a.K + r, q + a.K + r);
+        if (d) { r += (uint32_t)(__ffs((int)d) - 1) >> 1; break; }
+        r += 16;
+    }
+    r = min(r, rlim);
+    // left: symbols before the K-mer (:409-411); the loop of the reference stops ON symbol 0 without consuming it
+    const uint64_t llim = min(p, q);
+    uint64_t s = 0;
+    bool mism = false;
+    while (llim - s >= 16) {
+        const uint32_t d = diff16(a, p - s - 16, q - s - 16);
+        if (d) { s += (uint32_t)__clz((int)d) >> 1; mism = true; break; }
+        s += 16;
+    }
+    while (!mism && s < llim) {
+        if (diff16(a, p - s - 1, q - s - 1) & 1u) mism = true;
+        else s++;
+    }
+    const uint64_t start = mism ? p - s : p - s + 1;      // first source symbol of the match as the reference reports it
+    ostart[i] = start;
+    olen[i] = p + a.K + r - start;
+    oflag[i] = (uint8_t)fl;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+
+// maRushPrime1HashSparsified<K> over ASCII (matching/copmem/Hashes.h:54-76), for the few windows the host
+// re-examines; the low 32 bits of the u64 fold are closed under xor / multiply
+static uint32_t host_hash(int K, const char *s) {
+    uint32_t h = (uint32_t)K;
+    for (int j = 0; j < K / 4; j++) {
+        uint32_t w;
+        memcpy(&w, s + 4 * j, 4);
+        w &= (j < 3) ? 0x00FFFFFFu : 0x0000FFFFu;
+        h = (h ^ (w + (uint32_t)j)) * 171717u;
+    }
+    return h;
+}
+static uint32_t le32(const char *p) {
+    uint32_t v;
+    memcpy(&v, p, 4);
+    return v;
+}
+
+struct Replay {
+    pgrc_mem_ctx *m;
+    const char *dest;
+    uint64_t N2;
+    bool dest_is_src, rev_compl;
+    uint64_t skip, nmain;                        // probes jumped over after a hit; probes of the main loop (whole blocks of 256)
+    // history of the probes that ended with a jump: (probe, order of the entry that caused it, 1 = recorded a match)
+    struct Jump { uint64_t t; uint32_t order; uint32_t accepted; };
+    std::vector<Jump> jumps;
+    int lookup_err = 0;
+
+    uint64_t block_of(uint64_t t) const { return t < nmain ? t / 256 : nmain / 256 + 1; }   // the tail loop is one block
+    // was probe t visited, given the jumps recorded so far (all of them at probes < t)?
+    bool examined(uint64_t t) const {
+        // only the latest jump before t can still cover it (jumps are skip probes long, and recorded in order)
+        auto it = std::lower_bound(jumps.begin(), jumps.end(), t, [](const Jump &j, uint64_t v) { return j.t < v; });
+        if (it == jumps.begin()) return true;
+        --it;
+        return !(block_of(it->t) == block_of(t) && t <= it->t + skip);
+    }
+    const Jump *jump_at(uint64_t t) const {
+        auto it = std::lower_bound(jumps.begin(), jumps.end(), t, [](const Jump &j, uint64_t v) { return j.t < v; });
+        return (it != jumps.end() && it->t == t) ? &*it : nullptr;
+    }
+    // the bucket of a destination window, from the device (rare path)
+    int bucket(uint64_t q, uint64_t *pos) {
+        pgrc_match_ctx *c = m->base;
+        const uint32_t h = host_hash(m->K, dest + q) & (uint32_t)(c->cp.hash_size - 1);
+        unsigned long long hd[2];
+        if (hipMemcpy(hd, (const char *)c->d_head.p + (size_t)h * 16, 16, hipMemcpyDeviceToHost) != hipSuccess) { lookup_err = 1; return 0; }
+        if (hd[0] == HEAD_EMPTY) return 0;
+        pos[0] = (hd[0] & ENT_MASK) >> PGRC_FP_BITS;
+        if (!(hd[0] & HEAD_OVF)) {
+            if (hd[1] == HEAD_EMPTY) return 1;
+            pos[1] = hd[1] >> PGRC_FP_BITS;
+            return 2;
+        }
+        const int cnt = (int)((hd[1] >> 56) & 15u);
+        unsigned long long e[PGRC_BUCKET_CAP];
+        if (hipMemcpy(e, c->ent_ptr + (hd[1] & W1_BASE_MASK), (size_t)(cnt - 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) { lookup_err = 1; return 0; }
+        for (int j = 1; j < cnt; j++) pos[j] = e[j - 1] >> PGRC_FP_BITS;
+        return cnt;
+    }
+    bool self_filtered(uint64_t q, uint64_t p) const { return dest_is_src && (rev_compl ? N2 - p < q : q >= p); }
+
+    // Value of register l1 (left = true) or r1 when the entry at bucket order `order` of probe t is about to be
+    // tested and its own context lies outside the source: what the last entry examined before it left there.
+    uint32_t stale_src_reg(bool left, uint64_t t, uint32_t order) {
+        uint64_t pos[PGRC_BUCKET_CAP];
+        uint64_t tt = t;
+        uint32_t upto = order;                       // entries [0, upto) of probe tt were examined before
+        for (;;) {
+            const uint64_t q = tt * (uint64_t)m->k2;
+            const int cnt = bucket(q, pos);
+            for (int j = std::min<int>(cnt, (int)upto) - 1; j >= 0; j--) {
+                const uint64_t p = pos[j];
+                if (self_filtered(q, p)) continue;   // (a): never reached the register update
+                if (left ? p >= (uint64_t)m->LK2 : p + (uint64_t)m->KLK24 + 4 <= m->N)
+                    return le32(left ? m->src + p - m->LK2 : m->src + p + m->KLK24);
+            }
+            // previous examined probe
+            for (;;) {
+                if (tt == 0) return 0u;              // nothing before: the register still holds its initial 0
+                tt--;
+                if (examined(tt)) break;
+            }
+            const Jump *jp = jump_at(tt);
+            // a probe that jumped: the entry that recorded a match had updated its registers first (:401-413), an
+            // entry that triggered rule (b) had not (:393-399)
+            upto = jp ? (jp->accepted ? jp->order + 1 : jp->order) : PGRC_BUCKET_CAP;
+        }
+    }
+    // register r2 at probe t when t's own right context lies outside the destination (l2: always 0 there, the
+    // windows before LK2 come first)
+    uint32_t stale_r2(uint64_t t) {
+        uint64_t pos[PGRC_BUCKET_CAP];
+        uint64_t tt = t;
+        while (tt > 0) {
+            tt--;
+            if (!examined(tt)) continue;
+            const uint64_t q = tt * (uint64_t)m->k2;
+            if (q + (uint64_t)m->KLK24 + 4 > N2) continue;
+            if (bucket(q, pos) == 0) continue;       // empty bucket: the registers are not touched (:376-379)
+            return le32(dest + q + m->KLK24);
+        }
+        return 0u;
+    }
+};
+
+extern "C" {
+
+const char *pgrc_mem_last_error(const pgrc_mem_ctx *m) { return m ? m->err.c_str() : g_mem_create_err.c_str(); }
+
+int pgrc_mem_create(uint32_t target_len, uint32_t ctor_min_len, int32_t device, pgrc_mem_ctx **out) {
+    if (!out) return PGRC_E_PARAM;
+    *out = nullptr;
+    if (target_len > 255) { g_mem_create_err = "target match length above 255 is not supported"; return PGRC_E_PARAM; }
+    if (target_len < 24) { g_mem_create_err = "Minimal matching length too short"; return PGRC_E_SEED_SHORT; }   // CopMEMMatcher.cpp:77-80
+    if (ctor_min_len < target_len) { g_mem_create_err = "a constructor minMatchLength below the target length is not supported"; return PGRC_E_PARAM; }
+    pgrc_match_params prm;
+    memset(&prm, 0, sizeof prm);
+    prm.read_len = target_len;
+    prm.seed_len = target_len;
+    prm.mode = 'c';
+    prm.device = device;
+    pgrc_match_ctx *base = nullptr;
+    int e = pgrc_match_create(&prm, &base);
+    if (e) { g_mem_create_err = pgrc_match_last_error(nullptr); return e; }
+    pgrc_mem_ctx *m = new pgrc_mem_ctx();
+    m->base = base;
+    m->L = target_len;
+    *out = m;
+    return PGRC_OK;
+}
+
+void pgrc_mem_destroy(pgrc_mem_ctx *m) {
+    if (!m) return;
+    DevBuf *bufs[] = {&m->d_dest, &m->d_nmap, &m->d_stage, &m->d_flag, &m->d_cursor, &m->d_evk[0], &m->d_evk[1], &m->d_evv[0],
+                      &m->d_evv[1], &m->d_tmp, &m->d_ostart, &m->d_olen, &m->d_oflag};
+    for (DevBuf *b : bufs) pgrc_buf_free(*b);
+    pgrc_match_destroy(m->base);
+    delete m;
+}
+
+int pgrc_mem_get_counters(pgrc_mem_ctx *m, pgrc_mem_counters *out) {
+    if (!m || !out) return PGRC_E_PARAM;
+    *out = m->ctr;
+    return PGRC_OK;
+}
+
+int pgrc_mem_set_src_ascii(pgrc_mem_ctx *m, const char *src, uint64_t n) {
+    if (!m || !src) return PGRC_E_PARAM;
+    pgrc_match_ctx *c = m->base;
+    m->have_src = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    int e = pgrc_match_set_pg_ascii(c, src, n);
+    if (!e) e = pgrc_copmem_build_index(c, 0);
+    if (!e && hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "index build failed"; e = PGRC_E_NO_DEVICE; }
+    if (e) { m->err = c->err; return e; }
+    m->ctr.ms_index = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    m->K = c->cp.K; m->k1 = c->cp.k1; m->k2 = c->cp.k2;
+    m->LK2 = ((int)m->L - m->K) / 2;                       // CopMEMMatcher.cpp:87-89
+    m->KLK24 = m->K + m->LK2 - 4;
+    m->src = src;
+    m->N = n;
+    m->have_src = true;
+    return PGRC_OK;
+}
+
+void pgrc_mem_free_matches(pgrc_text_match *p) { free(p); }
+
+int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int dest_is_src, int rev_compl, uint32_t min_len,
+                         pgrc_text_match **matches, uint64_t *count) {
+    if (!m || !dest || !matches || !count) return PGRC_E_PARAM;
+    *matches = nullptr;
+    *count = 0;
+    if (!m->have_src) { m->err = "match_texts: set the source text first"; return PGRC_E_STATE; }
+    pgrc_match_ctx *c = m->base;
+    if ((int)min_len < m->K) { m->err = "Minimal matching length cannot be smaller than K"; return PGRC_E_PARAM; }   // :606-609
+    if (dest_is_src && N2 != m->N) { m->err = "match_texts: dest_is_src with a text of another length"; return PGRC_E_PARAM; }
+    if (N2 / (uint64_t)m->k2 + 1 >= (1ull << 40)) { m->err = "destination text too long"; return PGRC_E_PARAM; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    m->ctr.probes = m->ctr.events = m->ctr.stale_lookups = 0;
+    const uint64_t K = (uint64_t)m->K, k2 = (uint64_t)m->k2;
+    const uint64_t nprobes = N2 >= K ? (N2 - K) / k2 + 1 : 0;          // windows q = t * k2 with q + K <= N2
+    m->ctr.probes = nprobes;
+    if (nprobes == 0) return PGRC_OK;
+    int e;
+    hipEvent_t ev[4];
+    for (auto &x : ev) HIP_TRY(c, hipEventCreate(&x));
+    auto drop_events = [&]() { for (auto &x : ev) (void)hipEventDestroy(x); };
+
+    // ---- the destination in HBM
+    MemArgs a;
+    memset(&a, 0, sizeof a);
+    const uint64_t dwords = (N2 + 15) / 16;
+    if (dest_is_src) {
+        if (rev_compl) {
+            if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) { drop_events(); m->err = c->err; return e; }
+            c->have_rc = true;
+        }
+        a.dest = (const uint32_t *)c->pg2[rev_compl ? 1 : 0].p;
+        a.nmap = nullptr;
+        a.dest_words_alloc = c->pg_words + PGRC_PG_PAD_WORDS;
+    } else {
+        const uint64_t CH = 64ull << 20;
+        if ((e = pgrc_buf_ensure(c, m->d_dest, (dwords + PGRC_PG_PAD_WORDS) * 4)) || (e = pgrc_buf_ensure(c, m->d_nmap, (dwords + PGRC_PG_PAD_WORDS) * 2)) ||
+            (e = pgrc_buf_ensure(c, m->d_stage, (size_t)std::min(CH, N2))) || (e = pgrc_buf_ensure(c, m->d_flag, 4))) { drop_events(); m->err = c->err; return e; }
+        (void)hipMemsetAsync(m->d_dest.p, 0, (dwords + PGRC_PG_PAD_WORDS) * 4, c->stream);
+        (void)hipMemsetAsync(m->d_nmap.p, 0, (dwords + PGRC_PG_PAD_WORDS) * 2, c->stream);
+        (void)hipMemsetAsync(m->d_flag.p, 0, 4, c->stream);
+        for (uint64_t off = 0; off < N2; off += CH) {
+            const uint64_t len = std::min(CH, N2 - off);
+            hipError_t he = hipMemcpyAsync(m->d_stage.p, dest + off, len, hipMemcpyHostToDevice, c->stream);
+            if (he == hipSuccess) {
+                const uint64_t nw = (len + 15) / 16;
+                hipLaunchKernelGGL(k_mem_pack, dim3((uint32_t)std::min<uint64_t>((nw + 255) / 256, 65536)), dim3(256), 0, c->stream,
+                                   (const uint8_t *)m->d_stage.p, len, (uint32_t *)m->d_dest.p + off / 16, (uint16_t *)m->d_nmap.p + off / 16,
+                                   (uint32_t *)m->d_flag.p);
+                he = hipStreamSynchronize(c->stream);
+            }
+            if (he != hipSuccess) { drop_events(); m->err = std::string("destination upload: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
+        }
+        uint32_t fl = 0;
+        HIP_TRY(c, hipMemcpy(&fl, m->d_flag.p, 4, hipMemcpyDeviceToHost));
+        if (fl & 1u) { drop_events(); m->err = "destination text contains a symbol outside ACGNT"; return PGRC_E_SYMBOL; }
+        a.dest = (const uint32_t *)m->d_dest.p;
+        a.nmap = (fl & 2u) ? (const uint16_t *)m->d_nmap.p : nullptr;
+        a.dest_words_alloc = dwords + PGRC_PG_PAD_WORDS;
+    }
+    a.src = (const uint32_t *)c->pg2[0].p;
+    a.N = m->N;
+    a.N2 = N2;
+    a.head = (const ulonglong2 *)c->d_head.p;
+    a.ent = c->ent_ptr;
+    a.mask = (uint32_t)(c->cp.hash_size - 1);
+    a.K = (uint32_t)m->K;
+    a.k2 = (uint32_t)m->k2;
+    a.LK2 = (uint32_t)m->LK2;
+    a.KLK24 = (uint32_t)m->KLK24;
+    a.nprobes = nprobes;
+    a.dest_is_src = dest_is_src ? 1 : 0;
+    a.rev_compl = rev_compl ? 1 : 0;
+    if (c->index_strand != 0) {          // (only if somebody rebuilt the base index in between)
+        if ((e = pgrc_copmem_build_index(c, 0))) { drop_events(); m->err = c->err; return e; }
+        a.head = (const ulonglong2 *)c->d_head.p;
+        a.ent = c->ent_ptr;
+    }
+
+    // ---- 1. events
+    if ((e = pgrc_buf_ensure(c, m->d_cursor, 8))) { drop_events(); m->err = c->err; return e; }
+    uint64_t cap = std::max<uint64_t>(nprobes / 64 + 65536, m->d_evk[0].bytes / 8);
+    unsigned long long nev = 0;
+    (void)hipEventRecord(ev[0], c->stream);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        for (int k = 0; k < 2; k++)
+            if ((e = pgrc_buf_ensure(c, m->d_evk[k], cap * 8)) || (e = pgrc_buf_ensure(c, m->d_evv[k], cap * 8))) { drop_events(); m->err = c->err; return e; }
+        (void)hipMemsetAsync(m->d_cursor.p, 0, 8, c->stream);
+        hipLaunchKernelGGL(k_mem_probe, dim3((uint32_t)((nprobes + MEM_TPB - 1) / MEM_TPB)), dim3(MEM_TPB), 0, c->stream, a,
+                           (unsigned long long *)m->d_cursor.p, (uint64_t *)m->d_evk[0].p, (uint64_t *)m->d_evv[0].p, cap);
+        hipError_t he = hipGetLastError();
+        if (he == hipSuccess) he = hipMemcpyAsync(&nev, m->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) { drop_events(); m->err = std::string("probe kernel: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
+        if (nev <= cap) break;
+        cap = nev;                                          // the guess was too small: once more with the exact size
+    }
+    (void)hipEventRecord(ev[1], c->stream);
+    m->ctr.events = nev;
+    std::vector<uint64_t> hk(nev), hp(nev), hs(nev), hl(nev);
+    std::vector<uint8_t> hf(nev);
+    if (nev) {
+        // ---- 2. the order in which the reference meets them: by window, then by bucket order
+        int tb = 1;
+        while ((1ull << tb) < nprobes) tb++;
+        rocprim::double_buffer<uint64_t> keys((uint64_t *)m->d_evk[0].p, (uint64_t *)m->d_evk[1].p);
+        rocprim::double_buffer<uint64_t> vals((uint64_t *)m->d_evv[0].p, (uint64_t *)m->d_evv[1].p);
+        size_t tbytes = 0;
+        hipError_t he = rocprim::radix_sort_pairs(nullptr, tbytes, keys, vals, (size_t)nev, 0, 4 + tb, c->stream);
+        if (he == hipSuccess && (e = pgrc_buf_ensure(c, m->d_tmp, tbytes + 16))) { drop_events(); m->err = c->err; return e; }
+        if (he == hipSuccess) he = rocprim::radix_sort_pairs(m->d_tmp.p, tbytes, keys, vals, (size_t)nev, 0, 4 + tb, c->stream);
+        (void)hipEventRecord(ev[2], c->stream);
+        // ---- 3. side contexts and extensions
+        if (he == hipSuccess && ((e = pgrc_buf_ensure(c, m->d_ostart, nev * 8)) || (e = pgrc_buf_ensure(c, m->d_olen, nev * 8)) ||
+                                 (e = pgrc_buf_ensure(c, m->d_oflag, nev)))) { drop_events(); m->err = c->err; return e; }
+        if (he == hipSuccess) {
+            hipLaunchKernelGGL(k_mem_extend, dim3((uint32_t)((nev + 255) / 256)), dim3(256), 0, c->stream, a, (const uint64_t *)keys.current(),
+                               (const uint64_t *)vals.current(), (uint64_t)nev, (uint64_t *)m->d_ostart.p, (uint64_t *)m->d_olen.p, (uint8_t *)m->d_oflag.p);
+            he = hipGetLastError();
+        }
+        (void)hipEventRecord(ev[3], c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(hk.data(), keys.current(), nev * 8, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(hp.data(), vals.current(), nev * 8, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(hs.data(), m->d_ostart.p, nev * 8, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(hl.data(), m->d_olen.p, nev * 8, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(hf.data(), m->d_oflag.p, nev, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) { drop_events(); m->err = std::string("event passes: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
+        (void)hipEventElapsedTime(&m->ctr.ms_sort, ev[1], ev[2]);
+        (void)hipEventElapsedTime(&m->ctr.ms_extend, ev[2], ev[3]);
+    } else {
+        (void)hipEventSynchronize(ev[1]);
+    }
+    (void)hipEventElapsedTime(&m->ctr.ms_probe, ev[0], ev[1]);
+    drop_events();
+
+    // ---- 4. the sequential rules, over the events only
+    const auto th0 = std::chrono::steady_clock::now();
+    Replay rp;
+    rp.m = m; rp.dest = dest; rp.N2 = N2; rp.dest_is_src = dest_is_src != 0; rp.rev_compl = rev_compl != 0;
+    rp.skip = (uint64_t)(m->K / m->k1 - 1);                                        // :352
+    {   // main loop: blocks of 256 windows while i1 + K + 256 * k2 < N2 + 1 (:365)
+        const uint64_t block = 256 * k2;
+        const uint64_t lim = N2 + 1;                                               // i1 + K + block < lim
+        uint64_t nb = 0;
+        if (lim > K + block) nb = (lim - K - block + block - 1) / block;
+        rp.nmain = nb * 256;
+    }
+    std::vector<pgrc_text_match> res;
+    bool have_last = false;
+    pgrc_text_match last{0, 0, 0};
+    uint64_t i = 0;
+    while (i < nev) {
+        const uint64_t t = hk[i] >> 4;
+        uint64_t jend = i;
+        while (jend < nev && (hk[jend] >> 4) == t) jend++;
+        if (rp.examined(t)) {
+            const uint64_t q = t * k2;
+            for (uint64_t x = i; x < jend; x++) {
+                const uint64_t p = hp[x];
+                const uint32_t order = (uint32_t)(hk[x] & 15u);
+                // (b) the window lies inside the previous match, on its diagonal (:393-399)
+                if (have_last && q - p == last.pos_dest - last.pos_src && q + K < last.pos_dest + last.length) {
+                    rp.jumps.push_back({t, order, 0u});
+                    break;
+                }
+                // (c) side contexts (:401-404); registers whose 4 bytes lie outside a text keep their previous value
+                const uint32_t fl = hf[x];
+                bool pass;
+                if ((fl & 15u) == 15u) {
+                    pass = (fl & (MF_L_EQ | MF_R_EQ)) != 0;
+                } else {
+                    m->ctr.stale_lookups++;
+                    const uint32_t l1 = (fl & MF_L1_OK) ? le32(m->src + p - m->LK2) : rp.stale_src_reg(true, t, order);
+                    const uint32_t r1 = (fl & MF_R1_OK) ? le32(m->src + p + m->KLK24) : rp.stale_src_reg(false, t, order);
+                    const uint32_t l2 = (fl & MF_L2_OK) ? le32(dest + q - m->LK2) : 0u;   // windows below LK2 come first: still the initial 0
+                    const uint32_t r2 = (fl & MF_R2_OK) ? le32(dest + q + m->KLK24) : rp.stale_r2(t);
+                    pass = r1 == r2 || l1 == l2;
+                    if (rp.lookup_err) { m->err = "bucket lookup failed"; return PGRC_E_NO_DEVICE; }
+                }
+                if (!pass) continue;
+                // (d) long enough?  right - p1 > minMatchLength with right - p1 = length + 1 (:413)
+                if (hl[x] + 1 > (uint64_t)min_len) {
+                    last.pos_src = hs[x];
+                    last.length = hl[x];
+                    last.pos_dest = q - (p - hs[x]);
+                    have_last = true;
+                    res.push_back(last);
+                    rp.jumps.push_back({t, order, 1u});
+                    break;
+                }
+            }
+        }
+        i = jend;
+    }
+    m->ctr.ms_host = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - th0).count();
+    if (!res.empty()) {
+        pgrc_text_match *outp = (pgrc_text_match *)malloc(res.size() * sizeof(pgrc_text_match));
+        if (!outp) { m->err = "out of host memory"; return PGRC_E_ALLOC; }
+        memcpy(outp, res.data(), res.size() * sizeof(pgrc_text_match));
+        *matches = outp;
+    }
+    *count = res.size();
+    return PGRC_OK;
+}
+
+} // extern "C"

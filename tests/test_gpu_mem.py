@@ -1,0 +1,92 @@
+"""Pg-vs-Pg exact matching (row f2) on the GPU through the C ABI of include/pgrc_mem.h, against the oracle and the
+compiled reference: the same matches in the same discovery order."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from mem_util import COMBOS, make_pair, make_pg
+
+pytestmark = pytest.mark.gpu
+
+HAVE_REF = orc.have_ref() and hasattr(orc.ref(), "pgrc_ref_mem_match")
+
+
+def check(src, other, combos=COMBOS, target_len=45, min_len=None, what=""):
+    from pgrc_amd import CopMEMMatcher
+    m = CopMEMMatcher(src, target_len)
+    total = 0
+    for dest_is_src, rev_compl in combos:
+        d = orc.mem_dest(src, other, dest_is_src, rev_compl)
+        g = m.matchTexts(d, dest_is_src, rev_compl, min_len)
+        o = orc.oracle_mem_match(src, d, dest_is_src, rev_compl, target_len, min_len)
+        assert np.array_equal(g, o), f"{what} vs oracle: destIsSrc={dest_is_src} rc={rev_compl}: {len(g)} / {len(o)} matches"
+        if HAVE_REF:
+            r = orc.ref_mem_match(src, d, dest_is_src, rev_compl, target_len, min_len)
+            assert np.array_equal(g, r), f"{what} vs reference: destIsSrc={dest_is_src} rc={rev_compl}"
+        total += len(g)
+    m.close()
+    return total
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+@pytest.mark.parametrize("with_n,low_complexity", [(False, False), (True, False), (False, True), (True, True)])
+def test_mem_parity(seed, with_n, low_complexity):
+    src, other = make_pair(seed, with_n=with_n, low_complexity=low_complexity)
+    assert check(src, other, what=f"seed {seed}") > 100
+
+
+@pytest.mark.parametrize("target_len,min_len", [(45, 45), (45, 60), (50, 50), (36, 36), (64, 64), (120, 120), (24, 24), (255, 255)])
+def test_mem_other_lengths(target_len, min_len):
+    src, other = make_pair(7, G=150000, G2=50000)
+    check(src, other, COMBOS[:2], target_len, min_len, what=f"L={target_len}")
+
+
+def test_mem_short_and_ragged_texts():
+    src, other = make_pair(3, G=30000, G2=2000)
+    from pgrc_amd import CopMEMMatcher
+    m = CopMEMMatcher(src, 45)
+    for n2 in (1, 31, 32, 33, 45, 100, 400, 767, 768, 769, 770, 800, 1535, 1536, 1537, 2000):
+        d = orc.mem_dest(src, other[:n2], 0, 1)
+        g = m.matchTexts(d, False, True)
+        assert np.array_equal(g, orc.oracle_mem_match(src, d, 0, 1)), n2
+
+
+def test_mem_matches_touching_the_text_ends_and_stale_registers():
+    """Source K-mers at the very start / end of the source (their side contexts lie outside the text, so the
+    reference tests them against whatever an earlier entry left in its registers) copied all over the destination."""
+    rng = np.random.default_rng(5)
+    src = make_pg(120000, 55, nrep=50)
+    other = make_pg(40000, 56, nrep=5)
+    head, tail = src[:70].copy(), src[-70:].copy()
+    for k in range(40):
+        seg = (head, tail)[k % 2][: int(rng.integers(46, 70))] if k % 4 < 2 else (head, tail)[k % 2][-int(rng.integers(46, 70)):]
+        d = int(rng.integers(100, other.size - 100))
+        other[d:d + seg.size] = orc.revcomp_ascii(seg) if k % 3 else seg
+    other[:60] = orc.revcomp_ascii(src[-60:])
+    other[-60:] = orc.revcomp_ascii(src[:60])
+    from pgrc_amd import CopMEMMatcher
+    m = CopMEMMatcher(src, 45)
+    stale = 0
+    for dest_is_src, rev_compl in COMBOS:
+        d = orc.mem_dest(src, other, dest_is_src, rev_compl)
+        g = m.matchTexts(d, dest_is_src, rev_compl)
+        stale += m.counters()["stale_lookups"]
+        assert np.array_equal(g, orc.oracle_mem_match(src, d, dest_is_src, rev_compl)), (dest_is_src, rev_compl)
+        if HAVE_REF:
+            assert np.array_equal(g, orc.ref_mem_match(src, d, dest_is_src, rev_compl)), (dest_is_src, rev_compl)
+    assert stale > 0        # the host-side register emulation was exercised
+
+
+def test_mem_errors():
+    from pgrc_amd import CopMEMMatcher, PgrcMatchError
+    src, other = make_pair(1, G=20000, G2=3000)
+    with pytest.raises(PgrcMatchError):
+        CopMEMMatcher(src, 20)                       # "Minimal matching length too short" (CopMEMMatcher.cpp:77-80)
+    m = CopMEMMatcher(src, 45)
+    with pytest.raises(PgrcMatchError):
+        m.matchTexts(other, False, False, 20)        # minMatchLength < K (:606-609)
+    bad = other.copy()
+    bad[100] = ord("%")
+    with pytest.raises(PgrcMatchError) as e:
+        m.matchTexts(bad, False, False)
+    assert e.value.code == 5
