@@ -21,6 +21,8 @@
 #include "utils/helper.h"
 #ifdef PGRC_WITH_HIP_ADAPTER
 #include "HipReadsMatcher.h"
+#include "HipTextMatcher.h"
+#include "matching/SimplePgMatcher.h"
 #include "pgrc/pgrc-decoder.h"
 #include "pgrc/pgrc-encoder.h"
 #endif
@@ -271,6 +273,22 @@ namespace PgTools {
     }
 }
 
+// SimplePgMatcher's constructor (matching/SimplePgMatcher.cpp:12-19) with the matcher choice a maintainer would add
+// (INTEGRATION.md section 5); the reference's own definition is linked weak (oracle/Makefile).
+static bool g_gpu_text_matching = false;
+namespace PgTools {
+    SimplePgMatcher::SimplePgMatcher(const string &srcPg, uint32_t targetMatchLength, uint32_t minMatchLength)
+            : targetMatchLength(targetMatchLength), srcPg(srcPg) {
+        cout << "Source pseudogenome length: " << srcPg.length() << endl;
+        if (srcPg.size() >= targetMatchLength) {
+            if (g_gpu_text_matching)
+                matcher = new HipTextMatcher(srcPg.data(), srcPg.length(), targetMatchLength, minMatchLength);
+            else
+                matcher = new CopMEMMatcher(srcPg.data(), srcPg.length(), targetMatchLength, minMatchLength);
+        }
+    }
+}
+
 // Runs the reference's whole encoder (PgRC.cpp:244-262) on a FASTQ file with the CPU or the GPU matcher.
 // Returns the number of times the GPU mapReadsIntoPg ran (>= 0), or a negative error.
 extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const char *archive, int threads, int use_gpu,
@@ -279,7 +297,8 @@ extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const 
     Silence quiet;
     PgHelpers::numberOfThreads = threads;
     omp_set_num_threads(threads);
-    g_gpu_matching = use_gpu != 0;
+    g_gpu_matching = (use_gpu & 1) != 0;          // bit 0: reads -> Pg matching (stage 4) on the GPU
+    g_gpu_text_matching = (use_gpu & 2) != 0;     // bit 1: Pg -> Pg matching (stage 7) on the GPU
     g_gpu_calls = 0;
     PgRCParams *params = new PgRCParams();
     params->setSrcFastqFile(fastq);
@@ -297,10 +316,31 @@ extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const 
     }
     delete params;
     g_gpu_matching = false;
+    g_gpu_text_matching = false;
     return g_gpu_calls;
 }
 
 extern "C" uint64_t pgrc_ref_bulk_updates() { return HipReadsMatcher::bulkUpdatesServed; }
+extern "C" uint64_t pgrc_ref_text_match_calls() { return HipTextMatcher::callsServed; }
+
+// CopMEMMatcher::matchTexts through the adapter class (what SimplePgMatcher would call)
+extern "C" int pgrc_ref_mem_match_via_adapter(const char *src, uint64_t N, const char *dest, uint64_t N2, int dest_is_src,
+                                              int rev_compl, uint32_t target_len, uint32_t min_match_len, uint64_t **out,
+                                              uint64_t *count) {
+    Silence quiet;
+    HipTextMatcher matcher(src, (size_t) N, target_len);
+    std::vector<TextMatch> res;
+    const std::string d(dest, (size_t) N2);
+    static_cast<TextMatcher &>(matcher).matchTexts(res, d, dest_is_src != 0, rev_compl != 0, min_match_len);
+    *count = res.size();
+    *out = (uint64_t *) malloc((res.size() * 3 + 1) * sizeof(uint64_t));
+    for (size_t i = 0; i < res.size(); i++) {
+        (*out)[3 * i] = res[i].posSrcText;
+        (*out)[3 * i + 1] = res[i].length;
+        (*out)[3 * i + 2] = res[i].posDestText;
+    }
+    return 0;
+}
 
 extern "C" int pgrc_ref_decode(const char *archive, int threads) {
     Silence quiet;

@@ -2,9 +2,10 @@
 errors, so it must not run inside pytest).
 
 Drives the reference's WHOLE encoder (PgRCEncoder::executePgRCChain, pgrc/pgrc-encoder.cpp) compiled into
-oracle/_ref/libpgrc_ref.so twice on the same synthetic FASTQ: once untouched at -t 1, once with
+oracle/_ref/libpgrc_ref.so twice on the same synthetic FASTQ: once on the CPU at -t 1, once with
 PgTools::mapReadsIntoPg (matching/ReadsMatchers.cpp:693-796) replaced by the patched version of INTEGRATION.md
-section 1, i.e. with integration/HipReadsMatcher -> libpgrc_match.so in the matcher seam.  Then decodes the second
+section 1, i.e. with integration/HipReadsMatcher -> libpgrc_match.so in the matcher seam (stage 4), and with
+SimplePgMatcher holding integration/HipTextMatcher instead of its CopMEMMatcher (stage 7, Pg-vs-Pg matching).  Then decodes the second
 archive with the reference's decoder.  Prints one JSON line: archive sizes/digests, whether they are byte-identical,
 how often the GPU path ran, and whether the decoded reads equal the input.
 
@@ -83,6 +84,7 @@ def main():
     lib.pgrc_ref_encode.argtypes = [C.c_char_p] * 3 + [C.c_int] * 3 + [C.c_char, C.c_int, C.c_int, C.c_char, C.c_int]
     lib.pgrc_ref_decode.argtypes = [C.c_char_p, C.c_int]
     lib.pgrc_ref_bulk_updates.restype = C.c_uint64
+    lib.pgrc_ref_text_match_calls.restype = C.c_uint64
 
     G, L, n = 300000, 100, 60000
     reads = make_reads(11, G, L, n, paired)
@@ -91,7 +93,8 @@ def main():
     digests = {}
     # PGRC_E2E_CPU_ONLY=1: both legs on the CPU (no GPU needed) -- checks the harness itself: the reference encoder is
     # deterministic at -t 1 and its archive decodes to the input
-    gpu_leg = 0 if os.environ.get("PGRC_E2E_CPU_ONLY") == "1" else 1
+    # GPU leg: bit 0 = stage 4 (reads -> Pg, HipReadsMatcher), bit 1 = stage 7 (Pg -> Pg, HipTextMatcher)
+    gpu_leg = 0 if os.environ.get("PGRC_E2E_CPU_ONLY") == "1" else int(os.environ.get("PGRC_E2E_GPU_STAGES", "3"))
     for leg, use_gpu in (("cpu", 0), ("gpu", gpu_leg)):
         d = os.path.join(work, case, leg)
         os.makedirs(d, exist_ok=True)
@@ -110,6 +113,7 @@ def main():
         out[leg + "_bytes"] = len(blob)
         out[leg + "_gpu_calls"] = calls
         out[leg + "_bulk_updates"] = int(lib.pgrc_ref_bulk_updates())   # entries served by the device extraction
+        out[leg + "_text_match_calls"] = int(lib.pgrc_ref_text_match_calls())   # matchTexts calls served by HipTextMatcher
     out["identical"] = digests["cpu"] == digests["gpu"]
     out["sha256"] = digests
 

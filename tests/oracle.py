@@ -277,6 +277,24 @@ def oracle_mem_match(src, dest_text, dest_is_src, rev_compl, target_len=45, min_
     return res
 
 
+def ref_mem_match_via_adapter(src, dest_text, dest_is_src, rev_compl, target_len=45, min_len=None):
+    """CopMEMMatcher::matchTexts through integration/HipTextMatcher compiled against the reference (needs a GPU)."""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    d = np.ascontiguousarray(dest_text, dtype=np.uint8)
+    f = ref().pgrc_ref_mem_match_via_adapter
+    f.argtypes = [_P, C.c_uint64, _P, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                  C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
+    out = C.POINTER(C.c_uint64)()
+    cnt = C.c_uint64(0)
+    e = f(_ptr(src), src.size, _ptr(d), d.size, int(dest_is_src), int(rev_compl), target_len,
+          target_len if min_len is None else min_len, C.byref(out), C.byref(cnt))
+    if e:
+        raise RuntimeError(f"adapter mem_match returned {e}")
+    res = np.ctypeslib.as_array(out, shape=(cnt.value * 3,)).reshape(-1, 3).copy() if cnt.value else np.zeros((0, 3), np.uint64)
+    ref().pgrc_ref_free(C.cast(out, _P))
+    return res
+
+
 def ref_mem_match(src, dest_text, dest_is_src, rev_compl, target_len=45, min_len=None, threads=1):
     src = np.ascontiguousarray(src, dtype=np.uint8)
     d = np.ascontiguousarray(dest_text, dtype=np.uint8)

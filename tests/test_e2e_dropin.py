@@ -45,6 +45,7 @@ def test_archive_identical_with_gpu_matcher(tmp_path, case):
         pytest.skip("oracle/_ref was built without the encoder harness")
     r = _run(tmp_path, case, cpu_only=False)
     assert r["cpu_gpu_calls"] == 0 and r["gpu_gpu_calls"] >= 1, r     # the GPU leg really went through HipReadsMatcher
+    assert r["cpu_text_match_calls"] == 0 and r["gpu_text_match_calls"] >= 3, r   # ... and HipTextMatcher (lq, n, hq Pg)
     assert r["identical"], r
     assert r["roundtrip"], r
     if case not in ("se_modeD", "se_modeI"):     # (those match nothing: the sum-set quirk)

@@ -77,6 +77,19 @@ def test_mem_matches_touching_the_text_ends_and_stale_registers():
     assert stale > 0        # the host-side register emulation was exercised
 
 
+@pytest.mark.skipif(not HAVE_REF, reason="needs oracle/_ref")
+def test_mem_reference_adapter_drop_in():
+    """integration/HipTextMatcher inside the reference's TextMatcher hierarchy against the reference's CopMEMMatcher."""
+    if not hasattr(orc.ref(), "pgrc_ref_mem_match_via_adapter"):
+        pytest.skip("oracle/_ref was built without the adapter")
+    src, other = make_pair(11, with_n=True)
+    for dest_is_src, rev_compl in COMBOS:
+        d = orc.mem_dest(src, other, dest_is_src, rev_compl)
+        a = orc.ref_mem_match_via_adapter(src, d, dest_is_src, rev_compl)
+        r = orc.ref_mem_match(src, d, dest_is_src, rev_compl)
+        assert len(r) > 20 and np.array_equal(a, r), (dest_is_src, rev_compl)
+
+
 def test_mem_errors():
     from pgrc_amd import CopMEMMatcher, PgrcMatchError
     src, other = make_pair(1, G=20000, G2=3000)
