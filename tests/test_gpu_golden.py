@@ -44,3 +44,19 @@ def test_gpu_mismatch_lists_reproduce_reference():
         cum, c, o = pe if pair_file else se
         s, e = int(cum[i]), int(cum[i + 1])
         assert c[s:e].tolist() == codes and o[s:e].tolist() == offs, (i, pair_file)
+
+
+# ---- row f2: Pg-vs-Pg exact matching
+
+import mem_golden_util as mg  # noqa: E402
+import oracle as orc  # noqa: E402  (mem_dest: numpy only)
+
+
+@pytest.mark.parametrize("name", mg.NAMES)
+def test_gpu_mem_match_reproduces_reference_output(name):
+    from pgrc_amd import CopMEMMatcher
+    src, other, tl, ml, expected = mg.load(name)
+    m = CopMEMMatcher(src, tl)
+    for (dis, rc), want in expected.items():
+        got = m.matchTexts(orc.mem_dest(src, other, dis, rc), dis, rc, ml)
+        assert np.array_equal(got, want), (name, dis, rc)

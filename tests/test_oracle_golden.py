@@ -121,3 +121,16 @@ def test_map_params_derivation():
     assert orc.oracle().pgrc_or_map_derive(100, 200, 50, b"c", C.byref(mp)) == 0
     assert (mp.seed_len, mp.matcher) == (100, b"c")
     assert orc.oracle().pgrc_or_map_derive(100, 38, 50, b"x", C.byref(mp)) == 2
+
+
+# ---- row f2: Pg-vs-Pg exact matching
+
+import mem_golden_util as mg  # noqa: E402
+
+
+@pytest.mark.parametrize("name", mg.NAMES)
+def test_oracle_mem_match_reproduces_reference_output(name):
+    src, other, tl, ml, expected = mg.load(name)
+    for (dis, rc), want in expected.items():
+        got = orc.oracle_mem_match(src, orc.mem_dest(src, other, dis, rc), dis, rc, tl, ml)
+        assert len(want) > 5 and np.array_equal(got, want), (name, dis, rc)
