@@ -42,11 +42,27 @@ struct pgrc_mem_ctx {
     uint64_t N = 0;
     bool have_src = false;
     DevBuf d_dest, d_nmap, d_stage, d_flag, d_cursor, d_evk[2], d_evv[2], d_tmp, d_ostart, d_olen, d_oflag;
+    // pinned, grow-only host mirrors of the event arrays (a std::vector would zero-fill gigabytes per call)
+    struct HostBuf { void *p = nullptr; size_t bytes = 0; } h_key, h_pos, h_start, h_len, h_flag;
     pgrc_mem_counters ctr{};
     std::string err;
 };
 
 static std::string g_mem_create_err;
+
+static int host_ensure(pgrc_mem_ctx *m, pgrc_mem_ctx::HostBuf &b, size_t bytes) {
+    if (b.p && b.bytes >= bytes) return PGRC_OK;
+    if (b.p) (void)hipHostFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+    if (hipHostMalloc(&b.p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+        b.p = nullptr;
+        m->err = "hipHostMalloc(" + std::to_string(bytes) + ") failed";
+        return PGRC_E_ALLOC;
+    }
+    b.bytes = bytes;
+    return PGRC_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ device side
 
@@ -370,6 +386,8 @@ void pgrc_mem_destroy(pgrc_mem_ctx *m) {
     DevBuf *bufs[] = {&m->d_dest, &m->d_nmap, &m->d_stage, &m->d_flag, &m->d_cursor, &m->d_evk[0], &m->d_evk[1], &m->d_evv[0],
                       &m->d_evv[1], &m->d_tmp, &m->d_ostart, &m->d_olen, &m->d_oflag};
     for (DevBuf *b : bufs) pgrc_buf_free(*b);
+    for (pgrc_mem_ctx::HostBuf *h : {&m->h_key, &m->h_pos, &m->h_start, &m->h_len, &m->h_flag})
+        if (h->p) (void)hipHostFree(h->p);
     pgrc_match_destroy(m->base);
     delete m;
 }
@@ -499,8 +517,11 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     }
     (void)hipEventRecord(ev[1], c->stream);
     m->ctr.events = nev;
-    std::vector<uint64_t> hk(nev), hp(nev), hs(nev), hl(nev);
-    std::vector<uint8_t> hf(nev);
+    if ((e = host_ensure(m, m->h_key, nev * 8)) || (e = host_ensure(m, m->h_pos, nev * 8)) || (e = host_ensure(m, m->h_start, nev * 8)) ||
+        (e = host_ensure(m, m->h_len, nev * 8)) || (e = host_ensure(m, m->h_flag, nev))) { drop_events(); return e; }
+    const uint64_t *hk = (const uint64_t *)m->h_key.p, *hp = (const uint64_t *)m->h_pos.p, *hs = (const uint64_t *)m->h_start.p,
+                   *hl = (const uint64_t *)m->h_len.p;
+    const uint8_t *hf = (const uint8_t *)m->h_flag.p;
     if (nev) {
         // ---- 2. the order in which the reference meets them: by window, then by bucket order
         int tb = 1;
@@ -521,11 +542,11 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
             he = hipGetLastError();
         }
         (void)hipEventRecord(ev[3], c->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(hk.data(), keys.current(), nev * 8, hipMemcpyDeviceToHost, c->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(hp.data(), vals.current(), nev * 8, hipMemcpyDeviceToHost, c->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(hs.data(), m->d_ostart.p, nev * 8, hipMemcpyDeviceToHost, c->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(hl.data(), m->d_olen.p, nev * 8, hipMemcpyDeviceToHost, c->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(hf.data(), m->d_oflag.p, nev, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(m->h_key.p, keys.current(), nev * 8, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(m->h_pos.p, vals.current(), nev * 8, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(m->h_start.p, m->d_ostart.p, nev * 8, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(m->h_len.p, m->d_olen.p, nev * 8, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(m->h_flag.p, m->d_oflag.p, nev, hipMemcpyDeviceToHost, c->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) { drop_events(); m->err = std::string("event passes: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
         (void)hipEventElapsedTime(&m->ctr.ms_sort, ev[1], ev[2]);
@@ -556,7 +577,10 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
         const uint64_t t = hk[i] >> 4;
         uint64_t jend = i;
         while (jend < nev && (hk[jend] >> 4) == t) jend++;
-        if (rp.examined(t)) {
+        // probes come in ascending order: only the latest jump can still cover this one (Replay::examined, the
+        // general form, is for the walk-back of the stale registers)
+        const bool visited = rp.jumps.empty() || !(rp.block_of(rp.jumps.back().t) == rp.block_of(t) && t <= rp.jumps.back().t + rp.skip);
+        if (visited) {
             const uint64_t q = t * k2;
             for (uint64_t x = i; x < jend; x++) {
                 const uint64_t p = hp[x];
