@@ -23,6 +23,7 @@
 // All integer work, bound by the random head gathers (one per window): no MFMA.
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -500,6 +501,8 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     // ---- 1. events
     if ((e = pgrc_buf_ensure(c, m->d_cursor, 8))) { drop_events(); m->err = c->err; return e; }
     uint64_t cap = std::max<uint64_t>(nprobes / 64 + 65536, m->d_evk[0].bytes / 8);
+    if (const char *ev_cap = getenv("PGRC_MEM_EVENT_CAP"))   // test knob: start tiny to exercise the regrow-and-rerun path
+        cap = std::max<uint64_t>(1, (uint64_t)atoll(ev_cap));
     unsigned long long nev = 0;
     (void)hipEventRecord(ev[0], c->stream);
     for (int attempt = 0; attempt < 2; attempt++) {

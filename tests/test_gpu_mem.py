@@ -90,6 +90,13 @@ def test_mem_reference_adapter_drop_in():
         assert len(r) > 20 and np.array_equal(a, r), (dest_is_src, rev_compl)
 
 
+def test_mem_event_buffer_regrows(monkeypatch):
+    """more events than the first guess of the event buffer: the probe pass is rerun with the exact size"""
+    monkeypatch.setenv("PGRC_MEM_EVENT_CAP", "7")
+    src, other = make_pair(2, low_complexity=True)
+    assert check(src, other, COMBOS[:2], what="tiny event cap") > 50
+
+
 def test_mem_errors():
     from pgrc_amd import CopMEMMatcher, PgrcMatchError
     src, other = make_pair(1, G=20000, G2=3000)
