@@ -205,6 +205,14 @@ int pgrc_ref_mem_match(const char *src, uint64_t N, const char *dest, uint64_t N
 // (:783-792).  New code written against the reference's public interfaces.
 static bool g_gpu_matching = false;
 static int g_gpu_calls = 0;
+// wall time spent in the two accelerated stages, whichever implementation ran (tests/e2e_timing.py)
+static double g_map_reads_s = 0, g_text_match_s = 0;
+struct StageTimer {
+    double &acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit StageTimer(double &a) : acc(a) {}
+    ~StageTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 extern "C" const std::vector<bool> pgrc_ref_mapReadsIntoPg_original(
         SeparatedPseudoGenome *sPg, bool revComplPg, bool preserveOrderMode, ConstantLengthReadsSetInterface *readsSet,
@@ -220,6 +228,7 @@ namespace PgTools {
                                       uint16_t readsExactMatchingChars, uint16_t minCharsPerMismatch, char preMatchingMode,
                                       char matchingMode, bool dumpInfo, ostream &pgrcOut, uint8_t compressionLevel,
                                       const string &pgDestFilePrefix, IndexesMapping *orgIndexesMapping) {
+        StageTimer timer(g_map_reads_s);
         if (!g_gpu_matching)
             return pgrc_ref_mapReadsIntoPg_original(sPg, revComplPg, preserveOrderMode, readsSet, pairFileMode,
                                                     revComplPairFile, matchPrefixLength, preReadsExactMatchingChars,
@@ -277,15 +286,28 @@ namespace PgTools {
 // (INTEGRATION.md section 5); the reference's own definition is linked weak (oracle/Makefile).
 static bool g_gpu_text_matching = false;
 namespace PgTools {
+    // times whatever TextMatcher SimplePgMatcher holds (construction = index build included)
+    class TimedTextMatcher : public TextMatcher {
+        TextMatcher *inner = nullptr;
+    public:
+        TimedTextMatcher(bool gpu, const char *src, size_t n, uint32_t targetMatchLength, uint32_t minMatchLength) {
+            StageTimer timer(g_text_match_s);
+            if (gpu) inner = new HipTextMatcher(src, n, targetMatchLength, minMatchLength);
+            else inner = new CopMEMMatcher(src, n, targetMatchLength, minMatchLength);
+        }
+        ~TimedTextMatcher() override { delete inner; }
+        void matchTexts(vector<TextMatch> &resMatches, const string &destText, bool destIsSrc, bool revComplMatching,
+                        uint32_t minMatchLength) override {
+            StageTimer timer(g_text_match_s);
+            inner->matchTexts(resMatches, destText, destIsSrc, revComplMatching, minMatchLength);
+        }
+    };
+
     SimplePgMatcher::SimplePgMatcher(const string &srcPg, uint32_t targetMatchLength, uint32_t minMatchLength)
             : targetMatchLength(targetMatchLength), srcPg(srcPg) {
         cout << "Source pseudogenome length: " << srcPg.length() << endl;
-        if (srcPg.size() >= targetMatchLength) {
-            if (g_gpu_text_matching)
-                matcher = new HipTextMatcher(srcPg.data(), srcPg.length(), targetMatchLength, minMatchLength);
-            else
-                matcher = new CopMEMMatcher(srcPg.data(), srcPg.length(), targetMatchLength, minMatchLength);
-        }
+        if (srcPg.size() >= targetMatchLength)
+            matcher = new TimedTextMatcher(g_gpu_text_matching, srcPg.data(), srcPg.length(), targetMatchLength, minMatchLength);
     }
 }
 
@@ -300,6 +322,7 @@ extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const 
     g_gpu_matching = (use_gpu & 1) != 0;          // bit 0: reads -> Pg matching (stage 4) on the GPU
     g_gpu_text_matching = (use_gpu & 2) != 0;     // bit 1: Pg -> Pg matching (stage 7) on the GPU
     g_gpu_calls = 0;
+    g_map_reads_s = g_text_match_s = 0;
     PgRCParams *params = new PgRCParams();
     params->setSrcFastqFile(fastq);
     if (pair_fastq && pair_fastq[0]) params->setPairFastqFile(pair_fastq);
@@ -322,6 +345,11 @@ extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const 
 
 extern "C" uint64_t pgrc_ref_bulk_updates() { return HipReadsMatcher::bulkUpdatesServed; }
 extern "C" uint64_t pgrc_ref_text_match_calls() { return HipTextMatcher::callsServed; }
+// seconds the last pgrc_ref_encode spent in mapReadsIntoPg (stage 4) and in SimplePgMatcher's TextMatcher (stage 7)
+extern "C" void pgrc_ref_stage_seconds(double *map_reads_s, double *text_match_s) {
+    *map_reads_s = g_map_reads_s;
+    *text_match_s = g_text_match_s;
+}
 
 // CopMEMMatcher::matchTexts through the adapter class (what SimplePgMatcher would call)
 extern "C" int pgrc_ref_mem_match_via_adapter(const char *src, uint64_t N, const char *dest, uint64_t N2, int dest_is_src,

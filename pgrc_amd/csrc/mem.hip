@@ -45,9 +45,20 @@ struct pgrc_mem_ctx {
     DevBuf d_dest, d_nmap, d_stage, d_flag, d_cursor, d_evk[2], d_evv[2], d_tmp, d_ostart, d_olen, d_oflag;
     // pinned, grow-only host mirrors of the event arrays (a std::vector would zero-fill gigabytes per call)
     struct HostBuf { void *p = nullptr; size_t bytes = 0; } h_key, h_pos, h_start, h_len, h_flag;
+    hipEvent_t ev[4]{};               // phase timing (created on first use)
+    bool have_ev = false;
     pgrc_mem_counters ctr{};
     std::string err;
 };
+
+#define MEM_TRY(m, expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            (m)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                   \
+            return PGRC_E_NO_DEVICE;                                                         \
+        }                                                                                    \
+    } while (0)
 
 static std::string g_mem_create_err;
 
@@ -387,6 +398,8 @@ void pgrc_mem_destroy(pgrc_mem_ctx *m) {
     DevBuf *bufs[] = {&m->d_dest, &m->d_nmap, &m->d_stage, &m->d_flag, &m->d_cursor, &m->d_evk[0], &m->d_evk[1], &m->d_evv[0],
                       &m->d_evv[1], &m->d_tmp, &m->d_ostart, &m->d_olen, &m->d_oflag};
     for (DevBuf *b : bufs) pgrc_buf_free(*b);
+    if (m->have_ev)
+        for (auto &x : m->ev) (void)hipEventDestroy(x);
     for (pgrc_mem_ctx::HostBuf *h : {&m->h_key, &m->h_pos, &m->h_start, &m->h_len, &m->h_flag})
         if (h->p) (void)hipHostFree(h->p);
     pgrc_match_destroy(m->base);
@@ -430,16 +443,18 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     if ((int)min_len < m->K) { m->err = "Minimal matching length cannot be smaller than K"; return PGRC_E_PARAM; }   // :606-609
     if (dest_is_src && N2 != m->N) { m->err = "match_texts: dest_is_src with a text of another length"; return PGRC_E_PARAM; }
     if (N2 / (uint64_t)m->k2 + 1 >= (1ull << 40)) { m->err = "destination text too long"; return PGRC_E_PARAM; }
-    HIP_TRY(c, hipSetDevice(c->device));
+    MEM_TRY(m, hipSetDevice(c->device));
     m->ctr.probes = m->ctr.events = m->ctr.stale_lookups = 0;
     const uint64_t K = (uint64_t)m->K, k2 = (uint64_t)m->k2;
     const uint64_t nprobes = N2 >= K ? (N2 - K) / k2 + 1 : 0;          // windows q = t * k2 with q + K <= N2
     m->ctr.probes = nprobes;
     if (nprobes == 0) return PGRC_OK;
     int e;
-    hipEvent_t ev[4];
-    for (auto &x : ev) HIP_TRY(c, hipEventCreate(&x));
-    auto drop_events = [&]() { for (auto &x : ev) (void)hipEventDestroy(x); };
+    if (!m->have_ev) {
+        for (auto &x : m->ev) MEM_TRY(m, hipEventCreate(&x));
+        m->have_ev = true;
+    }
+    hipEvent_t *ev = m->ev;
 
     // ---- the destination in HBM
     MemArgs a;
@@ -447,7 +462,7 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     const uint64_t dwords = (N2 + 15) / 16;
     if (dest_is_src) {
         if (rev_compl) {
-            if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) { drop_events(); m->err = c->err; return e; }
+            if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) { m->err = c->err; return e; }
             c->have_rc = true;
         }
         a.dest = (const uint32_t *)c->pg2[rev_compl ? 1 : 0].p;
@@ -456,7 +471,7 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     } else {
         const uint64_t CH = 64ull << 20;
         if ((e = pgrc_buf_ensure(c, m->d_dest, (dwords + PGRC_PG_PAD_WORDS) * 4)) || (e = pgrc_buf_ensure(c, m->d_nmap, (dwords + PGRC_PG_PAD_WORDS) * 2)) ||
-            (e = pgrc_buf_ensure(c, m->d_stage, (size_t)std::min(CH, N2))) || (e = pgrc_buf_ensure(c, m->d_flag, 4))) { drop_events(); m->err = c->err; return e; }
+            (e = pgrc_buf_ensure(c, m->d_stage, (size_t)std::min(CH, N2))) || (e = pgrc_buf_ensure(c, m->d_flag, 4))) { m->err = c->err; return e; }
         (void)hipMemsetAsync(m->d_dest.p, 0, (dwords + PGRC_PG_PAD_WORDS) * 4, c->stream);
         (void)hipMemsetAsync(m->d_nmap.p, 0, (dwords + PGRC_PG_PAD_WORDS) * 2, c->stream);
         (void)hipMemsetAsync(m->d_flag.p, 0, 4, c->stream);
@@ -470,11 +485,11 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
                                    (uint32_t *)m->d_flag.p);
                 he = hipStreamSynchronize(c->stream);
             }
-            if (he != hipSuccess) { drop_events(); m->err = std::string("destination upload: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
+            if (he != hipSuccess) { m->err = std::string("destination upload: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
         }
         uint32_t fl = 0;
-        HIP_TRY(c, hipMemcpy(&fl, m->d_flag.p, 4, hipMemcpyDeviceToHost));
-        if (fl & 1u) { drop_events(); m->err = "destination text contains a symbol outside ACGNT"; return PGRC_E_SYMBOL; }
+        MEM_TRY(m, hipMemcpy(&fl, m->d_flag.p, 4, hipMemcpyDeviceToHost));
+        if (fl & 1u) { m->err = "destination text contains a symbol outside ACGNT"; return PGRC_E_SYMBOL; }
         a.dest = (const uint32_t *)m->d_dest.p;
         a.nmap = (fl & 2u) ? (const uint16_t *)m->d_nmap.p : nullptr;
         a.dest_words_alloc = dwords + PGRC_PG_PAD_WORDS;
@@ -493,13 +508,13 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     a.dest_is_src = dest_is_src ? 1 : 0;
     a.rev_compl = rev_compl ? 1 : 0;
     if (c->index_strand != 0) {          // (only if somebody rebuilt the base index in between)
-        if ((e = pgrc_copmem_build_index(c, 0))) { drop_events(); m->err = c->err; return e; }
+        if ((e = pgrc_copmem_build_index(c, 0))) { m->err = c->err; return e; }
         a.head = (const ulonglong2 *)c->d_head.p;
         a.ent = c->ent_ptr;
     }
 
     // ---- 1. events
-    if ((e = pgrc_buf_ensure(c, m->d_cursor, 8))) { drop_events(); m->err = c->err; return e; }
+    if ((e = pgrc_buf_ensure(c, m->d_cursor, 8))) { m->err = c->err; return e; }
     uint64_t cap = std::max<uint64_t>(nprobes / 64 + 65536, m->d_evk[0].bytes / 8);
     if (const char *ev_cap = getenv("PGRC_MEM_EVENT_CAP"))   // test knob: start tiny to exercise the regrow-and-rerun path
         cap = std::max<uint64_t>(1, (uint64_t)atoll(ev_cap));
@@ -507,21 +522,21 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     (void)hipEventRecord(ev[0], c->stream);
     for (int attempt = 0; attempt < 2; attempt++) {
         for (int k = 0; k < 2; k++)
-            if ((e = pgrc_buf_ensure(c, m->d_evk[k], cap * 8)) || (e = pgrc_buf_ensure(c, m->d_evv[k], cap * 8))) { drop_events(); m->err = c->err; return e; }
+            if ((e = pgrc_buf_ensure(c, m->d_evk[k], cap * 8)) || (e = pgrc_buf_ensure(c, m->d_evv[k], cap * 8))) { m->err = c->err; return e; }
         (void)hipMemsetAsync(m->d_cursor.p, 0, 8, c->stream);
         hipLaunchKernelGGL(k_mem_probe, dim3((uint32_t)((nprobes + MEM_TPB - 1) / MEM_TPB)), dim3(MEM_TPB), 0, c->stream, a,
                            (unsigned long long *)m->d_cursor.p, (uint64_t *)m->d_evk[0].p, (uint64_t *)m->d_evv[0].p, cap);
         hipError_t he = hipGetLastError();
         if (he == hipSuccess) he = hipMemcpyAsync(&nev, m->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-        if (he != hipSuccess) { drop_events(); m->err = std::string("probe kernel: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
+        if (he != hipSuccess) { m->err = std::string("probe kernel: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
         if (nev <= cap) break;
         cap = nev;                                          // the guess was too small: once more with the exact size
     }
     (void)hipEventRecord(ev[1], c->stream);
     m->ctr.events = nev;
     if ((e = host_ensure(m, m->h_key, nev * 8)) || (e = host_ensure(m, m->h_pos, nev * 8)) || (e = host_ensure(m, m->h_start, nev * 8)) ||
-        (e = host_ensure(m, m->h_len, nev * 8)) || (e = host_ensure(m, m->h_flag, nev))) { drop_events(); return e; }
+        (e = host_ensure(m, m->h_len, nev * 8)) || (e = host_ensure(m, m->h_flag, nev))) { return e; }
     const uint64_t *hk = (const uint64_t *)m->h_key.p, *hp = (const uint64_t *)m->h_pos.p, *hs = (const uint64_t *)m->h_start.p,
                    *hl = (const uint64_t *)m->h_len.p;
     const uint8_t *hf = (const uint8_t *)m->h_flag.p;
@@ -533,12 +548,12 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
         rocprim::double_buffer<uint64_t> vals((uint64_t *)m->d_evv[0].p, (uint64_t *)m->d_evv[1].p);
         size_t tbytes = 0;
         hipError_t he = rocprim::radix_sort_pairs(nullptr, tbytes, keys, vals, (size_t)nev, 0, 4 + tb, c->stream);
-        if (he == hipSuccess && (e = pgrc_buf_ensure(c, m->d_tmp, tbytes + 16))) { drop_events(); m->err = c->err; return e; }
+        if (he == hipSuccess && (e = pgrc_buf_ensure(c, m->d_tmp, tbytes + 16))) { m->err = c->err; return e; }
         if (he == hipSuccess) he = rocprim::radix_sort_pairs(m->d_tmp.p, tbytes, keys, vals, (size_t)nev, 0, 4 + tb, c->stream);
         (void)hipEventRecord(ev[2], c->stream);
         // ---- 3. side contexts and extensions
         if (he == hipSuccess && ((e = pgrc_buf_ensure(c, m->d_ostart, nev * 8)) || (e = pgrc_buf_ensure(c, m->d_olen, nev * 8)) ||
-                                 (e = pgrc_buf_ensure(c, m->d_oflag, nev)))) { drop_events(); m->err = c->err; return e; }
+                                 (e = pgrc_buf_ensure(c, m->d_oflag, nev)))) { m->err = c->err; return e; }
         if (he == hipSuccess) {
             hipLaunchKernelGGL(k_mem_extend, dim3((uint32_t)((nev + 255) / 256)), dim3(256), 0, c->stream, a, (const uint64_t *)keys.current(),
                                (const uint64_t *)vals.current(), (uint64_t)nev, (uint64_t *)m->d_ostart.p, (uint64_t *)m->d_olen.p, (uint8_t *)m->d_oflag.p);
@@ -551,14 +566,13 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
         if (he == hipSuccess) he = hipMemcpyAsync(m->h_len.p, m->d_olen.p, nev * 8, hipMemcpyDeviceToHost, c->stream);
         if (he == hipSuccess) he = hipMemcpyAsync(m->h_flag.p, m->d_oflag.p, nev, hipMemcpyDeviceToHost, c->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-        if (he != hipSuccess) { drop_events(); m->err = std::string("event passes: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
+        if (he != hipSuccess) { m->err = std::string("event passes: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
         (void)hipEventElapsedTime(&m->ctr.ms_sort, ev[1], ev[2]);
         (void)hipEventElapsedTime(&m->ctr.ms_extend, ev[2], ev[3]);
     } else {
         (void)hipEventSynchronize(ev[1]);
     }
     (void)hipEventElapsedTime(&m->ctr.ms_probe, ev[0], ev[1]);
-    drop_events();
 
     // ---- 4. the sequential rules, over the events only
     const auto th0 = std::chrono::steady_clock::now();
