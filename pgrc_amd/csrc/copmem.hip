@@ -13,7 +13,7 @@
 //   * what bounds hash probing on gfx950 is the number of random lane-addresses per second (~51 G/s,
 //     the same for 4-, 8- and 16-byte accesses: tools/ubench/gather2.hip), not HBM bytes.  The index
 //     is therefore laid out so that a probe is ONE 16-byte gather: a bucket head holding the bucket's
-//     two smallest entries; every entry carries a 24-bit fingerprint of the window symbols the
+//     two smallest entries; every entry carries a 22-bit fingerprint of the window symbols the
 //     sparsified hash ignores, so a false candidate is rejected -- with exactly the reference's
 //     head-reject accounting -- without fetching its text window.
 //   * index build without atomics: (bucket, entry) records in position order, one STABLE rocPRIM radix sort by
