@@ -48,3 +48,50 @@ def make_pair(seed, G=200000, G2=60000, with_n=False, low_complexity=False):
 
 
 COMBOS = ((0, 1), (1, 1), (0, 0), (1, 0))   # (dest_is_src, rev_compl); the encoder uses the first two
+
+
+# ---- differential sweep (tests/test_gpu_fuzz.py::test_mem_sweep, tests/test_mem_oracle_vs_ref.py)
+
+def mem_sweep_cases():
+    rng = np.random.default_rng(20260202)
+    out = []
+    for target in (24, 27, 28, 31, 33, 36, 38, 43, 45, 47, 50, 54, 60, 63, 64, 90, 111, 130, 200, 255):
+        out.append((target, target + int(rng.integers(0, 3)) * int(rng.integers(0, 30)), int(rng.integers(0, 1 << 30))))
+    for _ in range(12):
+        out.append((45, 45, int(rng.integers(0, 1 << 30))))
+    return out
+
+
+def mem_sweep_texts(seed, target):
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    G = int(rng.integers(20000, 90000))
+    src = rng.choice(acgt, size=G)
+    style = int(rng.integers(0, 4))
+    if style == 1:      # tandem / periodic stretches
+        for _ in range(6):
+            unit = rng.choice(acgt, size=int(rng.integers(1, 9)))
+            s, ln = int(rng.integers(0, G - 3000)), int(rng.integers(100, 2500))
+            src[s:s + ln] = np.resize(unit, ln)
+    for _ in range(int(rng.integers(5, 60))):       # internal repeats, both strands
+        ln = int(rng.integers(target - 5, 6 * target))
+        s, d = int(rng.integers(0, G - ln)), int(rng.integers(0, G - ln))
+        seg = src[s:s + ln].copy()
+        src[d:d + ln] = orc.revcomp_ascii(seg) if rng.random() < 0.5 else seg
+    G2 = int(rng.integers(1, 4)) * 768 + int(rng.integers(-3, 4)) if style == 3 else int(rng.integers(target, 30000))
+    other = rng.choice(acgt, size=max(G2, 1))
+    for _ in range(int(rng.integers(3, 40))):
+        ln = int(rng.integers(target - 5, 8 * target))
+        if ln >= other.size:
+            continue
+        s, d = int(rng.integers(0, G - ln)), int(rng.integers(0, other.size - ln))
+        seg = src[s:s + ln].copy()
+        other[d:d + ln] = orc.revcomp_ascii(seg) if rng.random() < 0.5 else seg
+    if style == 2 and other.size > 10:
+        for _ in range(int(rng.integers(1, 30))):
+            p = int(rng.integers(0, other.size - 3))
+            other[p:p + int(rng.integers(1, 4))] = ord("N")
+    if other.size > 2 * target:                     # the source's ends, where the side-context registers go stale
+        other[:target + 10] = orc.revcomp_ascii(src[-(target + 10):])
+        other[-(target + 10):] = src[:target + 10]
+    return src, other

@@ -45,3 +45,21 @@ def test_sweep(mode, L, seed_len, M, shortcut, rev, n_with_n):
     assert_same_results(g, o, f"{mode} L={L} seed={seed_len} M={M} shortcut={shortcut} rev={rev} N={n_with_n}")
     if mode != "e":
         assert g["matched"] > 0.5 * n * (0.5 if not rev else 1.0) * 0.5
+
+
+# ---- row f2: Pg-vs-Pg exact matching -- every K the reference can pick (through the target match length), texts with
+# periodic / low-complexity / duplicated content, N runs, ragged lengths around the 256-window block size
+
+from mem_util import mem_sweep_cases as _mem_cases, mem_sweep_texts as _mem_texts  # noqa: E402
+
+
+@pytest.mark.parametrize("target,min_len,seed", _mem_cases())
+def test_mem_sweep(target, min_len, seed):
+    from pgrc_amd import CopMEMMatcher
+    src, other = _mem_texts(seed, target)
+    m = CopMEMMatcher(src, target)
+    for dest_is_src, rev_compl in ((0, 1), (1, 1), (0, 0), (1, 0)):
+        d = orc.mem_dest(src, other, dest_is_src, rev_compl)
+        g = m.matchTexts(d, dest_is_src, rev_compl, min_len)
+        o = orc.oracle_mem_match(src, d, dest_is_src, rev_compl, target, min_len)
+        assert np.array_equal(g, o), f"target={target} min={min_len} seed={seed} destIsSrc={dest_is_src} rc={rev_compl}: {len(g)} vs {len(o)}"

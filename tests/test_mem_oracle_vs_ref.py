@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle as orc
-from mem_util import COMBOS, make_pair
+from mem_util import COMBOS, make_pair, mem_sweep_cases, mem_sweep_texts
 
 pytestmark = pytest.mark.skipif(not (orc.have_ref() and hasattr(orc.ref(), "pgrc_ref_mem_match")),
                                 reason="needs oracle/_ref with the text-matcher harness")
@@ -37,3 +37,14 @@ def test_mem_short_texts():
     for n2 in (31, 32, 33, 45, 100, 400, 767, 768, 769, 800, 2000):
         d = orc.mem_dest(src, other[:n2], 0, 1)
         assert np.array_equal(orc.oracle_mem_match(src, d, 0, 1), orc.ref_mem_match(src, d, 0, 1)), n2
+
+
+@pytest.mark.parametrize("target,min_len,seed", mem_sweep_cases())
+def test_mem_oracle_sweep(target, min_len, seed):
+    """the texts of the GPU sweep (tests/test_gpu_fuzz.py::test_mem_sweep): the oracle is pinned on them too"""
+    src, other = mem_sweep_texts(seed, target)
+    for dest_is_src, rev_compl in COMBOS:
+        d = orc.mem_dest(src, other, dest_is_src, rev_compl)
+        o = orc.oracle_mem_match(src, d, dest_is_src, rev_compl, target, min_len)
+        r = orc.ref_mem_match(src, d, dest_is_src, rev_compl, target, min_len)
+        assert np.array_equal(o, r), (target, min_len, seed, dest_is_src, rev_compl)
