@@ -3,6 +3,23 @@
 #include "pgrc_match.h"
 #include "readsset/PackedConstantLengthReadsSet.h"
 
+#include <chrono>
+
+namespace {
+    // PGRC_HIP_TIMING=1: phase times of the adapter on stderr (hand-over, device run, result fetch)
+    struct PhaseLog {
+        const char *what;
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        explicit PhaseLog(const char *w) : what(w) {}
+        ~PhaseLog() {
+            static const bool on = getenv("PGRC_HIP_TIMING") != nullptr;
+            if (on)
+                fprintf(stderr, "HipReadsMatcher: %s %.3f s\n", what,
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
+    };
+}
+
 namespace PgTools {
 
     uint64_t HipReadsMatcher::bulkUpdatesServed = 0;
@@ -56,6 +73,7 @@ namespace PgTools {
             if (indexed < deviceReads) deviceReads = indexed;
         }
         if (deviceReads == 0) return;
+        PhaseLog log("hand-over of the pseudogenome and the reads");
         const uint_reads_cnt_max readsCount = deviceReads;   // shadows the member for the rest of this function
         failOn(pgrc_match_set_pg_ascii(ctx, pgPtr, pgLength), "set_pg_ascii");
         auto *packed = dynamic_cast<PackedConstantLengthReadsSet *>(readsSet);
@@ -82,6 +100,7 @@ namespace PgTools {
     }
 
     void HipReadsMatcher::fetchResults() {
+        PhaseLog log("result fetch");
         readMatchPos.resize(readsCount);
         readMismatchesCount.resize(readsCount);
         readMatchRC.resize(readsCount, false);
@@ -124,6 +143,7 @@ namespace PgTools {
     // ---- export support: mismatch lists of all matched reads in one device pass (replaces the per-read
     //      getRead + reverseComplementInPlace + fillEntryWith(Reversed)Mismatches of ReadsMatchers.cpp:548-559) ----
     void HipReadsMatcher::initEntryUpdating() {
+        PhaseLog log("bulk mismatch extraction");
         bulkMismatches = false;
         if (!uploaded || deviceReads != readsCount || readsCount == 0) return;   // inherited per-read path
         mmCum.resize((size_t) readsCount + 1);
@@ -177,7 +197,10 @@ namespace PgTools {
 
     void HipReadsMatcher::matchConstantLengthReadsOnDevice() {
         initMatching();
-        if (deviceReads) failOn(pgrc_match_run(ctx, revComplPg ? 1 : 0), "run");
+        {
+            PhaseLog log("device run (both strands)");
+            if (deviceReads) failOn(pgrc_match_run(ctx, revComplPg ? 1 : 0), "run");
+        }
         fetchResults();
     }
 
