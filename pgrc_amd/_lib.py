@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpgrc_match.so")
+# PGRC_MATCH_LIB: another build of the same library (A/B runs of compile-time variants, tools/variants.sh)
+LIB_PATH = os.environ.get("PGRC_MATCH_LIB") or os.path.join(_HERE, "libpgrc_match.so")
 
 NOT_MATCHED_POS = 0xFFFFFFFFFFFFFFFF  # DefaultReadsMatcher::NOT_MATCHED_POSITION (ReadsMatchers.cpp:69)
 NOT_MATCHED_CNT = 255                 # NOT_MATCHED_COUNT (ReadsMatchers.h:17)

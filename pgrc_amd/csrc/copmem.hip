@@ -290,7 +290,10 @@ struct ReadState {
 //     later seed sampled there; their head/tail counts cannot change, only the limit they are judged
 //     against does, so the text window is fetched once.
 #define SM_MAX_SEEDS 240
-#define VC_SLOTS 4
+#ifndef VC_BITS
+#define VC_BITS 2           // verify-cache slots per read = 1 << VC_BITS (direct mapped)
+#endif
+#define VC_SLOTS (1 << VC_BITS)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) U32x4A4 { u32x4 v; }; // 16-B load that only needs 4-B alignment
 struct __attribute__((packed, aligned(8))) U64x2A8 { unsigned long long x, y; }; // 16-B load, 8-B aligned
@@ -316,7 +319,9 @@ __device__ __forceinline__ uint32_t hash_fp_window(const uint32_t w0, const uint
     return h;
 }
 
+#ifndef MATCH_CHUNK
 #define MATCH_CHUNK 256u // reads a wave reserves per visit to the global work counter
+#endif
 
 // Persistent, self-refilling lanes.  With one read per lane for the lifetime of a wave, ~35 % of the
 // lane-iterations are idle: reads that match exactly leave after a few seeds (30 % of the reads in the forward
@@ -472,7 +477,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                 mh += mism2(tw, rw, sym_mask(k, 0, H));
                 mt += mism2(tw, rw, sym_mask(k, H, (int)a.L));
             }
-            vcache[((uint32_t)cand_p * 0x9E3779B1u) >> 30][threadIdx.x] =
+            vcache[((uint32_t)cand_p * 0x9E3779B1u) >> (32 - VC_BITS)][threadIdx.x] =
                 make_uint2((uint32_t)cand_p, POS64 ? (mh | (mt << 8) | ((uint32_t)((uint64_t)cand_p >> 32) << 11) | (epoch << 19))
                                                    : (mh | (mt << 8) | (epoch << 16)));
             judge(mh, mt, cand_p);
@@ -509,7 +514,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                     if ((uint32_t)__popc((x | (x >> 1)) & fpm_tab[si]) > st.limit) {
                         st.falses += 1;                              // certain head reject
                     } else {
-                        const uint2 cv = vcache[((uint32_t)p * 0x9E3779B1u) >> 30][threadIdx.x];
+                        const uint2 cv = vcache[((uint32_t)p * 0x9E3779B1u) >> (32 - VC_BITS)][threadIdx.x];
                         const bool hit = POS64 ? (cv.x == (uint32_t)p && (cv.y >> 19) == epoch &&
                                                   ((cv.y >> 11) & 0xFFu) == (uint32_t)((uint64_t)p >> 32))
                                                : (cv.x == (uint32_t)p && (cv.y >> 16) == epoch);
