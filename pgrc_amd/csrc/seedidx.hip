@@ -182,36 +182,51 @@ k_seed_scan(const SeedArgs a, uint64_t nwin, uint64_t pg_words_alloc, unsigned l
             const uint64_t t = s0 + (uint64_t)(r0 + b) * cs;
             kv[b] = (worker && t < nwin) ? a.tkeys[slotv[b]] : SX_EMPTY;
         }
+        // collisions (the slot holds another key) of the whole batch are resolved together: every round issues the
+        // next-slot loads of all starts still searching before any of them is looked at
+        uint32_t srch = 0, fnd = 0;
 #pragma unroll
         for (int b = 0; b < SCAN_B; b++) {
-            bool searching = kv[b] != SX_EMPTY && kv[b] != keyv[b];     // rare: the slot holds another key
-            bool found = kv[b] == keyv[b];
-            while (__any(searching)) {
-                if (searching) {
+            if (kv[b] == keyv[b]) fnd |= 1u << b;
+            else if (kv[b] != SX_EMPTY) srch |= 1u << b;
+        }
+        while (__any(srch != 0)) {
+#pragma unroll
+            for (int b = 0; b < SCAN_B; b++)
+                if (srch & (1u << b)) {
                     slotv[b] = (slotv[b] + 1) & a.tmask;
-                    const uint64_t k = a.tkeys[slotv[b]];
-                    if (k == SX_EMPTY) searching = false;
-                    else if (k == keyv[b]) { found = true; searching = false; }
+                    kv[b] = a.tkeys[slotv[b]];
                 }
-            }
-            kv[b] = found ? 1ull : 0ull;
+#pragma unroll
+            for (int b = 0; b < SCAN_B; b++)
+                if (srch & (1u << b)) {
+                    if (kv[b] == SX_EMPTY) srch &= ~(1u << b);
+                    else if (kv[b] == keyv[b]) { fnd |= 1u << b; srch &= ~(1u << b); }
+                }
         }
 #pragma unroll
-        for (int b = 0; b < SCAN_B; b++) ev[b] = kv[b] ? a.theads[slotv[b]] : SX_NIL;
+        for (int b = 0; b < SCAN_B; b++) ev[b] = (fnd & (1u << b)) ? a.theads[slotv[b]] : SX_NIL;
+        // the chains of the batch are walked together as well (one round = the next link of every live chain)
+        for (;;) {
+            uint32_t live = 0;
 #pragma unroll
-        for (int b = 0; b < SCAN_B; b++) {
-            const uint64_t t = s0 + (uint64_t)(r0 + b) * cs;
-            uint32_t e = ev[b];
-            while (__any(e != SX_NIL)) {
+            for (int b = 0; b < SCAN_B; b++) live |= (ev[b] != SX_NIL) ? 1u << b : 0u;
+            if (!__any(live != 0)) break;
+            uint32_t nx[SCAN_B];
+#pragma unroll
+            for (int b = 0; b < SCAN_B; b++) nx[b] = (live & (1u << b)) ? a.next[ev[b]] : SX_NIL;
+#pragma unroll
+            for (int b = 0; b < SCAN_B; b++) {
+                const uint64_t t = s0 + (uint64_t)(r0 + b) * cs;
                 bool emit = false;
                 uint64_t rec = 0;
-                if (e != SX_NIL) {
+                if (live & (1u << b)) {
+                    const uint32_t e = ev[b];
                     const uint64_t i = e / a.P;
                     const uint32_t j = e % a.P;
                     const uint64_t shift = part_offset(a, j);
                     // ReadsMatchers.cpp:308-309 / :375-376 and :311-312 / :378-379
                     if (shift <= t && t - shift + a.L <= a.G) { emit = true; rec = (i << 36) | (t << 4) | (15u - j); }
-                    e = a.next[e];
                 }
                 const unsigned long long mk = __ballot(emit);
                 if (mk) {
@@ -234,6 +249,7 @@ k_seed_scan(const SeedArgs a, uint64_t nwin, uint64_t pg_words_alloc, unsigned l
                         }
                     }
                 }
+                ev[b] = nx[b];
             }
         }
     }
