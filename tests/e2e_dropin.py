@@ -86,7 +86,9 @@ def main():
     lib.pgrc_ref_bulk_updates.restype = C.c_uint64
     lib.pgrc_ref_text_match_calls.restype = C.c_uint64
 
-    G, L, n = 300000, 100, 60000
+    # default: small enough for the test suite; PGRC_E2E_READS / PGRC_E2E_GENOME scale it up for a one-off check
+    n = int(os.environ.get("PGRC_E2E_READS", "60000"))
+    G, L = int(os.environ.get("PGRC_E2E_GENOME", str(5 * n))), 100
     reads = make_reads(11, G, L, n, paired)
     lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
     out = {"case": case, "reads": n, "read_len": L}
