@@ -89,3 +89,39 @@ def test_c1_full_size_exact_matcher():
     win = pg[pos[idx, None].astype(np.int64) + np.arange(L)[None, :]]
     rd = np.where(rc[idx, None] != 0, revcomp(reads[idx].reshape(-1)).reshape(idx.size, L)[::-1], reads[idx])
     assert np.array_equal(win, rd)
+
+
+def test_pg_vs_pg_matching_full_size_properties():
+    """Row f2 at BASELINE's pseudogenome size (1.875 Gbp against itself, forward and reverse-complement): every
+    reported match is a real exact match, long enough, not extensible to the right, extensible to the left by at most
+    the reference's one symbol at a text start; the self-match filter holds.
+    (Identity with the reference at this size: tests/mem_scale.py, profiles/r01_mem_scale_C3.json.)"""
+    from pgrc_amd import CopMEMMatcher
+    G = 1_875_000_000
+    g = synth.pg_params(G, seed=12345)
+    d_pg = torch.zeros((G + 15) // 16 + 64, dtype=torch.int32, device="cuda")
+    synth.pg_device(g, d_pg.data_ptr())
+    torch.cuda.synchronize()
+    src = _unpack(d_pg.cpu().numpy().view(np.uint32)[: (G + 15) // 16], G).copy()
+    del d_pg
+    m = CopMEMMatcher(src, 45)
+    rng = np.random.default_rng(1)
+    for rev_compl in (False, True):
+        dest = orc.revcomp_ascii(src) if rev_compl else src
+        mt = m.matchTexts(dest, True, rev_compl)
+        ctr = m.counters()
+        assert ctr["probes"] == (G - 32) // 3 + 1
+        assert len(mt) > (100_000 if not rev_compl else 10_000)
+        ps, ln, pd = mt[:, 0].astype(np.int64), mt[:, 1].astype(np.int64), mt[:, 2].astype(np.int64)
+        assert ln.min() >= 45 and (ps + ln).max() <= G and (pd + ln).max() <= G
+        # self matches are dropped (CopMEMMatcher.cpp:389-392): the anchor lies before the source position (forward)
+        if not rev_compl:
+            assert (pd < ps).all()
+        # (the same match CAN be reported twice: a window near its end is no longer "inside" it, :393-399 -- the
+        #  reference removes such duplicates afterwards with sort + unique, SimplePgMatcher.cpp:95-96)
+        for k in rng.choice(len(mt), size=3000, replace=False):
+            a, b, n = ps[k], pd[k], ln[k]
+            assert np.array_equal(src[a:a + n], dest[b:b + n])
+            assert a + n == G or b + n == G or src[a + n] != dest[b + n]                  # right-maximal
+            if a > 0 and b > 0 and src[a - 1] == dest[b - 1]:                            # the off-by-one at a text start
+                assert a == 1 or b == 1
