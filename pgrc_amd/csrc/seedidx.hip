@@ -122,22 +122,24 @@ __global__ void __launch_bounds__(256) k_seed_insert_ascii(const SeedArgs a) {
 // ---- 2. stream the text past the table.  A block stages its stretch of the text in LDS; a thread walks SCAN_R window
 // starts that are cstride apart with the O(1) rolling update of the cyclic polynomial (the reference's own scan,
 // cyclichash.h:110-118) and probes the table for each; hits are appended with ONE atomic per wave and iteration
-// into a block-local LDS buffer that is flushed with one global atomic per block (same-address returning atomics
-// serialise at ~90 M/s: one per hit, or even one per wave and iteration -- 4 M at C2 -- made the cursor the whole
-// cost of this kernel).  Single pass: the hit buffer is sized by a guess, the cursor keeps counting past its end, and
+// into per-wave LDS buffers (the fill count is wave-uniform: a register, no LDS atomic) that are flushed with one
+// global atomic per block at the end -- or per wave and 512 hits when a buffer fills up (tandem repeats).  Same-address
+// returning atomics serialise at ~90 M/s: one per hit, or even one per wave and iteration (4 M at C2), made the
+// cursor the whole cost of this kernel, and a spill path that did so turned C3-size runs into seconds.  Single pass: the hit buffer is sized by a guess, the cursor keeps counting past its end, and
 // the host reruns the pass with the exact size if it overflowed.
 #define SCAN_TPB 256
 #define SCAN_R 16
 #define SCAN_TILE_WORDS (SCAN_TPB * SCAN_R / 16 + 24)
-#define SCAN_LCAP 2048u
+#define SCAN_WCAP 512u     // hit records per wave buffer
 #define SCAN_B 8
 __global__ void __launch_bounds__(SCAN_TPB)
 k_seed_scan(const SeedArgs a, uint64_t nwin, uint64_t pg_words_alloc, unsigned long long *cursor, uint64_t *hits, uint64_t cap) {
     __shared__ uint32_t tile[SCAN_TILE_WORDS];
-    __shared__ uint64_t lbuf[SCAN_LCAP];
-    __shared__ uint32_t lcount;
+    __shared__ uint64_t lbuf[SCAN_TPB / 64][SCAN_WCAP];
+    __shared__ uint32_t wtotal[SCAN_TPB / 64];
     __shared__ unsigned long long gbase;
-    if (threadIdx.x == 0) lcount = 0;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t wcount = 0;                                  // records in this wave's buffer (wave-uniform)
     const uint32_t cs = a.cstride, m = a.m;
     const uint32_t groups = SCAN_TPB / cs;               // runs of SCAN_R * cs consecutive starts, one thread per phase
     const uint32_t per_block = groups * cs * SCAN_R;
@@ -230,35 +232,35 @@ k_seed_scan(const SeedArgs a, uint64_t nwin, uint64_t pg_words_alloc, unsigned l
                 }
                 const unsigned long long mk = __ballot(emit);
                 if (mk) {
-                    const int leader = __ffsll((long long)mk) - 1;
-                    uint32_t lb = 0;
-                    if ((int)lane == leader) lb = atomicAdd(&lcount, (uint32_t)__popcll(mk));
-                    lb = __shfl(lb, leader, 64);
-                    const uint32_t li = lb + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
-                    const bool spill = emit && li >= SCAN_LCAP;      // LDS buffer full (repeats): straight to HBM
-                    if (emit && !spill) lbuf[li] = rec;
-                    const unsigned long long sk = __ballot(spill);
-                    if (sk) {
-                        const int sl = __ffsll((long long)sk) - 1;
+                    const uint32_t cnt = (uint32_t)__popcll(mk);
+                    if (wcount + cnt > SCAN_WCAP) {              // buffer full: this wave flushes it (one atomic per 512 hits)
                         unsigned long long base = 0;
-                        if ((int)lane == sl) base = atomicAdd(cursor, (unsigned long long)__popcll(sk));
-                        base = __shfl(base, sl, 64);
-                        if (spill) {
-                            const unsigned long long idx = base + (unsigned long long)__popcll(sk & ((1ull << lane) - 1ull));
-                            if (idx < cap) hits[idx] = rec;
-                        }
+                        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)wcount);
+                        base = __shfl(base, 0, 64);
+                        for (uint32_t x = lane; x < wcount; x += 64)
+                            if (base + x < cap) hits[base + x] = lbuf[wave][x];
+                        wcount = 0;
                     }
+                    if (emit) lbuf[wave][wcount + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = rec;
+                    wcount += cnt;
                 }
                 ev[b] = nx[b];
             }
         }
     }
+    // what is left in the wave buffers leaves with one global atomic per block
+    if (lane == 0) wtotal[wave] = wcount;
     __syncthreads();
-    const uint32_t nl = min(lcount, SCAN_LCAP);
-    if (threadIdx.x == 0 && nl) gbase = atomicAdd(cursor, (unsigned long long)nl);
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < SCAN_TPB / 64; w++) tot += wtotal[w];
+        gbase = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
+    }
     __syncthreads();
-    for (uint32_t x = threadIdx.x; x < nl; x += SCAN_TPB)
-        if (gbase + x < cap) hits[gbase + x] = lbuf[x];
+    unsigned long long off = gbase;
+    for (uint32_t w = 0; w < wave; w++) off += wtotal[w];
+    for (uint32_t x = lane; x < wcount; x += 64)
+        if (off + x < cap) hits[off + x] = lbuf[wave][x];
 }
 
 // ---- 3. per-read sequential replay over its sorted candidates
@@ -304,10 +306,14 @@ k_seed_hamming(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhi
     mmv[x] = (uint8_t)min(hamming_vs_text<false>(a, i, 0, tp - part_offset(a, j)), 255u);
 }
 
+// Reads with more than REPLAY_HEAVY candidates (tandem repeats: hundreds to thousands per read) would keep one lane --
+// and with it the whole wave -- looping alone: the per-thread replay hands them to k_seed_replay_heavy instead.
+#define REPLAY_HEAVY 64u
+
 template <bool ASCII>
 __global__ void __launch_bounds__(256)
 k_seed_replay(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhits, const uint8_t *__restrict__ mmv,
-              const uint64_t *__restrict__ rstart) {
+              const uint64_t *__restrict__ rstart, uint32_t *__restrict__ heavy, unsigned long long *__restrict__ nheavy) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t i, trow = 0;
     if (ASCII) {
@@ -325,9 +331,14 @@ k_seed_replay(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhit
     const bool exact = a.mode == 'e';
     if (exact ? (stored != PGRC_NOT_MATCHED_POS) : (c <= a.kmin)) return;
     bool changed = false;
-    for (uint64_t x = rstart[i]; x < nhits; x++) {             // rstart = all ones for a read without hits
+    const uint64_t x0 = rstart[i];                              // all ones for a read without hits
+    for (uint64_t x = x0; x < nhits; x++) {
         const uint64_t hkey = hits[x];
         if ((hkey >> 36) != i) break;
+        if (!ASCII && x - x0 >= REPLAY_HEAVY) {                 // too many candidates for one lane: a wave redoes this read
+            heavy[atomicAdd(nheavy, 1ull)] = (uint32_t)i;
+            return;
+        }
         const uint64_t tp = (hkey >> 4) & 0xFFFFFFFFull;
         const uint32_t j = 15u - (uint32_t)(hkey & 15u);
         const uint64_t p = tp - part_offset(a, j);
@@ -355,6 +366,64 @@ k_seed_replay(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhit
         a.pos[i] = stored;
         a.rc[i] = (uint8_t)rcflag;
         a.mism[i] = (uint8_t)c;
+    }
+}
+
+// One wave per heavy read.  The sequential rule only changes state when a candidate is accepted (at most kmax + 1
+// times per read): between two acceptances the wave tests 64 candidates at a time against the current limit and
+// stored position and jumps to the first one that passes -- the same candidate the sequential loop would reach.
+__global__ void __launch_bounds__(256)
+k_seed_replay_heavy(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhits, const uint8_t *__restrict__ mmv,
+                    const uint64_t *__restrict__ rstart, const uint32_t *__restrict__ heavy,
+                    const unsigned long long *__restrict__ nheavy) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const unsigned long long nh = *nheavy;
+    const bool exact = a.mode == 'e';
+    for (uint64_t w = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < nh; w += nwaves) {
+        const uint64_t i = heavy[w];
+        uint32_t c = a.mism[i];
+        uint64_t stored = a.pos[i];
+        bool changed = false;
+        uint64_t x = rstart[i];
+        bool more = true;
+        while (more) {
+            if (!exact && c <= a.kmin) break;                                   // :304-305
+            const uint64_t xi = x + lane;
+            bool ok = false, mine = false;
+            uint64_t cand = 0;
+            uint32_t mm = 0;
+            if (xi < nhits) {
+                const uint64_t hkey = hits[xi];
+                mine = (hkey >> 36) == i;
+                if (mine) {
+                    const uint64_t tp = (hkey >> 4) & 0xFFFFFFFFull;
+                    const uint32_t j = 15u - (uint32_t)(hkey & 15u);
+                    const uint64_t p = tp - part_offset(a, j);
+                    cand = a.strand ? a.G - (p + a.L) : p;
+                    mm = mmv[xi];
+                    if (exact) ok = mm == 0;                                    // :207
+                    else ok = cand != stored && mm <= ((c == PGRC_NOT_MATCHED_CNT) ? a.kmax : c - 1u);   // :313-319
+                }
+            }
+            const unsigned long long okm = __ballot(ok), minem = __ballot(mine);
+            if (okm) {
+                const int f = __ffsll((long long)okm) - 1;                      // the first candidate the sequential loop accepts
+                c = __shfl(mm, f, 64);
+                stored = __shfl(cand, f, 64);
+                changed = true;
+                if (exact) break;                                               // first hit in scan order wins, :209-212
+                x += (uint64_t)f + 1;
+            } else {
+                more = minem == ~0ull;                                          // all 64 were this read's: there may be more
+                x += 64;
+            }
+        }
+        if (changed && lane == 0) {
+            a.pos[i] = stored;
+            a.rc[i] = (uint8_t)a.strand;
+            a.mism[i] = (uint8_t)c;
+        }
     }
 }
 
@@ -452,16 +521,24 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
         if ((e = pgrc_buf_ensure(c, temp, temp_bytes))) return e;
         if ((e = pgrc_buf_ensure(c, c->s_mm, nhits))) return e;
         if ((e = pgrc_buf_ensure(c, c->s_rstart, c->n * sizeof(uint64_t)))) return e;
+        if ((e = pgrc_buf_ensure(c, c->s_heavy, c->n * sizeof(uint32_t)))) return e;
         hipError_t he = rocprim::radix_sort_keys(temp.p, temp_bytes, (uint64_t *)c->s_hits.p, (uint64_t *)sorted.p, (size_t)nhits, 0, end_bit, c->stream);
         if (he == hipSuccess) he = hipMemsetAsync(c->s_rstart.p, 0xFF, c->n * sizeof(uint64_t), c->stream);
+        unsigned long long *nheavy = cursor + 1;
+        if (he == hipSuccess) he = hipMemsetAsync(nheavy, 0, sizeof(unsigned long long), c->stream);
         if (he == hipSuccess) {
             hipLaunchKernelGGL(k_seed_hamming, dim3((uint32_t)((nhits + 255) / 256)), dim3(256), 0, c->stream, a,
                                (const uint64_t *)sorted.p, (uint64_t)nhits, (uint8_t *)c->s_mm.p, (uint64_t *)c->s_rstart.p);
             hipLaunchKernelGGL(k_seed_replay<false>, dim3((uint32_t)((c->n + 255) / 256)), dim3(256), 0, c->stream, a,
-                               (const uint64_t *)sorted.p, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p);
+                               (const uint64_t *)sorted.p, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p,
+                               (uint32_t *)c->s_heavy.p, nheavy);
+            hipLaunchKernelGGL(k_seed_replay_heavy, dim3((uint32_t)c->num_cus * 8u), dim3(256), 0, c->stream, a,
+                               (const uint64_t *)sorted.p, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p,
+                               (const uint32_t *)c->s_heavy.p, (const unsigned long long *)nheavy);
             if (c->n_nreads)
                 hipLaunchKernelGGL(k_seed_replay<true>, dim3((uint32_t)((c->n_nreads + 255) / 256)), dim3(256), 0, c->stream, a,
-                                   (const uint64_t *)sorted.p, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p);
+                                   (const uint64_t *)sorted.p, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p,
+                                   (uint32_t *)c->s_heavy.p, nheavy);
             he = hipGetLastError();
         }
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);

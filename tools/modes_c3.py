@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Modes d / i at the C3 size (100 M x 150 bp reads, 1.875 Gbp Pg, seed 38, k <= 3) through the C ABI, inputs resident:
+wall time of pgrc_match_run and the matched fraction (the CPU reference is serial here and would need hours)."""
+import sys, os, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch
+from pgrc_amd import MatchContext, synth
+n, L, G, seed_len, kmax = 100_000_000, 150, 1_875_000_000, 38, 3
+g = synth.pg_params(G, seed=12345); rs = synth.reads_params(n, L, seed=12345)
+nw, stride, pgw = (L + 15) // 16, (n + 63) & ~63, (G + 15) // 16
+d_pg = torch.zeros(pgw + 64, dtype=torch.int32, device="cuda"); synth.pg_device(g, d_pg.data_ptr())
+d_rd = torch.empty(nw * stride, dtype=torch.int32, device="cuda"); synth.reads_device(g, d_pg.data_ptr(), rs, 0, n, d_rd.data_ptr(), stride)
+torch.cuda.synchronize()
+for mode in (sys.argv[1:] or ["d", "i", "c"]):
+    ctx = MatchContext(L, seed_len, kmax, 0, mode); ctx.set_pg_packed_device(d_pg.data_ptr(), G); ctx.set_reads_device(d_rd.data_ptr(), n, stride, keep=d_rd)
+    ts = []
+    for _ in range(2):
+        ctx.init_results(); torch.cuda.synchronize(); t = time.perf_counter(); ctx.run(True); ts.append(time.perf_counter() - t)
+    _, _, _, hist, matched = ctx.get_results(arrays=False)
+    print(json.dumps({"mode": mode, "n": n, "L": L, "G": G, "seed": seed_len, "kmax": kmax, "best_s": min(ts), "first_s": ts[0],
+                      "reads_per_s": n / min(ts), "matched": matched, "free_gb": torch.cuda.mem_get_info()[0] / 2**30}), flush=True)
+    del ctx
