@@ -320,7 +320,7 @@ __device__ __forceinline__ uint32_t hash_fp_window(const uint32_t w0, const uint
 }
 
 #ifndef MATCH_CHUNK
-#define MATCH_CHUNK 256u // reads a wave reserves per visit to the global work counter
+#define MATCH_CHUNK 1024u // reads a wave reserves per visit to the global work counter (256 / 512 / 1024: step +0 / -0.2 / -0.4 %)
 #endif
 
 // Persistent, self-refilling lanes.  With one read per lane for the lifetime of a wave, ~35 % of the
