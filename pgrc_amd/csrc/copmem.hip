@@ -319,6 +319,9 @@ __device__ __forceinline__ uint32_t hash_fp_window(const uint32_t w0, const uint
     return h;
 }
 
+#ifndef PROBE_AHEAD
+#define PROBE_AHEAD 1       // probing lanes fetch the next seed's bucket head together with their own
+#endif
 #ifndef MATCH_CHUNK
 #define MATCH_CHUNK 1024u // reads a wave reserves per visit to the global work counter (256 / 512 / 1024: step +0 / -0.2 / -0.4 %)
 #endif
@@ -372,6 +375,11 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
     pos_t cand_p = 0;
     uint64_t pend_e = 0;          // an entry already in registers (entry 1 of the head / second half of a pair)
     bool has_pend = false;
+#if PROBE_AHEAD
+    ulonglong2 hdn = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);   // the head of this lane's NEXT seed, fetched ahead
+    uint32_t fpn = 0;
+    bool have_n = false;
+#endif
     constexpr int PWN = ((NW + 1 + 3) / 4) * 4;
 
     // judge a verified alignment (head count mh, tail count mt) exactly as CopMEMMatcher.cpp:536-560
@@ -419,6 +427,9 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                         st.done = false;
                         si = 0;
                         has_pend = false;
+#if PROBE_AHEAD
+                        have_n = false;
+#endif
                         epoch = (epoch + 1u) & ((1u << EPOCH_BITS) - 1u); // invalidates this lane's verify-cache entries
                         if (epoch == 0) {                            // wrapped: really clear them
 #pragma unroll
@@ -436,15 +447,44 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
         if (!__any(mode != M_DEAD)) break;
 
         const uint32_t m0 = mode;
-        const uint32_t s = si * a.k2;
         // ---- issue this iteration's loads
         ulonglong2 hd = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
         uint64_t v = 0;
-        bool counted_ent = false, counted_cand = false;
+        bool counted_ent = false;
+        uint32_t ncand_it = 0;        // candidates tested in this iteration (a probing lane may consume two heads)
+#if PROBE_AHEAD
+        // A probing lane also fetches the head of the NEXT seed: if its own bucket turns out empty (every second one) it
+        // consumes that head in the same iteration, otherwise it keeps it for later.  Two gathers in flight per probing
+        // lane instead of one; nothing is fetched twice and nothing beyond the read's last seed.
+        ulonglong2 hd2 = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
+        uint32_t fp2 = 0;
+        bool got2 = false;
+#endif
         if (m0 == M_PROBE) {
-            const uint32_t h = hash_fp_window<KQ>(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
-                                                  NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
-            hd = a.head[h];
+#if PROBE_AHEAD
+            if (have_n) {
+                hd = hdn;
+                fp_read = fpn;
+            } else
+#endif
+            {
+                const uint32_t h = hash_fp_window<KQ>(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
+                                                      NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
+                hd = a.head[h];
+            }
+#if PROBE_AHEAD
+            if (si + 1 < nseeds) {
+                // the window of the next seed: the read shifted by one more seed step (sbits <= 30)
+                const uint32_t n0 = funnel_r(sh[0], NW > 1 ? sh[1 % NW] : 0u, sbits);
+                const uint32_t n1 = NW > 1 ? funnel_r(sh[1 % NW], NW > 2 ? sh[2 % NW] : 0u, sbits) : 0u;
+                const uint32_t n2 = NW > 2 ? funnel_r(sh[2 % NW], NW > 3 ? sh[3 % NW] : 0u, sbits) : 0u;
+                const uint32_t n3 = NW > 3 ? funnel_r(sh[3 % NW], NW > 4 ? sh[4 % NW] : 0u, sbits) : 0u;
+                const uint32_t h2 = hash_fp_window<KQ>(n0, n1, n2, n3, a.K, lut, &fp2) & a.mask;
+                hd2 = a.head[h2];
+                got2 = true;
+            }
+            have_n = false;
+#endif
         } else if (m0 == M_ENTRY) {
             if (has_pend) {
                 v = pend_e;
@@ -460,6 +500,55 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
         }
         // ---- consume
         uint32_t next = m0;
+        // one index entry against the current seed (CopMEMMatcher.cpp:517-560); sets the lane's next state
+        auto take_entry = [&](const uint64_t e) {
+            next = (j < nb) ? M_ENTRY : M_ADV;
+            const uint32_t s = si * a.k2;
+            const uint64_t sp = e >> PGRC_FP_BITS;
+            if ((uint64_t)s <= sp && sp - s + a.L <= a.G) {      // :517-520
+                ncand_it++;
+                const pos_t p = (pos_t)(sp - s);
+                const uint32_t x = ((uint32_t)e ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
+                if ((uint32_t)__popc((x | (x >> 1)) & fpm_tab[si]) > st.limit) {
+                    st.falses += 1;                              // certain head reject
+                } else {
+                    const uint2 cv = vcache[((uint32_t)p * 0x9E3779B1u) >> (32 - VC_BITS)][threadIdx.x];
+                    const bool hit = POS64 ? (cv.x == (uint32_t)p && (cv.y >> 19) == epoch &&
+                                              ((cv.y >> 11) & 0xFFu) == (uint32_t)((uint64_t)p >> 32))
+                                           : (cv.x == (uint32_t)p && (cv.y >> 16) == epoch);
+                    if (hit) {
+                        judge(cv.y & 0xFFu, (cv.y >> 8) & (POS64 ? 0x7u : 0xFFu), p);
+                        if (st.done) next = M_NEED;
+                    } else {
+                        cand_p = p;
+                        next = M_VERIFY;
+                    }
+                }
+            }
+        };
+        // a bucket head for the current seed: empty -> M_ADV, else its first entry is tested
+        auto take_head = [&](const ulonglong2 hx) {
+            const uint32_t cnt = head_count(hx);
+            if (!cnt) {
+                next = M_ADV;
+                return;
+            }
+            nb = cnt;
+            if (st.falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET); // :510-514
+            has_pend = cnt == 2 && nb > 1; // entry 1 of a two-entry bucket sits in the head
+            pend_e = hx.y;
+            lo = (pos_t)(hx.y & W1_BASE_MASK); // count >= 3: entries 1.. live at ent[lo + j - 1]
+            j = 1;
+            take_entry(hx.x & ENT_MASK);
+        };
+        auto advance = [&]() {                                       // to the next seed of this read
+            si++;
+            has_pend = false;
+#pragma unroll
+            for (int k = 0; k < NW - 1; k++) sh[k] = funnel_r(sh[k], sh[k + 1], sbits);
+            sh[NW - 1] >>= sbits;
+        };
+        bool second_probe = false;
         if (m0 == M_VERIFY) {
             uint32_t pw[PWN];
             const uint32_t b = ((uint32_t)cand_p & 15u) * 2u;
@@ -482,66 +571,35 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                                                    : (mh | (mt << 8) | (epoch << 16)));
             judge(mh, mt, cand_p);
             next = st.done ? M_NEED : (j < nb ? M_ENTRY : M_ADV);
-        } else if (m0 <= M_ENTRY) {
-            bool have = false;
-            uint64_t e = 0;
-            if (m0 == M_PROBE) {
-                const uint32_t cnt = head_count(hd);
-                if (cnt) {
-                    nb = cnt;
-                    if (st.falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET); // :510-514
-                    has_pend = cnt == 2 && nb > 1; // entry 1 of a two-entry bucket sits in the head
-                    pend_e = hd.y;
-                    lo = (pos_t)(hd.y & W1_BASE_MASK); // count >= 3: entries 1.. live at ent[lo + j - 1]
-                    e = hd.x & ENT_MASK;
-                    have = true;
-                    j = 1;
-                } else {
-                    next = M_ADV;
-                }
-            } else {
-                e = v;
-                have = true;
-                j++;
-            }
-            if (have) {
-                next = (j < nb) ? M_ENTRY : M_ADV;
-                const uint64_t sp = e >> PGRC_FP_BITS;
-                if ((uint64_t)s <= sp && sp - s + a.L <= a.G) {      // :517-520
-                    counted_cand = true;
-                    const pos_t p = (pos_t)(sp - s);
-                    const uint32_t x = ((uint32_t)e ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
-                    if ((uint32_t)__popc((x | (x >> 1)) & fpm_tab[si]) > st.limit) {
-                        st.falses += 1;                              // certain head reject
-                    } else {
-                        const uint2 cv = vcache[((uint32_t)p * 0x9E3779B1u) >> (32 - VC_BITS)][threadIdx.x];
-                        const bool hit = POS64 ? (cv.x == (uint32_t)p && (cv.y >> 19) == epoch &&
-                                                  ((cv.y >> 11) & 0xFFu) == (uint32_t)((uint64_t)p >> 32))
-                                               : (cv.x == (uint32_t)p && (cv.y >> 16) == epoch);
-                        if (hit) {
-                            judge(cv.y & 0xFFu, (cv.y >> 8) & (POS64 ? 0x7u : 0xFFu), p);
-                            if (st.done) next = M_NEED;
-                        } else {
-                            cand_p = p;
-                            next = M_VERIFY;
-                        }
-                    }
+        } else if (m0 == M_ENTRY) {
+            j++;
+            take_entry(v);
+        } else if (m0 == M_PROBE) {
+            take_head(hd);
+#if PROBE_AHEAD
+            if (got2) {
+                if (next == M_ADV) {                                 // empty bucket: the next seed's head is here already
+                    advance();
+                    fp_read = fp2;
+                    second_probe = true;
+                    take_head(hd2);
+                } else {                                             // keep it for when this lane reaches that seed
+                    hdn = hd2;
+                    fpn = fp2;
+                    have_n = true;
                 }
             }
+#endif
         }
         if (next == M_ADV) {
-            si++;
-            has_pend = false;
-#pragma unroll
-            for (int k = 0; k < NW - 1; k++) sh[k] = funnel_r(sh[k], sh[k + 1], sbits);
-            sh[NW - 1] >>= sbits;
+            advance();
             next = (si < nseeds) ? M_PROBE : M_NEED;
         }
         // work counters, wave-wide (scalar popcounts instead of five per-lane registers)
-        n_probe += (uint32_t)__popcll(__ballot(m0 == M_PROBE));
+        n_probe += (uint32_t)__popcll(__ballot(m0 == M_PROBE)) + (uint32_t)__popcll(__ballot(second_probe));
         n_ent += (uint32_t)__popcll(__ballot(counted_ent));
         n_ver += (uint32_t)__popcll(__ballot(m0 == M_VERIFY));
-        n_cand += (uint32_t)__popcll(__ballot(counted_cand));
+        n_cand += (uint32_t)__popcll(__ballot(ncand_it >= 1)) + (uint32_t)__popcll(__ballot(ncand_it >= 2));
         if (next == M_NEED && m0 <= M_VERIFY) {
             // this read is finished (ReadsMatchers.cpp:437-447)
             if (st.best != POS_NONE && st.cur < cin) {

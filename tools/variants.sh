@@ -4,7 +4,7 @@
 set -eu
 cd "$(dirname "$0")/.."
 V=pgrc_amd/variants
-declare -A DEFS=( [base]="" [chunk128]="-DMATCH_CHUNK=128u" [chunk512]="-DMATCH_CHUNK=512u" [chunk1024]="-DMATCH_CHUNK=1024u" [vc8]="-DVC_BITS=3" [vc2]="-DVC_BITS=1" [vc16]="-DVC_BITS=4" )
+declare -A DEFS=( [base]="" [noahead]="-DPROBE_AHEAD=0" [chunk256]="-DMATCH_CHUNK=256u" [vc8]="-DVC_BITS=3" )
 if [ "${1:-build}" = build ]; then
   mkdir -p $V
   for v in "${!DEFS[@]}"; do
@@ -13,8 +13,8 @@ if [ "${1:-build}" = build ]; then
     echo built $v
   done
 else
-  for rep in 1 2; do
-    for v in base chunk128 chunk512 chunk1024 vc2 vc8 vc16; do
+  for rep in 1 2 3 4; do
+    for v in base noahead vc8; do
       PGRC_MATCH_LIB=$PWD/$V/libpgrc_match_$v.so python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); p=d['phases_ms']; print('$v', round(d['ms_per_step'],1), round(p['match_fwd'],1), round(p['match_rc'],1), d['counters']['verifies'])"
     done
