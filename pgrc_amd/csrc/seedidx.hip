@@ -465,7 +465,7 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
     // read-part table
     const uint64_t nent = c->n * a.P;
     uint64_t tsize = 1024;
-    while (tsize < 2 * nent) tsize <<= 1;
+    while (tsize < 2 * nent) tsize <<= 1;   // (4 * nent was tried: -1 % time for twice the memory)
     int e;
     if ((e = pgrc_buf_ensure(c, c->s_keys, tsize * sizeof(uint64_t)))) return e;
     if ((e = pgrc_buf_ensure(c, c->s_vals, tsize * sizeof(uint32_t)))) return e;
