@@ -105,6 +105,12 @@ def test_mem_errors():
     m = CopMEMMatcher(src, 45)
     with pytest.raises(PgrcMatchError):
         m.matchTexts(other, False, False, 20)        # minMatchLength < K (:606-609)
+    with pytest.raises(PgrcMatchError):
+        m.matchTexts(other, True, True)              # dest_is_src with a text of another length
+    with pytest.raises(PgrcMatchError) as e:
+        CopMEMMatcher(np.frombuffer(b"ACGTNACGT" * 20, dtype=np.uint8), 45)   # the source must be over ACGT
+    assert e.value.code == 5
+    assert len(m.matchTexts(other[:10], False, True)) == 0                    # shorter than K: no window, no match
     bad = other.copy()
     bad[100] = ord("%")
     with pytest.raises(PgrcMatchError) as e:
