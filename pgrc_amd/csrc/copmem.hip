@@ -621,31 +621,85 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
     }
 }
 
-// Byte path for reads containing 'N' (the reference's N read set, ACGNT-packed; an N never equals a
-// Pg symbol and is hashed as the byte 0x4E -- SURVEY.md Appendix A notes).  One read per lane.
-__global__ void __launch_bounds__(MATCH_TPB)
-k_copmem_match_ascii(const MatchArgs a, const uint32_t *__restrict__ nidx, const uint8_t *__restrict__ nascii, uint64_t nn) {
-    const uint64_t t = (uint64_t)blockIdx.x * MATCH_TPB + threadIdx.x;
+// Reads containing 'N' (the reference's N read set, ACGNT-packed; an N never equals a Pg symbol and is hashed as the
+// byte 0x4E -- SURVEY.md Appendix A notes).  One read per lane, plain loops (they are a percent or two of the reads),
+// but on the same packed representation as the main kernel: the read as 2-bit words (N packs as code 0) plus a 16-bit
+// mask of its N positions per word, both in LDS.  Windows without an N hash through the LUT and use the fingerprint
+// shortcut exactly like k_copmem_match_sm; windows with an N rebuild the ASCII bytes for the hash and always verify.
+#define NREAD_TPB 128
+__global__ void __launch_bounds__(NREAD_TPB)
+k_copmem_match_n(const MatchArgs a, const uint32_t *__restrict__ nidx, const uint8_t *__restrict__ nascii, uint64_t nn) {
+    __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
+    __shared__ uint32_t rdw[PGRC_MAX_NW + 1][NREAD_TPB];   // packed read (+ one zero word: windows read one word ahead)
+    __shared__ uint32_t nmw[PGRC_MAX_NW + 1][NREAD_TPB];   // bit k of word w: symbol 16 w + k is an N
+    hash_lut_init(lut);
+    const uint64_t t = (uint64_t)blockIdx.x * NREAD_TPB + threadIdx.x;
     bool active = t < nn;
-    uint64_t i = active ? nidx[t] : 0;
-    uint32_t cin = active ? a.mism[i] : 0u;
-    if (cin <= a.kmin) active = false;
+    const uint64_t i = active ? nidx[t] : 0;
+    const uint32_t cin = active ? a.mism[i] : 0u;
+    if (cin <= a.kmin) active = false;                       // ReadsMatchers.cpp:430
+    const uint32_t NWr = (a.L + 15) / 16;
+    for (uint32_t w = 0; w <= NWr; w++) {
+        uint32_t pw = 0, nm = 0;
+        if (active && w < NWr) {
+            const uint8_t *row = nascii + t * a.L + 16 * w;
+            for (uint32_t k = 0; k < 16 && 16 * w + k < a.L; k++) {
+                const uint32_t ch = row[k];
+                uint32_t x = (ch >> 1) & 3u;
+                x ^= x >> 1;                                 // A0 C1 G2 T3
+                if (ch == 'N') { nm |= 1u << k; x = 0; }
+                pw |= x << (2 * k);
+            }
+        }
+        rdw[w][threadIdx.x] = pw;
+        nmw[w][threadIdx.x] = nm;
+    }
+    __syncthreads();
     uint64_t n_cand = 0, n_probe = 0;
     if (active) {
-        const uint8_t *rd = nascii + t * a.L;
-        const uint32_t H = (a.L / 8) * 8;
-        uint32_t limit = (cin < a.kmax) ? cin - 1u : a.kmax;
+        const int H = ((int)a.L / 8) * 8;
+        uint32_t limit = (cin < a.kmax) ? cin - 1u : a.kmax;  // :488-489
         const uint32_t budget = (a.L + 1u - a.K) / a.k2;
         uint32_t falses = 0, cur = cin;
         uint64_t best = PGRC_NOT_MATCHED_POS;
         bool done = false;
         for (uint32_t s = 0; s + a.K <= a.L && !done; s += a.k2) {
-            uint32_t h = a.K;
-            for (uint32_t j = 0; j < a.K / 4; j++) {
-                const uint8_t *q = rd + s + 4 * j;
-                uint32_t w = (uint32_t)q[0] | ((uint32_t)q[1] << 8);
-                if (j < 3) w |= (uint32_t)q[2] << 16;
-                h = (h ^ (w + j)) * 171717u;
+            // the K-symbol window at s: four words of symbols and their N flags
+            const uint32_t q = s >> 4, sh2 = (s & 15u) * 2u, sh1 = s & 15u;
+            uint32_t ww[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t lo0 = (q + k <= NWr) ? rdw[q + k][threadIdx.x] : 0u, hi0 = (q + k + 1 <= NWr) ? rdw[q + k + 1][threadIdx.x] : 0u;
+                ww[k] = funnel_r(lo0, hi0, sh2);
+            }
+            // N flags of symbols s .. s+K-1 (K <= 56): bit x = symbol s + x
+            uint64_t nbits = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (q + k <= NWr) nbits |= (uint64_t)(nmw[q + k][threadIdx.x] & 0xFFFFu) << (16 * k);
+            if (sh1) {
+                const uint64_t top = (q + 4 <= NWr) ? (uint64_t)(nmw[q + 4][threadIdx.x] & 0xFFFFu) : 0ull;
+                nbits = (nbits >> sh1) | (top << (64 - sh1));
+            }
+            nbits &= (1ull << a.K) - 1ull;
+            const bool wn = nbits != 0;                        // the window holds an N
+            uint32_t fp_read = 0, h;
+            if (!wn) {
+                h = copmem_hash32_fp(ww[0], ww[1], ww[2], ww[3], a.K, lut, &fp_read);
+            } else {
+                // ASCII bytes of the window for maRushPrime1HashSparsified (Hashes.h:54-76): an N is the byte 0x4E
+                h = a.K;
+                for (uint32_t j = 0; j < a.K / 4; j++) {
+                    uint32_t w = 0;
+                    const uint32_t nby = (j < 3) ? 3u : 2u;
+                    for (uint32_t b = 0; b < nby; b++) {
+                        const uint32_t x = 4 * j + b;
+                        const uint32_t wsel = x < 16 ? ww[0] : x < 32 ? ww[1] : x < 48 ? ww[2] : ww[3];
+                        const uint32_t code = (wsel >> (2u * (x & 15u))) & 3u;
+                        w |= (((nbits >> x) & 1ull) ? (uint32_t)'N' : code2ascii(code)) << (8 * b);
+                    }
+                    h = (h ^ (w + j)) * 171717u;
+                }
             }
             h &= a.mask;
             n_probe++;
@@ -653,24 +707,39 @@ k_copmem_match_ascii(const MatchArgs a, const uint32_t *__restrict__ nidx, const
             const uint32_t cnt = head_count(hd);
             if (!cnt) continue;
             uint32_t nb = cnt;
-            if (falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET);
+            if (falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET);          // :510-514
+            const uint32_t fpm = wn ? 0u : fp_head_mask(a.K, s, (uint32_t)H);
             for (uint32_t j = 0; j < nb; j++) {
                 const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (cnt == 2 ? hd.y : a.ent[(hd.y & W1_BASE_MASK) + j - 1]);
                 const uint64_t sp = e >> PGRC_FP_BITS;
-                if ((uint64_t)s > sp) continue;
+                if ((uint64_t)s > sp) continue;                                 // :517-520
                 const uint64_t p = sp - s;
                 if (p + a.L > a.G) continue;
                 n_cand++;
-                uint32_t mh = 0, mt = 0;
-                for (uint32_t k = 0; k < a.L; k++) {
-                    const uint64_t x = p + k;
-                    const uint32_t code = (a.pg[x >> 4] >> (2u * ((uint32_t)x & 15u))) & 3u;
-                    const uint32_t ne = code2ascii(code) != (uint32_t)rd[k];
-                    if (k < H) mh += ne; else mt += ne;
+                if (!wn) {                                                      // certain head reject, as in k_copmem_match_sm
+                    const uint32_t x = ((uint32_t)e ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
+                    if ((uint32_t)__popc((x | (x >> 1)) & fpm) > limit) { falses += 1; continue; }
                 }
-                if (mh > limit) { falses += 1; continue; }
+                uint32_t mh = 0, mt = 0;
+                const uint32_t *src = a.pg + (p >> 4);
+                const uint32_t b = ((uint32_t)p & 15u) * 2u;
+                uint32_t lo = src[0];
+                for (uint32_t k = 0; k < NWr; k++) {
+                    const uint32_t hi = src[k + 1];
+                    const uint32_t x = funnel_r(lo, hi, b) ^ rdw[k][threadIdx.x];
+                    uint32_t nmb = nmw[k][threadIdx.x];                         // bit i -> bit 2 i
+                    nmb = (nmb | (nmb << 8)) & 0x00FF00FFu;
+                    nmb = (nmb | (nmb << 4)) & 0x0F0F0F0Fu;
+                    nmb = (nmb | (nmb << 2)) & 0x33333333u;
+                    nmb = (nmb | (nmb << 1)) & 0x55555555u;
+                    const uint32_t d = (x | (x >> 1) | nmb);
+                    mh += (uint32_t)__popc(d & sym_mask((int)k, 0, H));
+                    mt += (uint32_t)__popc(d & sym_mask((int)k, H, (int)a.L));
+                    lo = hi;
+                }
+                if (mh > limit) { falses += 1; continue; }                      // :536-539
                 const uint32_t m = mh + mt;
-                if (m > limit) { falses += 2; continue; }
+                if (m > limit) { falses += 2; continue; }                       // :542-551 (counted twice)
                 cur = m;
                 best = p;
                 if (m <= a.kmin) { done = true; break; }
@@ -746,8 +815,8 @@ int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
     }
     HIP_TRY(c, hipGetLastError());
     if (c->n_nreads) {
-        const uint32_t grid = (uint32_t)((c->n_nreads + MATCH_TPB - 1) / MATCH_TPB);
-        hipLaunchKernelGGL(k_copmem_match_ascii, dim3(grid), dim3(MATCH_TPB), 0, c->stream, a,
+        const uint32_t grid = (uint32_t)((c->n_nreads + NREAD_TPB - 1) / NREAD_TPB);
+        hipLaunchKernelGGL(k_copmem_match_n, dim3(grid), dim3(NREAD_TPB), 0, c->stream, a,
                            (const uint32_t *)c->nread_idx.p, (const uint8_t *)c->nread_ascii.p, c->n_nreads);
         HIP_TRY(c, hipGetLastError());
     }
