@@ -531,7 +531,7 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) { m->err = std::string("probe kernel: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
         if (nev <= cap) break;
-        cap = nev;                                          // the guess was too small: once more with the exact size
+        cap = nev + nev / 4;                                // the guess was too small: once more, with headroom for the next call
     }
     (void)hipEventRecord(ev[1], c->stream);
     m->ctr.events = nev;

@@ -505,7 +505,8 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
             HIP_TRY(c, hipMemcpyAsync(&nhits, cursor, sizeof nhits, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (nhits <= cap) break;
-            cap = nhits;                                    // the guess was too small: once more with the exact size
+            cap = nhits + nhits / 4;                        // the guess was too small: once more, with headroom for the other strand
+                                                            // (growing these multi-GB buffers again costs more than the pass itself)
         }
         if (nhits == 0) continue;
         int ibits = 1, tbits = 1;                           // only the key bits that can be set take part in the sort
@@ -514,12 +515,12 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
         const int end_bit = 36 + ibits;
         (void)tbits;
         size_t temp_bytes = 0;
-        HIP_TRY(c, rocprim::radix_sort_keys(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)nhits, 0, end_bit, c->stream));
+        HIP_TRY(c, rocprim::radix_sort_keys(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)cap, 0, end_bit, c->stream));
         // scratch lives in the context (grow-only): no hipMalloc / hipFree (= device synchronisation) per pass
         DevBuf &sorted = c->s_sorted, &temp = c->s_sorttmp;
-        if ((e = pgrc_buf_ensure(c, sorted, nhits * sizeof(uint64_t)))) return e;
+        if ((e = pgrc_buf_ensure(c, sorted, cap * sizeof(uint64_t)))) return e;       // sized like the hit buffer: no regrow
         if ((e = pgrc_buf_ensure(c, temp, temp_bytes))) return e;
-        if ((e = pgrc_buf_ensure(c, c->s_mm, nhits))) return e;
+        if ((e = pgrc_buf_ensure(c, c->s_mm, cap))) return e;
         if ((e = pgrc_buf_ensure(c, c->s_rstart, c->n * sizeof(uint64_t)))) return e;
         if ((e = pgrc_buf_ensure(c, c->s_heavy, c->n * sizeof(uint32_t)))) return e;
         hipError_t he = rocprim::radix_sort_keys(temp.p, temp_bytes, (uint64_t *)c->s_hits.p, (uint64_t *)sorted.p, (size_t)nhits, 0, end_bit, c->stream);
