@@ -110,8 +110,15 @@ namespace PgTools {
             std::vector<uint8_t> rc(deviceReads);
             failOn(pgrc_match_get_results(ctx, readMatchPos.data(), rc.data(), readMismatchesCount.data(), hist,
                                           &matched), "get_results");
-            for (uint_reads_cnt_max i = 0; i < deviceReads; i++)
-                readMatchRC[i] = rc[i] != 0;
+            // vector<bool> is bit-packed: threads may only share it along 64-bit word boundaries (the reference's own
+            // parallel loop does not respect that, ReadsMatchers.cpp:426-446)
+            const uint64_t chunk = 64u * 4096u, total = deviceReads;
+            #pragma omp parallel for schedule(static)
+            for (uint64_t c0 = 0; c0 < total; c0 += chunk) {
+                const uint64_t c1 = std::min<uint64_t>(c0 + chunk, total);
+                for (uint64_t i = c0; i < c1; i++)
+                    readMatchRC[i] = rc[i] != 0;
+            }
         }
         for (uint_reads_cnt_max i = deviceReads; i < readsCount; i++) {   // reads that never went to the device
             hist[readMismatchesCount[i]]++;
