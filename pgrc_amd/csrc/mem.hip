@@ -13,7 +13,8 @@
 //   1. k_mem_probe   : every destination window in parallel -- hash, ONE 16-byte head gather, fingerprint reject,
 //                      exact K-mer compare -- emits the equal pairs ("events") after filter (a);
 //   2. rocPRIM sort  : events by (window, bucket order) = the order the reference meets them;
-//   3. k_mem_extend  : per event the side-context test (c) and the maximal extension (d), word-parallel on 2-bit text;
+//   3. k_mem_flags .. k_mem_apply : the side-context test (c) per event; the maximal extension (d) once per RUN of
+//                      events that one match produces on its diagonal (linear in the text, however long the match);
 //   4. host          : one pass over the events replays (b), the jumps (which never leave a block of 256 windows in
 //                      the main loop, :365-424, but carry through in the tail loop, :428-476) and the acceptance.
 // The side-context registers l1/r1/l2/r2 are refreshed only when their 4 bytes lie inside the text (:381-382,
@@ -29,6 +30,7 @@
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "ctx.h"
 #include "devutil.h"
@@ -43,6 +45,7 @@ struct pgrc_mem_ctx {
     uint64_t N = 0;
     bool have_src = false;
     DevBuf d_dest, d_nmap, d_stage, d_flag, d_cursor, d_evk[2], d_evv[2], d_tmp, d_ostart, d_olen, d_oflag;
+    DevBuf d_skey[2], d_sidx[2], d_first, d_runid, d_rstart, d_rend;   // events by (diagonal, window): sort ping-pong, runs
     // pinned, grow-only host mirrors of the event arrays (a std::vector would zero-fill gigabytes per call)
     struct HostBuf { void *p = nullptr; size_t bytes = 0; } h_key, h_pos, h_start, h_len, h_flag;
     hipEvent_t ev[4]{};               // phase timing (created on first use)
@@ -216,10 +219,15 @@ k_mem_probe(const MemArgs a, unsigned long long *cursor, uint64_t *__restrict__ 
 #define MF_L_EQ 16u    // both left contexts fresh and equal
 #define MF_R_EQ 32u
 
-// 3. one thread per event: side-context test and maximal extension
+// 3. side contexts and extensions.  Every event of one maximal match (same diagonal, connected by equal symbols) has the
+// same extents, and a long match carries one event per lcm(k1, k2) symbols: extending each of them separately would be
+// quadratic in the match length (a 10 Mbp duplicate: 10^12 symbol compares).  So the events are ordered by (diagonal,
+// window) once, neighbours on a diagonal are tested for being CONNECTED (only the gap between their K-mers is
+// compared, usually nothing: the K-mers overlap), a prefix sum numbers the runs, the first event of a run extends to
+// the left, the last one to the right, and everybody takes its run's extents: linear in the text.
 __global__ void __launch_bounds__(256)
-k_mem_extend(const MemArgs a, const uint64_t *__restrict__ evk, const uint64_t *__restrict__ evv, uint64_t nev,
-             uint64_t *__restrict__ ostart, uint64_t *__restrict__ olen, uint8_t *__restrict__ oflag) {
+k_mem_flags(const MemArgs a, const uint64_t *__restrict__ evk, const uint64_t *__restrict__ evv, uint64_t nev,
+            uint8_t *__restrict__ oflag, uint64_t *__restrict__ qkey, uint64_t *__restrict__ idx) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nev) return;
     const uint64_t q = (evk[i] >> 4) * a.k2, p = evv[i];
@@ -230,32 +238,96 @@ k_mem_extend(const MemArgs a, const uint64_t *__restrict__ evk, const uint64_t *
     if (q + a.KLK24 + 4 <= a.N2) fl |= MF_R2_OK;
     if ((fl & (MF_L1_OK | MF_L2_OK)) == (MF_L1_OK | MF_L2_OK) && (diff16(a, p - a.LK2, q - a.LK2) & 0xFFu) == 0) fl |= MF_L_EQ;
     if ((fl & (MF_R1_OK | MF_R2_OK)) == (MF_R1_OK | MF_R2_OK) && (diff16(a, p + a.KLK24, q + a.KLK24) & 0xFFu) == 0) fl |= MF_R_EQ;
-    // right: symbols after the K-mer, up to the first difference or either text end (:405-407)
-    const uint64_t rlim = min(a.N - (p + a.K), a.N2 - (q + a.K));
-    uint64_t r = 0;
-    while (r < rlim) {
-        const uint32_t d = diff16(a, p + a.K + r, q + a.K + r);
-        if (d) { r += (uint32_t)(__ffs((int)d) - 1) >> 1; break; }
-        r += 16;
-    }
-    r = min(r, rlim);
-    // left: symbols before the K-mer (:409-411); the loop of the reference stops ON symbol 0 without consuming it
-    const uint64_t llim = min(p, q);
-    uint64_t s = 0;
-    bool mism = false;
-    while (llim - s >= 16) {
-        const uint32_t d = diff16(a, p - s - 16, q - s - 16);
-        if (d) { s += (uint32_t)__clz((int)d) >> 1; mism = true; break; }
-        s += 16;
-    }
-    while (!mism && s < llim) {
-        if (diff16(a, p - s - 1, q - s - 1) & 1u) mism = true;
-        else s++;
-    }
-    const uint64_t start = mism ? p - s : p - s + 1;      // first source symbol of the match as the reference reports it
-    ostart[i] = start;
-    olen[i] = p + a.K + r - start;
     oflag[i] = (uint8_t)fl;
+    qkey[i] = q;
+    idx[i] = i;
+}
+
+// diagonal of event idx[k] (offset by N so that it is not negative), as the key of the second, stable sort
+__global__ void __launch_bounds__(256)
+k_mem_diag(const MemArgs a, const uint64_t *__restrict__ evk, const uint64_t *__restrict__ evv, const uint64_t *__restrict__ idx,
+           uint64_t nev, uint64_t *__restrict__ dkey) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nev) return;
+    const uint64_t i = idx[k];
+    dkey[k] = (evk[i] >> 4) * a.k2 + a.N - evv[i];
+}
+
+// first[k] = 1 when event idx[k] starts a new run: another diagonal, or a difference in the gap to its predecessor
+__global__ void __launch_bounds__(256)
+k_mem_connect(const MemArgs a, const uint64_t *__restrict__ evk, const uint64_t *__restrict__ evv, const uint64_t *__restrict__ idx,
+              const uint64_t *__restrict__ dkey, uint64_t nev, uint32_t *__restrict__ first) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nev) return;
+    uint32_t f = 1;
+    if (k > 0 && dkey[k] == dkey[k - 1]) {
+        const uint64_t i = idx[k], j = idx[k - 1];
+        const uint64_t q1 = (evk[i] >> 4) * a.k2, p1 = evv[i];
+        const uint64_t q0 = (evk[j] >> 4) * a.k2, p0 = evv[j];      // q0 < q1 (sorted by window within the diagonal)
+        bool same = true;
+        for (uint64_t g = q0 + a.K; g < q1 && same; g += 16) {       // the symbols between the two K-mers, if any
+            uint32_t d = diff16(a, p0 + (g - q0), g);
+            if (q1 - g < 16) d &= (1u << (2 * (uint32_t)(q1 - g))) - 1u;
+            same = d == 0;
+        }
+        (void)p1;
+        f = same ? 0u : 1u;
+    }
+    first[k] = f;
+}
+
+// the first event of a run finds the match start, the last one the match end (runid = inclusive sum of first[] - 1)
+__global__ void __launch_bounds__(256)
+k_mem_run_ends(const MemArgs a, const uint64_t *__restrict__ evk, const uint64_t *__restrict__ evv, const uint64_t *__restrict__ idx,
+               const uint32_t *__restrict__ first, const uint32_t *__restrict__ runid, uint64_t nev,
+               uint64_t *__restrict__ run_start, uint64_t *__restrict__ run_end) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nev) return;
+    const bool leader = first[k] != 0, tail = (k + 1 == nev) || first[k + 1] != 0;
+    if (!leader && !tail) return;
+    const uint64_t i = idx[k];
+    const uint64_t q = (evk[i] >> 4) * a.k2, p = evv[i];
+    const uint32_t r = runid[k] - 1u;
+    if (tail) {
+        // right: symbols after the K-mer, up to the first difference or either text end (:405-407)
+        const uint64_t rlim = min(a.N - (p + a.K), a.N2 - (q + a.K));
+        uint64_t x = 0;
+        while (x < rlim) {
+            const uint32_t d = diff16(a, p + a.K + x, q + a.K + x);
+            if (d) { x += (uint32_t)(__ffs((int)d) - 1) >> 1; break; }
+            x += 16;
+        }
+        run_end[r] = p + a.K + min(x, rlim);                         // source position after the match
+    }
+    if (leader) {
+        // left: symbols before the K-mer (:409-411); the loop of the reference stops ON symbol 0 without consuming it
+        const uint64_t llim = min(p, q);
+        uint64_t s = 0;
+        bool mism = false;
+        while (llim - s >= 16) {
+            const uint32_t d = diff16(a, p - s - 16, q - s - 16);
+            if (d) { s += (uint32_t)__clz((int)d) >> 1; mism = true; break; }
+            s += 16;
+        }
+        while (!mism && s < llim) {
+            if (diff16(a, p - s - 1, q - s - 1) & 1u) mism = true;
+            else s++;
+        }
+        // first source symbol of the match as the reference reports it: the same number for every event of the run
+        // (they all walk left to the same stop)
+        run_start[r] = mism ? p - s : p - s + 1;
+    }
+}
+
+// every event takes the extents of its run
+__global__ void __launch_bounds__(256)
+k_mem_apply(const uint64_t *__restrict__ idx, const uint32_t *__restrict__ runid, const uint64_t *__restrict__ run_start,
+            const uint64_t *__restrict__ run_end, uint64_t nev, uint64_t *__restrict__ ostart, uint64_t *__restrict__ olen) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nev) return;
+    const uint32_t r = runid[k] - 1u;
+    ostart[idx[k]] = run_start[r];
+    olen[idx[k]] = run_end[r] - run_start[r];
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -396,7 +468,8 @@ int pgrc_mem_create(uint32_t target_len, uint32_t ctor_min_len, int32_t device, 
 void pgrc_mem_destroy(pgrc_mem_ctx *m) {
     if (!m) return;
     DevBuf *bufs[] = {&m->d_dest, &m->d_nmap, &m->d_stage, &m->d_flag, &m->d_cursor, &m->d_evk[0], &m->d_evk[1], &m->d_evv[0],
-                      &m->d_evv[1], &m->d_tmp, &m->d_ostart, &m->d_olen, &m->d_oflag};
+                      &m->d_evv[1], &m->d_tmp, &m->d_ostart, &m->d_olen, &m->d_oflag, &m->d_skey[0], &m->d_skey[1], &m->d_sidx[0],
+                      &m->d_sidx[1], &m->d_first, &m->d_runid, &m->d_rstart, &m->d_rend};
     for (DevBuf *b : bufs) pgrc_buf_free(*b);
     if (m->have_ev)
         for (auto &x : m->ev) (void)hipEventDestroy(x);
@@ -551,13 +624,46 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
         if (he == hipSuccess && (e = pgrc_buf_ensure(c, m->d_tmp, tbytes + 16))) { m->err = c->err; return e; }
         if (he == hipSuccess) he = rocprim::radix_sort_pairs(m->d_tmp.p, tbytes, keys, vals, (size_t)nev, 0, 4 + tb, c->stream);
         (void)hipEventRecord(ev[2], c->stream);
-        // ---- 3. side contexts and extensions
-        if (he == hipSuccess && ((e = pgrc_buf_ensure(c, m->d_ostart, nev * 8)) || (e = pgrc_buf_ensure(c, m->d_olen, nev * 8)) ||
-                                 (e = pgrc_buf_ensure(c, m->d_oflag, nev)))) { m->err = c->err; return e; }
+        // ---- 3. side contexts; extents per run of connected events on a diagonal
+        if (nev >= (1ull << 32)) { m->err = "more than 2^32 events"; return PGRC_E_PARAM; }
+        if (he == hipSuccess && ((e = pgrc_buf_ensure(c, m->d_ostart, cap * 8)) || (e = pgrc_buf_ensure(c, m->d_olen, cap * 8)) ||
+                                 (e = pgrc_buf_ensure(c, m->d_oflag, cap)) || (e = pgrc_buf_ensure(c, m->d_first, cap * 4)) ||
+                                 (e = pgrc_buf_ensure(c, m->d_runid, cap * 4)) || (e = pgrc_buf_ensure(c, m->d_rstart, cap * 8)) ||
+                                 (e = pgrc_buf_ensure(c, m->d_rend, cap * 8)))) { m->err = c->err; return e; }
+        for (int k = 0; k < 2 && he == hipSuccess; k++)
+            if ((e = pgrc_buf_ensure(c, m->d_skey[k], cap * 8)) || (e = pgrc_buf_ensure(c, m->d_sidx[k], cap * 8))) { m->err = c->err; return e; }
         if (he == hipSuccess) {
-            hipLaunchKernelGGL(k_mem_extend, dim3((uint32_t)((nev + 255) / 256)), dim3(256), 0, c->stream, a, (const uint64_t *)keys.current(),
-                               (const uint64_t *)vals.current(), (uint64_t)nev, (uint64_t *)m->d_ostart.p, (uint64_t *)m->d_olen.p, (uint8_t *)m->d_oflag.p);
-            he = hipGetLastError();
+            const uint32_t g = (uint32_t)((nev + 255) / 256);
+            const uint64_t *ek = (const uint64_t *)keys.current(), *ep = (const uint64_t *)vals.current();
+            rocprim::double_buffer<uint64_t> sk((uint64_t *)m->d_skey[0].p, (uint64_t *)m->d_skey[1].p);
+            rocprim::double_buffer<uint64_t> si((uint64_t *)m->d_sidx[0].p, (uint64_t *)m->d_sidx[1].p);
+            hipLaunchKernelGGL(k_mem_flags, dim3(g), dim3(256), 0, c->stream, a, ek, ep, (uint64_t)nev, (uint8_t *)m->d_oflag.p, sk.current(), si.current());
+            int qb = 1, db = 1;
+            while ((1ull << qb) < N2) qb++;
+            while ((1ull << db) < N2 + m->N) db++;
+            size_t t1 = 0, t2 = 0, t3 = 0;
+            he = rocprim::radix_sort_pairs(nullptr, t1, sk, si, (size_t)nev, 0, qb, c->stream);
+            if (he == hipSuccess) he = rocprim::radix_sort_pairs(nullptr, t2, sk, si, (size_t)nev, 0, db, c->stream);
+            if (he == hipSuccess) he = rocprim::inclusive_scan(nullptr, t3, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)nev, rocprim::plus<uint32_t>(), c->stream);
+            if (he == hipSuccess && (e = pgrc_buf_ensure(c, m->d_tmp, std::max(std::max(t1, t2), std::max(t3, tbytes)) + 16))) { m->err = c->err; return e; }
+            // stable sorts: by window first, then by diagonal => (diagonal, window)
+            if (he == hipSuccess) he = rocprim::radix_sort_pairs(m->d_tmp.p, t1, sk, si, (size_t)nev, 0, qb, c->stream);
+            if (he == hipSuccess) {
+                hipLaunchKernelGGL(k_mem_diag, dim3(g), dim3(256), 0, c->stream, a, ek, ep, (const uint64_t *)si.current(), (uint64_t)nev, sk.current());
+                he = rocprim::radix_sort_pairs(m->d_tmp.p, t2, sk, si, (size_t)nev, 0, db, c->stream);
+            }
+            if (he == hipSuccess) {
+                const uint64_t *sidx = si.current(), *skey = sk.current();
+                hipLaunchKernelGGL(k_mem_connect, dim3(g), dim3(256), 0, c->stream, a, ek, ep, sidx, skey, (uint64_t)nev, (uint32_t *)m->d_first.p);
+                he = rocprim::inclusive_scan(m->d_tmp.p, t3, (uint32_t *)m->d_first.p, (uint32_t *)m->d_runid.p, (size_t)nev, rocprim::plus<uint32_t>(), c->stream);
+                if (he == hipSuccess) {
+                    hipLaunchKernelGGL(k_mem_run_ends, dim3(g), dim3(256), 0, c->stream, a, ek, ep, sidx, (const uint32_t *)m->d_first.p,
+                                       (const uint32_t *)m->d_runid.p, (uint64_t)nev, (uint64_t *)m->d_rstart.p, (uint64_t *)m->d_rend.p);
+                    hipLaunchKernelGGL(k_mem_apply, dim3(g), dim3(256), 0, c->stream, sidx, (const uint32_t *)m->d_runid.p, (const uint64_t *)m->d_rstart.p,
+                                       (const uint64_t *)m->d_rend.p, (uint64_t)nev, (uint64_t *)m->d_ostart.p, (uint64_t *)m->d_olen.p);
+                    he = hipGetLastError();
+                }
+            }
         }
         (void)hipEventRecord(ev[3], c->stream);
         if (he == hipSuccess) he = hipMemcpyAsync(m->h_key.p, keys.current(), nev * 8, hipMemcpyDeviceToHost, c->stream);

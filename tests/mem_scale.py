@@ -46,6 +46,8 @@ def main():
             dest, dis, rc = src, 1, 0
         elif case == "rc":       # what the encoder runs on the HQ Pg (SimplePgMatcher.cpp:31-34)
             dest, dis, rc = orc.revcomp_ascii(src), 1, 1
+        elif case == "long":     # ONE 20 Mbp exact copy of the source: 1.7 M events that all belong to the same match
+            dest, dis, rc = src[G // 5: G // 5 + 20_000_000].copy(), 0, 1
         else:                    # an "LQ pseudogenome" that is the reverse complement of a slice of the source with a
             rng = np.random.default_rng(3)   # substitution every ~700 symbols: the text handed over is the slice (:36-38)
             sl = src[G // 3: G // 3 + a.lq_len].copy()

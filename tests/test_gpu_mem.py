@@ -90,6 +90,30 @@ def test_mem_reference_adapter_drop_in():
         assert len(r) > 20 and np.array_equal(a, r), (dest_is_src, rev_compl)
 
 
+def test_mem_long_matches():
+    """Matches of 50-150 kbp (thousands of events each, all with the same extents): the run-based extension must give
+    what the reference's per-event extension gives."""
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    src = rng.choice(acgt, size=500000)
+    src[300000:360000] = src[20000:80000]                      # a 60 kbp forward duplicate inside the source
+    src[400000:450000] = orc.revcomp_ascii(src[100000:150000])  # and a 50 kbp reverse-complement one
+    other = rng.choice(acgt, size=260000)
+    other[5000:155000] = src[200000:350000]                    # a 150 kbp copy (spans the internal duplicate)
+    other[160000:250000] = orc.revcomp_ascii(src[10000:100000])
+    other[100000] = ord("N") if other[100000] != ord("N") else ord("A")   # an N splits the long copy
+    from pgrc_amd import CopMEMMatcher
+    m = CopMEMMatcher(src, 45)
+    for dest_is_src, rev_compl in COMBOS:
+        d = orc.mem_dest(src, other, dest_is_src, rev_compl)
+        g = m.matchTexts(d, dest_is_src, rev_compl)
+        o = orc.oracle_mem_match(src, d, dest_is_src, rev_compl)
+        assert np.array_equal(g, o), (dest_is_src, rev_compl, len(g), len(o))
+        assert int(g[:, 1].max()) >= 49000
+        if HAVE_REF:
+            assert np.array_equal(g, orc.ref_mem_match(src, d, dest_is_src, rev_compl))
+
+
 def test_mem_event_buffer_regrows(monkeypatch):
     """more events than the first guess of the event buffer: the probe pass is rerun with the exact size"""
     monkeypatch.setenv("PGRC_MEM_EVENT_CAP", "7")
