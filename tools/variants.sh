@@ -1,6 +1,7 @@
 #!/bin/bash
 # Builds compile-time variants of the match kernel next to the product library (pgrc_amd/variants/, git-ignored) and
 # benches them back to back on ONE box (box-to-box variance is ~10 %): tools/variants.sh build | run
+# (the first round of a fresh box runs a few percent slower: read the later rounds)
 set -eu
 cd "$(dirname "$0")/.."
 V=pgrc_amd/variants
@@ -13,8 +14,8 @@ if [ "${1:-build}" = build ]; then
     echo built $v
   done
 else
-  for rep in 1 2 3 4; do
-    for v in base noahead vc8; do
+  for rep in 1 2 3; do
+    for v in base noahead chunk256 vc8; do
       PGRC_MATCH_LIB=$PWD/$V/libpgrc_match_$v.so python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); p=d['phases_ms']; print('$v', round(d['ms_per_step'],1), round(p['match_fwd'],1), round(p['match_rc'],1), d['counters']['verifies'])"
     done
