@@ -44,10 +44,10 @@ struct pgrc_mem_ctx {
     const char *src = nullptr;        // borrowed host text
     uint64_t N = 0;
     bool have_src = false;
-    DevBuf d_dest, d_nmap, d_stage, d_flag, d_cursor, d_evk[2], d_evv[2], d_tmp, d_ostart, d_olen, d_oflag;
+    DevBuf d_dest, d_nmap, d_stage, d_flag, d_cursor, d_evk[2], d_evv[2], d_tmp, d_orun, d_oflag;
     DevBuf d_skey[2], d_sidx[2], d_first, d_runid, d_rstart, d_rend;   // events by (diagonal, window): sort ping-pong, runs
     // pinned, grow-only host mirrors of the event arrays (a std::vector would zero-fill gigabytes per call)
-    struct HostBuf { void *p = nullptr; size_t bytes = 0; } h_key, h_pos, h_start, h_len, h_flag;
+    struct HostBuf { void *p = nullptr; size_t bytes = 0; } h_key, h_pos, h_run, h_rstart, h_rend, h_flag;
     hipEvent_t ev[4]{};               // phase timing (created on first use)
     bool have_ev = false;
     pgrc_mem_counters ctr{};
@@ -319,15 +319,12 @@ k_mem_run_ends(const MemArgs a, const uint64_t *__restrict__ evk, const uint64_t
     }
 }
 
-// every event takes the extents of its run
+// every event learns its run (the host reads the extents per run: 4 bytes per event instead of 16)
 __global__ void __launch_bounds__(256)
-k_mem_apply(const uint64_t *__restrict__ idx, const uint32_t *__restrict__ runid, const uint64_t *__restrict__ run_start,
-            const uint64_t *__restrict__ run_end, uint64_t nev, uint64_t *__restrict__ ostart, uint64_t *__restrict__ olen) {
+k_mem_apply(const uint64_t *__restrict__ idx, const uint32_t *__restrict__ runid, uint64_t nev, uint32_t *__restrict__ orun) {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nev) return;
-    const uint32_t r = runid[k] - 1u;
-    ostart[idx[k]] = run_start[r];
-    olen[idx[k]] = run_end[r] - run_start[r];
+    orun[idx[k]] = runid[k] - 1u;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -468,12 +465,12 @@ int pgrc_mem_create(uint32_t target_len, uint32_t ctor_min_len, int32_t device, 
 void pgrc_mem_destroy(pgrc_mem_ctx *m) {
     if (!m) return;
     DevBuf *bufs[] = {&m->d_dest, &m->d_nmap, &m->d_stage, &m->d_flag, &m->d_cursor, &m->d_evk[0], &m->d_evk[1], &m->d_evv[0],
-                      &m->d_evv[1], &m->d_tmp, &m->d_ostart, &m->d_olen, &m->d_oflag, &m->d_skey[0], &m->d_skey[1], &m->d_sidx[0],
+                      &m->d_evv[1], &m->d_tmp, &m->d_orun, &m->d_oflag, &m->d_skey[0], &m->d_skey[1], &m->d_sidx[0],
                       &m->d_sidx[1], &m->d_first, &m->d_runid, &m->d_rstart, &m->d_rend};
     for (DevBuf *b : bufs) pgrc_buf_free(*b);
     if (m->have_ev)
         for (auto &x : m->ev) (void)hipEventDestroy(x);
-    for (pgrc_mem_ctx::HostBuf *h : {&m->h_key, &m->h_pos, &m->h_start, &m->h_len, &m->h_flag})
+    for (pgrc_mem_ctx::HostBuf *h : {&m->h_key, &m->h_pos, &m->h_run, &m->h_rstart, &m->h_rend, &m->h_flag})
         if (h->p) (void)hipHostFree(h->p);
     pgrc_match_destroy(m->base);
     delete m;
@@ -608,10 +605,11 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     }
     (void)hipEventRecord(ev[1], c->stream);
     m->ctr.events = nev;
-    if ((e = host_ensure(m, m->h_key, nev * 8)) || (e = host_ensure(m, m->h_pos, nev * 8)) || (e = host_ensure(m, m->h_start, nev * 8)) ||
-        (e = host_ensure(m, m->h_len, nev * 8)) || (e = host_ensure(m, m->h_flag, nev))) { return e; }
-    const uint64_t *hk = (const uint64_t *)m->h_key.p, *hp = (const uint64_t *)m->h_pos.p, *hs = (const uint64_t *)m->h_start.p,
-                   *hl = (const uint64_t *)m->h_len.p;
+    if ((e = host_ensure(m, m->h_key, nev * 8)) || (e = host_ensure(m, m->h_pos, nev * 8)) || (e = host_ensure(m, m->h_run, nev * 4)) ||
+        (e = host_ensure(m, m->h_flag, nev))) { return e; }
+    const uint64_t *hk = (const uint64_t *)m->h_key.p, *hp = (const uint64_t *)m->h_pos.p;
+    const uint32_t *hr = (const uint32_t *)m->h_run.p;          // run of an event; the extents are per run
+    const uint64_t *hrs = nullptr, *hre = nullptr;
     const uint8_t *hf = (const uint8_t *)m->h_flag.p;
     if (nev) {
         // ---- 2. the order in which the reference meets them: by window, then by bucket order
@@ -626,7 +624,7 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
         (void)hipEventRecord(ev[2], c->stream);
         // ---- 3. side contexts; extents per run of connected events on a diagonal
         if (nev >= (1ull << 32)) { m->err = "more than 2^32 events"; return PGRC_E_PARAM; }
-        if (he == hipSuccess && ((e = pgrc_buf_ensure(c, m->d_ostart, cap * 8)) || (e = pgrc_buf_ensure(c, m->d_olen, cap * 8)) ||
+        if (he == hipSuccess && ((e = pgrc_buf_ensure(c, m->d_orun, cap * 4)) ||
                                  (e = pgrc_buf_ensure(c, m->d_oflag, cap)) || (e = pgrc_buf_ensure(c, m->d_first, cap * 4)) ||
                                  (e = pgrc_buf_ensure(c, m->d_runid, cap * 4)) || (e = pgrc_buf_ensure(c, m->d_rstart, cap * 8)) ||
                                  (e = pgrc_buf_ensure(c, m->d_rend, cap * 8)))) { m->err = c->err; return e; }
@@ -659,8 +657,8 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
                 if (he == hipSuccess) {
                     hipLaunchKernelGGL(k_mem_run_ends, dim3(g), dim3(256), 0, c->stream, a, ek, ep, sidx, (const uint32_t *)m->d_first.p,
                                        (const uint32_t *)m->d_runid.p, (uint64_t)nev, (uint64_t *)m->d_rstart.p, (uint64_t *)m->d_rend.p);
-                    hipLaunchKernelGGL(k_mem_apply, dim3(g), dim3(256), 0, c->stream, sidx, (const uint32_t *)m->d_runid.p, (const uint64_t *)m->d_rstart.p,
-                                       (const uint64_t *)m->d_rend.p, (uint64_t)nev, (uint64_t *)m->d_ostart.p, (uint64_t *)m->d_olen.p);
+                    hipLaunchKernelGGL(k_mem_apply, dim3(g), dim3(256), 0, c->stream, sidx, (const uint32_t *)m->d_runid.p, (uint64_t)nev,
+                                       (uint32_t *)m->d_orun.p);
                     he = hipGetLastError();
                 }
             }
@@ -668,8 +666,15 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
         (void)hipEventRecord(ev[3], c->stream);
         if (he == hipSuccess) he = hipMemcpyAsync(m->h_key.p, keys.current(), nev * 8, hipMemcpyDeviceToHost, c->stream);
         if (he == hipSuccess) he = hipMemcpyAsync(m->h_pos.p, vals.current(), nev * 8, hipMemcpyDeviceToHost, c->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(m->h_start.p, m->d_ostart.p, nev * 8, hipMemcpyDeviceToHost, c->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(m->h_len.p, m->d_olen.p, nev * 8, hipMemcpyDeviceToHost, c->stream);
+        uint32_t nruns = 0;
+        if (he == hipSuccess) he = hipMemcpyAsync(&nruns, (const uint32_t *)m->d_runid.p + (nev - 1), 4, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(m->h_run.p, m->d_orun.p, nev * 4, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he == hipSuccess && ((e = host_ensure(m, m->h_rstart, (size_t)nruns * 8)) || (e = host_ensure(m, m->h_rend, (size_t)nruns * 8)))) return e;
+        if (he == hipSuccess) he = hipMemcpyAsync(m->h_rstart.p, m->d_rstart.p, (size_t)nruns * 8, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(m->h_rend.p, m->d_rend.p, (size_t)nruns * 8, hipMemcpyDeviceToHost, c->stream);
+        hrs = (const uint64_t *)m->h_rstart.p;
+        hre = (const uint64_t *)m->h_rend.p;
         if (he == hipSuccess) he = hipMemcpyAsync(m->h_flag.p, m->d_oflag.p, nev, hipMemcpyDeviceToHost, c->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) { m->err = std::string("event passes: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
@@ -729,10 +734,11 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
                 }
                 if (!pass) continue;
                 // (d) long enough?  right - p1 > minMatchLength with right - p1 = length + 1 (:413)
-                if (hl[x] + 1 > (uint64_t)min_len) {
-                    last.pos_src = hs[x];
-                    last.length = hl[x];
-                    last.pos_dest = q - (p - hs[x]);
+                const uint64_t mstart = hrs[hr[x]], mlen = hre[hr[x]] - mstart;
+                if (mlen + 1 > (uint64_t)min_len) {
+                    last.pos_src = mstart;
+                    last.length = mlen;
+                    last.pos_dest = q - (p - mstart);
                     have_last = true;
                     res.push_back(last);
                     rp.jumps.push_back({t, order, 1u});
