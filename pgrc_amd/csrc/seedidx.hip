@@ -55,6 +55,8 @@ struct SeedArgs {
     const uint8_t *nflag;
     const uint32_t *nidx;
     const uint8_t *nascii;
+    const uint16_t *nmask;     // [nn][nwr]: bit k of entry w = symbol 16 w + k of that read is an N
+    uint32_t nwr;
     uint64_t nn;
     uint32_t L, m, P, cstride; // m = pattern length, P = parts, cstride = symbol stride inside a part (P for mode i)
     uint32_t mode;             // 'd', 'i', 'e'
@@ -264,30 +266,62 @@ k_seed_scan(const SeedArgs a, uint64_t nwin, uint64_t pg_words_alloc, unsigned l
 }
 
 // ---- 3. per-read sequential replay over its sorted candidates
-template <bool ASCII>
-__device__ __forceinline__ uint32_t hamming_vs_text(const SeedArgs &a, uint64_t i, uint64_t trow, uint64_t p) {
+__device__ __forceinline__ uint32_t hamming_vs_text(const SeedArgs &a, uint64_t i, uint64_t p) {
     uint32_t mm = 0;
-    if (ASCII) {
-        const uint8_t *row = a.nascii + trow * a.L;
-        for (uint32_t k = 0; k < a.L; k++) {
-            const uint64_t x = p + k;
-            const uint32_t c = (a.pg[x >> 4] >> (2u * ((uint32_t)x & 15u))) & 3u;
-            mm += code2ascii(c) != (uint32_t)row[k];
-        }
-    } else {
-        const uint32_t *src = a.pg + (p >> 4);
-        const uint32_t b = ((uint32_t)p & 15u) * 2u;
-        const uint32_t nw = (a.L + 15) / 16;
-        uint32_t lo = src[0];
-        for (uint32_t w = 0; w < nw; w++) {
-            const uint32_t hi = src[w + 1];
-            const uint32_t tw = funnel_r(lo, hi, b);
-            const uint32_t rw = a.reads[(uint64_t)w * a.stride + i];
-            mm += mism2(tw, rw, sym_mask((int)w, 0, (int)a.L));
-            lo = hi;
-        }
+    const uint32_t *src = a.pg + (p >> 4);
+    const uint32_t b = ((uint32_t)p & 15u) * 2u;
+    const uint32_t nw = (a.L + 15) / 16;
+    uint32_t lo = src[0];
+    for (uint32_t w = 0; w < nw; w++) {
+        const uint32_t hi = src[w + 1];
+        const uint32_t tw = funnel_r(lo, hi, b);
+        const uint32_t rw = a.reads[(uint64_t)w * a.stride + i];
+        mm += mism2(tw, rw, sym_mask((int)w, 0, (int)a.L));
+        lo = hi;
     }
     return mm;
+}
+
+// reads with N: their packed words hold code 0 at the N positions; a 16-bit mask per word forces those symbols to count
+// as mismatches (an N equals no text symbol)
+__global__ void __launch_bounds__(256)
+k_seed_nmask(const uint8_t *__restrict__ nascii, uint64_t nn, uint32_t L, uint32_t nwr, uint16_t *__restrict__ nmask) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nn * nwr) return;
+    const uint64_t t = x / nwr;
+    const uint32_t w = (uint32_t)(x % nwr);
+    const uint8_t *row = nascii + t * L + 16 * w;
+    uint32_t m = 0;
+    for (uint32_t k = 0; k < 16 && 16 * w + k < L; k++) m |= (row[k] == 'N') ? 1u << k : 0u;
+    nmask[x] = (uint16_t)m;
+}
+
+__device__ __forceinline__ uint32_t hamming_vs_text_n(const SeedArgs &a, uint64_t i, uint64_t trow, uint64_t p) {
+    uint32_t mm = 0;
+    const uint32_t *src = a.pg + (p >> 4);
+    const uint32_t b = ((uint32_t)p & 15u) * 2u;
+    uint32_t lo = src[0];
+    for (uint32_t w = 0; w < a.nwr; w++) {
+        const uint32_t hi = src[w + 1];
+        const uint32_t x = funnel_r(lo, hi, b) ^ a.reads[(uint64_t)w * a.stride + i];
+        uint32_t nb = a.nmask[trow * a.nwr + w];          // bit k -> bit 2 k
+        nb = (nb | (nb << 8)) & 0x00FF00FFu;
+        nb = (nb | (nb << 4)) & 0x0F0F0F0Fu;
+        nb = (nb | (nb << 2)) & 0x33333333u;
+        nb = (nb | (nb << 1)) & 0x55555555u;
+        mm += (uint32_t)__popc((x | (x >> 1) | nb) & sym_mask((int)w, 0, (int)a.L));
+        lo = hi;
+    }
+    return mm;
+}
+
+__device__ __forceinline__ uint64_t lower_bound_u32(const uint32_t *v, uint64_t n, uint32_t x) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (v[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
 }
 
 // Hamming count of EVERY hit, one thread per hit (the replay below only compares counts with the read's current limit,
@@ -300,31 +334,24 @@ k_seed_hamming(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhi
     const uint64_t hkey = hits[x];
     const uint64_t i = hkey >> 36;
     if (x == 0 || (hits[x - 1] >> 36) != i) rstart[i] = x;
-    if (a.nflag && a.nflag[i]) return;                     // byte-path read: k_seed_replay<true> compares itself
     const uint64_t tp = (hkey >> 4) & 0xFFFFFFFFull;
     const uint32_t j = 15u - (uint32_t)(hkey & 15u);
-    mmv[x] = (uint8_t)min(hamming_vs_text<false>(a, i, 0, tp - part_offset(a, j)), 255u);
+    const uint64_t p = tp - part_offset(a, j);
+    uint32_t mm;
+    if (a.nflag && a.nflag[i]) mm = hamming_vs_text_n(a, i, lower_bound_u32(a.nidx, a.nn, (uint32_t)i), p);   // a read with N
+    else mm = hamming_vs_text(a, i, p);
+    mmv[x] = (uint8_t)min(mm, 255u);
 }
 
 // Reads with more than REPLAY_HEAVY candidates (tandem repeats: hundreds to thousands per read) would keep one lane --
 // and with it the whole wave -- looping alone: the per-thread replay hands them to k_seed_replay_heavy instead.
 #define REPLAY_HEAVY 64u
 
-template <bool ASCII>
 __global__ void __launch_bounds__(256)
 k_seed_replay(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhits, const uint8_t *__restrict__ mmv,
               const uint64_t *__restrict__ rstart, uint32_t *__restrict__ heavy, unsigned long long *__restrict__ nheavy) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t i, trow = 0;
-    if (ASCII) {
-        if (t >= a.nn) return;
-        i = a.nidx[t];
-        trow = t;
-    } else {
-        if (t >= a.n) return;
-        i = t;
-        if (a.nflag && a.nflag[i]) return;
-    }
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
     uint32_t c = a.mism[i];
     uint64_t stored = a.pos[i];
     uint32_t rcflag = a.rc[i];
@@ -335,7 +362,7 @@ k_seed_replay(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhit
     for (uint64_t x = x0; x < nhits; x++) {
         const uint64_t hkey = hits[x];
         if ((hkey >> 36) != i) break;
-        if (!ASCII && x - x0 >= REPLAY_HEAVY) {                 // too many candidates for one lane: a wave redoes this read
+        if (x - x0 >= REPLAY_HEAVY) {                 // too many candidates for one lane: a wave redoes this read
             heavy[atomicAdd(nheavy, 1ull)] = (uint32_t)i;
             return;
         }
@@ -344,7 +371,7 @@ k_seed_replay(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhit
         const uint64_t p = tp - part_offset(a, j);
         const uint64_t cand = a.strand ? a.G - (p + a.L) : p;
         if (exact) {
-            if ((ASCII ? hamming_vs_text<true>(a, i, trow, p) : (uint32_t)mmv[x]) != 0) continue; // compareReadWithPattern == 0, :207
+            if (mmv[x] != 0) continue;                                  // compareReadWithPattern == 0, :207
             stored = cand;                                              // first hit in scan order wins, :209-212
             rcflag = a.strand;
             c = 0;
@@ -354,7 +381,7 @@ k_seed_replay(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhit
         if (c <= a.kmin) break;                                         // :304-305 (every later hit is skipped too)
         if (stored == cand) continue;                                   // :313-314
         const uint32_t limit = (c == PGRC_NOT_MATCHED_CNT) ? a.kmax : c - 1u; // :315-316
-        const uint32_t mm = ASCII ? hamming_vs_text<true>(a, i, trow, p) : (uint32_t)mmv[x];
+        const uint32_t mm = mmv[x];
         if (mm <= limit) {                                              // got < count  (:319-328)
             c = mm;
             stored = cand;
@@ -455,6 +482,8 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
     a.nidx = (const uint32_t *)c->nread_idx.p;
     a.nascii = (const uint8_t *)c->nread_ascii.p;
     a.nn = c->n_nreads;
+    a.nwr = (L + 15) / 16;
+    a.nmask = nullptr;
     a.kmax = c->prm.max_mismatches;
     a.kmin = c->prm.min_mismatches;
     a.pos = (uint64_t *)c->d_pos.p;
@@ -475,6 +504,12 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
     a.theads = (uint32_t *)c->s_vals.p;
     a.tmask = tsize - 1;
     a.next = (uint32_t *)c->s_tab.p;
+    if (c->n_nreads) {
+        if ((e = pgrc_buf_ensure(c, c->s_nmask, c->n_nreads * a.nwr * sizeof(uint16_t)))) return e;
+        a.nmask = (const uint16_t *)c->s_nmask.p;
+        hipLaunchKernelGGL(k_seed_nmask, dim3((uint32_t)((c->n_nreads * a.nwr + 255) / 256)), dim3(256), 0, c->stream, a.nascii, c->n_nreads, L,
+                           a.nwr, (uint16_t *)c->s_nmask.p);
+    }
     hipLaunchKernelGGL(k_seed_table_init, dim3(4096), dim3(256), 0, c->stream, a.tkeys, a.theads, tsize);
     hipLaunchKernelGGL(k_seed_insert, dim3((uint32_t)((nent + 255) / 256)), dim3(256), 0, c->stream, a);
     if (c->n_nreads)
@@ -530,16 +565,12 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
         if (he == hipSuccess) {
             hipLaunchKernelGGL(k_seed_hamming, dim3((uint32_t)((nhits + 255) / 256)), dim3(256), 0, c->stream, a,
                                (const uint64_t *)sorted.p, (uint64_t)nhits, (uint8_t *)c->s_mm.p, (uint64_t *)c->s_rstart.p);
-            hipLaunchKernelGGL(k_seed_replay<false>, dim3((uint32_t)((c->n + 255) / 256)), dim3(256), 0, c->stream, a,
+            hipLaunchKernelGGL(k_seed_replay, dim3((uint32_t)((c->n + 255) / 256)), dim3(256), 0, c->stream, a,
                                (const uint64_t *)sorted.p, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p,
                                (uint32_t *)c->s_heavy.p, nheavy);
             hipLaunchKernelGGL(k_seed_replay_heavy, dim3((uint32_t)c->num_cus * 8u), dim3(256), 0, c->stream, a,
                                (const uint64_t *)sorted.p, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p,
                                (const uint32_t *)c->s_heavy.p, (const unsigned long long *)nheavy);
-            if (c->n_nreads)
-                hipLaunchKernelGGL(k_seed_replay<true>, dim3((uint32_t)((c->n_nreads + 255) / 256)), dim3(256), 0, c->stream, a,
-                                   (const uint64_t *)sorted.p, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p,
-                                   (uint32_t *)c->s_heavy.p, nheavy);
             he = hipGetLastError();
         }
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
