@@ -630,8 +630,11 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
 __global__ void __launch_bounds__(NREAD_TPB)
 k_copmem_match_n(const MatchArgs a, const uint32_t *__restrict__ nidx, const uint8_t *__restrict__ nascii, uint64_t nn) {
     __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
-    __shared__ uint32_t rdw[PGRC_MAX_NW + 1][NREAD_TPB];   // packed read (+ one zero word: windows read one word ahead)
-    __shared__ uint32_t nmw[PGRC_MAX_NW + 1][NREAD_TPB];   // bit k of word w: symbol 16 w + k is an N
+    // dynamic LDS, sized for this read length: rdw[NWr + 1][NREAD_TPB] = the packed read (+ one zero word: windows read
+    // one word ahead), nmw[NWr + 1][NREAD_TPB] = bit k of word w: symbol 16 w + k is an N
+    extern __shared__ uint32_t nread_lds[];
+    uint32_t (*rdw)[NREAD_TPB] = reinterpret_cast<uint32_t (*)[NREAD_TPB]>(nread_lds);
+    uint32_t (*nmw)[NREAD_TPB] = reinterpret_cast<uint32_t (*)[NREAD_TPB]>(nread_lds + ((a.L + 15) / 16 + 1) * NREAD_TPB);
     hash_lut_init(lut);
     const uint64_t t = (uint64_t)blockIdx.x * NREAD_TPB + threadIdx.x;
     bool active = t < nn;
@@ -816,7 +819,8 @@ int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
     HIP_TRY(c, hipGetLastError());
     if (c->n_nreads) {
         const uint32_t grid = (uint32_t)((c->n_nreads + NREAD_TPB - 1) / NREAD_TPB);
-        hipLaunchKernelGGL(k_copmem_match_n, dim3(grid), dim3(NREAD_TPB), 0, c->stream, a,
+        const uint32_t lds = 2u * ((uint32_t)c->nw + 1u) * NREAD_TPB * (uint32_t)sizeof(uint32_t);
+        hipLaunchKernelGGL(k_copmem_match_n, dim3(grid), dim3(NREAD_TPB), lds, c->stream, a,
                            (const uint32_t *)c->nread_idx.p, (const uint8_t *)c->nread_ascii.p, c->n_nreads);
         HIP_TRY(c, hipGetLastError());
     }
