@@ -61,12 +61,31 @@ def test_c3_full_size_properties_and_sample():
     # 4. bit-identity on a sample against the reference (serial canonical index) or the oracle, whole Pg
     m = 100_000
     if orc.have_ref():
-        r = orc.ref_match("c", pg, reads[:m], seed_len, kmax, 0, True, 0, 1, 16)
+        r = orc.ref_match("c", pg, reads[:m], seed_len, kmax, 0, True, 0, 1, 1)   # one thread: the reference's RC-flag race
     else:
         r = orc.oracle_match("c", pg, reads[:m], seed_len, kmax, 0, True, 16)
     assert np.array_equal(pos[:m], r["pos"]) and np.array_equal(rc[:m], r["rc"]) and np.array_equal(mism[:m], r["mism"])
     # the generator plants 60 % exact reads (3 % of all reads are random): at least that many must match exactly
     assert hist[0] >= 0.55 * n and matched >= 0.85 * n
+    # 5. the read-side seed-index modes on the same inputs: reported alignments are real, the exact matches agree with mode c
+    exact_c = mism == 0
+    for mode in ("d", "i"):
+        cx = MatchContext(L, seed_len, kmax, 0, mode)
+        cx.set_pg_packed_device(d_pg.data_ptr(), G)
+        cx.set_reads_device(d_rd.data_ptr(), n, stride, keep=d_rd)
+        cx.init_results()
+        cx.run(True)
+        p2, r2, m2, h2, mt2 = cx.get_results()
+        assert int(h2.sum()) == n and np.array_equal(np.bincount(m2, minlength=256).astype(np.uint64), h2)
+        assert mt2 >= 0.85 * n and int(m2[m2 != 255].max()) <= kmax
+        # every part of a read with an exact occurrence hits there, so modes d / i find all of them; mode c can miss some
+        # (its index is sampled and its buckets are capped)
+        assert (m2 == 0)[exact_c].all() and int((m2 == 0).sum()) >= int(exact_c.sum())
+        idx2 = np.flatnonzero(m2[:ns] != 255)
+        win2 = pg[p2[idx2, None].astype(np.int64) + np.arange(L)[None, :]]
+        ham2 = np.where(r2[idx2, None] != 0, comp[reads[idx2][:, ::-1]] != win2, reads[idx2] != win2).sum(axis=1)
+        assert np.array_equal(ham2.astype(np.uint8), m2[idx2]), mode
+        del cx
 
 
 def test_c1_full_size_exact_matcher():
