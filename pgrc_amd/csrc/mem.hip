@@ -47,7 +47,7 @@ struct pgrc_mem_ctx {
     DevBuf d_dest, d_nmap, d_stage, d_flag, d_cursor, d_evk[2], d_evv[2], d_tmp, d_orun, d_oflag;
     DevBuf d_skey[2], d_sidx[2], d_first, d_runid, d_rstart, d_rend;   // events by (diagonal, window): sort ping-pong, runs
     // pinned, grow-only host mirrors of the event arrays (a std::vector would zero-fill gigabytes per call)
-    struct HostBuf { void *p = nullptr; size_t bytes = 0; } h_key, h_pos, h_run, h_rstart, h_rend, h_flag;
+    struct HostBuf { void *p = nullptr; size_t bytes = 0; bool pinned = false; } h_key, h_pos, h_run, h_rstart, h_rend, h_flag;
     hipEvent_t ev[4]{};               // phase timing (created on first use)
     bool have_ev = false;
     pgrc_mem_counters ctr{};
@@ -65,15 +65,28 @@ struct pgrc_mem_ctx {
 
 static std::string g_mem_create_err;
 
-static int host_ensure(pgrc_mem_ctx *m, pgrc_mem_ctx::HostBuf &b, size_t bytes) {
-    if (b.p && b.bytes >= bytes) return PGRC_OK;
-    if (b.p) (void)hipHostFree(b.p);
+static void host_release(pgrc_mem_ctx::HostBuf &b) {
+    if (b.p) {
+        if (b.pinned) (void)hipHostFree(b.p);
+        else free(b.p);
+    }
     b.p = nullptr;
     b.bytes = 0;
-    if (hipHostMalloc(&b.p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
-        b.p = nullptr;
-        m->err = "hipHostMalloc(" + std::to_string(bytes) + ") failed";
-        return PGRC_E_ALLOC;
+}
+
+static int host_ensure(pgrc_mem_ctx *m, pgrc_mem_ctx::HostBuf &b, size_t bytes) {
+    if (b.p && b.bytes >= bytes) return PGRC_OK;
+    host_release(b);
+    if (hipHostMalloc(&b.p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess) {
+        b.pinned = true;
+    } else {                              // no pinned memory left: pageable memory works too, the copies are just slower
+        (void)hipGetLastError();
+        b.p = malloc(bytes ? bytes : 16);
+        b.pinned = false;
+        if (!b.p) {
+            m->err = "host allocation of " + std::to_string(bytes) + " bytes failed";
+            return PGRC_E_ALLOC;
+        }
     }
     b.bytes = bytes;
     return PGRC_OK;
@@ -470,8 +483,7 @@ void pgrc_mem_destroy(pgrc_mem_ctx *m) {
     for (DevBuf *b : bufs) pgrc_buf_free(*b);
     if (m->have_ev)
         for (auto &x : m->ev) (void)hipEventDestroy(x);
-    for (pgrc_mem_ctx::HostBuf *h : {&m->h_key, &m->h_pos, &m->h_run, &m->h_rstart, &m->h_rend, &m->h_flag})
-        if (h->p) (void)hipHostFree(h->p);
+    for (pgrc_mem_ctx::HostBuf *h : {&m->h_key, &m->h_pos, &m->h_run, &m->h_rstart, &m->h_rend, &m->h_flag}) host_release(*h);
     pgrc_match_destroy(m->base);
     delete m;
 }
