@@ -133,6 +133,11 @@ int pgrc_match_create(const pgrc_match_params *p, pgrc_match_ctx **out) {
 }
 
 void pgrc_match_destroy(pgrc_match_ctx *c) {
+    if (c && c->side_stream) {
+        (void)hipStreamDestroy(c->side_stream);
+        (void)hipEventDestroy(c->side_ev[0]);
+        (void)hipEventDestroy(c->side_ev[1]);
+    }
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf *bufs[] = {&c->pg2[0], &c->pg2[1], &c->reads_own, &c->nread_idx, &c->nread_ascii, &c->nread_flag, &c->d_pos,

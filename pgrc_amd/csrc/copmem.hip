@@ -807,6 +807,23 @@ int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
     a.kmax = c->prm.max_mismatches;
     a.kmin = c->prm.min_mismatches;
     a.strand = (uint32_t)strand;
+    // The reads with N (a percent or two, one lane each, latency-bound) start first on a side stream and run beside the
+    // main kernel, whose persistent blocks simply take the remaining slots; the two kernels write disjoint reads.
+    if (c->n_nreads) {
+        if (!c->side_stream) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->side_ev[0], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->side_ev[1], hipEventDisableTiming));
+        }
+        HIP_TRY(c, hipEventRecord(c->side_ev[0], c->stream));               // the index (and the previous pass) are complete
+        HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->side_ev[0], 0));
+        const uint32_t grid = (uint32_t)((c->n_nreads + NREAD_TPB - 1) / NREAD_TPB);
+        const uint32_t lds = 2u * ((uint32_t)c->nw + 1u) * NREAD_TPB * (uint32_t)sizeof(uint32_t);
+        hipLaunchKernelGGL(k_copmem_match_n, dim3(grid), dim3(NREAD_TPB), lds, c->side_stream, a,
+                           (const uint32_t *)c->nread_idx.p, (const uint8_t *)c->nread_ascii.p, c->n_nreads);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(c->side_ev[1], c->side_stream));
+    }
     switch (c->nw) {
 #define CASE_NW(N) case N: launch_match<N>(c, a); break;
         CASE_NW(2) CASE_NW(3) CASE_NW(4) CASE_NW(5) CASE_NW(6) CASE_NW(7) CASE_NW(8) CASE_NW(9)
@@ -817,12 +834,6 @@ int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
         return PGRC_E_PARAM;
     }
     HIP_TRY(c, hipGetLastError());
-    if (c->n_nreads) {
-        const uint32_t grid = (uint32_t)((c->n_nreads + NREAD_TPB - 1) / NREAD_TPB);
-        const uint32_t lds = 2u * ((uint32_t)c->nw + 1u) * NREAD_TPB * (uint32_t)sizeof(uint32_t);
-        hipLaunchKernelGGL(k_copmem_match_n, dim3(grid), dim3(NREAD_TPB), lds, c->stream, a,
-                           (const uint32_t *)c->nread_idx.p, (const uint8_t *)c->nread_ascii.p, c->n_nreads);
-        HIP_TRY(c, hipGetLastError());
-    }
+    if (c->n_nreads) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_ev[1], 0));   // the pass ends when both kernels have
     return PGRC_OK;
 }

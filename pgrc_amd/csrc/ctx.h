@@ -35,6 +35,8 @@ struct pgrc_match_ctx {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;  // the kernel for reads with N runs beside the main match kernel (created on first use)
+    hipEvent_t side_ev[2]{};
     std::string err;
 
     // pseudogenome
