@@ -41,11 +41,12 @@ enum {
     PGRC_OK = 0,
     PGRC_E_PARAM = 1,       /* bad argument / unsupported configuration */
     PGRC_E_SEED_SHORT = 2,  /* copMEM needs seed >= 24 (CopMEMMatcher.cpp:77-80) */
-    PGRC_E_NO_DEVICE = 3,   /* no HIP device / HIP runtime error */
+    PGRC_E_NO_DEVICE = 3,   /* no usable HIP device */
     PGRC_E_ALLOC = 4,
     PGRC_E_SYMBOL = 5,      /* symbol outside ACGT (Pg) / ACGNT (reads) */
     PGRC_E_STATE = 6,       /* call order (e.g. run before set_pg) */
-    PGRC_E_MODE = 7         /* "Unknown matching mode" (ReadsMatchers.cpp:737-739) */
+    PGRC_E_MODE = 7,        /* "Unknown matching mode" (ReadsMatchers.cpp:737-739) */
+    PGRC_E_DEVICE = 8       /* HIP runtime failure other than out-of-memory (launch failure, invalid value, ...) */
 };
 
 typedef struct pgrc_match_ctx pgrc_match_ctx;

@@ -197,6 +197,20 @@ namespace PgTools {
         bulkMismatches = false;
     }
 
+    SeparatedPseudoGenomeOutputBuilder *HipReadsMatcher::createSeparatedPseudoGenomeOutputBuilder(
+            SeparatedPseudoGenome *sPg, bool allStreams) {
+        if (hipMode != 'e')
+            return AbstractReadsApproxMatcher::createSeparatedPseudoGenomeOutputBuilder(sPg, allStreams);
+        DefaultReadsListIteratorInterface *rlIt = sPg->getReadsList();
+        const bool isRevCompEnabled = allStreams || sPg->getReadsList()->isRevCompEnabled();
+        const bool areMismatchesEnabled = allStreams || sPg->getReadsList()->areMismatchesEnabled();
+        auto *builder = new SeparatedPseudoGenomeOutputBuilder(!isRevCompEnabled && !this->revComplPg,
+                                                               !areMismatchesEnabled);
+        builder->setReadsSourceIterator(rlIt);
+        builder->copyPseudoGenomeProperties(sPg);
+        return builder;
+    }
+
     void HipReadsMatcher::executeMatching(bool revCompMode) {
         if (deviceReads) failOn(pgrc_match_run_pass(ctx, revCompMode ? 1 : 0), "run_pass");
         fetchResults();

@@ -46,6 +46,12 @@ namespace PgTools {
         void updateEntry(DefaultReadsListEntry &entry, uint_reads_cnt_max matchIdx, bool revComplPairFile) override;
         void closeEntryUpdating() override;
 
+        // kind 'e' stands in for DefaultReadsExactMatcher, whose builder drops the mismatch streams on
+        // `!areMismatchesEnabled` alone (ReadsMatchers.cpp:534-544); the inherited approx rule (:521-532) also asks
+        // for maxMismatches == 0
+        SeparatedPseudoGenomeOutputBuilder *createSeparatedPseudoGenomeOutputBuilder(
+                SeparatedPseudoGenome *sPg, bool allStreams = true) override;
+
     public:
         HipReadsMatcher(char *pgPtr, const uint_pg_len_max pgLength, bool revComplPg,
                         ConstantLengthReadsSetInterface *readsSet, uint32_t matchPrefixLength,

@@ -17,7 +17,7 @@ NOT_MATCHED_POS = 0xFFFFFFFFFFFFFFFF  # DefaultReadsMatcher::NOT_MATCHED_POSITIO
 NOT_MATCHED_CNT = 255                 # NOT_MATCHED_COUNT (ReadsMatchers.h:17)
 
 ERR_NAMES = {0: "OK", 1: "E_PARAM", 2: "E_SEED_SHORT", 3: "E_NO_DEVICE", 4: "E_ALLOC",
-             5: "E_SYMBOL", 6: "E_STATE", 7: "E_MODE"}
+             5: "E_SYMBOL", 6: "E_STATE", 7: "E_MODE", 8: "E_DEVICE"}
 
 
 class PgrcMatchError(RuntimeError):

@@ -22,7 +22,7 @@ int pgrc_buf_ensure(pgrc_match_ctx *c, DevBuf &b, size_t bytes) {
     if (e != hipSuccess) {
         b.p = nullptr;
         c->err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
-        return e == hipErrorOutOfMemory ? PGRC_E_ALLOC : PGRC_E_NO_DEVICE;
+        return pgrc_hip_code(e);
     }
     b.bytes = bytes;
     return PGRC_OK;
@@ -110,8 +110,9 @@ int pgrc_match_create(const pgrc_match_params *p, pgrc_match_ctx **out) {
     if (dev < 0) {
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     }
-    if (dev >= ndev || (he = hipSetDevice(dev)) != hipSuccess) {
-        g_create_err = std::string("hipSetDevice(") + std::to_string(dev) + "): " + hipGetErrorString(he);
+    PgrcDeviceScope scope(dev < ndev ? dev : 0);   // the caller's current device is restored on return
+    if (dev >= ndev || !scope.ok) {
+        g_create_err = "hipSetDevice(" + std::to_string(dev) + ") failed (devices: " + std::to_string(ndev) + ")";
         return PGRC_E_NO_DEVICE;
     }
     (void)hipGetLastError(); // start from a clean sticky-error state
@@ -123,23 +124,25 @@ int pgrc_match_create(const pgrc_match_params *p, pgrc_match_ctx **out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     }
-    if (pgrc_buf_ensure(c, c->d_hist, 256 * sizeof(uint64_t)) || pgrc_buf_ensure(c, c->d_counters, 32 * sizeof(uint64_t))) {
+    int be;
+    if ((be = pgrc_buf_ensure(c, c->d_hist, 256 * sizeof(uint64_t))) || (be = pgrc_buf_ensure(c, c->d_counters, 32 * sizeof(uint64_t)))) {
         g_create_err = c->err;
+        pgrc_buf_free(c->d_hist);
         delete c;
-        return PGRC_E_NO_DEVICE;
+        return be;
     }
     *out = c;
     return PGRC_OK;
 }
 
 void pgrc_match_destroy(pgrc_match_ctx *c) {
-    if (c && c->side_stream) {
+    if (!c) return;
+    PgrcDeviceScope scope(c->device);
+    if (c->side_stream) {
         (void)hipStreamDestroy(c->side_stream);
         (void)hipEventDestroy(c->side_ev[0]);
         (void)hipEventDestroy(c->side_ev[1]);
     }
-    if (!c) return;
-    (void)hipSetDevice(c->device);
     DevBuf *bufs[] = {&c->pg2[0], &c->pg2[1], &c->reads_own, &c->nread_idx, &c->nread_ascii, &c->nread_flag, &c->d_pos,
                       &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_head, &c->d_skey[0], &c->d_skey[1], &c->d_sval[0], &c->d_sval[1], &c->d_sorttmp,
                       &c->s_keys, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp, &c->s_sorted, &c->s_sorttmp, &c->s_mm, &c->s_rstart, &c->s_heavy, &c->s_nmask};
@@ -159,7 +162,7 @@ int pgrc_match_set_stream(pgrc_match_ctx *c, void *s) {
 
 int pgrc_match_set_profiling(pgrc_match_ctx *c, int enabled) {
     if (!c) return PGRC_E_PARAM;
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     if (enabled && !c->have_events) {
         for (auto &e : c->ev) HIP_TRY(c, hipEventCreate(&e));
         c->have_events = true;
@@ -203,7 +206,7 @@ static int alloc_pg(pgrc_match_ctx *c, uint64_t G) {
 
 int pgrc_match_pack_pg_slice(pgrc_match_ctx *c, const char *pg, uint64_t count, void *d_words_out) {
     if (!c || (!pg && count) || !d_words_out) return PGRC_E_PARAM;
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     const uint64_t CH = 64ull << 20; // 64 Mi symbols per staging chunk (multiple of 16)
     DevBuf stage, flag;
     int e;
@@ -213,12 +216,12 @@ int pgrc_match_pack_pg_slice(pgrc_match_ctx *c, const char *pg, uint64_t count, 
     int rcode = PGRC_OK;
     for (uint64_t off = 0; off < count && rcode == PGRC_OK; off += CH) {
         const uint64_t len = std::min(CH, count - off);
-        if (hipMemcpyAsync(stage.p, pg + off, len, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_NO_DEVICE; break; }
+        if (hipMemcpyAsync(stage.p, pg + off, len, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
         rcode = pgrc_launch_pack_ascii(c, (const uint8_t *)stage.p, len, (uint32_t *)d_words_out + off / 16, (uint32_t *)flag.p);
-        if (hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_NO_DEVICE;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_DEVICE;
     }
     uint32_t bad = 0;
-    if (rcode == PGRC_OK && hipMemcpy(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) rcode = PGRC_E_NO_DEVICE;
+    if (rcode == PGRC_OK && hipMemcpy(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) rcode = PGRC_E_DEVICE;
     pgrc_buf_free(stage);
     pgrc_buf_free(flag);
     if (rcode == PGRC_OK && bad) {
@@ -231,7 +234,7 @@ int pgrc_match_pack_pg_slice(pgrc_match_ctx *c, const char *pg, uint64_t count, 
 
 int pgrc_match_set_pg_ascii(pgrc_match_ctx *c, const char *pg, uint64_t G) {
     if (!c || !pg) return PGRC_E_PARAM;
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     int e = alloc_pg(c, G);
     if (e) return e;
     if ((e = pgrc_match_pack_pg_slice(c, pg, G, c->pg2[0].p))) return e;
@@ -241,7 +244,7 @@ int pgrc_match_set_pg_ascii(pgrc_match_ctx *c, const char *pg, uint64_t G) {
 
 int pgrc_match_set_pg_packed_device(pgrc_match_ctx *c, const void *d_words, uint64_t G) {
     if (!c || !d_words) return PGRC_E_PARAM;
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     int e = alloc_pg(c, G);
     if (e) return e;
     HIP_TRY(c, hipMemcpyAsync(c->pg2[0].p, d_words, c->pg_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
@@ -261,7 +264,7 @@ int pgrc_match_set_pg_packed_device(pgrc_match_ctx *c, const void *d_words, uint
 int pgrc_match_export_pg(pgrc_match_ctx *c, int strand, uint32_t *words) {
     if (!c || !words || strand < 0 || strand > 1) return PGRC_E_PARAM;
     if (!c->have_pg) { c->err = "export_pg: no pseudogenome set"; return PGRC_E_STATE; }
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     if (strand == 1 && !c->have_rc) {
         int e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G);
         if (e) return e;
@@ -302,7 +305,7 @@ static int begin_reads(pgrc_match_ctx *c, uint64_t n, bool own) {
 // through a bounded host buffer.
 int pgrc_match_begin_reads(pgrc_match_ctx *c, uint64_t n) {
     if (!c) return PGRC_E_PARAM;
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     int e = begin_reads(c, n, true);
     if (e) return e;
     if ((e = pgrc_buf_ensure(c, c->nread_flag, n))) return e;
@@ -317,7 +320,7 @@ int pgrc_match_begin_reads(pgrc_match_ctx *c, uint64_t n) {
 int pgrc_match_append_reads_ascii(pgrc_match_ctx *c, const char *reads, uint64_t count) {
     if (!c || (!reads && count)) return PGRC_E_PARAM;
     if (!c->up_open || c->up_next + count > c->n) { c->err = "append_reads: outside begin/end or too many rows"; return PGRC_E_STATE; }
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     const uint32_t L = c->prm.read_len;
     DevBuf stage, flag;
     int e;
@@ -330,14 +333,14 @@ int pgrc_match_append_reads_ascii(pgrc_match_ctx *c, const char *reads, uint64_t
     for (uint64_t off = 0; off < count && rcode == PGRC_OK; off += CHR) {
         const uint64_t cnt = std::min(CHR, count - off);
         const uint64_t first = c->up_next + off;
-        if (hipMemcpyAsync(stage.p, reads + off * L, cnt * L, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_NO_DEVICE; break; }
+        if (hipMemcpyAsync(stage.p, reads + off * L, cnt * L, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
         rcode = pgrc_launch_pack_reads_ascii(c, (const uint8_t *)stage.p, first, cnt, L, (uint32_t *)c->reads_own.p, c->stride,
                                              (uint8_t *)c->nread_flag.p, (uint32_t *)flag.p);
-        if (hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_NO_DEVICE;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_DEVICE;
         if (rcode != PGRC_OK) break;
         // reads with 'N' -> byte path: keep their rows (they are a small minority)
         nf.resize(cnt);
-        if (hipMemcpy(nf.data(), (const uint8_t *)c->nread_flag.p + first, cnt, hipMemcpyDeviceToHost) != hipSuccess) { rcode = PGRC_E_NO_DEVICE; break; }
+        if (hipMemcpy(nf.data(), (const uint8_t *)c->nread_flag.p + first, cnt, hipMemcpyDeviceToHost) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
         for (uint64_t k = 0; k < cnt; k++)
             if (nf[k]) {
                 c->up_nidx.push_back((uint32_t)(first + k));
@@ -345,7 +348,7 @@ int pgrc_match_append_reads_ascii(pgrc_match_ctx *c, const char *reads, uint64_t
             }
     }
     uint32_t bad = 0;
-    if (rcode == PGRC_OK && hipMemcpy(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) rcode = PGRC_E_NO_DEVICE;
+    if (rcode == PGRC_OK && hipMemcpy(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) rcode = PGRC_E_DEVICE;
     pgrc_buf_free(stage);
     pgrc_buf_free(flag);
     if (rcode != PGRC_OK) { if (c->err.empty()) c->err = "append_reads_ascii: HIP error"; return rcode; }
@@ -357,7 +360,7 @@ int pgrc_match_append_reads_ascii(pgrc_match_ctx *c, const char *reads, uint64_t
 int pgrc_match_end_reads(pgrc_match_ctx *c) {
     if (!c) return PGRC_E_PARAM;
     if (!c->up_open || c->up_next != c->n) { c->err = "end_reads: fewer rows appended than announced"; return PGRC_E_STATE; }
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     int e;
     c->n_nreads = c->up_nidx.size();
     if (c->n_nreads) {
@@ -385,7 +388,7 @@ int pgrc_match_set_reads_ascii(pgrc_match_ctx *c, const char *reads, uint64_t n)
 
 int pgrc_match_set_reads_packed(pgrc_match_ctx *c, const uint8_t *packed, uint64_t n) {
     if (!c || (!packed && n)) return PGRC_E_PARAM;
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     int e = begin_reads(c, n, true);
     if (e) return e;
     const uint32_t L = c->prm.read_len, pb = (L + 3) / 4;
@@ -395,9 +398,9 @@ int pgrc_match_set_reads_packed(pgrc_match_ctx *c, const uint8_t *packed, uint64
     int rcode = PGRC_OK;
     for (uint64_t off = 0; off < n && rcode == PGRC_OK; off += CHR) {
         const uint64_t cnt = std::min(CHR, n - off);
-        if (hipMemcpyAsync(stage.p, packed + off * pb, cnt * pb, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_NO_DEVICE; break; }
+        if (hipMemcpyAsync(stage.p, packed + off * pb, cnt * pb, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
         rcode = pgrc_launch_repack_reads_ref(c, (const uint8_t *)stage.p, off, cnt, L, (uint32_t *)c->reads_own.p, c->stride);
-        if (hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_NO_DEVICE;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_DEVICE;
     }
     pgrc_buf_free(stage);
     if (rcode != PGRC_OK) { if (c->err.empty()) c->err = "set_reads_packed: HIP error"; return rcode; }
@@ -407,7 +410,7 @@ int pgrc_match_set_reads_packed(pgrc_match_ctx *c, const uint8_t *packed, uint64
 
 int pgrc_match_set_reads_device(pgrc_match_ctx *c, const void *d_words, uint64_t n, uint64_t stride) {
     if (!c || (!d_words && n) || stride < n) return PGRC_E_PARAM;
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     int e = begin_reads(c, n, false);
     if (e) return e;
     c->reads2 = (const uint32_t *)d_words;
@@ -421,7 +424,7 @@ int pgrc_match_set_reads_device(pgrc_match_ctx *c, const void *d_words, uint64_t
 int pgrc_match_init_results(pgrc_match_ctx *c) {
     if (!c) return PGRC_E_PARAM;
     if (!c->have_reads) { c->err = "init_results: no reads set"; return PGRC_E_STATE; }
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     int e = pgrc_launch_init_results(c);
     if (e) return e;
     c->have_results = true;
@@ -431,7 +434,7 @@ int pgrc_match_init_results(pgrc_match_ctx *c) {
 int pgrc_match_set_results(pgrc_match_ctx *c, const uint64_t *pos, const uint8_t *rc, const uint8_t *mism) {
     if (!c || !pos || !rc || !mism) return PGRC_E_PARAM;
     if (!c->have_reads) { c->err = "set_results: no reads set"; return PGRC_E_STATE; }
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     if (c->n) {
         HIP_TRY(c, hipMemcpyAsync(c->d_pos.p, pos, c->n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->d_rc.p, rc, c->n, hipMemcpyHostToDevice, c->stream));
@@ -445,7 +448,7 @@ int pgrc_match_set_results(pgrc_match_ctx *c, const uint64_t *pos, const uint8_t
 static int run_passes(pgrc_match_ctx *c, int first, int last) {
     if (!c) return PGRC_E_PARAM;
     if (!c->have_pg || !c->have_reads) { c->err = "run: set the pseudogenome and the reads first"; return PGRC_E_STATE; }
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     int e;
     if (!c->have_results && (e = pgrc_match_init_results(c))) return e;
     HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, 32 * sizeof(uint64_t), c->stream));
@@ -511,7 +514,7 @@ int pgrc_match_run_pass(pgrc_match_ctx *c, int strand) {
 int pgrc_match_get_results(pgrc_match_ctx *c, uint64_t *pos, uint8_t *rc, uint8_t *mism, uint64_t hist[256], uint64_t *matched) {
     if (!c) return PGRC_E_PARAM;
     if (!c->have_results) { c->err = "get_results: nothing computed"; return PGRC_E_STATE; }
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->n) {
         if (pos) HIP_TRY(c, hipMemcpy(pos, c->d_pos.p, c->n * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -543,14 +546,14 @@ int pgrc_match_extract_mismatches(pgrc_match_ctx *c, const uint8_t *reversed_fla
                                   uint16_t *offsets) {
     if (!c || !cum) return PGRC_E_PARAM;
     if (!c->have_results || !c->have_pg) { c->err = "extract_mismatches: run first"; return PGRC_E_STATE; }
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     return pgrc_extract_mismatches(c, reversed_flags, cum, codes, offsets);
 }
 
 int pgrc_match_export_index(pgrc_match_ctx *c, int strand, uint32_t *cumm, uint32_t *positions, uint64_t *count) {
     if (!c || strand < 0 || strand > 1) return PGRC_E_PARAM;
     if (!c->have_pg || c->prm.mode != 'c') { c->err = "export_index: mode c with a pseudogenome only"; return PGRC_E_STATE; }
-    HIP_TRY(c, hipSetDevice(c->device));
+    PGRC_ON_DEVICE(c);
     int e;
     if (strand == 1 && !c->have_rc) {
         if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) return e;

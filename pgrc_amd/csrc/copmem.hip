@@ -173,7 +173,7 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     rocprim::double_buffer<uint64_t> vals((uint64_t *)c->d_sval[0].p, (uint64_t *)c->d_sval[1].p);
     size_t tbytes = 0;
     hipError_t he = rocprim::radix_sort_pairs(nullptr, tbytes, keys, vals, (size_t)npos, 0, hbits, c->stream);
-    if (he != hipSuccess) { c->err = "rocprim size query failed"; return PGRC_E_NO_DEVICE; }
+    if (he != hipSuccess) { c->err = "rocprim size query failed"; return PGRC_E_DEVICE; }
     if ((e = pgrc_buf_ensure(c, c->d_sorttmp, tbytes + 16))) return e;
 
     const uint64_t ntiles = (npos + IDX_TPB - 1) / IDX_TPB;
@@ -182,7 +182,7 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
                        c->pg_words + PGRC_PG_PAD_WORDS, npos, k1, K, (uint32_t)(hs - 1), keys.current(), vals.current());
     HIP_TRY(c, hipGetLastError());
     he = rocprim::radix_sort_pairs(c->d_sorttmp.p, tbytes, keys, vals, (size_t)npos, 0, hbits, c->stream);
-    if (he != hipSuccess) { c->err = std::string("index sort: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
+    if (he != hipSuccess) { c->err = std::string("index sort: ") + hipGetErrorString(he); return PGRC_E_DEVICE; }
     hipLaunchKernelGGL(k_copmem_index_heads, dim3((uint32_t)((npos + HEADS_REC - 1) / HEADS_REC)), dim3(HEADS_TPB), 0, c->stream,
                        (const uint32_t *)keys.current(), (const uint64_t *)vals.current(), npos, hs, (ulonglong2 *)c->d_head.p);
     HIP_TRY(c, hipGetLastError());
@@ -231,9 +231,9 @@ int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_po
     uint32_t total = 0;
     if (he == hipSuccess) he = hipMemcpyAsync(&total, (uint32_t *)cumm.p + hs, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-    if (he != hipSuccess) { cleanup(); c->err = std::string("export_index: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
+    if (he != hipSuccess) { cleanup(); c->err = std::string("export_index: ") + hipGetErrorString(he); return PGRC_E_DEVICE; }
     if (count) *count = total;
-    if (h_cumm && hipMemcpy(h_cumm, cumm.p, (hs + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return PGRC_E_NO_DEVICE; }
+    if (h_cumm && hipMemcpy(h_cumm, cumm.p, (hs + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return PGRC_E_DEVICE; }
     if (h_positions && total) {
         if ((e = pgrc_buf_ensure(c, pos, (size_t)total * sizeof(uint32_t)))) { cleanup(); return e; }
         hipLaunchKernelGGL(k_export_positions, dim3(sgrid), dim3(256), 0, c->stream, (const ulonglong2 *)c->d_head.p,
@@ -242,7 +242,7 @@ int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_po
             hipMemcpy(h_positions, pos.p, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
             cleanup();
             c->err = "export_index: positions";
-            return PGRC_E_NO_DEVICE;
+            return PGRC_E_DEVICE;
         }
     }
     cleanup();
@@ -810,10 +810,21 @@ int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
     // The reads with N (a percent or two, one lane each, latency-bound) start first on a side stream and run beside the
     // main kernel, whose persistent blocks simply take the remaining slots; the two kernels write disjoint reads.
     if (c->n_nreads) {
-        if (!c->side_stream) {
-            HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->side_ev[0], hipEventDisableTiming));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->side_ev[1], hipEventDisableTiming));
+        if (!c->side_stream) {   // stream and both events, or nothing
+            hipStream_t st = nullptr;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            hipError_t he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&e0, hipEventDisableTiming);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+            if (he != hipSuccess) {
+                if (e0) (void)hipEventDestroy(e0);
+                if (st) (void)hipStreamDestroy(st);
+                c->err = std::string("side stream: ") + hipGetErrorString(he);
+                return pgrc_hip_code(he);
+            }
+            c->side_stream = st;
+            c->side_ev[0] = e0;
+            c->side_ev[1] = e1;
         }
         HIP_TRY(c, hipEventRecord(c->side_ev[0], c->stream));               // the index (and the previous pass) are complete
         HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->side_ev[0], 0));

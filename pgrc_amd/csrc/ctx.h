@@ -90,14 +90,43 @@ struct pgrc_match_ctx {
     bool have_events = false;
 };
 
+// HIP failure -> ABI error code: out of memory is PGRC_E_ALLOC, a missing / invalid device PGRC_E_NO_DEVICE, anything
+// else (launch failure, invalid value, ...) PGRC_E_DEVICE
+static inline int pgrc_hip_code(hipError_t e) {
+    if (e == hipErrorOutOfMemory) return PGRC_E_ALLOC;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return PGRC_E_NO_DEVICE;
+    return PGRC_E_DEVICE;
+}
+
 #define HIP_TRY(ctx, expr)                                                                   \
     do {                                                                                     \
         hipError_t e__ = (expr);                                                             \
         if (e__ != hipSuccess) {                                                             \
             (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                 \
-            return PGRC_E_NO_DEVICE;                                                         \
+            return pgrc_hip_code(e__);                                                       \
         }                                                                                    \
     } while (0)
+
+// Every ABI entry point runs on its context's device and leaves the caller's current device (e.g. torch's) as it
+// found it.
+struct PgrcDeviceScope {
+    int prev = -1;
+    bool ok = true;
+    explicit PgrcDeviceScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev == dev) prev = -1;                       // nothing to switch, nothing to restore
+        else ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~PgrcDeviceScope() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define PGRC_ON_DEVICE(ctx)                                                                  \
+    PgrcDeviceScope dev_scope__((ctx)->device);                                              \
+    if (!dev_scope__.ok) {                                                                   \
+        (ctx)->err = "hipSetDevice(" + std::to_string((ctx)->device) + ") failed";           \
+        return PGRC_E_NO_DEVICE;                                                             \
+    }
 
 int pgrc_buf_ensure(pgrc_match_ctx *c, DevBuf &b, size_t bytes);
 void pgrc_buf_free(DevBuf &b);

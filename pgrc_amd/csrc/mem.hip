@@ -59,11 +59,11 @@ struct pgrc_mem_ctx {
         hipError_t e__ = (expr);                                                             \
         if (e__ != hipSuccess) {                                                             \
             (m)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                   \
-            return PGRC_E_NO_DEVICE;                                                         \
+            return pgrc_hip_code(e__);                                                       \
         }                                                                                    \
     } while (0)
 
-static std::string g_mem_create_err;
+static thread_local std::string g_mem_create_err; // reported by pgrc_mem_last_error(NULL)
 
 static void host_release(pgrc_mem_ctx::HostBuf &b) {
     if (b.p) {
@@ -498,10 +498,12 @@ int pgrc_mem_set_src_ascii(pgrc_mem_ctx *m, const char *src, uint64_t n) {
     if (!m || !src) return PGRC_E_PARAM;
     pgrc_match_ctx *c = m->base;
     m->have_src = false;
+    PgrcDeviceScope dev_scope__(c->device);
+    if (!dev_scope__.ok) { m->err = "hipSetDevice failed"; return PGRC_E_NO_DEVICE; }
     const auto t0 = std::chrono::steady_clock::now();
     int e = pgrc_match_set_pg_ascii(c, src, n);
     if (!e) e = pgrc_copmem_build_index(c, 0);
-    if (!e && hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "index build failed"; e = PGRC_E_NO_DEVICE; }
+    if (!e && hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "index build failed"; e = PGRC_E_DEVICE; }
     if (e) { m->err = c->err; return e; }
     m->ctr.ms_index = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     m->K = c->cp.K; m->k1 = c->cp.k1; m->k2 = c->cp.k2;
@@ -525,7 +527,8 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     if ((int)min_len < m->K) { m->err = "Minimal matching length cannot be smaller than K"; return PGRC_E_PARAM; }   // :606-609
     if (dest_is_src && N2 != m->N) { m->err = "match_texts: dest_is_src with a text of another length"; return PGRC_E_PARAM; }
     if (N2 / (uint64_t)m->k2 + 1 >= (1ull << 40)) { m->err = "destination text too long"; return PGRC_E_PARAM; }
-    MEM_TRY(m, hipSetDevice(c->device));
+    PgrcDeviceScope dev_scope__(c->device);
+    if (!dev_scope__.ok) { m->err = "hipSetDevice failed"; return PGRC_E_NO_DEVICE; }
     m->ctr.probes = m->ctr.events = m->ctr.stale_lookups = 0;
     const uint64_t K = (uint64_t)m->K, k2 = (uint64_t)m->k2;
     const uint64_t nprobes = N2 >= K ? (N2 - K) / k2 + 1 : 0;          // windows q = t * k2 with q + K <= N2
@@ -567,7 +570,7 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
                                    (uint32_t *)m->d_flag.p);
                 he = hipStreamSynchronize(c->stream);
             }
-            if (he != hipSuccess) { m->err = std::string("destination upload: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
+            if (he != hipSuccess) { m->err = std::string("destination upload: ") + hipGetErrorString(he); return PGRC_E_DEVICE; }
         }
         uint32_t fl = 0;
         MEM_TRY(m, hipMemcpy(&fl, m->d_flag.p, 4, hipMemcpyDeviceToHost));
@@ -611,7 +614,7 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
         hipError_t he = hipGetLastError();
         if (he == hipSuccess) he = hipMemcpyAsync(&nev, m->d_cursor.p, 8, hipMemcpyDeviceToHost, c->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-        if (he != hipSuccess) { m->err = std::string("probe kernel: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
+        if (he != hipSuccess) { m->err = std::string("probe kernel: ") + hipGetErrorString(he); return PGRC_E_DEVICE; }
         if (nev <= cap) break;
         cap = nev + nev / 4;                                // the guess was too small: once more, with headroom for the next call
     }
@@ -689,7 +692,7 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
         hre = (const uint64_t *)m->h_rend.p;
         if (he == hipSuccess) he = hipMemcpyAsync(m->h_flag.p, m->d_oflag.p, nev, hipMemcpyDeviceToHost, c->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-        if (he != hipSuccess) { m->err = std::string("event passes: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
+        if (he != hipSuccess) { m->err = std::string("event passes: ") + hipGetErrorString(he); return PGRC_E_DEVICE; }
         (void)hipEventElapsedTime(&m->ctr.ms_sort, ev[1], ev[2]);
         (void)hipEventElapsedTime(&m->ctr.ms_extend, ev[2], ev[3]);
     } else {
@@ -742,7 +745,7 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
                     const uint32_t l2 = (fl & MF_L2_OK) ? le32(dest + q - m->LK2) : 0u;   // windows below LK2 come first: still the initial 0
                     const uint32_t r2 = (fl & MF_R2_OK) ? le32(dest + q + m->KLK24) : rp.stale_r2(t);
                     pass = r1 == r2 || l1 == l2;
-                    if (rp.lookup_err) { m->err = "bucket lookup failed"; return PGRC_E_NO_DEVICE; }
+                    if (rp.lookup_err) { m->err = "bucket lookup failed"; return PGRC_E_DEVICE; }
                 }
                 if (!pass) continue;
                 // (d) long enough?  right - p1 > minMatchLength with right - p1 = length + 1 (:413)

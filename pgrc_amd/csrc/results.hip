@@ -206,14 +206,14 @@ int pgrc_extract_mismatches(pgrc_match_ctx *c, const uint8_t *reversed_flags, ui
         hipStreamSynchronize(c->stream) != hipSuccess) {
         cleanup();
         c->err = "extract: scan failed";
-        return PGRC_E_NO_DEVICE;
+        return PGRC_E_DEVICE;
     }
     const uint64_t total = cum[n];
     if (!codes || !offsets || !total) { cleanup(); return PGRC_OK; }
     if ((e = pgrc_buf_ensure(c, d_codes, total)) || (e = pgrc_buf_ensure(c, d_offs, total * sizeof(uint16_t)))) { cleanup(); return e; }
     if (reversed_flags) {
         if ((e = pgrc_buf_ensure(c, d_flags, n))) { cleanup(); return e; }
-        if (hipMemcpyAsync(d_flags.p, reversed_flags, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) { cleanup(); return PGRC_E_NO_DEVICE; }
+        if (hipMemcpyAsync(d_flags.p, reversed_flags, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) { cleanup(); return PGRC_E_DEVICE; }
     }
     ExtractArgs a;
     a.pg = (const uint32_t *)c->pg2[0].p;
@@ -240,6 +240,6 @@ int pgrc_extract_mismatches(pgrc_match_ctx *c, const uint8_t *reversed_flags, ui
               hipMemcpyAsync(offsets, d_offs.p, total * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
               hipStreamSynchronize(c->stream) == hipSuccess;
     cleanup();
-    if (!ok) { c->err = "extract: kernel failed"; return PGRC_E_NO_DEVICE; }
+    if (!ok) { c->err = "extract: kernel failed"; return PGRC_E_DEVICE; }
     return PGRC_OK;
 }

@@ -574,7 +574,7 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
             he = hipGetLastError();
         }
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-        if (he != hipSuccess) { c->err = std::string("seed-index pass: ") + hipGetErrorString(he); return PGRC_E_NO_DEVICE; }
+        if (he != hipSuccess) { c->err = std::string("seed-index pass: ") + hipGetErrorString(he); return PGRC_E_DEVICE; }
         c->ctr.searched[pass] = c->n;
         c->ctr.candidates[pass] = nhits;
     }

@@ -53,7 +53,7 @@ extern "C" int pgrc_synth_pg_device(const pgrc_synth_pg *g, void *d_words_out, v
     if (!nwords) return PGRC_OK;
     uint32_t grid = (uint32_t)((nwords + 255) / 256 < 65536 * 4 ? (nwords + 255) / 256 : 65536 * 4);
     hipLaunchKernelGGL(k_synth_pg, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, *g, (uint32_t *)d_words_out, nwords);
-    return hipGetLastError() == hipSuccess ? PGRC_OK : PGRC_E_NO_DEVICE;
+    return hipGetLastError() == hipSuccess ? PGRC_OK : PGRC_E_DEVICE;
 }
 
 // one read per thread; bases gathered from the packed Pg already in HBM
@@ -96,5 +96,5 @@ extern "C" int pgrc_synth_reads_device(const pgrc_synth_pg *g, const void *d_pg_
     const uint32_t grid = (uint32_t)((count + 255) / 256);
     hipLaunchKernelGGL(k_synth_reads, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, *g, (const uint32_t *)d_pg_words,
                        *rs, first_read, count, (uint32_t *)d_words_out, stride);
-    return hipGetLastError() == hipSuccess ? PGRC_OK : PGRC_E_NO_DEVICE;
+    return hipGetLastError() == hipSuccess ? PGRC_OK : PGRC_E_DEVICE;
 }

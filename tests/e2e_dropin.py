@@ -9,7 +9,7 @@ SimplePgMatcher holding integration/HipTextMatcher instead of its CopMEMMatcher 
 archive with the reference's decoder.  Prints one JSON line: archive sizes/digests, whether they are byte-identical,
 how often the GPU path ran, and whether the decoded reads equal the input.
 
-usage: python tests/e2e_dropin.py WORKDIR CASE        (CASE: se | se_order | pe | pe_order | se_pre | se_modeD)
+usage: python tests/e2e_dropin.py WORKDIR CASE        (CASE: one of CASES below)
 """
 import ctypes as C
 import hashlib
@@ -31,6 +31,7 @@ CASES = {
     "se_pre":    (False, False, "c", 32, 4, "c", 64),   # two-phase flow (ReadsMatchers.cpp:749-779)
     "se_modeD":  (False, False, "d", 36, 3, None, 0),   # read-side seed index instead of copMEM
     "se_modeI":  (False, False, "I", 34, 5, None, 0),   # interleaved + "shortcut" (upper case) rule
+    "se_exact":  (False, False, "d", 100, 3, None, 0),  # seed == read length: DefaultReadsExactMatcher's seat (kind 'e')
 }
 
 

@@ -39,7 +39,7 @@ def test_reference_encoder_harness_cpu(tmp_path, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["se", "se_order", "pe", "pe_order", "se_pre", "se_modeD", "se_modeI"])
+@pytest.mark.parametrize("case", ["se", "se_order", "pe", "pe_order", "se_pre", "se_modeD", "se_modeI", "se_exact"])
 def test_archive_identical_with_gpu_matcher(tmp_path, case):
     if not _have_e2e():
         pytest.skip("oracle/_ref was built without the encoder harness")
@@ -48,5 +48,5 @@ def test_archive_identical_with_gpu_matcher(tmp_path, case):
     assert r["cpu_text_match_calls"] == 0 and r["gpu_text_match_calls"] >= 3, r   # ... and HipTextMatcher (lq, n, hq Pg)
     assert r["identical"], r
     assert r["roundtrip"], r
-    if case not in ("se_modeD", "se_modeI"):     # (those match nothing: the sum-set quirk)
+    if case not in ("se_modeD", "se_modeI", "se_exact"):     # (those match nothing: the sum-set quirk)
         assert r["gpu_bulk_updates"] > 1000 and r["cpu_bulk_updates"] == 0, r   # export used the device mismatch lists
