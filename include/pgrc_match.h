@@ -68,6 +68,23 @@ int pgrc_match_derive_params(uint32_t read_len, uint32_t seed_len, uint32_t min_
                              char mode_char, pgrc_match_params *out);
 
 int pgrc_match_create(const pgrc_match_params *params, pgrc_match_ctx **out);
+/* One matcher over SEVERAL GPUs of this node, in one process (the reference is one process with one matcher object,
+ * pgrc-encoder.cpp:342-374, and shards its per-read loop over threads, ReadsMatchers.cpp:426-428; here the same
+ * loop shards over devices).  The returned context answers every entry point of this header: reads are split into
+ * contiguous, even-aligned ranges (PE mates 2q, 2q+1 stay on one device, ReadsMatchers.cpp:553), every device packs
+ * 1/n of the text handed to pgrc_match_set_pg_ascii and ONE all-gather (RCCL over xGMI; peer copies when a device is
+ * listed twice, which only makes sense for rehearsals on a smaller box) replicates the packed text, every device
+ * builds the index and matches its reads, results land in the caller's arrays at the shard offsets and the
+ * histograms are summed.  params->device is ignored; n_devices in [1, 32].  pgrc_match_set_stream,
+ * pgrc_match_set_reads_device and pgrc_match_get_results_device need a single-device context. */
+int pgrc_match_create_multi(const pgrc_match_params *params, int32_t n_devices, const int32_t *devices,
+                            pgrc_match_ctx **out);
+/* visible HIP devices (what "all" means for an adapter that honours PGRC_DEVICES) */
+int pgrc_match_device_count(int32_t *count);
+/* shards of a context: 1 for pgrc_match_create; per shard its device and (after the reads were set) read range */
+int32_t pgrc_match_shard_count(const pgrc_match_ctx *ctx);
+int pgrc_match_shard_info(const pgrc_match_ctx *ctx, int32_t shard, int32_t *device, uint64_t *first_read,
+                          uint64_t *n_reads);
 void pgrc_match_destroy(pgrc_match_ctx *ctx);
 const char *pgrc_match_last_error(const pgrc_match_ctx *ctx);
 /* hipStream_t to issue all work on (0 = the null stream). */
@@ -92,9 +109,16 @@ int pgrc_match_set_reads_ascii(pgrc_match_ctx *ctx, const char *reads, uint64_t 
 int pgrc_match_begin_reads(pgrc_match_ctx *ctx, uint64_t n);
 int pgrc_match_append_reads_ascii(pgrc_match_ctx *ctx, const char *reads, uint64_t count);
 int pgrc_match_end_reads(pgrc_match_ctx *ctx);
-/* The reference's own packed layout for an ACGT set: ceil(read_len/4) bytes per read,
- * 4 symbols per byte, first symbol most significant
- * (PackedConstantLengthReadsSet::getPackedRead, coders/SymbolsPackingFacility.cpp:143-178). */
+/* The reference's own packed read sets, taken as they are (PackedConstantLengthReadsSet::getPackedRead,
+ * readsset/PackedConstantLengthReadsSet.h:40; layout: coders/SymbolsPackingFacility.cpp:133-178, base-sigma digits,
+ * first symbol most significant, a partial last byte padded with digit 0):
+ *   symbols = 4: an "ACGT" set, ceil(read_len/4) bytes per read, 4 symbols per byte;
+ *   symbols = 5: an "ACGNT" set (A0 C1 G2 N3 T4), ceil(read_len/3) bytes per read, 3 symbols per byte
+ * (the two set kinds of readsset/DividedPCLReadsSets.cpp:10-21).  Streamed like the ASCII rows; the LQ + N sum set
+ * of pgrc-encoder.cpp:349-352 is begin(n_lq + n_n), append_packed(lq rows, n_lq, 4), append_packed(n rows, n_n, 5),
+ * end.  Unpacking to the library's 2-bit words (+ the side list of reads with N) happens on the device. */
+int pgrc_match_append_reads_packed(pgrc_match_ctx *ctx, const uint8_t *packed, uint64_t count, int32_t symbols);
+/* one ACGT set in one call (= begin, append_packed(..., 4), end) */
 int pgrc_match_set_reads_packed(pgrc_match_ctx *ctx, const uint8_t *packed, uint64_t n);
 /* Reads already in HBM in the library's layout: word-major u32 [words_per_read][stride]
  * (word w of read i at d_words[w*stride + i]), 16 symbols per word.  Borrowed, not copied. */
@@ -154,6 +178,7 @@ typedef struct {
     float ms_match[2];
     float ms_other;
     float ms_total;
+    float ms_allgather;     /* multi-device contexts: the last all-gather of the packed text (host clock) */
 } pgrc_match_counters;
 /* enable per-kernel HIP-event timing + work counters for subsequent runs */
 int pgrc_match_set_profiling(pgrc_match_ctx *ctx, int enabled);

@@ -1,3 +1,24 @@
+// SumOfConstantLengthReadsSets (readsset/ReadsSetInterface.h:45-58) -- the LQ + N set the encoder hands to
+// mapReadsIntoPg (pgrc-encoder.cpp:349-352) -- keeps its two halves private and has no accessor.  In a PgRC tree the
+// maintainer adds `friend class PgTools::HipReadsMatcher;` to that class.  Built against
+// an UNPATCHED tree (-DPGRC_UNPATCHED_TREE; oracle/Makefile compiles the reference's sources where they lie and
+// must not edit them) this one translation unit opens the class up instead; layout and ABI are unaffected.
+#ifdef PGRC_UNPATCHED_TREE
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+#define private public
+#include "readsset/ReadsSetInterface.h"
+#undef private
+#endif
+
 #include "HipReadsMatcher.h"
 
 #include "pgrc_match.h"
@@ -23,6 +44,7 @@ namespace {
 namespace PgTools {
 
     uint64_t HipReadsMatcher::bulkUpdatesServed = 0;
+    uint64_t HipReadsMatcher::packedHandOvers = 0;
 
     HipReadsMatcher::HipReadsMatcher(char *pgPtr, const uint_pg_len_max pgLength, bool revComplPg,
                                      ConstantLengthReadsSetInterface *readsSet, uint32_t matchPrefixLength,
@@ -42,7 +64,29 @@ namespace PgTools {
         prm.min_mismatches = minMismatches;
         prm.mode = hipMode;
         prm.device = -1;
-        int e = pgrc_match_create(&prm, &ctx);
+        // PGRC_DEVICES = "all" or a comma-separated list of HIP device ordinals: ONE matcher over several GPUs (reads
+        // sharded, text all-gathered; include/pgrc_match.h, pgrc_match_create_multi).  Unset: the current device.
+        int e;
+        std::vector<int32_t> devices;
+        if (const char *dv = getenv("PGRC_DEVICES")) {
+            if (strcmp(dv, "all") == 0) {
+                int32_t cnt = 0;
+                pgrc_match_device_count(&cnt);
+                for (int32_t d = 0; d < cnt; d++) devices.push_back(d);
+            } else {
+                for (const char *p = dv; *p;) {
+                    char *end = nullptr;
+                    const long d = strtol(p, &end, 10);
+                    if (end == p) break;
+                    devices.push_back((int32_t) d);
+                    p = (*end == ',') ? end + 1 : end;
+                }
+            }
+        }
+        if (!devices.empty())
+            e = pgrc_match_create_multi(&prm, (int32_t) devices.size(), devices.data(), &ctx);
+        else
+            e = pgrc_match_create(&prm, &ctx);
         if (e) {
             fprintf(stderr, "HipReadsMatcher: %s (error %d)\n", pgrc_match_last_error(nullptr), e);
             exit(EXIT_FAILURE); // the reference's error convention (ReadsMatchers.cpp:738-739)
@@ -76,15 +120,36 @@ namespace PgTools {
         PhaseLog log("hand-over of the pseudogenome and the reads");
         const uint_reads_cnt_max readsCount = deviceReads;   // shadows the member for the rest of this function
         failOn(pgrc_match_set_pg_ascii(ctx, pgPtr, pgLength), "set_pg_ascii");
-        auto *packed = dynamic_cast<PackedConstantLengthReadsSet *>(readsSet);
-        if (packed && packed->getReadsSetProperties()->symbolsCount == 4 &&
-            strncmp(packed->getReadsSetProperties()->symbolsList, "ACGT", 4) == 0) {
-            // the LQ set alone: hand over the reference's own packed rows, no unpacking
-            failOn(pgrc_match_set_reads_packed(ctx, readsCount ? packed->getPackedRead(0) : nullptr, readsCount),
-                   "set_reads_packed");
+        // The reference's packed sets go over as they are (f3): an "ACGT" set (4 symbols per byte), an "ACGNT" set (3 per
+        // byte), or the LQ + N sum of two such sets; the device unpacks them (pgrc_match_append_reads_packed).
+        auto packedSymbols = [](PackedConstantLengthReadsSet *p) -> int32_t {
+            if (!p) return 0;
+            const ReadsSetProperties *pr = p->getReadsSetProperties();
+            if (pr->symbolsCount == 4 && strncmp(pr->symbolsList, "ACGT", 4) == 0) return 4;
+            if (pr->symbolsCount == 5 && strncmp(pr->symbolsList, "ACGNT", 5) == 0) return 5;
+            return 0;
+        };
+        PackedConstantLengthReadsSet *half[2] = {dynamic_cast<PackedConstantLengthReadsSet *>(readsSet), nullptr};
+        if (auto *sum = dynamic_cast<SumOfConstantLengthReadsSets *>(readsSet)) {
+            half[0] = dynamic_cast<PackedConstantLengthReadsSet *>(sum->clrs1);
+            half[1] = dynamic_cast<PackedConstantLengthReadsSet *>(sum->clrs2);
+            if (!half[1]) half[0] = nullptr;
+        }
+        const int32_t sym0 = packedSymbols(half[0]), sym1 = packedSymbols(half[1]);
+        if (sym0 && (!half[1] || sym1)) {
+            failOn(pgrc_match_begin_reads(ctx, readsCount), "begin_reads");
+            uint_reads_cnt_max left = readsCount;
+            for (int h = 0; h < 2 && half[h]; h++) {
+                const uint_reads_cnt_max cnt = std::min<uint64_t>(left, half[h]->readsCount());
+                failOn(pgrc_match_append_reads_packed(ctx, cnt ? half[h]->getPackedRead(0) : nullptr, cnt, h ? sym1 : sym0),
+                       "append_reads_packed");
+                left -= cnt;
+            }
+            failOn(pgrc_match_end_reads(ctx), "end_reads");
+            packedHandOver = true;
+            packedHandOvers++;
         } else {
-            // any other ConstantLengthReadsSetInterface (e.g. the LQ + N sum set, pgrc-encoder.cpp:349-352):
-            // stream the rows through getRead(i, buf) in bounded blocks
+            // any other ConstantLengthReadsSetInterface: stream the rows through getRead(i, buf) in bounded blocks
             const uint_reads_cnt_max block = 1u << 20;
             std::vector<char> buf((size_t) std::min<uint64_t>(block, readsCount ? readsCount : 1) * readLength);
             failOn(pgrc_match_begin_reads(ctx, readsCount), "begin_reads");

@@ -21,6 +21,7 @@ namespace PgTools {
         const char hipMode;                  // 'c', 'd', 'i' or 'e' (the matcher the reference would have built)
         const uint16_t seedChars;
         bool uploaded = false;
+        bool packedHandOver = false;         // the reads went over in the reference's own packed layout (no getRead)
         uint_reads_cnt_max deviceReads = 0;  // reads that take part (all in mode c; see upload() for modes d/i/e)
 
         // mismatch lists of all matched reads, filled by initEntryUpdating() (CSR: mmCum[i] .. mmCum[i+1])
@@ -69,6 +70,8 @@ namespace PgTools {
 
         // entries whose mismatch list was served from the device extraction (diagnostics / tests)
         static uint64_t bulkUpdatesServed;
+        // uploads that took the reference's packed rows as they are (no getRead)
+        static uint64_t packedHandOvers;
     };
 }
 

@@ -344,6 +344,7 @@ extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const 
 }
 
 extern "C" uint64_t pgrc_ref_bulk_updates() { return HipReadsMatcher::bulkUpdatesServed; }
+extern "C" uint64_t pgrc_ref_packed_handovers() { return HipReadsMatcher::packedHandOvers; }
 extern "C" uint64_t pgrc_ref_text_match_calls() { return HipTextMatcher::callsServed; }
 // seconds the last pgrc_ref_encode spent in mapReadsIntoPg (stage 4) and in SimplePgMatcher's TextMatcher (stage 7)
 extern "C" void pgrc_ref_stage_seconds(double *map_reads_s, double *text_match_s) {

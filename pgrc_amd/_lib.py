@@ -38,7 +38,7 @@ class CopmemParams(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("searched", C.c_uint64 * 2), ("candidates", C.c_uint64 * 2), ("probes", C.c_uint64 * 2),
                 ("entry_fetches", C.c_uint64 * 2), ("verifies", C.c_uint64 * 2), ("index_entries", C.c_uint64 * 2), ("ms_index", C.c_float * 2), ("ms_match", C.c_float * 2),
-                ("ms_other", C.c_float), ("ms_total", C.c_float)]
+                ("ms_other", C.c_float), ("ms_total", C.c_float), ("ms_allgather", C.c_float)]
 
 
 class SynthPg(C.Structure):
@@ -66,6 +66,10 @@ _PROTOS = [
     ("pgrc_match_version", C.c_char_p, []),
     ("pgrc_match_derive_params", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_char, C.POINTER(MatchParams)]),
     ("pgrc_match_create", C.c_int, [C.POINTER(MatchParams), C.POINTER(_P)]),
+    ("pgrc_match_create_multi", C.c_int, [C.POINTER(MatchParams), C.c_int32, C.POINTER(C.c_int32), C.POINTER(_P)]),
+    ("pgrc_match_device_count", C.c_int, [C.POINTER(C.c_int32)]),
+    ("pgrc_match_shard_count", C.c_int32, [_P]),
+    ("pgrc_match_shard_info", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("pgrc_match_destroy", None, [_P]),
     ("pgrc_match_last_error", C.c_char_p, [_P]),
     ("pgrc_match_set_stream", C.c_int, [_P, _P]),
@@ -76,6 +80,7 @@ _PROTOS = [
     ("pgrc_match_begin_reads", C.c_int, [_P, C.c_uint64]),
     ("pgrc_match_append_reads_ascii", C.c_int, [_P, _P, C.c_uint64]),
     ("pgrc_match_end_reads", C.c_int, [_P]),
+    ("pgrc_match_append_reads_packed", C.c_int, [_P, _P, C.c_uint64, C.c_int32]),
     ("pgrc_match_set_reads_packed", C.c_int, [_P, _P, C.c_uint64]),
     ("pgrc_match_set_reads_device", C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
     ("pgrc_match_words_per_read", C.c_uint32, [C.c_uint32]),

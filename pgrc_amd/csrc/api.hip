@@ -137,6 +137,7 @@ int pgrc_match_create(const pgrc_match_params *p, pgrc_match_ctx **out) {
 
 void pgrc_match_destroy(pgrc_match_ctx *c) {
     if (!c) return;
+    if (c->multi) { pgrc_multi_destroy(c); return; }
     PgrcDeviceScope scope(c->device);
     if (c->side_stream) {
         (void)hipStreamDestroy(c->side_stream);
@@ -156,12 +157,14 @@ const char *pgrc_match_last_error(const pgrc_match_ctx *c) { return c ? c->err.c
 
 int pgrc_match_set_stream(pgrc_match_ctx *c, void *s) {
     if (!c) return PGRC_E_PARAM;
+    if (c->multi) { c->err = "set_stream: a multi-device context runs on one stream per device"; return PGRC_E_PARAM; }
     c->stream = (hipStream_t)s;
     return PGRC_OK;
 }
 
 int pgrc_match_set_profiling(pgrc_match_ctx *c, int enabled) {
     if (!c) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_set_profiling(c, enabled);
     PGRC_ON_DEVICE(c);
     if (enabled && !c->have_events) {
         for (auto &e : c->ev) HIP_TRY(c, hipEventCreate(&e));
@@ -173,7 +176,7 @@ int pgrc_match_set_profiling(pgrc_match_ctx *c, int enabled) {
 
 // ------------------------------------------------------------------ pseudogenome
 
-static int alloc_pg(pgrc_match_ctx *c, uint64_t G) {
+int pgrc_pg_alloc(pgrc_match_ctx *c, uint64_t G) {
     if (G + 256 >= (1ull << 40)) {
         c->err = "pseudogenome of 2^40 symbols or more is not supported (entries keep 40 position bits)";
         return PGRC_E_PARAM;
@@ -206,6 +209,7 @@ static int alloc_pg(pgrc_match_ctx *c, uint64_t G) {
 
 int pgrc_match_pack_pg_slice(pgrc_match_ctx *c, const char *pg, uint64_t count, void *d_words_out) {
     if (!c || (!pg && count) || !d_words_out) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_pack_pg_slice(c, pg, count, d_words_out);
     PGRC_ON_DEVICE(c);
     const uint64_t CH = 64ull << 20; // 64 Mi symbols per staging chunk (multiple of 16)
     DevBuf stage, flag;
@@ -234,8 +238,9 @@ int pgrc_match_pack_pg_slice(pgrc_match_ctx *c, const char *pg, uint64_t count, 
 
 int pgrc_match_set_pg_ascii(pgrc_match_ctx *c, const char *pg, uint64_t G) {
     if (!c || !pg) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_set_pg_ascii(c, pg, G);
     PGRC_ON_DEVICE(c);
-    int e = alloc_pg(c, G);
+    int e = pgrc_pg_alloc(c, G);
     if (e) return e;
     if ((e = pgrc_match_pack_pg_slice(c, pg, G, c->pg2[0].p))) return e;
     c->have_pg = true;
@@ -244,10 +249,11 @@ int pgrc_match_set_pg_ascii(pgrc_match_ctx *c, const char *pg, uint64_t G) {
 
 int pgrc_match_set_pg_packed_device(pgrc_match_ctx *c, const void *d_words, uint64_t G) {
     if (!c || !d_words) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_set_pg_packed_device(c, d_words, G);
     PGRC_ON_DEVICE(c);
-    int e = alloc_pg(c, G);
+    int e = pgrc_pg_alloc(c, G);
     if (e) return e;
-    HIP_TRY(c, hipMemcpyAsync(c->pg2[0].p, d_words, c->pg_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->pg2[0].p, d_words, c->pg_words * sizeof(uint32_t), hipMemcpyDefault, c->stream));   // (the source may live on another device)
     // clear the bits after symbol G-1 in the last word: padding must read as zero
     if (G % 16) {
         uint32_t last;
@@ -263,6 +269,7 @@ int pgrc_match_set_pg_packed_device(pgrc_match_ctx *c, const void *d_words, uint
 
 int pgrc_match_export_pg(pgrc_match_ctx *c, int strand, uint32_t *words) {
     if (!c || !words || strand < 0 || strand > 1) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_export_pg(c, strand, words);
     if (!c->have_pg) { c->err = "export_pg: no pseudogenome set"; return PGRC_E_STATE; }
     PGRC_ON_DEVICE(c);
     if (strand == 1 && !c->have_rc) {
@@ -305,6 +312,7 @@ static int begin_reads(pgrc_match_ctx *c, uint64_t n, bool own) {
 // through a bounded host buffer.
 int pgrc_match_begin_reads(pgrc_match_ctx *c, uint64_t n) {
     if (!c) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_begin_reads(c, n);
     PGRC_ON_DEVICE(c);
     int e = begin_reads(c, n, true);
     if (e) return e;
@@ -317,48 +325,85 @@ int pgrc_match_begin_reads(pgrc_match_ctx *c, uint64_t n) {
     return PGRC_OK;
 }
 
-int pgrc_match_append_reads_ascii(pgrc_match_ctx *c, const char *reads, uint64_t count) {
-    if (!c || (!reads && count)) return PGRC_E_PARAM;
+// One block of rows in any of the three host formats: `symbols` 0 = ASCII rows (read_len bytes), 4 = the reference's
+// ACGT packing (4 symbols per byte), 5 = its ACGNT packing (3 symbols per byte).  Staged through a bounded device
+// buffer and converted to the word-major 2-bit layout there; reads holding an N are flagged, and their ASCII rows
+// (made on the device for the packed formats) are kept for the side list of end_reads.
+static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, int32_t symbols) {
     if (!c->up_open || c->up_next + count > c->n) { c->err = "append_reads: outside begin/end or too many rows"; return PGRC_E_STATE; }
     PGRC_ON_DEVICE(c);
     const uint32_t L = c->prm.read_len;
-    DevBuf stage, flag;
+    const uint32_t rb = symbols == 0 ? L : symbols == 4 ? (L + 3) / 4 : (L + 2) / 3;   // host bytes per row
+    DevBuf stage, flag, lidx, nrows;
+    auto cleanup = [&]() { pgrc_buf_free(stage); pgrc_buf_free(flag); pgrc_buf_free(lidx); pgrc_buf_free(nrows); };
     int e;
-    const uint64_t CHR = std::max<uint64_t>(1, (256ull << 20) / L); // reads per staging chunk (~256 MiB)
-    if ((e = pgrc_buf_ensure(c, stage, (size_t)std::min(CHR, std::max<uint64_t>(count, 1)) * L))) return e;
-    if ((e = pgrc_buf_ensure(c, flag, sizeof(uint32_t)))) { pgrc_buf_free(stage); return e; }
+    const uint64_t CHR = std::max<uint64_t>(1, (256ull << 20) / rb); // rows per staging chunk (~256 MiB)
+    if ((e = pgrc_buf_ensure(c, stage, (size_t)std::min(CHR, std::max<uint64_t>(count, 1)) * rb))) return e;
+    if ((e = pgrc_buf_ensure(c, flag, sizeof(uint32_t)))) { cleanup(); return e; }
     (void)hipMemsetAsync(flag.p, 0, sizeof(uint32_t), c->stream);
     int rcode = PGRC_OK;
     std::vector<uint8_t> nf;
+    std::vector<uint32_t> local;
     for (uint64_t off = 0; off < count && rcode == PGRC_OK; off += CHR) {
         const uint64_t cnt = std::min(CHR, count - off);
         const uint64_t first = c->up_next + off;
-        if (hipMemcpyAsync(stage.p, reads + off * L, cnt * L, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
-        rcode = pgrc_launch_pack_reads_ascii(c, (const uint8_t *)stage.p, first, cnt, L, (uint32_t *)c->reads_own.p, c->stride,
-                                             (uint8_t *)c->nread_flag.p, (uint32_t *)flag.p);
+        if (hipMemcpyAsync(stage.p, rows + off * rb, cnt * rb, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
+        if (symbols == 0)
+            rcode = pgrc_launch_pack_reads_ascii(c, (const uint8_t *)stage.p, first, cnt, L, (uint32_t *)c->reads_own.p, c->stride,
+                                                 (uint8_t *)c->nread_flag.p, (uint32_t *)flag.p);
+        else if (symbols == 4)
+            rcode = pgrc_launch_repack_reads_ref(c, (const uint8_t *)stage.p, first, cnt, L, (uint32_t *)c->reads_own.p, c->stride);
+        else
+            rcode = pgrc_launch_unpack_reads_acgnt(c, (const uint8_t *)stage.p, first, cnt, L, (uint32_t *)c->reads_own.p, c->stride,
+                                                   (uint8_t *)c->nread_flag.p, (uint32_t *)flag.p);
         if (hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_DEVICE;
-        if (rcode != PGRC_OK) break;
-        // reads with 'N' -> byte path: keep their rows (they are a small minority)
+        if (rcode != PGRC_OK || symbols == 4) continue;      // (an ACGT set cannot hold an N)
+        // reads with 'N' -> side list: keep their ASCII rows (they are a small minority)
         nf.resize(cnt);
         if (hipMemcpy(nf.data(), (const uint8_t *)c->nread_flag.p + first, cnt, hipMemcpyDeviceToHost) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
+        local.clear();
         for (uint64_t k = 0; k < cnt; k++)
             if (nf[k]) {
                 c->up_nidx.push_back((uint32_t)(first + k));
-                c->up_nrows.insert(c->up_nrows.end(), reads + (off + k) * L, reads + (off + k + 1) * L);
+                if (symbols == 0) c->up_nrows.insert(c->up_nrows.end(), rows + (off + k) * rb, rows + (off + k + 1) * rb);
+                else local.push_back((uint32_t)k);
             }
+        if (!local.empty()) {      // packed rows with an N: their ASCII form comes from the device as well
+            const size_t nn = local.size();
+            if ((e = pgrc_buf_ensure(c, lidx, nn * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, nrows, nn * L))) { rcode = e; break; }
+            if (hipMemcpyAsync(lidx.p, local.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
+            rcode = pgrc_launch_nrows_ascii_acgnt(c, (const uint8_t *)stage.p, (const uint32_t *)lidx.p, nn, L, (uint8_t *)nrows.p);
+            const size_t at = c->up_nrows.size();
+            c->up_nrows.resize(at + nn * L);
+            if (rcode == PGRC_OK && (hipMemcpyAsync(c->up_nrows.data() + at, nrows.p, nn * L, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                                     hipStreamSynchronize(c->stream) != hipSuccess))
+                rcode = PGRC_E_DEVICE;
+        }
     }
     uint32_t bad = 0;
     if (rcode == PGRC_OK && hipMemcpy(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) rcode = PGRC_E_DEVICE;
-    pgrc_buf_free(stage);
-    pgrc_buf_free(flag);
-    if (rcode != PGRC_OK) { if (c->err.empty()) c->err = "append_reads_ascii: HIP error"; return rcode; }
-    if (bad) { c->err = "reads contain a symbol outside ACGNT"; return PGRC_E_SYMBOL; }
+    cleanup();
+    if (rcode != PGRC_OK) { if (c->err.empty()) c->err = "append_reads: HIP error"; return rcode; }
+    if (bad) { c->err = symbols == 5 ? "packed reads hold a byte outside the ACGNT code range" : "reads contain a symbol outside ACGNT"; return PGRC_E_SYMBOL; }
     c->up_next += count;
     return PGRC_OK;
 }
 
+int pgrc_match_append_reads_ascii(pgrc_match_ctx *c, const char *reads, uint64_t count) {
+    if (!c || (!reads && count)) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_append_reads(c, reads, count, 0);
+    return append_rows(c, (const uint8_t *)reads, count, 0);
+}
+
+int pgrc_match_append_reads_packed(pgrc_match_ctx *c, const uint8_t *packed, uint64_t count, int32_t symbols) {
+    if (!c || (!packed && count) || (symbols != 4 && symbols != 5)) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_append_reads(c, packed, count, symbols);
+    return append_rows(c, packed, count, symbols);
+}
+
 int pgrc_match_end_reads(pgrc_match_ctx *c) {
     if (!c) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_end_reads(c);
     if (!c->up_open || c->up_next != c->n) { c->err = "end_reads: fewer rows appended than announced"; return PGRC_E_STATE; }
     PGRC_ON_DEVICE(c);
     int e;
@@ -388,28 +433,15 @@ int pgrc_match_set_reads_ascii(pgrc_match_ctx *c, const char *reads, uint64_t n)
 
 int pgrc_match_set_reads_packed(pgrc_match_ctx *c, const uint8_t *packed, uint64_t n) {
     if (!c || (!packed && n)) return PGRC_E_PARAM;
-    PGRC_ON_DEVICE(c);
-    int e = begin_reads(c, n, true);
+    int e = pgrc_match_begin_reads(c, n);
     if (e) return e;
-    const uint32_t L = c->prm.read_len, pb = (L + 3) / 4;
-    DevBuf stage;
-    const uint64_t CHR = std::max<uint64_t>(1, (256ull << 20) / pb);
-    if ((e = pgrc_buf_ensure(c, stage, (size_t)std::min(CHR, std::max<uint64_t>(n, 1)) * pb))) return e;
-    int rcode = PGRC_OK;
-    for (uint64_t off = 0; off < n && rcode == PGRC_OK; off += CHR) {
-        const uint64_t cnt = std::min(CHR, n - off);
-        if (hipMemcpyAsync(stage.p, packed + off * pb, cnt * pb, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
-        rcode = pgrc_launch_repack_reads_ref(c, (const uint8_t *)stage.p, off, cnt, L, (uint32_t *)c->reads_own.p, c->stride);
-        if (hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_DEVICE;
-    }
-    pgrc_buf_free(stage);
-    if (rcode != PGRC_OK) { if (c->err.empty()) c->err = "set_reads_packed: HIP error"; return rcode; }
-    c->have_reads = true;
-    return PGRC_OK;
+    if ((e = pgrc_match_append_reads_packed(c, packed, n, 4))) return e;
+    return pgrc_match_end_reads(c);
 }
 
 int pgrc_match_set_reads_device(pgrc_match_ctx *c, const void *d_words, uint64_t n, uint64_t stride) {
     if (!c || (!d_words && n) || stride < n) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_set_reads_device(c, d_words, n, stride);
     PGRC_ON_DEVICE(c);
     int e = begin_reads(c, n, false);
     if (e) return e;
@@ -423,6 +455,7 @@ int pgrc_match_set_reads_device(pgrc_match_ctx *c, const void *d_words, uint64_t
 
 int pgrc_match_init_results(pgrc_match_ctx *c) {
     if (!c) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_init_results(c);
     if (!c->have_reads) { c->err = "init_results: no reads set"; return PGRC_E_STATE; }
     PGRC_ON_DEVICE(c);
     int e = pgrc_launch_init_results(c);
@@ -433,6 +466,7 @@ int pgrc_match_init_results(pgrc_match_ctx *c) {
 
 int pgrc_match_set_results(pgrc_match_ctx *c, const uint64_t *pos, const uint8_t *rc, const uint8_t *mism) {
     if (!c || !pos || !rc || !mism) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_set_results(c, pos, rc, mism);
     if (!c->have_reads) { c->err = "set_results: no reads set"; return PGRC_E_STATE; }
     PGRC_ON_DEVICE(c);
     if (c->n) {
@@ -447,6 +481,7 @@ int pgrc_match_set_results(pgrc_match_ctx *c, const uint64_t *pos, const uint8_t
 
 static int run_passes(pgrc_match_ctx *c, int first, int last) {
     if (!c) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_run(c, first, last);
     if (!c->have_pg || !c->have_reads) { c->err = "run: set the pseudogenome and the reads first"; return PGRC_E_STATE; }
     PGRC_ON_DEVICE(c);
     int e;
@@ -513,6 +548,7 @@ int pgrc_match_run_pass(pgrc_match_ctx *c, int strand) {
 
 int pgrc_match_get_results(pgrc_match_ctx *c, uint64_t *pos, uint8_t *rc, uint8_t *mism, uint64_t hist[256], uint64_t *matched) {
     if (!c) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_get_results(c, pos, rc, mism, hist, matched);
     if (!c->have_results) { c->err = "get_results: nothing computed"; return PGRC_E_STATE; }
     PGRC_ON_DEVICE(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -528,6 +564,7 @@ int pgrc_match_get_results(pgrc_match_ctx *c, uint64_t *pos, uint8_t *rc, uint8_
 
 int pgrc_match_get_results_device(pgrc_match_ctx *c, void **d_pos, void **d_rc, void **d_mism) {
     if (!c) return PGRC_E_PARAM;
+    if (c->multi) { c->err = "get_results_device: the results of a multi-device context live on several devices"; return PGRC_E_PARAM; }
     if (!c->have_reads) { c->err = "get_results_device: no reads set"; return PGRC_E_STATE; }
     if (d_pos) *d_pos = c->d_pos.p;
     if (d_rc) *d_rc = c->d_rc.p;
@@ -537,6 +574,7 @@ int pgrc_match_get_results_device(pgrc_match_ctx *c, void **d_pos, void **d_rc, 
 
 int pgrc_match_get_counters(pgrc_match_ctx *c, pgrc_match_counters *out) {
     if (!c || !out) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_get_counters(c, out);
     *out = c->ctr;
     out->index_entries[0] = out->index_entries[1] = c->npos;
     return PGRC_OK;
@@ -545,6 +583,7 @@ int pgrc_match_get_counters(pgrc_match_ctx *c, pgrc_match_counters *out) {
 int pgrc_match_extract_mismatches(pgrc_match_ctx *c, const uint8_t *reversed_flags, uint64_t *cum, uint8_t *codes,
                                   uint16_t *offsets) {
     if (!c || !cum) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_extract_mismatches(c, reversed_flags, cum, codes, offsets);
     if (!c->have_results || !c->have_pg) { c->err = "extract_mismatches: run first"; return PGRC_E_STATE; }
     PGRC_ON_DEVICE(c);
     return pgrc_extract_mismatches(c, reversed_flags, cum, codes, offsets);
@@ -552,6 +591,7 @@ int pgrc_match_extract_mismatches(pgrc_match_ctx *c, const uint8_t *reversed_fla
 
 int pgrc_match_export_index(pgrc_match_ctx *c, int strand, uint32_t *cumm, uint32_t *positions, uint64_t *count) {
     if (!c || strand < 0 || strand > 1) return PGRC_E_PARAM;
+    if (c->multi) return pgrc_multi_export_index(c, strand, cumm, positions, count);
     if (!c->have_pg || c->prm.mode != 'c') { c->err = "export_index: mode c with a pseudogenome only"; return PGRC_E_STATE; }
     PGRC_ON_DEVICE(c);
     int e;

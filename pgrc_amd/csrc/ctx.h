@@ -30,7 +30,13 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
+struct pgrc_multi;   // multi.hip
+
 struct pgrc_match_ctx {
+    // several devices behind this object (pgrc_match_create_multi): it is then only the front, the work happens in
+    // one child context per device
+    pgrc_multi *multi = nullptr;
+
     pgrc_match_params prm{};
     int device = 0;
     int num_cus = 256;
@@ -131,6 +137,29 @@ struct PgrcDeviceScope {
 int pgrc_buf_ensure(pgrc_match_ctx *c, DevBuf &b, size_t bytes);
 void pgrc_buf_free(DevBuf &b);
 
+// api.hip: (re)allocates and clears both strands' text buffers for a text of G symbols
+extern "C" int pgrc_pg_alloc(pgrc_match_ctx *c, uint64_t G);
+
+// multi.hip: the front context's side of every entry point
+int pgrc_multi_set_pg_ascii(pgrc_match_ctx *f, const char *pg, uint64_t G);
+int pgrc_multi_set_pg_packed_device(pgrc_match_ctx *f, const void *d_words, uint64_t G);
+int pgrc_multi_pack_pg_slice(pgrc_match_ctx *f, const char *pg, uint64_t count, void *d_words_out);
+int pgrc_multi_begin_reads(pgrc_match_ctx *f, uint64_t n);
+int pgrc_multi_append_reads(pgrc_match_ctx *f, const void *rows, uint64_t count, int32_t symbols /* 0 = ASCII */);
+int pgrc_multi_end_reads(pgrc_match_ctx *f);
+int pgrc_multi_set_reads_device(pgrc_match_ctx *f, const void *d_words, uint64_t n, uint64_t stride);
+int pgrc_multi_init_results(pgrc_match_ctx *f);
+int pgrc_multi_set_results(pgrc_match_ctx *f, const uint64_t *pos, const uint8_t *rc, const uint8_t *mism);
+int pgrc_multi_run(pgrc_match_ctx *f, int first, int last);
+int pgrc_multi_get_results(pgrc_match_ctx *f, uint64_t *pos, uint8_t *rc, uint8_t *mism, uint64_t hist[256], uint64_t *matched);
+int pgrc_multi_extract_mismatches(pgrc_match_ctx *f, const uint8_t *reversed_flags, uint64_t *cum, uint8_t *codes,
+                                  uint16_t *offsets);
+int pgrc_multi_export_index(pgrc_match_ctx *f, int strand, uint32_t *cumm, uint32_t *positions, uint64_t *count);
+int pgrc_multi_export_pg(pgrc_match_ctx *f, int strand, uint32_t *words);
+int pgrc_multi_set_profiling(pgrc_match_ctx *f, int enabled);
+int pgrc_multi_get_counters(pgrc_match_ctx *f, pgrc_match_counters *out);
+void pgrc_multi_destroy(pgrc_match_ctx *f);
+
 // pack.hip
 int pgrc_launch_pack_ascii(pgrc_match_ctx *c, const uint8_t *d_ascii, uint64_t count, uint32_t *d_words,
                            uint32_t *d_errflag);
@@ -140,6 +169,10 @@ int pgrc_launch_pack_reads_ascii(pgrc_match_ctx *c, const uint8_t *d_ascii, uint
                                  uint32_t *d_errflag);
 int pgrc_launch_repack_reads_ref(pgrc_match_ctx *c, const uint8_t *d_packed, uint64_t first, uint64_t count,
                                  uint32_t L, uint32_t *d_words, uint64_t stride);
+int pgrc_launch_unpack_reads_acgnt(pgrc_match_ctx *c, const uint8_t *d_packed, uint64_t first, uint64_t count,
+                                   uint32_t L, uint32_t *d_words, uint64_t stride, uint8_t *d_nflag, uint32_t *d_errflag);
+int pgrc_launch_nrows_ascii_acgnt(pgrc_match_ctx *c, const uint8_t *d_packed, const uint32_t *d_local_idx, uint64_t count,
+                                  uint32_t L, uint8_t *d_ascii);
 
 // copmem.hip
 int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand);

@@ -161,3 +161,93 @@ int pgrc_launch_repack_reads_ref(pgrc_match_ctx *c, const uint8_t *d_packed, uin
     HIP_TRY(c, hipGetLastError());
     return PGRC_OK;
 }
+
+// The reference's ACGNT packing (the N read set, readsset/DividedPCLReadsSets.cpp:16-19): 3 symbols per byte as base-5
+// digits, first symbol most significant, order A0 C1 G2 N3 T4 (SymbolsPackingFacility.cpp:133-178; a partial last
+// byte is padded with digit 0).  lut[v]: bits 0-5 the three 2-bit codes (N packs as 0), bits 8-10 the N flags,
+// bit 15 = not a code (v >= 125).
+__device__ __forceinline__ void acgnt_lut_init(uint32_t *lut) {
+    for (uint32_t v = threadIdx.x; v < 256; v += blockDim.x) {
+        uint32_t out = 0;
+        if (v >= 125) out = 1u << 15;
+        else {
+            const uint32_t d[3] = {v / 25u, (v / 5u) % 5u, v % 5u};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (d[k] == 3u) out |= 1u << (8 + k);
+                else out |= (d[k] == 4u ? 3u : d[k]) << (2 * k);
+            }
+        }
+        lut[v] = out;
+    }
+}
+
+// thread t = w * count + i: word w of read i (stores coalesced along i)
+__global__ void __launch_bounds__(256)
+k_unpack_reads_acgnt(const uint8_t *__restrict__ packed, uint64_t first, uint64_t count, uint32_t L, uint32_t nw, uint32_t pb,
+                     uint32_t *__restrict__ words, uint64_t stride, uint8_t *__restrict__ nflag, uint32_t *errflag) {
+    __shared__ uint32_t lut[256];
+    acgnt_lut_init(lut);
+    __syncthreads();
+    const uint64_t total = count * nw;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = t % count;
+        const uint32_t w = (uint32_t)(t / count);
+        const uint8_t *row = packed + i * pb;
+        const uint32_t x0 = 16 * w, x1 = min(L, x0 + 16);
+        uint32_t out = 0;
+        bool hasn = false, bad = false;
+        for (uint32_t b = x0 / 3; 3 * b < x1; b++) {            // the (at most 7) bytes that overlap symbols [x0, x1)
+            const uint32_t e = lut[row[b]];
+            bad |= (e >> 15) != 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 3; k++) {
+                const uint32_t x = 3 * b + k;
+                if (x >= x0 && x < x1) {
+                    out |= ((e >> (2 * k)) & 3u) << (2 * (x - x0));
+                    hasn |= ((e >> (8 + k)) & 1u) != 0;
+                }
+            }
+        }
+        words[(uint64_t)w * stride + first + i] = out;
+        if (hasn) nflag[first + i] = 1;
+        if (bad) atomicOr(errflag, 1u);
+    }
+}
+
+int pgrc_launch_unpack_reads_acgnt(pgrc_match_ctx *c, const uint8_t *d_packed, uint64_t first, uint64_t count, uint32_t L,
+                                   uint32_t *d_words, uint64_t stride, uint8_t *d_nflag, uint32_t *d_errflag) {
+    if (!count) return PGRC_OK;
+    const uint32_t nw = (L + 15) / 16, pb = (L + 2) / 3;
+    const uint64_t total = count * nw;
+    const uint32_t grid = (uint32_t)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
+    hipLaunchKernelGGL(k_unpack_reads_acgnt, dim3(grid), dim3(256), 0, c->stream, d_packed, first, count, L, nw, pb, d_words,
+                       stride, d_nflag, d_errflag);
+    HIP_TRY(c, hipGetLastError());
+    return PGRC_OK;
+}
+
+// ASCII rows of selected ACGNT-packed reads (the reads with N: the side list keeps them as bytes); one thread per symbol
+__global__ void __launch_bounds__(256)
+k_nrows_ascii_acgnt(const uint8_t *__restrict__ packed, const uint32_t *__restrict__ local_idx, uint64_t count, uint32_t L,
+                    uint32_t pb, uint8_t *__restrict__ ascii) {
+    const uint64_t total = count * L;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = t / L;
+        const uint32_t x = (uint32_t)(t % L);
+        const uint32_t v = packed[(uint64_t)local_idx[r] * pb + x / 3];
+        const uint32_t d = x % 3 == 0 ? v / 25u : x % 3 == 1 ? (v / 5u) % 5u : v % 5u;
+        ascii[t] = (uint8_t)"ACGNT"[d < 4u ? d : 4u];   // (a byte outside the code range is reported by the unpack kernel)
+    }
+}
+
+int pgrc_launch_nrows_ascii_acgnt(pgrc_match_ctx *c, const uint8_t *d_packed, const uint32_t *d_local_idx, uint64_t count,
+                                  uint32_t L, uint8_t *d_ascii) {
+    if (!count) return PGRC_OK;
+    const uint64_t total = count * L;
+    const uint32_t grid = (uint32_t)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(k_nrows_ascii_acgnt, dim3(grid), dim3(256), 0, c->stream, d_packed, d_local_idx, count, L, (L + 2) / 3,
+                       d_ascii);
+    HIP_TRY(c, hipGetLastError());
+    return PGRC_OK;
+}

@@ -40,6 +40,11 @@ def all_gather_packed_pg(local_words, world: int, group=None):
     out = torch.empty(world * local_words.numel(), dtype=local_words.dtype, device=local_words.device)
     if world == 1:
         out.copy_(local_words)
+    elif local_words.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal on a box without RCCL peers (several ranks sharing one GPU): the collective runs on host copies
+        host = torch.empty(out.numel(), dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local_words.cpu(), group=group)
+        out.copy_(host)
     else:
         dist.all_gather_into_tensor(out, local_words, group=group)
     return out

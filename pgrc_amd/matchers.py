@@ -57,10 +57,17 @@ class MatchContext:
     """RAII wrapper of `pgrc_match_ctx*`."""
 
     def __init__(self, read_len: int, seed_len: int, max_mismatches: int, min_mismatches: int, mode: str,
-                 device: int = -1):
+                 device: int = -1, devices=None):
+        """devices: a list of HIP device ordinals -> ONE matcher over several GPUs in this process
+        (pgrc_match_create_multi: reads sharded, text all-gathered); a device may be listed twice to rehearse the
+        sharded path on a smaller box."""
         prm = MatchParams(read_len, seed_len, max_mismatches, min_mismatches, mode.encode(), device)
         self._h = C.c_void_p()
-        rc = lib.pgrc_match_create(C.byref(prm), C.byref(self._h))
+        if devices is None:
+            rc = lib.pgrc_match_create(C.byref(prm), C.byref(self._h))
+        else:
+            arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            rc = lib.pgrc_match_create_multi(C.byref(prm), len(devices), arr, C.byref(self._h))
         if rc:
             self._h = C.c_void_p()
             raise PgrcMatchError(rc, "pgrc_match_create: " + (lib.pgrc_match_last_error(None) or b"").decode())
@@ -109,6 +116,26 @@ class MatchContext:
         self._ck(lib.pgrc_match_set_reads_packed(self._h, a.ctypes.data_as(C.c_void_p), n))
         self.n = int(n)
 
+    def set_reads_packed_sets(self, sets):
+        """sets: [(packed uint8 rows, n, symbols)], symbols 4 = an ACGT set, 5 = an ACGNT set, in read order -- e.g. the
+        LQ + N sum set of pgrc-encoder.cpp:349-352 as [(lq_rows, n_lq, 4), (n_rows, n_n, 5)]."""
+        total = sum(int(n) for _, n, _ in sets)
+        self._ck(lib.pgrc_match_begin_reads(self._h, total))
+        for rows, n, symbols in sets:
+            a = np.ascontiguousarray(rows, dtype=np.uint8)
+            self._ck(lib.pgrc_match_append_reads_packed(self._h, a.ctypes.data_as(C.c_void_p), int(n), int(symbols)))
+        self._ck(lib.pgrc_match_end_reads(self._h))
+        self.n = total
+
+    def shards(self):
+        """[(device, first_read, n_reads)] -- one entry for a single-device context"""
+        out = []
+        for k in range(lib.pgrc_match_shard_count(self._h)):
+            d, a, b = C.c_int32(), C.c_uint64(), C.c_uint64()
+            self._ck(lib.pgrc_match_shard_info(self._h, k, C.byref(d), C.byref(a), C.byref(b)))
+            out.append((d.value, a.value, b.value))
+        return out
+
     def set_reads_device(self, dev_ptr: int, n: int, stride: int, keep=None):
         self._ck(lib.pgrc_match_set_reads_device(self._h, C.c_void_p(dev_ptr), n, stride))
         self.n = int(n)
@@ -128,6 +155,10 @@ class MatchContext:
 
     def run(self, rev_compl_pg: bool = True):
         self._ck(lib.pgrc_match_run(self._h, 1 if rev_compl_pg else 0))
+
+    def run_pass(self, strand: int):
+        """one executeMatching(revCompMode) (ReadsMatchers.h:46)"""
+        self._ck(lib.pgrc_match_run_pass(self._h, int(strand)))
 
     def get_results(self, arrays: bool = True):
         n = self.n
@@ -193,7 +224,7 @@ class MatchContext:
         self._ck(lib.pgrc_match_get_counters(self._h, C.byref(c)))
         return {"searched": list(c.searched), "candidates": list(c.candidates), "probes": list(c.probes),
                 "entry_fetches": list(c.entry_fetches), "verifies": list(c.verifies), "index_entries": list(c.index_entries), "ms_index": list(c.ms_index), "ms_match": list(c.ms_match),
-                "ms_other": c.ms_other, "ms_total": c.ms_total}
+                "ms_other": c.ms_other, "ms_total": c.ms_total, "ms_allgather": c.ms_allgather}
 
 
 class DefaultReadsMatcher:

@@ -1,5 +1,12 @@
-"""BASELINE.json's full sizes (C3: 100 M x 150 bp against a 1.875 Gbp Pg; C1: exact matcher) through
-size-independent properties, plus a sample checked against the reference / oracle on the whole pseudogenome."""
+"""Every BASELINE.json config at its FULL size, through size-independent properties plus a sample checked bit for bit
+against the reference (serial canonical index, whole pseudogenome) -- or the oracle port where oracle/_ref is absent:
+  C1  1 M x 100 bp, exact matcher                     test_c1_full_size_exact_matcher
+  C2  10 M x 100 bp, k <= 2, Pg 125 Mbp               test_c2_full_size
+  C3  100 M x 150 bp SE, k <= 3, Pg 1.875 Gbp         test_c3_full_size_properties_and_sample
+  C4  100 M x 150 bp PE, reads in 8 shards, the packed Pg assembled from 8 slices    test_c4_full_size_eight_shards
+  C5  one GPU's 1/8 of 500 M x 250 bp, k <= 5, Pg 3.1 Gbp (hash 2^30)               test_c5_shard_full_size
+  P64 Pg of 4.4 Gbp: the 64-bit-position kernels at a real >= 4 Gi text             test_p64_full_size
+and row f2 (Pg-vs-Pg) at the C3 Pg size."""
 import numpy as np
 import pytest
 import torch
@@ -10,25 +17,87 @@ from util import revcomp
 
 pytestmark = pytest.mark.gpu
 
+_LUT = np.zeros((256, 4), dtype=np.uint8)
+for _b in range(256):
+    for _k in range(4):
+        _LUT[_b, _k] = b"ACGT"[(_b >> (2 * _k)) & 3]
+_COMP = np.zeros(256, dtype=np.uint8)
+for _x, _y in zip(b"ACGTN", b"TGCAN"):
+    _COMP[_x] = _y
+
 
 def _unpack(words, G):
-    lut = np.zeros((256, 4), dtype=np.uint8)
-    for b in range(256):
-        for k in range(4):
-            lut[b, k] = b"ACGT"[(b >> (2 * k)) & 3]
-    return lut[words.view(np.uint8)].reshape(-1)[:G]
+    return _LUT[words.view(np.uint8)].reshape(-1)[:G]
 
 
-def test_c3_full_size_properties_and_sample():
-    n, L, G, seed_len, kmax = 100_000_000, 150, 1_875_000_000, 38, 3
-    g = synth.pg_params(G, seed=12345)
-    rs = synth.reads_params(n, L, seed=12345)
-    nw, stride, pgw = (L + 15) // 16, (n + 63) & ~63, (G + 15) // 16
-    d_pg = torch.zeros(pgw + 64, dtype=torch.int32, device="cuda")
-    synth.pg_device(g, d_pg.data_ptr())
-    d_rd = torch.empty(nw * stride, dtype=torch.int32, device="cuda")
-    synth.reads_device(g, d_pg.data_ptr(), rs, 0, n, d_rd.data_ptr(), stride)
-    torch.cuda.synchronize()
+def _check(mode, pg, reads, seed_len, kmax, threads=16):
+    """the checker: the compiled reference with its serial index and one thread in the per-read loop (its RC-flag
+    race), else the oracle port"""
+    if orc.have_ref():
+        return orc.ref_match(mode, pg, reads, seed_len, kmax, 0, True, 0, 1, 1)
+    return orc.oracle_match(mode, pg, reads, seed_len, kmax, 0, True, threads)
+
+
+def _bookkeeping(n, G, L, kmax, pos, rc, mism, hist, matched):
+    assert int(hist.sum()) == n and matched == n - int(hist[255])
+    assert np.array_equal(np.bincount(mism, minlength=256).astype(np.uint64), hist)
+    assert np.array_equal(pos == np.uint64(2**64 - 1), mism == 255)
+    assert int(mism[mism != 255].max()) <= kmax and not rc[mism == 255].any()
+    assert int(pos[mism != 255].max()) <= G - L
+
+
+def _alignments_are_real(pg, reads, pos, rc, mism):
+    """recompute the Hamming distance at every reported place of a sample"""
+    L = reads.shape[1]
+    idx = np.flatnonzero(mism != 255)
+    win = pg[pos[idx, None].astype(np.int64) + np.arange(L)[None, :]]
+    rd = reads[idx]
+    ham = np.where(rc[idx, None] != 0, _COMP[rd[:, ::-1]] != win, rd != win).sum(axis=1)
+    assert np.array_equal(ham.astype(np.uint8), mism[idx])
+
+
+class _C3World:
+    """The C3 / C4 pseudogenome (1.875 Gbp, seed 12345) in HBM and on the host, and ONE reference run over it for the
+    samples of both tests (the reference's index build over the whole text is what costs: ~15 s)."""
+    n, L, G, seed_len, kmax, ns = 100_000_000, 150, 1_875_000_000, 38, 3, 100_000
+
+    def __init__(self):
+        self.g = synth.pg_params(self.G, seed=12345)
+        self.pgw = (self.G + 15) // 16
+        self.d_pg = torch.zeros(self.pgw + 64, dtype=torch.int32, device="cuda")
+        synth.pg_device(self.g, self.d_pg.data_ptr())
+        torch.cuda.synchronize()
+        self.pg = _unpack(self.d_pg.cpu().numpy().view(np.uint32)[: self.pgw], self.G)
+        self.rs_se = synth.reads_params(self.n, self.L, seed=12345)
+        self.rs_pe = synth.reads_params(self.n, self.L, seed=12345, paired=True)
+        self.reads_se = synth.reads_host(self.g, self.pg, self.rs_se, 0, 3 * self.ns)
+        self.reads_pe = synth.reads_host(self.g, self.pg, self.rs_pe, 0, self.ns)
+        both = np.concatenate([self.reads_se[: self.ns], self.reads_pe])
+        r = _check("c", self.pg, both, self.seed_len, self.kmax)
+        self.ref_se = {k: r[k][: self.ns] for k in ("pos", "rc", "mism")}
+        self.ref_pe = {k: r[k][self.ns:] for k in ("pos", "rc", "mism")}
+
+    def device_reads(self, rs):
+        nw, stride = (self.L + 15) // 16, (self.n + 63) & ~63
+        d_rd = torch.empty(nw * stride, dtype=torch.int32, device="cuda")
+        synth.reads_device(self.g, self.d_pg.data_ptr(), rs, 0, self.n, d_rd.data_ptr(), stride)
+        torch.cuda.synchronize()
+        return d_rd, stride
+
+
+@pytest.fixture(scope="module")
+def c3world():
+    w = _C3World()
+    yield w
+    del w.d_pg
+    torch.cuda.empty_cache()
+
+
+def test_c3_full_size_properties_and_sample(c3world):
+    w = c3world
+    n, L, G, seed_len, kmax = w.n, w.L, w.G, w.seed_len, w.kmax
+    d_pg, pg, g, rs = w.d_pg, w.pg, w.g, w.rs_se
+    d_rd, stride = w.device_reads(rs)
     ctx = MatchContext(L, seed_len, kmax, 0, "c")
     ctx.set_pg_packed_device(d_pg.data_ptr(), G)
     ctx.set_reads_device(d_rd.data_ptr(), n, stride, keep=d_rd)
@@ -36,34 +105,19 @@ def test_c3_full_size_properties_and_sample():
     ctx.run(True)
     pos, rc, mism, hist, matched = ctx.get_results()
     # 1. bookkeeping: histogram = histogram of the per-read counts; matched = reads with a position
-    assert int(hist.sum()) == n and matched == n - int(hist[255])
-    assert np.array_equal(np.bincount(mism, minlength=256).astype(np.uint64), hist)
-    assert np.array_equal(pos == np.uint64(2**64 - 1), mism == 255)
-    assert int(mism[mism != 255].max()) <= kmax and not rc[mism == 255].any()
-    assert int(pos[mism != 255].max()) <= G - L
+    _bookkeeping(n, G, L, kmax, pos, rc, mism, hist, matched)
     # 2. idempotence: a second run over the finished state changes nothing (every pass must strictly improve)
     ctx.run(True)
     pos2, rc2, mism2, hist2, _ = ctx.get_results()
     assert np.array_equal(pos, pos2) and np.array_equal(rc, rc2) and np.array_equal(mism, mism2) and np.array_equal(hist, hist2)
     # 3. planted truth + reported alignments are real: on a sample, recompute the Hamming distance at the reported place
-    pg = _unpack(ctx.export_pg(0), G)
     ns = 300_000
-    reads = synth.reads_host(g, pg, rs, 0, ns)
-    idx = np.flatnonzero(mism[:ns] != 255)
-    win = pg[pos[idx, None].astype(np.int64) + np.arange(L)[None, :]]
-    rd = reads[idx]
-    comp = np.zeros(256, dtype=np.uint8)
-    for a, b in zip(b"ACGT", b"TGCA"):
-        comp[a] = b
-    rd_rc = comp[rd[:, ::-1]]
-    ham = np.where(rc[idx, None] != 0, rd_rc != win, rd != win).sum(axis=1)
-    assert np.array_equal(ham.astype(np.uint8), mism[idx])
+    reads = w.reads_se
+    _alignments_are_real(pg, reads, pos[:ns], rc[:ns], mism[:ns])
+    comp = _COMP
     # 4. bit-identity on a sample against the reference (serial canonical index) or the oracle, whole Pg
-    m = 100_000
-    if orc.have_ref():
-        r = orc.ref_match("c", pg, reads[:m], seed_len, kmax, 0, True, 0, 1, 1)   # one thread: the reference's RC-flag race
-    else:
-        r = orc.oracle_match("c", pg, reads[:m], seed_len, kmax, 0, True, 16)
+    m = w.ns
+    r = w.ref_se
     assert np.array_equal(pos[:m], r["pos"]) and np.array_equal(rc[:m], r["rc"]) and np.array_equal(mism[:m], r["mism"])
     # the generator plants 60 % exact reads (3 % of all reads are random): at least that many must match exactly
     assert hist[0] >= 0.55 * n and matched >= 0.85 * n
@@ -88,6 +142,103 @@ def test_c3_full_size_properties_and_sample():
         del cx
 
 
+def test_c4_full_size_eight_shards(c3world):
+    """configs[3]: 100 M x 150 bp PE, reads sharded 8 ways, the packed Pg assembled from 8 slices.  The 8 ranks' work
+    runs back to back on this device: every rank's slice of the host text is packed by pgrc_match_pack_pg_slice into
+    its place of the gathered buffer (what the all-gather assembles), that buffer becomes the text
+    (pgrc_match_set_pg_packed_device), and every shard's reads -- even-aligned ranges, PE mates together -- are matched
+    against it.  The concatenation must equal the one-shot run bit for bit, and a sample the reference."""
+    from pgrc_amd import dist as pdist
+    w = c3world
+    n, L, G, seed_len, kmax = w.n, w.L, w.G, w.seed_len, w.kmax
+    world = 8
+    d_rd, stride = w.device_reads(w.rs_pe)
+    one = MatchContext(L, seed_len, kmax, 0, "c")
+    one.set_pg_packed_device(w.d_pg.data_ptr(), G)
+    one.set_reads_device(d_rd.data_ptr(), n, stride, keep=d_rd)
+    one.init_results()
+    one.run(True)
+    pos, rc, mism, hist, matched = one.get_results()
+    _bookkeeping(n, G, L, kmax, pos, rc, mism, hist, matched)
+    assert hist[0] >= 0.55 * n and matched >= 0.85 * n
+    m = w.ns
+    _alignments_are_real(w.pg, w.reads_pe, pos[:m], rc[:m], mism[:m])
+    for k in ("pos", "rc", "mism"):
+        assert np.array_equal({"pos": pos, "rc": rc, "mism": mism}[k][:m], w.ref_pe[k]), k
+    del one
+    # the gathered text, slice by slice
+    sw = pdist.pg_slice(G, 0, world)[2]
+    d_full = torch.zeros(sw * world + 64, dtype=torch.int32, device="cuda")
+    ctx = MatchContext(L, seed_len, kmax, 0, "c")
+    for r in range(world):
+        lo, hi, _ = pdist.pg_slice(G, r, world)
+        ctx.pack_pg_slice(w.pg[lo:hi], d_full.data_ptr() + 4 * r * sw)
+    torch.cuda.synchronize()
+    assert torch.equal(d_full[: w.pgw], w.d_pg[: w.pgw])
+    ctx.set_pg_packed_device(d_full.data_ptr(), G)
+    total_hist = np.zeros(256, dtype=np.uint64)
+    end = 0
+    for r in range(world):
+        lo, hi = pdist.shard_range(n, r, world)
+        assert lo == end and lo % 2 == 0
+        end = hi
+        # word w of read i lives at words[w * stride + i]: a shard is the same array seen from read `lo` on
+        ctx.set_reads_device(d_rd.data_ptr() + 4 * lo, hi - lo, stride, keep=d_rd)
+        ctx.init_results()
+        ctx.run(True)
+        p, c, mm, h, _ = ctx.get_results()
+        assert np.array_equal(p, pos[lo:hi]) and np.array_equal(c, rc[lo:hi]) and np.array_equal(mm, mism[lo:hi]), r
+        total_hist += h
+    assert end == n and np.array_equal(total_hist, hist)
+
+
+def _full_size_run(n, L, G, seed_len, kmax, sample):
+    """inputs generated in HBM, one run over all n reads, properties, and the first `sample` reads against the checker
+    on the whole text"""
+    g = synth.pg_params(G, seed=12345)
+    rs = synth.reads_params(n, L, seed=12345)
+    nw, stride, pgw = (L + 15) // 16, (n + 63) & ~63, (G + 15) // 16
+    d_pg = torch.zeros(pgw + 64, dtype=torch.int32, device="cuda")
+    synth.pg_device(g, d_pg.data_ptr())
+    d_rd = torch.empty(nw * stride, dtype=torch.int32, device="cuda")
+    synth.reads_device(g, d_pg.data_ptr(), rs, 0, n, d_rd.data_ptr(), stride)
+    torch.cuda.synchronize()
+    ctx = MatchContext(L, seed_len, kmax, 0, "c")
+    ctx.set_pg_packed_device(d_pg.data_ptr(), G)
+    ctx.set_reads_device(d_rd.data_ptr(), n, stride, keep=d_rd)
+    ctx.init_results()
+    ctx.run(True)
+    pos, rc, mism, hist, matched = ctx.get_results()
+    _bookkeeping(n, G, L, kmax, pos, rc, mism, hist, matched)
+    assert hist[0] >= 0.55 * n and matched >= 0.85 * n
+    pg = _unpack(d_pg.cpu().numpy().view(np.uint32)[:pgw], G)
+    reads = synth.reads_host(g, pg, rs, 0, sample)
+    _alignments_are_real(pg, reads, pos[:sample], rc[:sample], mism[:sample])
+    r = _check("c", pg, reads, seed_len, kmax)
+    for k, v in (("pos", pos), ("rc", rc), ("mism", mism)):
+        assert np.array_equal(v[:sample], r[k]), k
+    return ctx, pos, mism
+
+
+def test_c2_full_size():
+    """configs[1]: 10 M x 100 bp SE, k <= 2 (-M 50), Pg 125 Mbp"""
+    _full_size_run(10_000_000, 100, 125_000_000, 38, 2, 200_000)
+
+
+def test_c5_shard_full_size():
+    """configs[4]: one GPU's share (1/8) of 500 M x 250 bp, k <= 5, against the 3.1 Gbp Pg (hash table 2^30, positions
+    still 32-bit)."""
+    ctx, pos, mism = _full_size_run(62_500_000, 250, 3_100_000_000, 38, 5, 50_000)
+    assert ctx.counters()["index_entries"][0] > 600_000_000
+
+
+def test_p64_full_size():
+    """A text of 4.4 Gbp (>= 4 Gi symbols): the reference's u64 index branch (CopMEMMatcher.cpp:579-586), here the
+    64-bit-position kernels, at a size where positions really leave 32 bits."""
+    ctx, pos, mism = _full_size_run(50_000_000, 150, 4_400_000_000, 38, 3, 50_000)
+    assert int((pos[mism != 255] >= np.uint64(2**32)).sum()) > 100_000
+
+
 def test_c1_full_size_exact_matcher():
     """configs[0]: 1 M x 100 bp, exact match against a 12.5 Mbp Pg (DefaultReadsExactMatcher)."""
     n, L, G = 1_000_000, 100, 12_500_000
@@ -110,19 +261,14 @@ def test_c1_full_size_exact_matcher():
     assert np.array_equal(win, rd)
 
 
-def test_pg_vs_pg_matching_full_size_properties():
+def test_pg_vs_pg_matching_full_size_properties(c3world):
     """Row f2 at BASELINE's pseudogenome size (1.875 Gbp against itself, forward and reverse-complement): every
     reported match is a real exact match, long enough, not extensible to the right, extensible to the left by at most
     the reference's one symbol at a text start; the self-match filter holds.
     (Identity with the reference at this size: tests/mem_scale.py, profiles/r01_mem_scale_C3.json.)"""
     from pgrc_amd import CopMEMMatcher
-    G = 1_875_000_000
-    g = synth.pg_params(G, seed=12345)
-    d_pg = torch.zeros((G + 15) // 16 + 64, dtype=torch.int32, device="cuda")
-    synth.pg_device(g, d_pg.data_ptr())
-    torch.cuda.synchronize()
-    src = _unpack(d_pg.cpu().numpy().view(np.uint32)[: (G + 15) // 16], G).copy()
-    del d_pg
+    G = c3world.G
+    src = c3world.pg
     m = CopMEMMatcher(src, 45)
     rng = np.random.default_rng(1)
     for rev_compl in (False, True):

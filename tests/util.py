@@ -43,20 +43,32 @@ def assert_same_results(a, b, what=""):
     assert a["matched"] == b["matched"], what
 
 
-def gpu_match(mode, pg, reads, seed_len, kmax, kmin, rev_compl=True, packed_ref=False):
-    """Runs the HIP path through the C ABI; returns the same dict shape as the oracle helpers."""
+def pack_rows(reads, alphabet=b"ACGT"):
+    """The reference's packed rows (SymbolsPackingFacility layout) of ASCII reads, made by the oracle's restatement
+    of packSequence (checked against the real one in tests/test_oracle_vs_ref.py)."""
+    import ctypes as C
+    import oracle as orc
+    n, L = reads.shape
+    spe = 4 if len(alphabet) == 4 else 3
+    buf = np.zeros((n, (L + spe - 1) // spe), dtype=np.uint8)
+    f = orc.oracle().pgrc_or_pack_read
+    for i in range(n):
+        f(reads[i].ctypes.data_as(C.c_void_p), L, alphabet, buf[i].ctypes.data_as(C.c_void_p))
+    return buf
+
+
+def gpu_match(mode, pg, reads, seed_len, kmax, kmin, rev_compl=True, packed_ref=False, devices=None, n_nset=None):
+    """Runs the HIP path through the C ABI; returns the same dict shape as the oracle helpers.
+    packed_ref: hand the reads over in the reference's ACGT packing; n_nset: ... as the LQ + N sum set (the last
+    n_nset reads ACGNT-packed); devices: one matcher over these devices (pgrc_match_create_multi)."""
     from pgrc_amd import MatchContext
-    ctx = MatchContext(reads.shape[1], seed_len, kmax, kmin, mode)
+    ctx = MatchContext(reads.shape[1], seed_len, kmax, kmin, mode, devices=devices)
     ctx.set_pg_ascii(pg)
-    if packed_ref:
-        import oracle as orc
-        import ctypes as C
-        L = reads.shape[1]
-        pb = (L + 3) // 4
-        buf = np.zeros((reads.shape[0], pb), dtype=np.uint8)
-        for i in range(reads.shape[0]):
-            orc.oracle().pgrc_or_pack_read(reads[i].ctypes.data_as(C.c_void_p), L, b"ACGT", buf[i].ctypes.data_as(C.c_void_p))
-        ctx.set_reads_packed(buf, reads.shape[0])
+    if n_nset is not None:
+        n_lq = reads.shape[0] - n_nset
+        ctx.set_reads_packed_sets([(pack_rows(reads[:n_lq]), n_lq, 4), (pack_rows(reads[n_lq:], b"ACGNT"), n_nset, 5)])
+    elif packed_ref:
+        ctx.set_reads_packed(pack_rows(reads), reads.shape[0])
     else:
         ctx.set_reads_ascii(reads)
     ctx.init_results()
