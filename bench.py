@@ -30,7 +30,9 @@ WORKLOADS = {
     "P64": (50_000_000, 150, 4_400_000_000, 38, 50, "c", False),  # Pg >= 4 Gi: the 64-bit-position kernels
     "tiny": (1_000_000, 150, 18_750_000, 38, 50, "c", False),
 }
-GATHER_CEILING_GPS = 51.0  # measured: tools/ubench/gather2.hip, profiles/r01_ubench_gather_width_ilp.txt
+# measured random-request ceiling of the chip (tools/ubench/gather.hip): 51 G/s at a 4 GiB footprint, 48 G/s at the
+# 8-32 GiB footprints where the 8.6 GB bucket-head table of C3 lives (profiles/r01_ubench_gather_footprint.txt)
+GATHER_CEILING_GPS = 48.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -43,6 +45,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-sample-reads", type=int, default=3_000_000)
+    ap.add_argument("--parity-sample-reads", type=int, default=100_000,
+                    help="reads checked bit for bit against the SERIAL-index reference (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + PGRC_BENCH_FORCE_DEVICE=0 rehearses the N>1 path on a one-GPU box (collectives staged through the host)")
     args = ap.parse_args()
@@ -52,6 +56,7 @@ def main():
     import torch.distributed as dist
 
     from pgrc_amd import MatchContext, copmem_params, synth
+    from pgrc_amd import dist as pdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -91,25 +96,19 @@ def main():
     # multi-GPU: every rank owns 1/world of the packed Pg (what it would pack from its slice of the host text);
     # one all-gather per step rebuilds the replicated text
     if world > 1:
-        slice_words = (pg_words + world - 1) // world
+        slo, shi, slice_words = pdist.pg_slice(G, rank, world)     # the symbols this rank packs: words [lo/16, ...)
         d_slice = torch.zeros(slice_words, dtype=torch.int32, device=dev)
-        lo = rank * slice_words
-        hi = min(pg_words, lo + slice_words)
-        if hi > lo:
-            d_slice[: hi - lo] = d_pg[lo:hi]
-        d_full = torch.zeros(slice_words * world + 64, dtype=torch.int32, device=dev)
+        wlo, whi = slo // 16, (shi + 15) // 16
+        if whi > wlo:
+            d_slice[: whi - wlo] = d_pg[wlo:whi]
         del d_pg
     else:
         ctx.set_pg_packed_device(d_pg.data_ptr(), G)
 
     def step():
         if world > 1:
-            if args.dist_backend == "nccl":
-                dist.all_gather_into_tensor(d_full[: slice_words * world], d_slice)
-            else:
-                host = torch.empty(slice_words * world, dtype=torch.int32)
-                dist.all_gather_into_tensor(host, d_slice.cpu())
-                d_full[: slice_words * world].copy_(host)
+            # the ONE data-path collective: all-gather of the packed text (RCCL over xGMI; pgrc_amd/dist.py)
+            d_full = pdist.all_gather_packed_pg(d_slice, world)
             torch.cuda.current_stream().synchronize()
             ctx.set_pg_packed_device(d_full.data_ptr(), G)
         ctx.init_results()
@@ -154,11 +153,19 @@ def main():
         # (tools/ubench: the chip sustains ~51 G independent random requests per second, whatever their width)
         gathers = int(ctr["probes"][dom] + ctr["entry_fetches"][dom] + ctr["verifies"][dom] * (1.0 + max(rb - 4, 0) / 64.0))
         gather_rate = gathers / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        # the bytes THIS kernel's algorithm needs (its fingerprints reject 99.9 % of the false candidates without
+        # touching the text, so the reference's text-window bytes above are mostly never moved): a 16-B head per
+        # probe, 16 B per fetched entry pair, a window only per VERIFIED candidate, the read and the result
+        kernel_bytes = (ctr["probes"][dom] * 16 + ctr["entry_fetches"][dom] * 16 + ctr["verifies"][dom] * (5 + rb) +
+                        ctr["searched"][dom] * (rb + 10))
+        kernel_gbs = kernel_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         # HBM traffic of that launch from the PMC counters (FETCH_SIZE + WRITE_SIZE): they cannot be read from inside
         # this process, so the value comes from the committed separate `rocprofv3 --pmc` passes of this very command
         # (tools/pmc_groups.sh + tools/pmc_traffic.py -> profiles/); null for workloads that were not profiled.
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", f"r01_final_{args.workload.lower()}_traffic.json")
+        tp = os.path.join(ROOT, "profiles", f"r02_{args.workload.lower()}_traffic.json")
+        if not os.path.exists(tp):
+            tp = os.path.join(ROOT, "profiles", f"r01_final_{args.workload.lower()}_traffic.json")
         if world == 1 and os.path.exists(tp):
             try:
                 traffic = json.load(open(tp))["dispatches"][dom]["hbm_bytes"]
@@ -188,10 +195,14 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_copmem_match" + ("(fwd)" if dom == 0 else "(rc)"),
                          "kernel_ms": ms, "algorithmic_bytes": alg_bytes,
+                         "kernel_bytes": kernel_bytes, "achieved_kernel_bytes": kernel_gbs,
+                         "frac_kernel_bytes": kernel_gbs / HBM_PEAK_GBS,
+                         "limiter": "random 64-B line requests (one per bucket head / entry pair / text window)",
                          "random_gathers": gathers, "gather_rate_G_per_s": gather_rate,
                          "gather_ceiling_G_per_s": GATHER_CEILING_GPS, "gather_frac": gather_rate / GATHER_CEILING_GPS},
             "phases_ms": {"index_fwd": ctr["ms_index"][0], "match_fwd": ctr["ms_match"][0], "index_rc": ctr["ms_index"][1],
                           "match_rc": ctr["ms_match"][1], "other": ctr["ms_other"], "total_device": ctr["ms_total"]},
+            "dist_backend": args.dist_backend if world > 1 else None,
             "counters": {k: ctr[k] for k in ("searched", "candidates", "probes", "entry_fetches", "verifies", "index_entries")},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -199,6 +210,11 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax)
             except Exception as e:  # the GPU measurement must not be lost to a host-side problem
                 out["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(e)}
+            if args.parity_sample_reads > 0:
+                try:
+                    out["parity_sample"] = parity_sample(args, ctx, g, rs, n_per, L, G, seed_len, kmax)
+                except Exception as e:
+                    out["parity_sample"] = {"diff": None, "error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -225,7 +241,7 @@ def cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax):
     from pgrc_amd import synth
     threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
     t_prep = time.perf_counter()
-    pg = unpack_pg_to_ascii(ctx.export_pg(0))[:G]
+    pg = host_text(ctx, G)
     ns = min(args.cpu_sample_reads, n_per)
     reads = synth.reads_host(g, pg, rs, 0, ns)
     prep_s = time.perf_counter() - t_prep
@@ -256,14 +272,52 @@ def cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax):
     # (tests/fullscale_parity.py, tests/).
     pos, rc, mism, _, _ = ctx.get_results()
     diff = int((mism[:ns] != r["mism"]).sum())
-    return {"value": value, "unit": "reads/s", "cores": threads, "kind": kind,
-            "sample": f"whole {G}-bp Pg, first {ns} reads of the workload, both strands incl. index builds; two runs "
+    return {"value": value, "unit": "reads/s", "cores": threads, "kind": kind, "extrapolated": True,
+            "sample": f"EXTRAPOLATED from a bounded sample: whole {G}-bp Pg, first {ns} reads of the workload, both strands incl. index builds; two runs "
                       f"(n={n_small}: {t_small:.2f}s, n={ns}: {t_big:.2f}s) => fixed {a:.2f}s + {b * 1e6:.3f}us/read, "
                       f"extrapolated to {n_per} reads; sample-only rate {ns / t_big:.0f} reads/s",
             "fixed_s": a, "per_read_us": b * 1e6, "prep_s": prep_s,
             "sample_reads_with_other_mismatch_count_than_gpu": diff,
             "note": "reference timed as shipped at -t %d (racy multithreaded index build); bit-parity is pinned against "
                     "its serial index build elsewhere" % threads}
+
+
+_TEXT = {}
+
+
+def host_text(ctx, G):
+    """ASCII copy of the text in HBM (checker input), unpacked once"""
+    if G not in _TEXT:
+        _TEXT[G] = unpack_pg_to_ascii(ctx.export_pg(0))[:G]
+    return _TEXT[G]
+
+
+def parity_sample(args, ctx, g, rs, n_per, L, G, seed_len, kmax):
+    """Bit-parity evidence inside the bench line: the first reads of the workload, matched by the reference with its
+    SERIAL canonical index build (PgHelpers::numberOfThreads = 1) and one thread in its per-read loop (its RC-flag
+    race) against the whole text, compared with what the GPU run above produced for the same reads.  Outside the
+    timed region; the oracle port stands in where oracle/_ref is absent."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as orc
+    from pgrc_amd import synth
+    ns = min(args.parity_sample_reads, n_per)
+    pg = host_text(ctx, G)
+    reads = synth.reads_host(g, pg, rs, 0, ns)
+    t = time.perf_counter()
+    if orc.have_ref():
+        r = orc.ref_match("c", pg, reads, seed_len, kmax, 0, True, 0, 1, 1)
+        checker = "reference, serial index (PgHelpers::numberOfThreads = 1)"
+    else:
+        r = orc.oracle_match("c", pg, reads, seed_len, kmax, 0, True, max(1, min(args.cpu_threads, os.cpu_count() or 1)))
+        checker = "oracle port"
+    secs = time.perf_counter() - t
+    pos, rc, mism, _, _ = ctx.get_results()
+    d_pos = int((pos[:ns] != r["pos"]).sum())
+    d_rc = int((rc[:ns] != r["rc"]).sum())
+    d_mism = int((mism[:ns] != r["mism"]).sum())
+    return {"reads": ns, "checker": checker, "diff": d_pos + d_rc + d_mism, "diff_pos": d_pos, "diff_rc": d_rc,
+            "diff_mism": d_mism, "matched_in_sample": int((r["mism"] != 255).sum()), "checker_s": secs}
 
 
 if __name__ == "__main__":
