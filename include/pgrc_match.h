@@ -153,6 +153,52 @@ int pgrc_match_get_results_device(pgrc_match_ctx *ctx, void **d_pos, void **d_rc
 int pgrc_match_extract_mismatches(pgrc_match_ctx *ctx, const uint8_t *reversed_flags, uint64_t *cum,
                                   uint8_t *codes, uint16_t *offsets);
 
+/* ---- export of the matches as reads-list streams (DefaultReadsMatcher::exportMatchesInPgOrder /
+ *      exportMatchesInOriginalOrder, ReadsMatchers.cpp:563-675; SeparatedPseudoGenomeOutputBuilder::writeReadEntry /
+ *      writeReadsFromIterator, pseudogenome/persistence/SeparatedPseudoGenomePersistence.cpp:961-1019) ---- */
+/* The byte streams the builder would have appended, ready to be written into its destinations in one piece each.
+ * Read-length values (offsets) take off_width bytes: 1 with PgHelpers::bytePerReadLengthMode, else 2
+ * (writeReadLengthValue, utils/helper.cpp:198-203).  Arrays are malloc'ed by the library: pgrc_match_free_export. */
+typedef struct {
+    uint64_t n_entries;     /* entries of the output reads list (old list entries + matched reads, or the given entries) */
+    uint64_t n_mismatches;  /* mismatches over all entries */
+    uint32_t off_width;
+    uint8_t *off;           /* rlOff:       n_entries offsets to the previously written entry (:966) */
+    uint32_t *org_idx;      /* rlOrgIdx:    n_entries original read indexes (:967) */
+    uint8_t *rev_comp;      /* rlRevComp:   n_entries flags (:969) */
+    uint8_t *mis_cnt;       /* rlMisCnt:    n_entries counts (:971) */
+    uint8_t *mis_sym;       /* rlMisSym:    n_mismatches codes (actual << 4) + mismatch (:973-974) */
+    uint8_t *mis_rev_off;   /* rlMisRevOff: n_mismatches offsets coded backwards from the read end (:975-981) */
+    uint64_t last_pos;      /* position of the last entry (the builder's lastWrittenPos) */
+} pgrc_export_streams;
+
+/* exportMatchesInPgOrder: the matched reads, in the order `order` gives them (ascending match position; the order among
+ * reads matched at ONE position is whatever the caller's sort made it -- the reference's std::sort /
+ * __gnu_parallel::sort order is an artefact of that algorithm, so the adapter reproduces it on (position, index)
+ * pairs and passes the permutation in), merged with the reads list already on the pseudogenome (offset deltas,
+ * original indexes, RC flags of SeparatedPseudoGenome::getReadsList(); it must carry no mismatches): in front of a new
+ * entry go all old entries at SMALLER positions, an old entry at the same position follows it (:1004-1019). */
+typedef struct {
+    const uint32_t *order;        /* n_matched read indexes */
+    uint64_t n_matched;
+    const uint32_t *read_org_idx; /* original index of every READ (IndexesMapping::getReadOriginalIndex), NULL = identity */
+    const uint8_t *list_off;      /* the old list: list_count offset deltas */
+    const uint32_t *list_org_idx;
+    const uint8_t *list_rev_comp; /* NULL = all forward */
+    uint64_t list_count;
+    int32_t rev_compl_pair_file;  /* mismatch lists in the original read's orientation iff rc != (orgIdx odd) (:553) */
+    int32_t byte_per_read_length; /* PgHelpers::bytePerReadLengthMode */
+} pgrc_export_pg_order_args;
+int pgrc_match_export_pg_order(pgrc_match_ctx *ctx, const pgrc_export_pg_order_args *args, pgrc_export_streams *out);
+/* exportMatchesInOriginalOrder: the caller walks the original read order (the :616-667 loops) and lists the entries:
+ * entry_read[k] = the read entry k describes, or UINT32_MAX for a filler entry (position 0, no mismatches);
+ * entry_org_idx[k] = its original index.  Offsets are the entries' own positions (every entry starts from a fresh
+ * DefaultReadsListEntry(0), :655-667). */
+int pgrc_match_export_entries(pgrc_match_ctx *ctx, const uint32_t *entry_read, const uint32_t *entry_org_idx,
+                              uint64_t n_entries, int32_t rev_compl_pair_file, int32_t byte_per_read_length,
+                              pgrc_export_streams *out);
+void pgrc_match_free_export(pgrc_export_streams *streams);
+
 /* ---- introspection (tests, bench) ---- */
 typedef struct {
     int32_t K, k1, k2;

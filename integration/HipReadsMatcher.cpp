@@ -16,6 +16,9 @@
 #include <vector>
 #define private public
 #include "readsset/ReadsSetInterface.h"
+// ... and SeparatedPseudoGenomeOutputBuilder keeps its stream destinations private; the device export appends whole
+// streams to them (in a PgRC tree: `friend class HipReadsMatcher;` in that class as well)
+#include "pseudogenome/persistence/SeparatedPseudoGenomePersistence.h"
 #undef private
 #endif
 
@@ -25,6 +28,11 @@
 #include "readsset/PackedConstantLengthReadsSet.h"
 
 #include <chrono>
+#include <parallel/algorithm>
+
+struct pgrc_export_streams_view {
+    const pgrc_export_streams *s;
+};
 
 namespace {
     // PGRC_HIP_TIMING=1: phase times of the adapter on stderr (hand-over, device run, result fetch)
@@ -45,6 +53,7 @@ namespace PgTools {
 
     uint64_t HipReadsMatcher::bulkUpdatesServed = 0;
     uint64_t HipReadsMatcher::packedHandOvers = 0;
+    uint64_t HipReadsMatcher::deviceExports = 0;
 
     HipReadsMatcher::HipReadsMatcher(char *pgPtr, const uint_pg_len_max pgLength, bool revComplPg,
                                      ConstantLengthReadsSetInterface *readsSet, uint32_t matchPrefixLength,
@@ -274,6 +283,202 @@ namespace PgTools {
         builder->setReadsSourceIterator(rlIt);
         builder->copyPseudoGenomeProperties(sPg);
         return builder;
+    }
+
+    // ---- export on the device (row f1) ----
+
+    bool HipReadsMatcher::deviceExportPossible(SeparatedPseudoGenome *sPg) const {
+        if (getenv("PGRC_HOST_EXPORT")) return false;                    // A/B knob: the inherited export
+        if (!uploaded || deviceReads != readsCount || readsCount == 0) return false;
+        if (pgrc_match_shard_count(ctx) != 1) return false;
+        if (SeparatedPseudoGenomePersistence::enableReadPositionRepresentation ||
+            !SeparatedPseudoGenomePersistence::enableRevOffsetMismatchesRepresentation)
+            return false;
+        ExtendedReadsListWithConstantAccessOption *rl = sPg->getReadsList();
+        if (!rl || !rl->misCnt.empty()) return false;                    // old entries with mismatches: inherited path
+        if (rl->off.size() < rl->readsCount || rl->orgIdx.size() < rl->readsCount) return false;
+        if (!rl->revComp.empty() && rl->revComp.size() < rl->readsCount) return false;
+        return true;
+    }
+
+    // what writeReadEntry (SeparatedPseudoGenomePersistence.cpp:961-989) appends entry by entry, as whole streams
+    void HipReadsMatcher::appendStreams(SeparatedPseudoGenomeOutputBuilder *builder, const pgrc_export_streams_view &v) {
+        const pgrc_export_streams &s = *v.s;
+        builder->rlOffDest->write((const char *) s.off, (std::streamsize) (s.n_entries * s.off_width));
+        builder->rlOrgIdxDest->write((const char *) s.org_idx, (std::streamsize) (s.n_entries * sizeof(uint_reads_cnt_std)));
+        if (!builder->disableRevComp)
+            builder->rlRevCompDest->write((const char *) s.rev_comp, (std::streamsize) s.n_entries);
+        if (!builder->disableMismatches) {
+            builder->rlMisCntDest->write((const char *) s.mis_cnt, (std::streamsize) s.n_entries);
+            builder->rlMisSymDest->write((const char *) s.mis_sym, (std::streamsize) s.n_mismatches);
+            builder->rlMisRevOffDest->write((const char *) s.mis_rev_off, (std::streamsize) (s.n_mismatches * s.off_width));
+        }
+        builder->readsCounter += s.n_entries;
+        builder->lastWrittenPos = s.last_pos;
+    }
+
+    // The reference sorts the matched reads' INDEXES with a comparator that looks their positions up
+    // (`readMatchPos[idx1] < readMatchPos[idx2]`, ReadsMatchers.cpp:573-574).  The same algorithm
+    // (parallel_algorithm::sort = __gnu_parallel::sort, sequential std::sort below its size / thread thresholds) on
+    // (position, index) pairs, compared by position alone, sees the same outcome for every comparison it makes and so
+    // moves its elements the same way: the same permutation, ties included, without the comparator's random accesses.
+    void HipReadsMatcher::positionOrder(const vector<uint64_t> &readMatchPos, uint_reads_cnt_max matchedReadsCount,
+                                        std::vector<uint32_t> &order) {
+        typedef std::pair<uint64_t, uint_reads_cnt_max> PosIdx;
+        std::vector<PosIdx> byPos;
+        byPos.reserve(matchedReadsCount);
+        const uint_reads_cnt_max n = readMatchPos.size();
+        for (uint_reads_cnt_max i = 0; i < n; i++)
+            if (readMatchPos[i] != NOT_MATCHED_POSITION)
+                byPos.emplace_back(readMatchPos[i], i);
+        __gnu_parallel::sort(byPos.begin(), byPos.end(),
+                             [](const PosIdx &a, const PosIdx &b) -> bool { return a.first < b.first; });
+        order.resize(byPos.size());
+        for (size_t k = 0; k < byPos.size(); k++) order[k] = byPos[k].second;
+    }
+
+    void HipReadsMatcher::exportMatchesInPgOrderOnDevice(SeparatedPseudoGenome *sPg, ostream &pgrcOut,
+                                                         uint8_t compressionLevel, const string &outPgPrefix,
+                                                         IndexesMapping *orgIndexesMapping, bool pairFileMode,
+                                                         bool revComplPairFile) {
+        if (!deviceExportPossible(sPg)) {
+            exportMatchesInPgOrder(sPg, pgrcOut, compressionLevel, outPgPrefix, orgIndexesMapping, pairFileMode,
+                                   revComplPairFile);
+            return;
+        }
+        deviceExports++;
+        std::vector<uint32_t> order;
+        {
+            PhaseLog log("export: position sort");
+            positionOrder(readMatchPos, matchedReadsCount, order);
+        }
+        std::vector<uint32_t> readOrg(readsCount);
+        #pragma omp parallel for
+        for (uint_reads_cnt_max i = 0; i < readsCount; i++)
+            readOrg[i] = orgIndexesMapping->getReadOriginalIndex(i);
+        pgrc_export_streams st;
+        SeparatedPseudoGenomeOutputBuilder *builder = this->createSeparatedPseudoGenomeOutputBuilder(sPg);
+        {
+            PhaseLog log("export: streams from the device");
+            ExtendedReadsListWithConstantAccessOption *rl = sPg->getReadsList();
+            pgrc_export_pg_order_args a;
+            a.order = order.data();
+            a.n_matched = order.size();
+            a.read_org_idx = readOrg.data();
+            a.list_off = rl->off.data();
+            a.list_org_idx = rl->orgIdx.data();
+            a.list_rev_comp = rl->revComp.empty() ? nullptr : rl->revComp.data();
+            a.list_count = rl->readsCount;
+            a.rev_compl_pair_file = revComplPairFile ? 1 : 0;
+            a.byte_per_read_length = PgHelpers::bytePerReadLengthMode ? 1 : 0;
+            failOn(pgrc_match_export_pg_order(ctx, &a, &st), "export_pg_order");
+            pgrc_export_streams_view v{&st};
+            appendStreams(builder, v);
+            pgrc_match_free_export(&st);
+        }
+        PhaseLog log("export: the reference's stream compression");
+        builder->build(outPgPrefix);
+        builder->compressedBuild(pgrcOut, compressionLevel);
+        if (pairFileMode)
+            builder->updateOriginalIndexesIn(sPg);
+        delete (builder);
+    }
+
+    void HipReadsMatcher::exportMatchesInOriginalOrderOnDevice(SeparatedPseudoGenome *sPg, ostream &pgrcOut,
+                                                               uint8_t compressionLevel, const string &outPgPrefix,
+                                                               IndexesMapping *orgIndexesMapping, bool pairFileMode,
+                                                               bool revComplPairFile) {
+        if (!deviceExportPossible(sPg)) {
+            exportMatchesInOriginalOrder(sPg, pgrcOut, compressionLevel, outPgPrefix, orgIndexesMapping, pairFileMode,
+                                         revComplPairFile);
+            return;
+        }
+        deviceExports++;
+        // the walk of ReadsMatchers.cpp:600-667 over the original read order, listing the entries instead of writing them
+        const uint_reads_cnt_std readsTotalCount = orgIndexesMapping->getReadsTotalCount();
+        std::vector<uint_pg_len_max> orgIdx2pgPos(readsTotalCount, -1);
+        ExtendedReadsListWithConstantAccessOption *const pgRl = sPg->getReadsList();
+        uint_pg_len_max pos = 0;
+        for (uint_reads_cnt_std i = 0; i < pgRl->readsCount; i++) {
+            pos += pgRl->off[i];
+            orgIdx2pgPos[pgRl->orgIdx[i]] = pos;
+        }
+        pgRl->off.clear();
+        pgRl->orgIdx.clear();
+        SeparatedPseudoGenomeOutputBuilder *builder = this->createSeparatedPseudoGenomeOutputBuilder(sPg);
+        std::vector<uint32_t> readOrg(readsCount);
+        #pragma omp parallel for
+        for (uint_reads_cnt_max i = 0; i < readsCount; i++)
+            readOrg[i] = orgIndexesMapping->getReadOriginalIndex(i);
+        std::vector<uint32_t> entryRead, entryOrg;
+        entryRead.reserve(readsTotalCount);
+        entryOrg.reserve(readsTotalCount);
+        {
+            PhaseLog log("export: entry list in original order");
+            uint_reads_cnt_max nI_start = readsCount;
+            int64_t curOrgIdx = 0;
+            for (uint_reads_cnt_std i = 0; i < readsCount; i++) {
+                const uint_reads_cnt_max oIdx = readOrg[i];
+                if (curOrgIdx > oIdx) {
+                    nI_start = i;
+                    break;
+                }
+                curOrgIdx = oIdx;
+            }
+            const uint8_t parts = pairFileMode ? 2 : 1;
+            const int inc = parts;
+            for (uint8_t p = 0; p < parts; p++) {
+                curOrgIdx = p - inc;
+                uint_reads_cnt_max lqI = 0;
+                uint_reads_cnt_max nI = nI_start;
+                while (lqI < nI_start || nI < readsCount) {
+                    uint_reads_cnt_max matchIdx;
+                    uint_reads_cnt_max oIdx;
+                    do {
+                        matchIdx = readsCount;
+                        if (lqI < nI_start)
+                            matchIdx = lqI;
+                        if (nI < readsCount && (lqI == nI_start || readOrg[nI] < readOrg[lqI]))
+                            matchIdx = nI++;
+                        else
+                            lqI++;
+                        if (matchIdx == readsCount)
+                            break;
+                        oIdx = readOrg[matchIdx];
+                    } while (parts != 1 && (oIdx % parts != p));
+                    if (matchIdx == readsCount)
+                        break;
+                    while ((curOrgIdx += inc) < oIdx) {
+                        entryRead.push_back(UINT32_MAX);
+                        entryOrg.push_back((uint32_t) curOrgIdx);
+                    }
+                    if (readMatchPos[matchIdx] != NOT_MATCHED_POSITION) {
+                        entryRead.push_back((uint32_t) matchIdx);
+                        entryOrg.push_back((uint32_t) oIdx);
+                        orgIdx2pgPos[oIdx] = readMatchPos[matchIdx];
+                    }
+                }
+                while ((curOrgIdx += inc) < readsTotalCount) {
+                    entryRead.push_back(UINT32_MAX);
+                    entryOrg.push_back((uint32_t) curOrgIdx);
+                }
+            }
+        }
+        {
+            PhaseLog log("export: streams from the device");
+            pgrc_export_streams st;
+            failOn(pgrc_match_export_entries(ctx, entryRead.data(), entryOrg.data(), entryRead.size(),
+                                             revComplPairFile ? 1 : 0, PgHelpers::bytePerReadLengthMode ? 1 : 0, &st),
+                   "export_entries");
+            pgrc_export_streams_view v{&st};
+            appendStreams(builder, v);
+            pgrc_match_free_export(&st);
+        }
+        PhaseLog log("export: the reference's stream compression");
+        builder->build(outPgPrefix);
+        builder->compressedBuild(pgrcOut, compressionLevel, true);
+        delete (builder);
+        sPg->getReadsList()->pos = std::move(orgIdx2pgPos);
     }
 
     void HipReadsMatcher::executeMatching(bool revCompMode) {

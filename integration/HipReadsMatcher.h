@@ -12,6 +12,7 @@
 #include "matching/ReadsMatchers.h"
 
 struct pgrc_match_ctx;
+struct pgrc_export_streams_view;
 
 namespace PgTools {
 
@@ -33,6 +34,8 @@ namespace PgTools {
         void failOn(int code, const char *what);
         void upload();
         void fetchResults();
+        bool deviceExportPossible(SeparatedPseudoGenome *sPg) const;
+        void appendStreams(SeparatedPseudoGenomeOutputBuilder *builder, const struct pgrc_export_streams_view &s);
 
     protected:
         void initMatching() override;
@@ -67,6 +70,28 @@ namespace PgTools {
 
         // Same contract as continueMatchingConstantLengthReads (ReadsMatchers.cpp:174-184).
         void continueMatchingConstantLengthReadsOnDevice(DefaultReadsMatcher *pMatcher);
+
+        // Same contracts -- and the same archive bytes -- as exportMatchesInPgOrder / exportMatchesInOriginalOrder
+        // (ReadsMatchers.cpp:563-675).  The host keeps the reference's sort of the matched reads (its tie order is
+        // an artefact of std::sort / __gnu_parallel::sort that reaches the archive) but runs it on compact
+        // (position, index) pairs; the merge with the reads list already on the pseudogenome, the offset deltas,
+        // the mismatch lists and their reverse-offset coding come from the device as whole streams
+        // (pgrc_match_export_pg_order / pgrc_match_export_entries) and go into the builder's destinations in one
+        // write each, instead of seven stream writes per entry.  Whatever the device path does not cover (a reads
+        // list that carries mismatches, the position / plain-offset representations of PgRC.cpp:158-162, several
+        // devices) takes the inherited export with the bulk mismatch lists.
+        void exportMatchesInPgOrderOnDevice(SeparatedPseudoGenome *sPg, ostream &pgrcOut, uint8_t compressionLevel,
+                                            const string &outPgPrefix, IndexesMapping *orgIndexesMapping,
+                                            bool pairFileMode, bool revComplPairFile);
+        void exportMatchesInOriginalOrderOnDevice(SeparatedPseudoGenome *sPg, ostream &pgrcOut, uint8_t compressionLevel,
+                                                  const string &outPgPrefix, IndexesMapping *orgIndexesMapping,
+                                                  bool pairFileMode, bool revComplPairFile);
+        // exports that took the device path (diagnostics / tests)
+        static uint64_t deviceExports;
+        // the matched reads in the order exportMatchesInPgOrder walks them (ReadsMatchers.cpp:567-574): the reference's
+        // sort algorithm with the reference's comparator outcome, run on (position, index) pairs
+        static void positionOrder(const vector<uint64_t> &readMatchPos, uint_reads_cnt_max matchedReadsCount,
+                                  std::vector<uint32_t> &order);
 
         // entries whose mismatch list was served from the device extraction (diagnostics / tests)
         static uint64_t bulkUpdatesServed;

@@ -575,6 +575,120 @@ void pgrc_or_extract_mismatches(const char *pg, uint64_t pos, const char *read, 
     }
 }
 
+/* ------------------------------------------------------ export of the matches */
+
+/* One sink = the six ostringstreams SeparatedPseudoGenomeOutputBuilder::writeReadEntry appends to
+ * (pseudogenome/persistence/SeparatedPseudoGenomePersistence.cpp:961-989). */
+typedef struct {
+    pgrc_or_export_streams *s;
+    uint64_t last_written_pos;   /* lastWrittenPos (:962) */
+    uint32_t L, width;
+} ex_sink;
+
+static void ex_put_len(uint8_t *dst, uint64_t at, uint32_t width, uint16_t v) {   /* writeReadLengthValue, helper.cpp:198-203 */
+    if (width == 1) dst[at] = (uint8_t)v;
+    else memcpy(dst + 2 * at, &v, 2);
+}
+
+static void ex_write_entry(ex_sink *k, uint64_t pos, uint16_t offset, uint32_t idx, int rev_comp, uint8_t cnt,
+                           const uint8_t *codes, const uint16_t *offs) {
+    pgrc_or_export_streams *s = k->s;
+    k->last_written_pos = pos;                                                     /* :962 */
+    ex_put_len(s->off, s->n_entries, k->width, offset);                             /* :966 */
+    s->org_idx[s->n_entries] = idx;                                                 /* :967 */
+    s->rev_comp[s->n_entries] = rev_comp ? 1 : 0;                                   /* :969 */
+    s->mis_cnt[s->n_entries] = cnt;                                                 /* :971 */
+    for (uint8_t i = 0; i < cnt; i++) s->mis_sym[s->n_mismatches + i] = codes[i];   /* :973-974 */
+    uint8_t current = (uint8_t)(k->L - 1);                                          /* :976 */
+    uint64_t at = s->n_mismatches;
+    for (int i = (int)cnt - 1; i >= 0; i--) {                                       /* :977-981 */
+        ex_put_len(s->mis_rev_off, at++, k->width, (uint16_t)(current - offs[i]));
+        current = (uint8_t)(offs[i] - 1);
+    }
+    s->n_mismatches += cnt;
+    s->n_entries++;                                                                 /* readsCounter, :988 */
+}
+
+/* updateEntry (ReadsMatchers.cpp:548-559) for read i at original index org */
+static uint8_t ex_mismatches(const char *pg, const char *reads, uint32_t L, uint64_t i, uint64_t pos, int rc, uint8_t cnt,
+                             uint32_t org, int pair_file, uint8_t *codes, uint16_t *offs) {
+    const int reversed = pair_file ? (rc != (int)(org & 1u)) : rc;                  /* :553 */
+    pgrc_or_extract_mismatches(pg, pos, reads + i * L, L, rc, reversed, cnt, codes, offs);
+    return cnt;
+}
+
+/* DefaultReadsMatcher::exportMatchesInPgOrder (ReadsMatchers.cpp:563-595) after its sort: `order` lists the matched
+ * reads by ascending position.  The reads list already on the pseudogenome is walked exactly like
+ * writeReadsFromIterator does (:1004-1019), pause state and the -1 it returns once the list is exhausted included. */
+int pgrc_or_export_pg_order(const char *pg, const char *reads, uint32_t L, const uint64_t *pos, const uint8_t *rc,
+                            const uint8_t *mism, const uint32_t *order, uint64_t m, const uint32_t *read_org,
+                            const uint8_t *list_off, const uint32_t *list_org, const uint8_t *list_rc, uint64_t h,
+                            int pair_file, int byte_per_read_length, pgrc_or_export_streams *s) {
+    ex_sink k = {s, 0, L, byte_per_read_length ? 1u : 2u};
+    s->n_entries = s->n_mismatches = 0;
+    s->off_width = k.width;
+    /* iterator state: entry.pos / entry.offset of the list entry under the cursor (ExtendedReadsListWithConstantAccessOption::moveNext) */
+    uint64_t it_pos = 0, cur = 0;
+    uint16_t it_off = 0;
+    int paused = 0, have = 0;                 /* have: the cursor stands on entry cur-1 */
+    uint8_t codes[256];
+    uint16_t offs[256];
+    for (uint64_t j = 0; j <= m; j++) {
+        const uint64_t stop = j < m ? pos[order[j]] : UINT64_MAX;                   /* the final writeReadsFromIterator() */
+        uint64_t ret = UINT64_MAX;            /* what writeReadsFromIterator returns */
+        int returned = 0;
+        if (paused) {                                                               /* :1005-1010 */
+            if (it_pos >= stop) { ret = k.last_written_pos; returned = 1; }
+            else {
+                ex_write_entry(&k, it_pos, it_off, list_org[cur - 1], list_rc ? list_rc[cur - 1] : 0, 0, codes, offs);
+                paused = 0;
+            }
+        }
+        while (!returned && cur < h) {                                              /* :1011-1017 */
+            const uint64_t np = it_pos + list_off[cur];                             /* advanceEntryByOffset */
+            it_off = (uint16_t)(np - it_pos);
+            it_pos = np;
+            cur++;
+            have = 1;
+            if (it_pos >= stop) { paused = 1; ret = k.last_written_pos; returned = 1; break; }
+            ex_write_entry(&k, it_pos, it_off, list_org[cur - 1], list_rc ? list_rc[cur - 1] : 0, 0, codes, offs);
+        }
+        if (j == m) break;
+        const uint64_t i = order[j];
+        const uint64_t curr_pos = ret;                                              /* :579-580: entry(currPos), -1 once exhausted */
+        const uint16_t offset = (uint16_t)(pos[i] - curr_pos);                      /* advanceEntryByPosition */
+        const uint32_t org = read_org ? read_org[i] : (uint32_t)i;
+        const uint8_t cnt = ex_mismatches(pg, reads, L, i, pos[i], rc[i], mism[i], org, pair_file, codes, offs);
+        ex_write_entry(&k, pos[i], offset, org, rc[i], cnt, codes, offs);
+        if (have) it_off = (uint16_t)(it_off - offset);                             /* writeExtraReadEntry, :991-997 */
+    }
+    s->last_pos = k.last_written_pos;
+    return 0;
+}
+
+/* the per-entry part of exportMatchesInOriginalOrder (ReadsMatchers.cpp:655-667): every entry starts from a fresh
+ * DefaultReadsListEntry(0); entry_read[k] == UINT32_MAX is a filler (position 0, no mismatches) */
+int pgrc_or_export_entries(const char *pg, const char *reads, uint32_t L, const uint64_t *pos, const uint8_t *rc,
+                           const uint8_t *mism, const uint32_t *entry_read, const uint32_t *entry_org, uint64_t ne,
+                           int pair_file, int byte_per_read_length, pgrc_or_export_streams *s) {
+    ex_sink k = {s, 0, L, byte_per_read_length ? 1u : 2u};
+    s->n_entries = s->n_mismatches = 0;
+    s->off_width = k.width;
+    uint8_t codes[256];
+    uint16_t offs[256];
+    for (uint64_t e = 0; e < ne; e++) {
+        const uint32_t i = entry_read[e];
+        if (i == UINT32_MAX || mism[i] == PGRC_OR_NOT_MATCHED_CNT) {
+            ex_write_entry(&k, 0, 0, entry_org[e], 0, 0, codes, offs);
+            continue;
+        }
+        const uint8_t cnt = ex_mismatches(pg, reads, L, i, pos[i], rc[i], mism[i], entry_org[e], pair_file, codes, offs);
+        ex_write_entry(&k, pos[i], (uint16_t)pos[i], entry_org[e], rc[i], cnt, codes, offs);
+    }
+    s->last_pos = k.last_written_pos;
+    return 0;
+}
+
 /* ------------------------------------------------------ Pg-vs-Pg exact matches */
 
 /* CopMEMMatcher::matchTexts -> processExactMatchQueryTight, matching/copmem/CopMEMMatcher.cpp:333-481, :604-622,

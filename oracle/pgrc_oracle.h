@@ -137,6 +137,26 @@ int pgrc_or_mem_match(const char *src, uint64_t N, const char *dest, uint64_t N2
                       uint32_t target_len, uint32_t min_match_len, pgrc_or_text_match **out, uint64_t *count);
 void pgrc_or_mem_free(pgrc_or_text_match *m);
 
+/* ---- export of the matches (row f1): the streams SeparatedPseudoGenomeOutputBuilder collects
+ *      (ReadsMatchers.cpp:563-675, SeparatedPseudoGenomePersistence.cpp:961-1019).  The caller provides the arrays:
+ *      off / mis_rev_off 2 bytes per value are always enough. */
+typedef struct {
+    uint64_t n_entries, n_mismatches;
+    uint32_t off_width;
+    uint8_t *off;
+    uint32_t *org_idx;
+    uint8_t *rev_comp, *mis_cnt, *mis_sym, *mis_rev_off;
+    uint64_t last_pos;
+} pgrc_or_export_streams;
+int pgrc_or_export_pg_order(const char *pg, const char *reads, uint32_t L, const uint64_t *pos, const uint8_t *rc,
+                            const uint8_t *mism, const uint32_t *order, uint64_t m, const uint32_t *read_org,
+                            const uint8_t *list_off, const uint32_t *list_org, const uint8_t *list_rc, uint64_t h,
+                            int pair_file, int byte_per_read_length, pgrc_or_export_streams *s);
+int pgrc_or_export_entries(const char *pg, const char *reads, uint32_t L, const uint64_t *pos, const uint8_t *rc,
+                           const uint8_t *mism, const uint32_t *entry_read, const uint32_t *entry_org, uint64_t ne,
+                           int pair_file, int byte_per_read_length, pgrc_or_export_streams *s);
+
+
 /* helpers */
 void pgrc_or_revcomp(char *seq, uint64_t n);                 /* helper.cpp:383-393 */
 uint8_t pgrc_or_sym2val(char c);                             /* helper.cpp:277-283: A0 C1 G2 T3 N4 */

@@ -271,11 +271,11 @@ namespace PgTools {
         const vector<bool> res = matcher->getMatchedReadsBitmap();
         if (matchPrefixLength == DefaultReadsMatcher::DISABLED_PREFIX_MODE) {
             if (preserveOrderMode)
-                matcher->exportMatchesInOriginalOrder(sPg, pgrcOut, compressionLevel, pgDestFilePrefix, orgIndexesMapping,
-                                                      pairFileMode, revComplPairFile);
+                matcher->exportMatchesInOriginalOrderOnDevice(sPg, pgrcOut, compressionLevel, pgDestFilePrefix,
+                                                              orgIndexesMapping, pairFileMode, revComplPairFile);
             else
-                matcher->exportMatchesInPgOrder(sPg, pgrcOut, compressionLevel, pgDestFilePrefix, orgIndexesMapping,
-                                                pairFileMode, revComplPairFile);
+                matcher->exportMatchesInPgOrderOnDevice(sPg, pgrcOut, compressionLevel, pgDestFilePrefix,
+                                                        orgIndexesMapping, pairFileMode, revComplPairFile);
         }
         delete matcher;
         return res;
@@ -345,6 +345,18 @@ extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const 
 
 extern "C" uint64_t pgrc_ref_bulk_updates() { return HipReadsMatcher::bulkUpdatesServed; }
 extern "C" uint64_t pgrc_ref_packed_handovers() { return HipReadsMatcher::packedHandOvers; }
+extern "C" uint64_t pgrc_ref_device_exports() { return HipReadsMatcher::deviceExports; }
+// the adapter's position order (the reference's sort on (position, index) pairs) of a given result state
+extern "C" uint64_t pgrc_ref_position_order(const uint64_t *pos, uint64_t n, int omp_threads, uint32_t *order) {
+    omp_set_num_threads(omp_threads);
+    std::vector<uint64_t> p(pos, pos + n);
+    uint64_t matched = 0;
+    for (uint64_t i = 0; i < n; i++) matched += pos[i] != UINT64_MAX;
+    std::vector<uint32_t> o;
+    HipReadsMatcher::positionOrder(p, (uint_reads_cnt_max) matched, o);
+    memcpy(order, o.data(), o.size() * sizeof(uint32_t));
+    return o.size();
+}
 extern "C" uint64_t pgrc_ref_text_match_calls() { return HipTextMatcher::callsServed; }
 // seconds the last pgrc_ref_encode spent in mapReadsIntoPg (stage 4) and in SimplePgMatcher's TextMatcher (stage 7)
 extern "C" void pgrc_ref_stage_seconds(double *map_reads_s, double *text_match_s) {
@@ -382,6 +394,62 @@ extern "C" int pgrc_ref_decode(const char *archive, int threads) {
         decoder.decompressPgRC();
     }
     delete params;
+    return 0;
+}
+
+// Matching + export of a synthetic case with an explicit reads list on the pseudogenome, stream files written by
+// SeparatedPseudoGenomeOutputBuilder::build(prefix): <prefix>_rl_{off,idx,rc,mis_cnt,mis_sym,mis_roff}.pg.
+// use_adapter 0: the reference's matcher and its exportMatchesInPgOrder / exportMatchesInOriginalOrder
+// (ReadsMatchers.cpp:563-675); 1: HipReadsMatcher and its device export.  archive receives the bytes written to pgrcOut.
+extern "C" int pgrc_ref_export_run(int use_adapter, const char *pg, uint64_t G, const char *reads, uint64_t n_lq, uint64_t n_n,
+                                   uint32_t L, uint32_t seed, uint8_t kmax, uint8_t kmin, const uint8_t *list_off,
+                                   const uint32_t *list_org, const uint8_t *list_rc, uint64_t list_count,
+                                   const uint32_t *read_org, uint32_t reads_total, int preserve_order, int pair_file_mode,
+                                   int rev_compl_pair_file, int omp_threads, const char *prefix, const char *archive) {
+    Silence quiet;
+    PgHelpers::numberOfThreads = 1;           // serial (canonical) copMEM index
+    omp_set_num_threads(omp_threads);
+    const uint64_t n = n_lq + n_n;
+    ReadsHolder rh(reads, n_lq, n_n, L);
+    ReadsSetProperties props;
+    props.readsCount = list_count;
+    props.allReadsLength = list_count * L;
+    props.constantReadLength = true;
+    props.minReadLength = props.maxReadLength = L;
+    props.symbolsCount = 4;
+    strcpy(props.symbolsList, "ACGT");
+    props.generateSymbolOrder();
+    auto *rl = new ExtendedReadsListWithConstantAccessOption(L);
+    rl->off.assign(list_off, list_off + list_count);
+    rl->orgIdx.assign(list_org, list_org + list_count);
+    if (list_rc) rl->revComp.assign(list_rc, list_rc + list_count);
+    SeparatedPseudoGenome sPg(std::string(pg, G), rl, &props);
+    IndexesMapping *mapping;
+    if (read_org) {
+        std::vector<uint_reads_cnt_max> mv(read_org, read_org + n);
+        mapping = new VectorMapping(std::move(mv), reads_total);
+    } else
+        mapping = new DirectMapping((uint_reads_cnt_max) n);
+    std::ostringstream out;
+    const uint32_t pm = DefaultReadsMatcher::DISABLED_PREFIX_MODE;
+    char *text = (char *) sPg.getPgSequence().data();
+    if (use_adapter) {
+        HipReadsMatcher m(text, G, true, rh.iface, pm, seed, kmax, kmin, 'c');
+        m.matchConstantLengthReadsOnDevice();
+        if (preserve_order)
+            m.exportMatchesInOriginalOrderOnDevice(&sPg, out, CODER_LEVEL_NORMAL, prefix, mapping, pair_file_mode, rev_compl_pair_file);
+        else
+            m.exportMatchesInPgOrderOnDevice(&sPg, out, CODER_LEVEL_NORMAL, prefix, mapping, pair_file_mode, rev_compl_pair_file);
+    } else {
+        CopMEMReadsApproxMatcher m(text, G, true, rh.iface, pm, seed, kmax, kmin);
+        m.matchConstantLengthReads();
+        if (preserve_order)
+            m.exportMatchesInOriginalOrder(&sPg, out, CODER_LEVEL_NORMAL, prefix, mapping, pair_file_mode, rev_compl_pair_file);
+        else
+            m.exportMatchesInPgOrder(&sPg, out, CODER_LEVEL_NORMAL, prefix, mapping, pair_file_mode, rev_compl_pair_file);
+    }
+    delete mapping;
+    PgHelpers::writeStringToFile(archive, out.str());
     return 0;
 }
 

@@ -51,6 +51,18 @@ class SynthReads(C.Structure):
                 ("n_with_n", C.c_uint64)]
 
 
+class ExportStreams(C.Structure):   # pgrc_export_streams
+    _fields_ = [("n_entries", C.c_uint64), ("n_mismatches", C.c_uint64), ("off_width", C.c_uint32), ("off", C.POINTER(C.c_uint8)),
+                ("org_idx", C.POINTER(C.c_uint32)), ("rev_comp", C.POINTER(C.c_uint8)), ("mis_cnt", C.POINTER(C.c_uint8)),
+                ("mis_sym", C.POINTER(C.c_uint8)), ("mis_rev_off", C.POINTER(C.c_uint8)), ("last_pos", C.c_uint64)]
+
+
+class ExportPgOrderArgs(C.Structure):   # pgrc_export_pg_order_args
+    _fields_ = [("order", C.c_void_p), ("n_matched", C.c_uint64), ("read_org_idx", C.c_void_p), ("list_off", C.c_void_p),
+                ("list_org_idx", C.c_void_p), ("list_rev_comp", C.c_void_p), ("list_count", C.c_uint64),
+                ("rev_compl_pair_file", C.c_int32), ("byte_per_read_length", C.c_int32)]
+
+
 class TextMatch(C.Structure):     # pgrc_text_match (include/pgrc_mem.h) = TextMatch, matching/TextMatchers.h:10-16
     _fields_ = [("pos_src", C.c_uint64), ("length", C.c_uint64), ("pos_dest", C.c_uint64)]
 
@@ -91,6 +103,9 @@ _PROTOS = [
     ("pgrc_match_get_results", C.c_int, [_P, _P, _P, _P, _P, C.POINTER(C.c_uint64)]),
     ("pgrc_match_get_results_device", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     ("pgrc_match_extract_mismatches", C.c_int, [_P, _P, _P, _P, _P]),
+    ("pgrc_match_export_pg_order", C.c_int, [_P, C.POINTER(ExportPgOrderArgs), C.POINTER(ExportStreams)]),
+    ("pgrc_match_export_entries", C.c_int, [_P, _P, _P, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(ExportStreams)]),
+    ("pgrc_match_free_export", None, [C.POINTER(ExportStreams)]),
     ("pgrc_match_copmem_params", C.c_int, [C.c_uint32, C.c_uint64, C.POINTER(CopmemParams)]),
     ("pgrc_match_export_index", C.c_int, [_P, C.c_int, _P, _P, C.POINTER(C.c_uint64)]),
     ("pgrc_match_export_pg", C.c_int, [_P, C.c_int, _P]),

@@ -148,6 +148,7 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
                       &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_head, &c->d_skey[0], &c->d_skey[1], &c->d_sval[0], &c->d_sval[1], &c->d_sorttmp,
                       &c->s_keys, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp, &c->s_sorted, &c->s_sorttmp, &c->s_mm, &c->s_rstart, &c->s_heavy, &c->s_nmask};
     for (DevBuf *b : bufs) pgrc_buf_free(*b);
+    for (DevBuf &b : c->up_nchunks) pgrc_buf_free(b);
     if (c->have_events)
         for (auto &e : c->ev) (void)hipEventDestroy(e);
     delete c;
@@ -320,7 +321,9 @@ int pgrc_match_begin_reads(pgrc_match_ctx *c, uint64_t n) {
     HIP_TRY(c, hipMemsetAsync(c->nread_flag.p, 0, n ? n : 1, c->stream));
     c->up_next = 0;
     c->up_nidx.clear();
-    c->up_nrows.clear();
+    for (DevBuf &b : c->up_nchunks) pgrc_buf_free(b);
+    c->up_nchunks.clear();
+    c->up_nchunk_rows.clear();
     c->up_open = true;
     return PGRC_OK;
 }
@@ -334,15 +337,15 @@ static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, i
     PGRC_ON_DEVICE(c);
     const uint32_t L = c->prm.read_len;
     const uint32_t rb = symbols == 0 ? L : symbols == 4 ? (L + 3) / 4 : (L + 2) / 3;   // host bytes per row
-    DevBuf stage, flag, lidx, nrows;
-    auto cleanup = [&]() { pgrc_buf_free(stage); pgrc_buf_free(flag); pgrc_buf_free(lidx); pgrc_buf_free(nrows); };
+    DevBuf stage, flag, lidx;
+    auto cleanup = [&]() { pgrc_buf_free(stage); pgrc_buf_free(flag); pgrc_buf_free(lidx); };
     int e;
     const uint64_t CHR = std::max<uint64_t>(1, (256ull << 20) / rb); // rows per staging chunk (~256 MiB)
     if ((e = pgrc_buf_ensure(c, stage, (size_t)std::min(CHR, std::max<uint64_t>(count, 1)) * rb))) return e;
     if ((e = pgrc_buf_ensure(c, flag, sizeof(uint32_t)))) { cleanup(); return e; }
     (void)hipMemsetAsync(flag.p, 0, sizeof(uint32_t), c->stream);
     int rcode = PGRC_OK;
-    std::vector<uint8_t> nf;
+    std::vector<uint8_t> nf, hrows;
     std::vector<uint32_t> local;
     for (uint64_t off = 0; off < count && rcode == PGRC_OK; off += CHR) {
         const uint64_t cnt = std::min(CHR, count - off);
@@ -362,22 +365,27 @@ static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, i
         nf.resize(cnt);
         if (hipMemcpy(nf.data(), (const uint8_t *)c->nread_flag.p + first, cnt, hipMemcpyDeviceToHost) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
         local.clear();
+        hrows.clear();
         for (uint64_t k = 0; k < cnt; k++)
             if (nf[k]) {
                 c->up_nidx.push_back((uint32_t)(first + k));
-                if (symbols == 0) c->up_nrows.insert(c->up_nrows.end(), rows + (off + k) * rb, rows + (off + k + 1) * rb);
+                if (symbols == 0) hrows.insert(hrows.end(), rows + (off + k) * rb, rows + (off + k + 1) * rb);
                 else local.push_back((uint32_t)k);
             }
-        if (!local.empty()) {      // packed rows with an N: their ASCII form comes from the device as well
-            const size_t nn = local.size();
-            if ((e = pgrc_buf_ensure(c, lidx, nn * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, nrows, nn * L))) { rcode = e; break; }
-            if (hipMemcpyAsync(lidx.p, local.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
-            rcode = pgrc_launch_nrows_ascii_acgnt(c, (const uint8_t *)stage.p, (const uint32_t *)lidx.p, nn, L, (uint8_t *)nrows.p);
-            const size_t at = c->up_nrows.size();
-            c->up_nrows.resize(at + nn * L);
-            if (rcode == PGRC_OK && (hipMemcpyAsync(c->up_nrows.data() + at, nrows.p, nn * L, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                                     hipStreamSynchronize(c->stream) != hipSuccess))
-                rcode = PGRC_E_DEVICE;
+        const size_t nn = symbols == 0 ? hrows.size() / L : local.size();
+        if (nn) {      // their ASCII rows stay in HBM: uploaded (ASCII input) or made there (packed input)
+            DevBuf nrows;
+            if ((e = pgrc_buf_ensure(c, nrows, nn * L))) { rcode = e; break; }
+            c->up_nchunks.push_back(nrows);
+            c->up_nchunk_rows.push_back(nn);
+            if (symbols == 0) {
+                if (hipMemcpy(nrows.p, hrows.data(), nn * L, hipMemcpyHostToDevice) != hipSuccess) rcode = PGRC_E_DEVICE;
+            } else {
+                if ((e = pgrc_buf_ensure(c, lidx, nn * sizeof(uint32_t)))) { rcode = e; break; }
+                if (hipMemcpyAsync(lidx.p, local.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
+                rcode = pgrc_launch_nrows_ascii_acgnt(c, (const uint8_t *)stage.p, (const uint32_t *)lidx.p, nn, L, (uint8_t *)nrows.p);
+                if (hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_DEVICE;    // (stage is reused by the next block)
+            }
         }
     }
     uint32_t bad = 0;
@@ -409,15 +417,22 @@ int pgrc_match_end_reads(pgrc_match_ctx *c) {
     int e;
     c->n_nreads = c->up_nidx.size();
     if (c->n_nreads) {
+        const uint32_t L = c->prm.read_len;
         if ((e = pgrc_buf_ensure(c, c->nread_idx, c->up_nidx.size() * sizeof(uint32_t)))) return e;
-        if ((e = pgrc_buf_ensure(c, c->nread_ascii, c->up_nrows.size()))) return e;
+        if ((e = pgrc_buf_ensure(c, c->nread_ascii, c->n_nreads * L))) return e;
         HIP_TRY(c, hipMemcpy(c->nread_idx.p, c->up_nidx.data(), c->up_nidx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->nread_ascii.p, c->up_nrows.data(), c->up_nrows.size(), hipMemcpyHostToDevice));
+        uint64_t at = 0;
+        for (size_t k = 0; k < c->up_nchunks.size(); k++) {
+            HIP_TRY(c, hipMemcpyAsync((uint8_t *)c->nread_ascii.p + at * L, c->up_nchunks[k].p, c->up_nchunk_rows[k] * L, hipMemcpyDeviceToDevice, c->stream));
+            at += c->up_nchunk_rows[k];
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    for (DevBuf &b : c->up_nchunks) pgrc_buf_free(b);
+    c->up_nchunks.clear();
+    c->up_nchunk_rows.clear();
     c->up_nidx.clear();
     c->up_nidx.shrink_to_fit();
-    c->up_nrows.clear();
-    c->up_nrows.shrink_to_fit();
     c->up_open = false;
     c->have_reads = true;
     return PGRC_OK;

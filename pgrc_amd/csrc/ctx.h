@@ -66,8 +66,9 @@ struct pgrc_match_ctx {
     // chunked upload state (pgrc_match_begin_reads / _append_ / _end_)
     bool up_open = false;
     uint64_t up_next = 0;
-    std::vector<uint32_t> up_nidx;
-    std::vector<char> up_nrows;
+    std::vector<uint32_t> up_nidx;                  // reads with N seen so far (ascending)
+    std::vector<DevBuf> up_nchunks;                 // their ASCII rows, one device buffer per appended block that had some
+    std::vector<uint64_t> up_nchunk_rows;
 
     // results
     DevBuf d_pos, d_rc, d_mism, d_hist, d_counters;

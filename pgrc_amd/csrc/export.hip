@@ -1,0 +1,484 @@
+// export.hip -- row f1: the export of the matches as the SoA streams of the output reads list, on the device.
+//
+// Reference behaviour restated (not translated):
+//   DefaultReadsMatcher::exportMatchesInPgOrder        matching/ReadsMatchers.cpp:563-595
+//   DefaultReadsMatcher::exportMatchesInOriginalOrder  matching/ReadsMatchers.cpp:597-675
+//   SeparatedPseudoGenomeOutputBuilder::writeReadsFromIterator / writeExtraReadEntry / writeReadEntry
+//                                                      pseudogenome/persistence/SeparatedPseudoGenomePersistence.cpp:961-1019
+//   AbstractReadsApproxMatcher::updateEntry            matching/ReadsMatchers.cpp:548-559
+//
+// In Pg order the reference walks the matched reads sorted by position, copies the entries of the reads list that is
+// already on the pseudogenome in front of each of them (every old entry with a SMALLER position: an old entry at the
+// same position follows the new one), and appends one record per entry to seven byte streams: offset delta to the
+// previously written entry, original index, RC flag, mismatch count, mismatch codes, and the mismatch offsets coded
+// backwards from the read end.  All of it is a merge of two sorted lists plus per-entry independent work:
+//   positions of the old list  = prefix sum of its offset deltas                     (k_scan_*)
+//   rank of every entry        = its index + a binary search in the OTHER list       (k_export_place_*)
+//   offset deltas              = difference of neighbours in the merged order        (k_export_offsets)
+//   mismatch lists             = prefix sum of the counts, then one thread per entry (k_export_mismatches)
+// What stays on the host is only the ORDER of the matched reads: the reference sorts with std::sort / __gnu_parallel::sort
+// under a comparator that looks at the position alone, so the order of reads matched at one position is an artefact of
+// that algorithm and reaches the archive bytes; the adapter reproduces it with the same algorithm on (position, index)
+// pairs and hands the permutation in.
+#include <stdlib.h>
+#include <string.h>
+
+#include "ctx.h"
+#include "devutil.h"
+
+#define EX_NONE 0xFFFFFFFFu
+
+// ---------------------------------------------------------------- exclusive scan: u8 or u32 values -> u64
+#define SC_TPB 256
+#define SC_EPT 16
+#define SC_EPB (SC_TPB * SC_EPT)
+
+template <typename T>
+__device__ __forceinline__ uint64_t sc_block_scan(uint64_t v, uint64_t *smem, uint64_t *total) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint64_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t u = __shfl_up(inc, o, 64);
+        if (lane >= (uint32_t)o) inc += u;
+    }
+    if (lane == 63) smem[wv] = inc;
+    __syncthreads();
+    uint64_t woff = 0, tot = 0;
+    for (uint32_t k = 0; k < SC_TPB / 64; k++) {
+        const uint64_t s = smem[k];
+        if (k < wv) woff += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + inc - v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(SC_TPB) k_scan_sums(const T *__restrict__ in, uint64_t n, uint64_t *bsum) {
+    __shared__ uint64_t smem[SC_TPB / 64 + 1];
+    const uint64_t base = (uint64_t)blockIdx.x * SC_EPB + (uint64_t)threadIdx.x * SC_EPT;
+    uint64_t s = 0;
+    for (int k = 0; k < SC_EPT; k++)
+        if (base + k < n) s += in[base + k];
+    uint64_t tot;
+    sc_block_scan<T>(s, smem, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+// block sums -> exclusive block offsets (one block: nb = n / 4096 values, a few passes of 256)
+__global__ void __launch_bounds__(SC_TPB) k_scan_bsums(uint64_t *bsum, uint64_t nb) {
+    __shared__ uint64_t smem[SC_TPB / 64 + 1];
+    uint64_t run = 0;
+    for (uint64_t b0 = 0; b0 < nb; b0 += SC_TPB) {
+        const uint64_t i = b0 + threadIdx.x;
+        const uint64_t v = i < nb ? bsum[i] : 0;
+        uint64_t tot;
+        const uint64_t ex = sc_block_scan<uint64_t>(v, smem, &tot);
+        if (i < nb) bsum[i] = run + ex;
+        run += tot;
+    }
+    if (threadIdx.x == 0) bsum[nb] = run;
+}
+
+// out[i] = (INCLUSIVE ? in[0..i] : in[0..i-1]) summed; out has n (+1 for the exclusive form: out[n] = total) entries
+template <typename T, bool INCLUSIVE>
+__global__ void __launch_bounds__(SC_TPB)
+k_scan_write(const T *__restrict__ in, uint64_t n, const uint64_t *__restrict__ bsum, uint64_t nb, uint64_t *out) {
+    __shared__ uint64_t smem[SC_TPB / 64 + 1];
+    const uint64_t base = (uint64_t)blockIdx.x * SC_EPB + (uint64_t)threadIdx.x * SC_EPT;
+    uint64_t v[SC_EPT], s = 0;
+#pragma unroll
+    for (int k = 0; k < SC_EPT; k++) {
+        v[k] = (base + k < n) ? (uint64_t)in[base + k] : 0;
+        s += v[k];
+    }
+    uint64_t tot;
+    uint64_t off = sc_block_scan<T>(s, smem, &tot) + bsum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SC_EPT; k++) {
+        if (base + k < n) out[base + k] = INCLUSIVE ? off + v[k] : off;
+        off += v[k];
+    }
+    if (!INCLUSIVE && blockIdx.x == 0 && threadIdx.x == 0) out[n] = bsum[nb];
+}
+
+template <typename T, bool INCLUSIVE>
+static int device_scan(pgrc_match_ctx *c, const T *d_in, uint64_t n, uint64_t *d_out, DevBuf &bs) {
+    const uint64_t nb = (n + SC_EPB - 1) / SC_EPB;
+    int e;
+    if ((e = pgrc_buf_ensure(c, bs, (nb + 2) * sizeof(uint64_t)))) return e;
+    if (!n) {
+        if (!INCLUSIVE) HIP_TRY(c, hipMemsetAsync(d_out, 0, sizeof(uint64_t), c->stream));
+        return PGRC_OK;
+    }
+    hipLaunchKernelGGL((k_scan_sums<T>), dim3((uint32_t)nb), dim3(SC_TPB), 0, c->stream, d_in, n, (uint64_t *)bs.p);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(SC_TPB), 0, c->stream, (uint64_t *)bs.p, nb);
+    hipLaunchKernelGGL((k_scan_write<T, INCLUSIVE>), dim3((uint32_t)nb), dim3(SC_TPB), 0, c->stream, d_in, n, (const uint64_t *)bs.p, nb, d_out);
+    HIP_TRY(c, hipGetLastError());
+    return PGRC_OK;
+}
+
+// ---------------------------------------------------------------- merge of the two sorted lists
+
+struct ExportArgs {
+    // results and inputs of the matcher
+    const uint64_t *pos;
+    const uint8_t *rc, *mism;
+    // the matched reads in export order, their original indexes
+    const uint32_t *order;
+    uint64_t m;
+    const uint32_t *read_org;     // per read, nullptr = identity
+    // the reads list already on the pseudogenome
+    const uint64_t *lpos;         // positions (inclusive scan of the offset deltas)
+    const uint32_t *lorg;
+    const uint8_t *lrc;           // nullptr = all forward
+    uint64_t h;
+    // merged entries
+    uint64_t *epos;               // position; bit 63 marks a new entry written after the old list ran out
+    uint32_t *eread;              // the matched read an entry describes, EX_NONE for an old entry / a filler
+    uint32_t *eorg;
+    uint8_t *erc, *emc;
+};
+
+// first index in a[0, n) with a[i] >= x (UPPER: a[i] > x)
+template <bool UPPER>
+__device__ __forceinline__ uint64_t bound(const uint64_t *__restrict__ a, uint64_t n, uint64_t x) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        const uint64_t v = a[mid];
+        if (UPPER ? v <= x : v < x) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// new entry j: every old entry with a smaller position precedes it (writeReadsFromIterator stops at pos >= stopPos,
+// SeparatedPseudoGenomePersistence.cpp:1004-1019)
+__global__ void __launch_bounds__(256) k_export_place_new(const ExportArgs a) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.m; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t i = a.order[j];
+        const uint64_t p = a.pos[i];
+        const uint64_t before = bound<false>(a.lpos, a.h, p);
+        const uint64_t r = j + before;
+        // once the old list is exhausted writeReadsFromIterator returns -1 instead of the last written position (:1018)
+        a.epos[r] = p | (before == a.h ? (1ull << 63) : 0ull);
+        a.eread[r] = i;
+        a.eorg[r] = a.read_org ? a.read_org[i] : i;
+        a.erc[r] = a.rc[i];
+        a.emc[r] = a.mism[i];
+    }
+}
+
+// old entry k: the new entries at positions <= its own precede it.  pm(j) = pos[order[j]] is sorted ascending.
+__global__ void __launch_bounds__(256) k_export_place_old(const ExportArgs a) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.h; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p = a.lpos[k];
+        uint64_t lo = 0, hi = a.m;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (a.pos[a.order[mid]] <= p) lo = mid + 1;
+            else hi = mid;
+        }
+        const uint64_t r = k + lo;
+        a.epos[r] = p;
+        a.eread[r] = EX_NONE;
+        a.eorg[r] = a.lorg[k];
+        a.erc[r] = a.lrc ? a.lrc[k] : 0;
+        a.emc[r] = 0;
+    }
+}
+
+// offset of every entry = its position minus the position of the entry written before it, in the 16-bit arithmetic of
+// ReadsListEntry::offset (ExtendedReadsListIteratorInterface.h:31-37), stored as 1 or 2 bytes (writeReadLengthValue,
+// utils/helper.cpp:198-203)
+template <typename OFF>
+__global__ void __launch_bounds__(256) k_export_offsets(const uint64_t *__restrict__ epos, uint64_t ne, OFF *__restrict__ off) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < ne; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t e = epos[r];
+        const uint64_t p = e & ~(1ull << 63);
+        const uint64_t prev = (e >> 63) ? ~0ull : (r ? (epos[r - 1] & ~(1ull << 63)) : 0ull);
+        off[r] = (OFF)(uint16_t)(p - prev);
+    }
+}
+
+// entries given by the caller (original-order export): field arrays from the per-read results
+__global__ void __launch_bounds__(256)
+k_export_fill_entries(const uint32_t *__restrict__ eread, uint64_t ne, const uint64_t *__restrict__ pos, const uint8_t *__restrict__ rc,
+                      const uint8_t *__restrict__ mism, uint64_t *__restrict__ epos, uint8_t *__restrict__ erc, uint8_t *__restrict__ emc) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < ne; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t i = eread[r];
+        const bool real = i != EX_NONE && mism[i] != PGRC_NOT_MATCHED_CNT;
+        // DefaultReadsListEntry entry(0); entry.advanceEntryByPosition(pos, ...): offset = pos - 0 (ReadsMatchers.cpp:655-667)
+        epos[r] = real ? pos[i] : 0ull;
+        erc[r] = real ? rc[i] : 0;
+        emc[r] = real ? mism[i] : 0;
+    }
+}
+
+template <typename OFF>
+__global__ void __launch_bounds__(256) k_export_offsets_abs(const uint64_t *__restrict__ epos, uint64_t ne, OFF *__restrict__ off) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < ne; r += (uint64_t)gridDim.x * blockDim.x)
+        off[r] = (OFF)(uint16_t)epos[r];
+}
+
+// ---------------------------------------------------------------- mismatch streams
+
+struct MisArgs {
+    const uint32_t *pg;
+    const uint32_t *reads;
+    uint64_t stride;
+    const uint8_t *nflag;
+    const uint32_t *nidx;
+    const uint8_t *nascii;
+    uint64_t nn;
+    const uint64_t *pos;
+    const uint8_t *rc;
+    const uint32_t *eread, *eorg;
+    const uint8_t *emc;
+    const uint64_t *mbase;        // exclusive scan of emc
+    uint64_t ne;
+    uint8_t *sym;
+    void *revoff;
+    uint32_t L, pair_file;
+};
+
+__device__ __forceinline__ uint32_t ex_compl(uint32_t v) { return v < 4u ? 3u - v : 4u; } // N <-> N
+
+// One thread per entry.  updateEntry (ReadsMatchers.cpp:548-559): the read is reverse-complemented if it matched the RC
+// strand; the mismatch list is taken in the ORIGINAL read's orientation ("reversed": scan from the end, complemented
+// symbols, fillEntryWithReversedMismatches :53-66) iff rc (SE) resp. rc != (orgIdx odd) (revComplPairFile), else in the
+// pseudogenome's (fillEntryWithMismatches :40-51).  writeReadEntry then emits the codes in list order and the offsets
+// coded backwards: L-1 - off[last], off[last]-1 - off[last-1], ... (SeparatedPseudoGenomePersistence.cpp:975-981).
+template <typename OFF>
+__global__ void __launch_bounds__(256) k_export_mismatches(const MisArgs a) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.ne) return;
+    const uint32_t cnt = a.emc[r];
+    if (!cnt) return;
+    const uint32_t i = a.eread[r];
+    const uint32_t L = a.L;
+    // reads with N keep their symbols as ASCII rows in a side list ordered by read index
+    const uint8_t *row = nullptr;
+    if (a.nflag && a.nflag[i]) {
+        uint64_t lo = 0, hi = a.nn;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (a.nidx[mid] < i) lo = mid + 1;
+            else hi = mid;
+        }
+        row = a.nascii + lo * L;
+    }
+    auto rval = [&](uint32_t x) -> uint32_t {
+        if (row) {
+            const uint8_t ch = row[x];
+            return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+        }
+        return (a.reads[(uint64_t)(x >> 4) * a.stride + i] >> (2u * (x & 15u))) & 3u;
+    };
+    const uint64_t p = a.pos[i];
+    const bool rc = a.rc[i] != 0;
+    const bool reversed = a.pair_file ? (rc != (bool)(a.eorg[r] & 1u)) : rc;
+    const uint64_t o = a.mbase[r];
+    OFF *ro = (OFF *)a.revoff;
+    uint32_t emitted = 0, prev_off = 0;
+    for (uint32_t step = 0; step < L && emitted < cnt; step++) {
+        const uint32_t x = reversed ? L - 1u - step : step;     // index into the (possibly RC'd) read / Pg window
+        uint32_t rv = rc ? ex_compl(rval(L - 1u - x)) : rval(x);
+        const uint64_t g = p + x;
+        uint32_t pv = (a.pg[g >> 4] >> (2u * ((uint32_t)g & 15u))) & 3u;
+        if (rv != pv) {
+            if (reversed) { pv = ex_compl(pv); rv = ex_compl(rv); }
+            a.sym[o + emitted] = (uint8_t)((pv << 4) + rv);
+            // list offset of this mismatch = step; the value for the PREVIOUS one is known now
+            if (emitted) ro[o + cnt - emitted] = (OFF)(step - 1u - prev_off);
+            prev_off = step;
+            emitted++;
+        }
+    }
+    if (emitted) ro[o] = (OFF)(L - 1u - prev_off);
+}
+
+// ---------------------------------------------------------------- host side
+
+static uint32_t grid_for(uint64_t n) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>((n + 255) / 256, 1), 65536ull * 4); }
+
+extern "C" void pgrc_match_free_export(pgrc_export_streams *s) {
+    if (!s) return;
+    free(s->off); free(s->org_idx); free(s->rev_comp); free(s->mis_cnt); free(s->mis_sym); free(s->mis_rev_off);
+    memset(s, 0, sizeof *s);
+}
+
+namespace {
+struct Bufs {
+    DevBuf order, rorg, loff, lorg, lrc, lpos, epos, eread, eorg, erc, emc, off, mbase, sym, roff, bs;
+    void release() {
+        for (DevBuf *b : {&order, &rorg, &loff, &lorg, &lrc, &lpos, &epos, &eread, &eorg, &erc, &emc, &off, &mbase, &sym, &roff, &bs}) pgrc_buf_free(*b);
+    }
+};
+}
+
+// emc / eread / eorg (device) are filled: scan the counts, extract the mismatch streams, bring everything to the host
+static int finish_export(pgrc_match_ctx *c, Bufs &b, uint64_t ne, int pair_file, uint32_t width, pgrc_export_streams *out) {
+    int e;
+    if ((e = pgrc_buf_ensure(c, b.mbase, (ne + 1) * sizeof(uint64_t)))) return e;
+    if ((e = device_scan<uint8_t, false>(c, (const uint8_t *)b.emc.p, ne, (uint64_t *)b.mbase.p, b.bs))) return e;
+    uint64_t total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, (uint64_t *)b.mbase.p + ne, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (total) {
+        if ((e = pgrc_buf_ensure(c, b.sym, total)) || (e = pgrc_buf_ensure(c, b.roff, total * width))) return e;
+        MisArgs a;
+        a.pg = (const uint32_t *)c->pg2[0].p;
+        a.reads = c->reads2;
+        a.stride = c->stride;
+        a.nflag = c->n_nreads ? (const uint8_t *)c->nread_flag.p : nullptr;
+        a.nidx = (const uint32_t *)c->nread_idx.p;
+        a.nascii = (const uint8_t *)c->nread_ascii.p;
+        a.nn = c->n_nreads;
+        a.pos = (const uint64_t *)c->d_pos.p;
+        a.rc = (const uint8_t *)c->d_rc.p;
+        a.eread = (const uint32_t *)b.eread.p;
+        a.eorg = (const uint32_t *)b.eorg.p;
+        a.emc = (const uint8_t *)b.emc.p;
+        a.mbase = (const uint64_t *)b.mbase.p;
+        a.ne = ne;
+        a.sym = (uint8_t *)b.sym.p;
+        a.revoff = b.roff.p;
+        a.L = c->prm.read_len;
+        a.pair_file = pair_file ? 1u : 0u;
+        const uint32_t grid = (uint32_t)((ne + 255) / 256);
+        if (width == 1) hipLaunchKernelGGL(k_export_mismatches<uint8_t>, dim3(grid), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL(k_export_mismatches<uint16_t>, dim3(grid), dim3(256), 0, c->stream, a);
+        HIP_TRY(c, hipGetLastError());
+    }
+    out->n_entries = ne;
+    out->n_mismatches = total;
+    out->off_width = width;
+    out->off = (uint8_t *)malloc(std::max<uint64_t>(ne * width, 1));
+    out->org_idx = (uint32_t *)malloc(std::max<uint64_t>(ne * sizeof(uint32_t), 1));
+    out->rev_comp = (uint8_t *)malloc(std::max<uint64_t>(ne, 1));
+    out->mis_cnt = (uint8_t *)malloc(std::max<uint64_t>(ne, 1));
+    out->mis_sym = (uint8_t *)malloc(std::max<uint64_t>(total, 1));
+    out->mis_rev_off = (uint8_t *)malloc(std::max<uint64_t>(total * width, 1));
+    if (!out->off || !out->org_idx || !out->rev_comp || !out->mis_cnt || !out->mis_sym || !out->mis_rev_off) {
+        c->err = "export: host allocation failed";
+        return PGRC_E_ALLOC;
+    }
+    if (ne) {
+        HIP_TRY(c, hipMemcpyAsync(out->off, b.off.p, ne * width, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(out->org_idx, b.eorg.p, ne * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(out->rev_comp, b.erc.p, ne, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(out->mis_cnt, b.emc.p, ne, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (total) {
+        HIP_TRY(c, hipMemcpyAsync(out->mis_sym, b.sym.p, total, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(out->mis_rev_off, b.roff.p, total * width, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PGRC_OK;
+}
+
+static int upload(pgrc_match_ctx *c, DevBuf &b, const void *src, size_t bytes) {
+    int e = pgrc_buf_ensure(c, b, bytes);
+    if (e) return e;
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return PGRC_OK;
+}
+
+static int export_pg_order(pgrc_match_ctx *c, const pgrc_export_pg_order_args *x, Bufs &b, pgrc_export_streams *out) {
+    const uint64_t m = x->n_matched, h = x->list_count, ne = m + h;
+    const uint32_t width = x->byte_per_read_length ? 1u : 2u;
+    int e;
+    if ((e = upload(c, b.order, x->order, m * sizeof(uint32_t)))) return e;
+    if (x->read_org_idx && (e = upload(c, b.rorg, x->read_org_idx, c->n * sizeof(uint32_t)))) return e;
+    if ((e = upload(c, b.loff, x->list_off, h)) || (e = upload(c, b.lorg, x->list_org_idx, h * sizeof(uint32_t)))) return e;
+    if (x->list_rev_comp && (e = upload(c, b.lrc, x->list_rev_comp, h))) return e;
+    if ((e = pgrc_buf_ensure(c, b.lpos, (h + 1) * sizeof(uint64_t)))) return e;
+    if ((e = device_scan<uint8_t, true>(c, (const uint8_t *)b.loff.p, h, (uint64_t *)b.lpos.p, b.bs))) return e;
+    if ((e = pgrc_buf_ensure(c, b.epos, ne * sizeof(uint64_t))) || (e = pgrc_buf_ensure(c, b.eread, ne * sizeof(uint32_t))) ||
+        (e = pgrc_buf_ensure(c, b.eorg, ne * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, b.erc, ne)) ||
+        (e = pgrc_buf_ensure(c, b.emc, ne)) || (e = pgrc_buf_ensure(c, b.off, ne * width)))
+        return e;
+    ExportArgs a;
+    a.pos = (const uint64_t *)c->d_pos.p;
+    a.rc = (const uint8_t *)c->d_rc.p;
+    a.mism = (const uint8_t *)c->d_mism.p;
+    a.order = (const uint32_t *)b.order.p;
+    a.m = m;
+    a.read_org = x->read_org_idx ? (const uint32_t *)b.rorg.p : nullptr;
+    a.lpos = (const uint64_t *)b.lpos.p;
+    a.lorg = (const uint32_t *)b.lorg.p;
+    a.lrc = x->list_rev_comp ? (const uint8_t *)b.lrc.p : nullptr;
+    a.h = h;
+    a.epos = (uint64_t *)b.epos.p;
+    a.eread = (uint32_t *)b.eread.p;
+    a.eorg = (uint32_t *)b.eorg.p;
+    a.erc = (uint8_t *)b.erc.p;
+    a.emc = (uint8_t *)b.emc.p;
+    if (m) hipLaunchKernelGGL(k_export_place_new, dim3(grid_for(m)), dim3(256), 0, c->stream, a);
+    if (h) hipLaunchKernelGGL(k_export_place_old, dim3(grid_for(h)), dim3(256), 0, c->stream, a);
+    if (ne) {
+        if (width == 1) hipLaunchKernelGGL(k_export_offsets<uint8_t>, dim3(grid_for(ne)), dim3(256), 0, c->stream, (const uint64_t *)b.epos.p, ne, (uint8_t *)b.off.p);
+        else hipLaunchKernelGGL(k_export_offsets<uint16_t>, dim3(grid_for(ne)), dim3(256), 0, c->stream, (const uint64_t *)b.epos.p, ne, (uint16_t *)b.off.p);
+    }
+    HIP_TRY(c, hipGetLastError());
+    if ((e = finish_export(c, b, ne, x->rev_compl_pair_file, width, out))) return e;
+    // the builder's lastWrittenPos: the position of the last entry written
+    out->last_pos = 0;
+    if (ne) {
+        uint64_t last = 0;
+        HIP_TRY(c, hipMemcpy(&last, (const uint64_t *)b.epos.p + ne - 1, sizeof last, hipMemcpyDeviceToHost));
+        out->last_pos = last & ~(1ull << 63);
+    }
+    return PGRC_OK;
+}
+
+extern "C" int pgrc_match_export_pg_order(pgrc_match_ctx *c, const pgrc_export_pg_order_args *x, pgrc_export_streams *out) {
+    if (!c || !x || !out || (x->n_matched && !x->order) || (x->list_count && (!x->list_off || !x->list_org_idx))) return PGRC_E_PARAM;
+    memset(out, 0, sizeof *out);
+    if (c->multi) { c->err = "export_pg_order: single-device contexts only (the adapter falls back to per-entry mismatch lists)"; return PGRC_E_PARAM; }
+    if (!c->have_results || !c->have_pg || !c->have_reads) { c->err = "export: run first"; return PGRC_E_STATE; }
+    if (x->n_matched > c->n) { c->err = "export: more matched reads than reads"; return PGRC_E_PARAM; }
+    PGRC_ON_DEVICE(c);
+    Bufs b;
+    int e = export_pg_order(c, x, b, out);
+    b.release();
+    if (e) pgrc_match_free_export(out);
+    return e;
+}
+
+static int export_entries(pgrc_match_ctx *c, const uint32_t *entry_read, const uint32_t *entry_org_idx, uint64_t ne, int pair_file,
+                          uint32_t width, Bufs &b, pgrc_export_streams *out) {
+    int e;
+    if ((e = upload(c, b.eread, entry_read, ne * sizeof(uint32_t))) || (e = upload(c, b.eorg, entry_org_idx, ne * sizeof(uint32_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, b.epos, ne * sizeof(uint64_t))) || (e = pgrc_buf_ensure(c, b.erc, ne)) || (e = pgrc_buf_ensure(c, b.emc, ne)) ||
+        (e = pgrc_buf_ensure(c, b.off, ne * width)))
+        return e;
+    if (ne) {
+        hipLaunchKernelGGL(k_export_fill_entries, dim3(grid_for(ne)), dim3(256), 0, c->stream, (const uint32_t *)b.eread.p, ne,
+                           (const uint64_t *)c->d_pos.p, (const uint8_t *)c->d_rc.p, (const uint8_t *)c->d_mism.p, (uint64_t *)b.epos.p,
+                           (uint8_t *)b.erc.p, (uint8_t *)b.emc.p);
+        if (width == 1) hipLaunchKernelGGL(k_export_offsets_abs<uint8_t>, dim3(grid_for(ne)), dim3(256), 0, c->stream, (const uint64_t *)b.epos.p, ne, (uint8_t *)b.off.p);
+        else hipLaunchKernelGGL(k_export_offsets_abs<uint16_t>, dim3(grid_for(ne)), dim3(256), 0, c->stream, (const uint64_t *)b.epos.p, ne, (uint16_t *)b.off.p);
+        HIP_TRY(c, hipGetLastError());
+    }
+    return finish_export(c, b, ne, pair_file, width, out);
+}
+
+extern "C" int pgrc_match_export_entries(pgrc_match_ctx *c, const uint32_t *entry_read, const uint32_t *entry_org_idx, uint64_t n_entries,
+                                         int32_t rev_compl_pair_file, int32_t byte_per_read_length, pgrc_export_streams *out) {
+    if (!c || !out || (n_entries && (!entry_read || !entry_org_idx))) return PGRC_E_PARAM;
+    memset(out, 0, sizeof *out);
+    if (c->multi) { c->err = "export_entries: single-device contexts only (the adapter falls back to per-entry mismatch lists)"; return PGRC_E_PARAM; }
+    if (!c->have_results || !c->have_pg || !c->have_reads) { c->err = "export: run first"; return PGRC_E_STATE; }
+    for (uint64_t k = 0; k < n_entries; k++)
+        if (entry_read[k] != EX_NONE && entry_read[k] >= c->n) { c->err = "export_entries: read index out of range"; return PGRC_E_PARAM; }
+    PGRC_ON_DEVICE(c);
+    Bufs b;
+    int e = export_entries(c, entry_read, entry_org_idx, n_entries, rev_compl_pair_file, byte_per_read_length ? 1u : 2u, b, out);
+    b.release();
+    if (e) pgrc_match_free_export(out);
+    return e;
+}

@@ -200,6 +200,52 @@ class MatchContext:
                                                        codes.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p)))
         return cum, codes, offs
 
+    # ---- export of the matches as reads-list streams (row f1)
+    @staticmethod
+    def _streams(st):
+        n, m, w = int(st.n_entries), int(st.n_mismatches), int(st.off_width)
+        ot = np.uint8 if w == 1 else np.uint16
+
+        def arr(ptr, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * np.dtype(dtype).itemsize,))
+            return raw.view(dtype).copy()
+        out = {"off": arr(st.off, n, ot), "org_idx": arr(st.org_idx, n, np.uint32), "rev_comp": arr(st.rev_comp, n, np.uint8),
+               "mis_cnt": arr(st.mis_cnt, n, np.uint8), "mis_sym": arr(st.mis_sym, m, np.uint8),
+               "mis_rev_off": arr(st.mis_rev_off, m, ot), "last_pos": int(st.last_pos)}
+        lib.pgrc_match_free_export(C.byref(st))
+        return out
+
+    def export_pg_order(self, order, list_off, list_org_idx, list_rev_comp=None, read_org_idx=None,
+                        rev_compl_pair_file: bool = False, byte_per_read_length: bool = True) -> dict:
+        """exportMatchesInPgOrder's streams (see pgrc_match_export_pg_order)."""
+        keep = [np.ascontiguousarray(order, dtype=np.uint32), np.ascontiguousarray(list_off, dtype=np.uint8),
+                np.ascontiguousarray(list_org_idx, dtype=np.uint32)]
+        a = _lib.ExportPgOrderArgs()
+        a.order, a.n_matched = keep[0].ctypes.data, keep[0].size
+        a.list_off, a.list_org_idx, a.list_count = keep[1].ctypes.data, keep[2].ctypes.data, keep[1].size
+        if list_rev_comp is not None:
+            keep.append(np.ascontiguousarray(list_rev_comp, dtype=np.uint8))
+            a.list_rev_comp = keep[-1].ctypes.data
+        if read_org_idx is not None:
+            keep.append(np.ascontiguousarray(read_org_idx, dtype=np.uint32))
+            a.read_org_idx = keep[-1].ctypes.data
+        a.rev_compl_pair_file, a.byte_per_read_length = int(rev_compl_pair_file), int(byte_per_read_length)
+        st = _lib.ExportStreams()
+        self._ck(lib.pgrc_match_export_pg_order(self._h, C.byref(a), C.byref(st)))
+        return self._streams(st)
+
+    def export_entries(self, entry_read, entry_org_idx, rev_compl_pair_file: bool = False,
+                       byte_per_read_length: bool = True) -> dict:
+        """exportMatchesInOriginalOrder's streams for a caller-made entry list (see pgrc_match_export_entries)."""
+        er = np.ascontiguousarray(entry_read, dtype=np.uint32)
+        eo = np.ascontiguousarray(entry_org_idx, dtype=np.uint32)
+        st = _lib.ExportStreams()
+        self._ck(lib.pgrc_match_export_entries(self._h, er.ctypes.data_as(C.c_void_p), eo.ctypes.data_as(C.c_void_p), er.size,
+                                               int(rev_compl_pair_file), int(byte_per_read_length), C.byref(st)))
+        return self._streams(st)
+
     # ---- introspection
     def export_index(self, strand: int = 0):
         cnt = C.c_uint64(0)

@@ -86,6 +86,7 @@ def main():
     lib.pgrc_ref_decode.argtypes = [C.c_char_p, C.c_int]
     lib.pgrc_ref_bulk_updates.restype = C.c_uint64
     lib.pgrc_ref_text_match_calls.restype = C.c_uint64
+    lib.pgrc_ref_device_exports.restype = C.c_uint64
 
     # default: small enough for the test suite; PGRC_E2E_READS / PGRC_E2E_GENOME scale it up for a one-off check
     n = int(os.environ.get("PGRC_E2E_READS", "60000"))
@@ -98,6 +99,7 @@ def main():
     # deterministic at -t 1 and its archive decodes to the input
     # GPU leg: bit 0 = stage 4 (reads -> Pg, HipReadsMatcher), bit 1 = stage 7 (Pg -> Pg, HipTextMatcher)
     gpu_leg = 0 if os.environ.get("PGRC_E2E_CPU_ONLY") == "1" else int(os.environ.get("PGRC_E2E_GPU_STAGES", "3"))
+    exports_seen = 0
     for leg, use_gpu in (("cpu", 0), ("gpu", gpu_leg)):
         d = os.path.join(work, case, leg)
         os.makedirs(d, exist_ok=True)
@@ -117,6 +119,8 @@ def main():
         out[leg + "_gpu_calls"] = calls
         out[leg + "_bulk_updates"] = int(lib.pgrc_ref_bulk_updates())   # entries served by the device extraction
         out[leg + "_text_match_calls"] = int(lib.pgrc_ref_text_match_calls())   # matchTexts calls served by HipTextMatcher
+        out[leg + "_device_exports"] = int(lib.pgrc_ref_device_exports()) - exports_seen   # exports whose streams came from the device
+        exports_seen = int(lib.pgrc_ref_device_exports())
     out["identical"] = digests["cpu"] == digests["gpu"]
     out["sha256"] = digests
 

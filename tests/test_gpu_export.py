@@ -1,0 +1,109 @@
+"""Row f1 on the GPU: the export streams made on the device (pgrc_match_export_pg_order / _export_entries) against the
+oracle's restatement and -- through HipReadsMatcher inside the compiled reference -- against the reference's own
+export: identical stream files and identical archive bytes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import export_util as xu
+from util import gpu_match
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "se": dict(seed=1),
+    "pe_pairfile": dict(seed=2, paired=True),
+    "short_list": dict(seed=3, short_list=True),
+    "no_list": dict(seed=4, empty_list=True),
+    "L250": dict(seed=5, L=250, n=6000, list_gap=110),
+    "L37": dict(seed=6, L=37, n=5000, list_gap=20, n_with_n=100),
+}
+
+
+def _case(name):
+    kw = dict(CASES[name])
+    pair = kw.pop("paired", False)
+    return xu.export_case(paired=pair, **kw), pair
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_streams_equal_oracle_streams(name):
+    case, pair = _case(name)
+    L = case["L"]
+    seed_len = 38 if L >= 100 else 24
+    kmax = L // 3
+    n = case["reads"].shape[0]
+    g = gpu_match("c", case["pg"], case["reads"], seed_len, kmax, 0, n_nset=case["n_n"])
+    res = {k: g[k] for k in ("pos", "rc", "mism")}
+    order = xu.stable_order(res["pos"])          # any order by position will do here: both sides get the same one
+    for byte_mode in (True, False):
+        for with_org in (True, False):
+            want = xu.oracle_export_pg_order(case, res, order, pair_file=pair, byte_mode=byte_mode, with_read_org=with_org)
+            got = g["ctx"].export_pg_order(order, case["list_off"], case["list_org"], case["list_rc"],
+                                           case["read_org"] if with_org else None, pair, byte_mode)
+            for k in xu.STREAMS:
+                assert np.array_equal(got[k], want[k]), (name, byte_mode, with_org, k)
+            assert got["last_pos"] == want["last_pos"]
+    # no RC stream on the old list
+    c2 = dict(case, list_rc=None)
+    want = xu.oracle_export_pg_order(c2, res, order, pair_file=pair)
+    got = g["ctx"].export_pg_order(order, case["list_off"], case["list_org"], None, case["read_org"], pair, True)
+    for k in xu.STREAMS:
+        assert np.array_equal(got[k], want[k]), (name, "no rc", k)
+    # original order: a caller-made entry list with fillers and unmatched reads left out
+    er, eo = xu.original_order_entries(case["read_org"], res["mism"] != 255, case["total"], pair, n - case["n_n"])
+    want = xu.oracle_export_entries(case, res, er, eo, pair_file=pair)
+    got = g["ctx"].export_entries(er, eo, pair, True)
+    for k in xu.STREAMS:
+        assert np.array_equal(got[k], want[k]), (name, "entries", k)
+
+
+def test_export_edge_cases():
+    case, _ = _case("se")
+    g = gpu_match("c", case["pg"], case["reads"], 38, 33, 0, n_nset=case["n_n"])
+    res = {k: g[k] for k in ("pos", "rc", "mism")}
+    # nothing matched + a list; matches + nothing else; nothing at all
+    none = np.zeros(0, dtype=np.uint32)
+    got = g["ctx"].export_pg_order(none, case["list_off"], case["list_org"], case["list_rc"], case["read_org"])
+    want = xu.oracle_export_pg_order(case, res, none)
+    for k in xu.STREAMS:
+        assert np.array_equal(got[k], want[k]), k
+    assert got["off"].size == case["list_off"].size and np.array_equal(got["off"], case["list_off"])
+    got = g["ctx"].export_entries(none, none)
+    assert all(got[k].size == 0 for k in xu.STREAMS)
+    from pgrc_amd import MatchContext, PgrcMatchError
+    many = MatchContext(100, 38, 33, 0, "c", devices=[0, 0])
+    with pytest.raises(PgrcMatchError):
+        many.export_entries(none, none)
+
+
+@pytest.mark.parametrize("name", ["se", "pe_pairfile", "short_list", "no_list"])
+@pytest.mark.parametrize("preserve_order", [False, True])
+def test_adapter_export_equals_reference_export(tmp_path, name, preserve_order):
+    """HipReadsMatcher's device export inside the compiled reference vs the reference's own export: the six stream
+    files and the compressed bytes handed to the archive stream."""
+    if not orc.have_adapter():
+        pytest.skip("oracle/_ref was built without the adapter")
+    r = orc.ref()
+    r.pgrc_ref_device_exports.restype = C.c_uint64
+    case, pair = _case(name)
+    kw = dict(kmax=33, preserve_order=preserve_order, pair_file_mode=pair, rev_compl_pair_file=pair)
+    want = xu.ref_export_run(case, str(tmp_path / "cpu"), 0, **kw)
+    before = r.pgrc_ref_device_exports()
+    got = xu.ref_export_run(case, str(tmp_path / "gpu"), 1, **kw)
+    assert r.pgrc_ref_device_exports() == before + 1          # the device path ran (no silent fallback)
+    for k in list(xu.STREAMS) + ["archive"]:
+        assert got[k] == want[k], (name, preserve_order, k)
+    assert len(want["archive"]) > 1000
+
+
+def test_adapter_export_with_a_parallel_sort(tmp_path):
+    if not orc.have_adapter():
+        pytest.skip("oracle/_ref was built without the adapter")
+    case = xu.export_case(seed=7, n=60_000, G=500_000, dups=3000)
+    want = xu.ref_export_run(case, str(tmp_path / "cpu"), 0, threads=8)
+    got = xu.ref_export_run(case, str(tmp_path / "gpu"), 1, threads=8)
+    for k in xu.STREAMS:
+        assert got[k] == want[k], k
