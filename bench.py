@@ -210,11 +210,12 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax)
             except Exception as e:  # the GPU measurement must not be lost to a host-side problem
                 out["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(e)}
-            if args.parity_sample_reads > 0:
-                try:
-                    out["parity_sample"] = parity_sample(args, ctx, g, rs, n_per, L, G, seed_len, kmax)
-                except Exception as e:
-                    out["parity_sample"] = {"diff": None, "error": repr(e)}
+
+        if world == 1 and args.parity_sample_reads > 0:
+            try:
+                out["parity_sample"] = parity_sample(args, ctx, g, rs, n_per, L, G, seed_len, kmax)
+            except Exception as e:
+                out["parity_sample"] = {"diff": None, "error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

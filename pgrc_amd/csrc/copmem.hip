@@ -164,6 +164,20 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     }
     int hbits = 0;
     while ((1ull << hbits) < hs) hbits++;
+    // How the records get grouped by bucket (all three give the serial reference index, byte for byte):
+    //   "hybrid" (default): record generation + the library's radix sort over the TOP bucket bits only (two 8-bit passes
+    //             instead of four), then one block per partition of 8192 buckets finishes counting, cap, order and
+    //             heads in LDS (idxsort.hip);
+    //   "own":    the same finish behind hand-written scatter passes that hash the text themselves (no library call);
+    //   "rocprim": round 1's path -- full library sort, streaming head kernel (also taken for 2^32 or more samples).
+    const char *sel = getenv("PGRC_INDEX_SORT");
+    const bool want_lib = sel && !strcmp(sel, "rocprim"), want_own = sel && !strcmp(sel, "own");
+    const bool partition = !want_lib && pgrc_ps_applicable(c, (uint32_t)hbits);
+    const uint32_t cb = pgrc_ps_partition_bits((uint32_t)hbits);
+    if (partition && want_own) {
+        if ((e = pgrc_ps_scatter_front(c, strand, (uint32_t)hbits, cb))) return e;
+        return pgrc_ps_finish(c, (const uint32_t *)c->d_skey[1].p, (const uint64_t *)c->d_sval[1].p, (uint32_t)hbits, cb, (uint64_t *)c->d_sval[0].p);
+    }
     // scratch lives in the context (grow-only): no hipMalloc / hipFree (= device synchronisation) per build
     for (int k = 0; k < 2; k++) {
         if ((e = pgrc_buf_ensure(c, c->d_skey[k], (npos + 16) * sizeof(uint32_t)))) return e;
@@ -172,7 +186,8 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     rocprim::double_buffer<uint32_t> keys((uint32_t *)c->d_skey[0].p, (uint32_t *)c->d_skey[1].p);
     rocprim::double_buffer<uint64_t> vals((uint64_t *)c->d_sval[0].p, (uint64_t *)c->d_sval[1].p);
     size_t tbytes = 0;
-    hipError_t he = rocprim::radix_sort_pairs(nullptr, tbytes, keys, vals, (size_t)npos, 0, hbits, c->stream);
+    const unsigned bit0 = partition ? cb : 0u;
+    hipError_t he = rocprim::radix_sort_pairs(nullptr, tbytes, keys, vals, (size_t)npos, bit0, hbits, c->stream);
     if (he != hipSuccess) { c->err = "rocprim size query failed"; return PGRC_E_DEVICE; }
     if ((e = pgrc_buf_ensure(c, c->d_sorttmp, tbytes + 16))) return e;
 
@@ -181,8 +196,9 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     hipLaunchKernelGGL(k_copmem_index_gen, dim3(grid), dim3(IDX_TPB), 0, c->stream, (const uint32_t *)c->pg2[strand].p,
                        c->pg_words + PGRC_PG_PAD_WORDS, npos, k1, K, (uint32_t)(hs - 1), keys.current(), vals.current());
     HIP_TRY(c, hipGetLastError());
-    he = rocprim::radix_sort_pairs(c->d_sorttmp.p, tbytes, keys, vals, (size_t)npos, 0, hbits, c->stream);
+    he = rocprim::radix_sort_pairs(c->d_sorttmp.p, tbytes, keys, vals, (size_t)npos, bit0, hbits, c->stream);
     if (he != hipSuccess) { c->err = std::string("index sort: ") + hipGetErrorString(he); return PGRC_E_DEVICE; }
+    if (partition) return pgrc_ps_finish(c, keys.current(), vals.current(), (uint32_t)hbits, cb, vals.alternate());
     hipLaunchKernelGGL(k_copmem_index_heads, dim3((uint32_t)((npos + HEADS_REC - 1) / HEADS_REC)), dim3(HEADS_TPB), 0, c->stream,
                        (const uint32_t *)keys.current(), (const uint64_t *)vals.current(), npos, hs, (ulonglong2 *)c->d_head.p);
     HIP_TRY(c, hipGetLastError());

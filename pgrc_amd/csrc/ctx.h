@@ -177,6 +177,11 @@ int pgrc_launch_nrows_ascii_acgnt(pgrc_match_ctx *c, const uint8_t *d_packed, co
 
 // copmem.hip
 int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand);
+// idxsort.hip: the partition build of the same index (hand-written scatter passes, in-LDS finish of a partition)
+uint32_t pgrc_ps_partition_bits(uint32_t hbits);
+bool pgrc_ps_applicable(const pgrc_match_ctx *c, uint32_t hbits);
+int pgrc_ps_scatter_front(pgrc_match_ctx *c, int strand, uint32_t hbits, uint32_t cb);
+int pgrc_ps_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uint64_t *d_vals, uint32_t hbits, uint32_t cb, uint64_t *d_ent);
 int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand);
 int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_positions, uint64_t *count);
 

@@ -1,0 +1,670 @@
+// idxsort.hip -- the copMEM seed index built by a hand-written partition sort (mode c).
+//
+// What is built (reference semantics: CopMEMMatcher::processRef / genCumm, matching/copmem/CopMEMMatcher.cpp:140-231,
+// SERIAL build): bucket h = the first 13 sampled positions, ascending, whose hash (Hashes.h:54-76) & mask equals h.
+// The records (bucket, entry = position << 22 | fingerprint) are generated in position order, so any STABLE
+// arrangement by bucket reproduces the serial index.  rocPRIM's general radix sort did that in four 8-bit passes
+// (11.7 ms at C3) between a generator kernel and a head-writing kernel (16.3 ms per strand in all).  This build
+// knows more about the job than a general sort can:
+//   * the keys are hash values: cheap to RECOMPUTE from the text, so the first pass needs no stored input at all
+//     (its histogram pre-pass and its scatter both hash the text: k_ps_hist_gen, k_ps_scatter_gen);
+//   * a full sort is not needed: after two stable scatter passes over the TOP hbits-13 bucket bits the records of
+//     8192 consecutive buckets are contiguous (a "partition", ~5.7 k records at C3), and one block finishes a
+//     partition in LDS -- counting, the 13-entry cap, placement, bucket heads -- and streams its 128 KB of heads out
+//     (k_ps_finish).  Entries past a bucket's 13th are never written (the reference drops them: "skippedList").
+// Passes:  hist(text) -> scan -> scatter(text -> A) -> hist(A keys) -> scan -> scatter(A -> B) -> bounds(B keys) -> finish.
+// Bytes moved at C3: 0.5 + 0.5+4.5 + 1.5 + 9.0 + 1.5 + 4.5(+4.5 from L2) + 11.6 = 34 GB (rocPRIM path: 55 GB).
+// Everything is deterministic: ranks come from ballots and prefix sums, never from the arrival order of atomics
+// (the one place where LDS atomics place records, k_ps_finish, re-sorts a bucket's <= 13 entries by position and
+// resolves the cap with a deterministic rank).
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "ctx.h"
+#include "devutil.h"
+#include "headfmt.h"
+
+#define PS_TPB 512
+#define PS_NW (PS_TPB / 64)
+#define PS_E 8
+#define PS_TILE (PS_TPB * PS_E)          // 4096 records per tile
+#define PS_WSPAN (64 * PS_E)             // 512 consecutive records per wave
+#define PS_MAXD 512                      // digits per scatter pass (<= 9 bits)
+#define PS_CB 13u                        // bucket bits finished in LDS: 8192 buckets per partition
+#define PS_TXT_WORDS 80                  // text words one wave stages for 64 sampled positions: (15 + 63*16 + 56 + 15)/16 + 5
+
+struct PsPlan {
+    uint32_t hbits, b1, b2;              // pass 1 sorts bucket bits [13, 13+b1), pass 2 bits [13+b1, hbits)
+    uint64_t n, ntiles;
+};
+
+// ---------------------------------------------------------------- exclusive scan u32 -> u32 (counts of one pass)
+#define PSC_TPB 256
+#define PSC_EPT 16
+#define PSC_EPB (PSC_TPB * PSC_EPT)
+
+__device__ __forceinline__ uint32_t psc_block_scan(uint32_t v, uint32_t *smem, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    uint32_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(inc, o, 64);
+        if (lane >= (uint32_t)o) inc += u;
+    }
+    if (lane == 63) smem[wv] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (uint32_t k = 0; k < nwv; k++) {
+        const uint32_t s = smem[k];
+        if (k < wv) woff += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + inc - v;
+}
+
+__global__ void __launch_bounds__(PSC_TPB) k_psc_sums(const uint32_t *__restrict__ in, uint64_t n, uint32_t *bsum) {
+    __shared__ uint32_t smem[PSC_TPB / 64 + 1];
+    const uint64_t base = (uint64_t)blockIdx.x * PSC_EPB + (uint64_t)threadIdx.x * PSC_EPT;
+    uint32_t s = 0;
+    if (base + PSC_EPT <= n) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(in + base);
+#pragma unroll
+        for (int k = 0; k < PSC_EPT / 4; k++) { const uint4 q = p[k]; s += q.x + q.y + q.z + q.w; }
+    } else {
+        for (int k = 0; k < PSC_EPT; k++)
+            if (base + k < n) s += in[base + k];
+    }
+    uint32_t tot;
+    psc_block_scan(s, smem, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(PSC_TPB) k_psc_bsums(uint32_t *bsum, uint64_t nb) {
+    __shared__ uint32_t smem[PSC_TPB / 64 + 1];
+    uint32_t run = 0;
+    for (uint64_t b0 = 0; b0 < nb; b0 += PSC_TPB) {
+        const uint64_t i = b0 + threadIdx.x;
+        const uint32_t v = i < nb ? bsum[i] : 0;
+        uint32_t tot;
+        const uint32_t ex = psc_block_scan(v, smem, &tot);
+        if (i < nb) bsum[i] = run + ex;
+        run += tot;
+    }
+}
+
+__global__ void __launch_bounds__(PSC_TPB) k_psc_write(uint32_t *__restrict__ io, uint64_t n, const uint32_t *__restrict__ bsum) {
+    __shared__ uint32_t smem[PSC_TPB / 64 + 1];
+    const uint64_t base = (uint64_t)blockIdx.x * PSC_EPB + (uint64_t)threadIdx.x * PSC_EPT;
+    uint32_t v[PSC_EPT], s = 0;
+#pragma unroll
+    for (int k = 0; k < PSC_EPT; k++) {
+        v[k] = (base + k < n) ? io[base + k] : 0;
+        s += v[k];
+    }
+    uint32_t tot;
+    uint32_t off = psc_block_scan(s, smem, &tot) + bsum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < PSC_EPT; k++) {
+        if (base + k < n) io[base + k] = off;
+        off += v[k];
+    }
+}
+
+// in place: counts -> exclusive prefix sums
+static int ps_scan(pgrc_match_ctx *c, uint32_t *d_io, uint64_t n, uint32_t *d_bsum) {
+    const uint64_t nb = (n + PSC_EPB - 1) / PSC_EPB;
+    hipLaunchKernelGGL(k_psc_sums, dim3((uint32_t)nb), dim3(PSC_TPB), 0, c->stream, (const uint32_t *)d_io, n, d_bsum);
+    hipLaunchKernelGGL(k_psc_bsums, dim3(1), dim3(PSC_TPB), 0, c->stream, d_bsum, nb);
+    hipLaunchKernelGGL(k_psc_write, dim3((uint32_t)nb), dim3(PSC_TPB), 0, c->stream, d_io, n, (const uint32_t *)d_bsum);
+    HIP_TRY(c, hipGetLastError());
+    return PGRC_OK;
+}
+
+// ---------------------------------------------------------------- record generation (one wave = 64 consecutive sampled positions)
+
+struct GenArgs {
+    const uint32_t *pg;
+    uint64_t pg_words_alloc, npos;
+    uint32_t k1, K, mask;
+};
+
+// hashes sampled position t (valid lanes only compute meaningful values); txt = this wave's staging area
+__device__ __forceinline__ void ps_gen64(const GenArgs &g, uint64_t t_first, uint32_t lane, uint32_t *txt, const uint32_t *lut,
+                                         uint32_t *key, uint64_t *val) {
+    const uint64_t p0 = t_first * g.k1;
+    const uint64_t w0 = p0 >> 4;
+    const uint32_t need = (uint32_t)((((p0 & 15) + 63ull * g.k1 + g.K + 15) >> 4) + 5);
+    for (uint32_t w = lane; w < need; w += 64) txt[w] = (w0 + w < g.pg_words_alloc) ? g.pg[w0 + w] : 0u;
+    __syncthreads();
+    const uint64_t p = (t_first + lane) * g.k1;
+    const uint32_t q = (uint32_t)((p >> 4) - w0);
+    const uint32_t sh = ((uint32_t)p & 15u) * 2u;
+    const uint32_t a0 = txt[q], a1 = txt[q + 1], a2 = txt[q + 2], a3 = txt[q + 3], a4 = txt[q + 4];
+    uint32_t fp;
+    *key = copmem_hash32_fp(funnel_r(a0, a1, sh), funnel_r(a1, a2, sh), funnel_r(a2, a3, sh), funnel_r(a3, a4, sh), g.K, lut, &fp) & g.mask;
+    *val = (p << PGRC_FP_BITS) | fp;
+    __syncthreads();
+}
+
+// pass-1 histogram straight from the text: cnt[d * ntiles + tile]
+__global__ void __launch_bounds__(PS_TPB)
+k_ps_hist_gen(const GenArgs g, uint32_t shift, uint32_t dmask, uint64_t ntiles, uint32_t *__restrict__ cnt) {
+    __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
+    __shared__ uint32_t txt[PS_NW][PS_TXT_WORDS];
+    __shared__ uint32_t hist[PS_MAXD];
+    hash_lut_init(lut);
+    for (uint32_t d = threadIdx.x; d <= dmask; d += PS_TPB) hist[d] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t tile = blockIdx.x;
+    const uint64_t wbase = tile * PS_TILE + (uint64_t)wv * PS_WSPAN;
+    for (int i = 0; i < PS_E; i++) {
+        const uint64_t tf = wbase + (uint64_t)i * 64;
+        uint32_t key;
+        uint64_t val;
+        ps_gen64(g, tf, lane, txt[wv], lut, &key, &val);
+        if (tf + lane < g.npos) atomicAdd(&hist[(key >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d <= dmask; d += PS_TPB) cnt[(uint64_t)d * ntiles + tile] = hist[d];
+}
+
+// histogram of a later pass from stored keys
+__global__ void __launch_bounds__(PS_TPB)
+k_ps_hist_keys(const uint32_t *__restrict__ keys, uint64_t n, uint32_t shift, uint32_t dmask, uint64_t ntiles, uint32_t *__restrict__ cnt) {
+    __shared__ uint32_t hist[PS_MAXD];
+    for (uint32_t d = threadIdx.x; d <= dmask; d += PS_TPB) hist[d] = 0;
+    __syncthreads();
+    const uint64_t tile = blockIdx.x;
+    const uint64_t base = tile * PS_TILE;
+    for (int i = 0; i < PS_E; i++) {
+        const uint64_t x = base + (uint64_t)i * PS_TPB + threadIdx.x;
+        if (x < n) atomicAdd(&hist[(keys[x] >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d <= dmask; d += PS_TPB) cnt[(uint64_t)d * ntiles + tile] = hist[d];
+}
+
+// ---------------------------------------------------------------- stable scatter of one tile
+
+struct ScatterLds {
+    uint32_t keyS[PS_TILE];
+    uint64_t valS[PS_TILE];
+    uint16_t hist[PS_NW][PS_MAXD];      // per wave: running count (<= 4096), then the wave's offset inside its digit
+    uint32_t dstart[PS_MAXD];           // first slot of a digit in the sorted tile
+    uint32_t gbase[PS_MAXD];            // where the tile's run of a digit starts in the output
+    uint32_t scan_tmp[PS_NW + 1];
+};
+
+// Records arrive as PS_E groups per wave; group i of wave w holds tile-local records w*512 + i*64 + lane, so "earlier
+// wave, then earlier group, then lower lane" is the input order.  Ranks: lanes of a group with the same digit find
+// each other with `dbits` ballots; the group's lowest such lane bumps the wave's counter for that digit.
+template <bool GEN>
+__device__ __forceinline__ void ps_scatter_tile(ScatterLds &s, const uint32_t (&key)[PS_E], const uint64_t (&val)[PS_E], uint64_t nvalid,
+                                                uint32_t shift, uint32_t dbits, uint64_t ntiles, uint64_t tile,
+                                                const uint32_t *__restrict__ base, uint32_t *__restrict__ keys_out,
+                                                uint64_t *__restrict__ vals_out) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t D = 1u << dbits, dmask = D - 1u;
+    for (uint32_t x = threadIdx.x; x < PS_NW * PS_MAXD; x += PS_TPB) (&s.hist[0][0])[x] = (uint16_t)0;
+    for (uint32_t d = threadIdx.x; d < D; d += PS_TPB) s.gbase[d] = base[(uint64_t)d * ntiles + tile];
+    __syncthreads();
+    uint32_t rank[PS_E];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int i = 0; i < PS_E; i++) {
+        const bool valid = (uint64_t)wv * PS_WSPAN + (uint64_t)i * 64 + lane < nvalid;
+        const uint32_t d = (key[i] >> shift) & dmask;
+        unsigned long long peers = __ballot(valid);
+        for (uint32_t b = 0; b < dbits; b++) {
+            const unsigned long long bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        // the lowest lane of every peer group (always a valid lane) advances the wave's counter of that digit
+        const uint32_t leader = valid ? (uint32_t)__ffsll((long long)peers) - 1u : lane;
+        uint32_t old = 0;
+        if (valid && lane == leader) {
+            old = s.hist[wv][d];
+            s.hist[wv][d] = (uint16_t)(old + (uint32_t)__popcll(peers));
+        }
+        old = __shfl(old, leader, 64);
+        rank[i] = old + (uint32_t)__popcll(peers & lt);
+    }
+    __syncthreads();
+    // per digit: the waves' counts -> their offsets inside the digit; digit totals -> digit starts
+    uint32_t tot = 0;
+    if (threadIdx.x < D) {
+        const uint32_t d = threadIdx.x;
+        for (uint32_t w = 0; w < PS_NW; w++) {
+            const uint32_t t = s.hist[w][d];
+            s.hist[w][d] = (uint16_t)tot;
+            tot += t;
+        }
+    }
+    uint32_t all;
+    const uint32_t ex = psc_block_scan(tot, s.scan_tmp, &all);
+    if (threadIdx.x < D) s.dstart[threadIdx.x] = ex;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PS_E; i++) {
+        const bool valid = (uint64_t)wv * PS_WSPAN + (uint64_t)i * 64 + lane < nvalid;
+        if (valid) {
+            const uint32_t d = (key[i] >> shift) & dmask;
+            const uint32_t slot = s.dstart[d] + s.hist[wv][d] + rank[i];
+            s.keyS[slot] = key[i];
+            s.valS[slot] = val[i];
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < (uint32_t)nvalid; j += PS_TPB) {
+        const uint32_t k = s.keyS[j];
+        const uint32_t d = (k >> shift) & dmask;
+        const uint64_t dest = (uint64_t)s.gbase[d] + (j - s.dstart[d]);
+        keys_out[dest] = k;
+        vals_out[dest] = s.valS[j];
+    }
+}
+
+// pass 1: records from the text, scattered by their first digit
+__global__ void __launch_bounds__(PS_TPB)
+k_ps_scatter_gen(const GenArgs g, uint32_t shift, uint32_t dbits, uint64_t ntiles, const uint32_t *__restrict__ base,
+                 uint32_t *__restrict__ keys_out, uint64_t *__restrict__ vals_out) {
+    __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
+    __shared__ uint32_t txt[PS_NW][PS_TXT_WORDS];
+    __shared__ ScatterLds s;
+    hash_lut_init(lut);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t tile = blockIdx.x;
+    const uint64_t t0 = tile * PS_TILE;
+    uint32_t key[PS_E];
+    uint64_t val[PS_E];
+#pragma unroll
+    for (int i = 0; i < PS_E; i++) ps_gen64(g, t0 + (uint64_t)wv * PS_WSPAN + (uint64_t)i * 64, lane, txt[wv], lut, &key[i], &val[i]);
+    const uint64_t nvalid = min((uint64_t)PS_TILE, g.npos - t0);
+    ps_scatter_tile<true>(s, key, val, nvalid, shift, dbits, ntiles, tile, base, keys_out, vals_out);
+}
+
+// pass 2: stored records, scattered by their second digit
+__global__ void __launch_bounds__(PS_TPB)
+k_ps_scatter_keys(const uint32_t *__restrict__ keys_in, const uint64_t *__restrict__ vals_in, uint64_t n, uint32_t shift,
+                  uint32_t dbits, uint64_t ntiles, const uint32_t *__restrict__ base, uint32_t *__restrict__ keys_out,
+                  uint64_t *__restrict__ vals_out) {
+    __shared__ ScatterLds s;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t tile = blockIdx.x;
+    const uint64_t t0 = tile * PS_TILE;
+    uint32_t key[PS_E];
+    uint64_t val[PS_E];
+#pragma unroll
+    for (int i = 0; i < PS_E; i++) {
+        const uint64_t x = t0 + (uint64_t)wv * PS_WSPAN + (uint64_t)i * 64 + lane;
+        key[i] = x < n ? keys_in[x] : 0u;
+        val[i] = x < n ? vals_in[x] : 0ull;
+    }
+    const uint64_t nvalid = min((uint64_t)PS_TILE, n - t0);
+    ps_scatter_tile<false>(s, key, val, nvalid, shift, dbits, ntiles, tile, base, keys_out, vals_out);
+}
+
+// ---------------------------------------------------------------- partition bounds
+
+// pstart[p] = index of the first record of partition p (records are sorted by partition); untouched for empty ones
+__global__ void __launch_bounds__(256) k_ps_bounds(const uint32_t *__restrict__ keys, uint64_t n, uint32_t cb, uint32_t *__restrict__ pstart) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t p = keys[i] >> cb;
+        if (i == 0 || (keys[i - 1] >> cb) != p) pstart[p] = (uint32_t)i;
+    }
+}
+
+// an empty partition starts where the next non-empty one does; pstart2[np] = n
+__global__ void __launch_bounds__(256) k_ps_bounds_fill(const uint32_t *__restrict__ pstart, uint32_t np, uint32_t n, uint32_t *__restrict__ pstart2) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p <= np; p += gridDim.x * blockDim.x) {
+        uint32_t q = p;
+        while (q < np && pstart[q] == 0xFFFFFFFFu) q++;
+        pstart2[p] = q < np ? pstart[q] : n;
+    }
+}
+
+// ---------------------------------------------------------------- the last bucket bits, one block per partition
+
+// A partition = the records of 2^cb consecutive buckets (cb = 13 unless the table is larger than 2^29: the scatter
+// passes / the library sort cover at most 16 bits), contiguous after the top bits are sorted, in position order.
+// One block turns it into its slice of ent[] and its 2^cb bucket heads, 4096 buckets (a "round") at a time:
+//   1. count per bucket (LDS atomics; order is irrelevant for counting);
+//   2. kept = min(count, 13); exclusive scan -> where a bucket's entries go;
+//   3. placement: a record of a bucket with <= 13 entries takes the next free slot of its bucket (any order: step 4
+//      sorts); a record of an overflowing bucket gets the deterministic rank "entries placed by earlier chunks +
+//      same-bucket records before it in this chunk" and is dropped once that reaches 13 -- the serial build's
+//      `cumm[h] <= 12` cap (CopMEMMatcher.cpp:156-159);
+//   4. every bucket with >= 2 entries puts its <= 13 entries in ascending order (entry order = position order); the
+//      heads are built and streamed out as one contiguous run, the entries as another.
+// Fast kernel: the partition's records sit in registers (one load burst), entries are staged in LDS, nothing is
+// read back from HBM.  Partitions it cannot take (more records than its registers hold, more kept entries than its
+// staging area: repeats and low-complexity text) are flagged and finished by the general kernel below.
+// TPB threads hold E records each; SUB = 2^SUBBITS buckets per round, CAP staged entries per round
+#define PFF_PAD(b) ((b) + ((b) >> 4))    // one pad word per 16: a thread's 8 consecutive words never share banks with its neighbours'
+// packed bucket word: bits 0-16 first slot, 17-20 kept (14 = more than 13), 21-24 placed so far
+#define PFF_OFF(w) ((w) & 0x1FFFFu)
+#define PFF_KEPT(w) (((w) >> 17) & 15u)
+#define PFF_FILL(w) (((w) >> 21) & 15u)
+
+template <int E, int PFF_TPB, int PFF_SUBBITS, int CAPI>
+__global__ void __launch_bounds__(PFF_TPB)
+k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals, const uint32_t *__restrict__ pstart, uint32_t cb,
+                 uint64_t *__restrict__ ent, ulonglong2 *__restrict__ head, uint32_t *__restrict__ slow_flag) {
+    constexpr uint32_t PFF_SUB = 1u << PFF_SUBBITS, PFF_CAP = (uint32_t)CAPI;
+    __shared__ uint32_t pk[PFF_SUB + PFF_SUB / 16];
+    __shared__ uint64_t entS[PFF_CAP];
+    __shared__ uint32_t ckey[PFF_TPB];
+    __shared__ uint32_t scan_tmp[PFF_TPB / 64 + 1];
+    __shared__ uint32_t flags[2];            // [0] a bucket of this round overflows, [1] bail out
+    const uint32_t p = blockIdx.x;
+    const uint64_t s = pstart[p], e = pstart[p + 1];
+    if (e - s > (uint64_t)E * PFF_TPB) {
+        if (threadIdx.x == 0) slow_flag[p] = 1;
+        return;
+    }
+    uint32_t k[E];
+    uint64_t v[E];
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        const uint64_t x = s + (uint64_t)i * PFF_TPB + threadIdx.x;
+        k[i] = x < e ? keys[x] : 0xFFFFFFFFu;
+        v[i] = x < e ? vals[x] : 0ull;
+    }
+    const uint32_t nb = 1u << cb, cbmask = nb - 1u;
+    uint64_t out = s;                                         // where this round's entries start in ent[]
+    for (uint32_t r0 = 0; r0 < nb; r0 += PFF_SUB) {
+        for (uint32_t b = threadIdx.x; b < PFF_SUB + PFF_SUB / 16; b += PFF_TPB) pk[b] = 0;
+        if (threadIdx.x < 2) flags[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const uint32_t b = (k[i] & cbmask) - r0;          // (an invalid record has all key bits set: never in range... unless it is: checked)
+            if (k[i] != 0xFFFFFFFFu && b < PFF_SUB) atomicAdd(&pk[PFF_PAD(b)], 1u);
+        }
+        __syncthreads();
+        // 2. scan of the kept counts: 8 consecutive buckets per thread
+        uint32_t total;
+        {
+            const uint32_t b0 = threadIdx.x * (PFF_SUB / PFF_TPB);
+            uint32_t c[PFF_SUB / PFF_TPB], sum = 0;
+            bool ovf = false;
+#pragma unroll
+            for (uint32_t q = 0; q < PFF_SUB / PFF_TPB; q++) {
+                c[q] = pk[PFF_PAD(b0 + q)];
+                ovf |= c[q] > PGRC_BUCKET_CAP;
+                sum += min(c[q], PGRC_BUCKET_CAP);
+            }
+            uint32_t off = psc_block_scan(sum, scan_tmp, &total);
+#pragma unroll
+            for (uint32_t q = 0; q < PFF_SUB / PFF_TPB; q++) {
+                pk[PFF_PAD(b0 + q)] = off | (min(c[q], 14u) << 17);
+                off += min(c[q], PGRC_BUCKET_CAP);
+            }
+            if (ovf) flags[0] = 1;
+            if (total > PFF_CAP && threadIdx.x == 0) flags[1] = 1;
+        }
+        __syncthreads();
+        if (flags[1]) {                                       // more entries than the staging area holds: the general kernel redoes the partition
+            if (threadIdx.x == 0) slow_flag[p] = 1;
+            return;
+        }
+        // 3. placement into the staging area
+        if (!flags[0]) {
+#pragma unroll
+            for (int i = 0; i < E; i++) {
+                const uint32_t b = (k[i] & cbmask) - r0;
+                if (k[i] != 0xFFFFFFFFu && b < PFF_SUB) {
+                    const uint32_t w = atomicAdd(&pk[PFF_PAD(b)], 1u << 21);
+                    entS[PFF_OFF(w) + PFF_FILL(w)] = v[i];
+                }
+            }
+        } else {
+            for (int i = 0; i < E; i++) {                     // chunk i = 512 consecutive records
+                const uint32_t b = (k[i] & cbmask) - r0;
+                const bool mine = k[i] != 0xFFFFFFFFu && b < PFF_SUB;
+                const uint32_t w0 = mine ? pk[PFF_PAD(b)] : 0u;     // state before this chunk
+                ckey[threadIdx.x] = mine ? b : 0xFFFFFFFFu;
+                __syncthreads();
+                if (mine) {
+                    if (PFF_KEPT(w0) <= PGRC_BUCKET_CAP) {
+                        const uint32_t w = atomicAdd(&pk[PFF_PAD(b)], 1u << 21);
+                        entS[PFF_OFF(w) + PFF_FILL(w)] = v[i];
+                    } else if (PFF_FILL(w0) < PGRC_BUCKET_CAP) {
+                        uint32_t before = 0;                  // same-bucket records earlier in this chunk
+                        for (uint32_t y = 0; y < threadIdx.x; y++) before += ckey[y] == b;
+                        const uint32_t r = PFF_FILL(w0) + before;
+                        if (r < PGRC_BUCKET_CAP) {
+                            entS[PFF_OFF(w0) + r] = v[i];
+                            atomicAdd(&pk[PFF_PAD(b)], 1u << 21);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        // 4. order inside the buckets, heads (from LDS), then the entries
+        for (uint32_t b = threadIdx.x; b < PFF_SUB; b += PFF_TPB) {
+            const uint32_t w = pk[PFF_PAD(b)];
+            const uint32_t c = min(PFF_KEPT(w), PGRC_BUCKET_CAP), o = PFF_OFF(w);
+            ulonglong2 hd = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
+            if (c) {
+                uint64_t v0 = entS[o], v1 = c > 1 ? entS[o + 1] : 0;
+                if (c == 2) {
+                    if (v1 < v0) { const uint64_t t = v0; v0 = v1; v1 = t; entS[o] = v0; entS[o + 1] = v1; }
+                } else if (c > 2) {
+                    for (uint32_t i = 1; i < c; i++) {      // insertion sort of <= 13 values
+                        const uint64_t x = entS[o + i];
+                        uint32_t j = i;
+                        while (j > 0 && entS[o + j - 1] > x) { entS[o + j] = entS[o + j - 1]; j--; }
+                        entS[o + j] = x;
+                    }
+                    v0 = entS[o];
+                }
+                hd.x = v0;
+                if (c == 2) hd.y = v1;
+                else if (c > 2) {
+                    hd.x |= HEAD_OVF;
+                    hd.y = (out + o + 1) | ((uint64_t)c << 56);   // entries 1.. at ent[base + j - 1]
+                }
+            }
+            head[((uint64_t)p << cb) + r0 + b] = hd;
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < total; j += PFF_TPB) ent[out + j] = entS[j];
+        out += total;
+        __syncthreads();
+    }
+}
+
+// The general kernel: any partition size, entries placed straight into ent[] and read back for the heads.  Runs only
+// for partitions the fast kernel flagged (slow_flag == nullptr: for all).  8192 buckets per round.
+#define PF_TPB 256
+#define PF_NB 8192u
+
+__global__ void __launch_bounds__(PF_TPB)
+k_ps_finish(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals, const uint32_t *__restrict__ pstart, uint32_t cb,
+            uint64_t *__restrict__ ent, ulonglong2 *__restrict__ head, const uint32_t *__restrict__ slow_flag) {
+    __shared__ uint32_t cnt[PF_NB];          // 1: count; from 2 on: first slot of the bucket (relative to this round's base)
+    __shared__ uint8_t kept[PF_NB];          // min(count, 14): 14 = "more than 13"
+    __shared__ uint32_t fill[PF_NB / 4];     // entries placed so far, one byte per bucket
+    __shared__ uint32_t ckey[PF_TPB];
+    __shared__ uint32_t scan_tmp[PF_TPB / 64 + 1];
+    const uint32_t p = blockIdx.x;
+    if (slow_flag && !slow_flag[p]) return;
+    const uint64_t s = pstart[p], e = pstart[p + 1];
+    const uint32_t nb = 1u << cb, cbmask = nb - 1u;
+    uint64_t out = s;
+    for (uint32_t r0 = 0; r0 < nb; r0 += PF_NB) {
+        for (uint32_t b = threadIdx.x; b < PF_NB; b += PF_TPB) cnt[b] = 0;
+        for (uint32_t b = threadIdx.x; b < PF_NB / 4; b += PF_TPB) fill[b] = 0;
+        __syncthreads();
+        for (uint64_t x = s + threadIdx.x; x < e; x += PF_TPB) {
+            const uint32_t b = (keys[x] & cbmask) - r0;
+            if (b < PF_NB) atomicAdd(&cnt[b], 1u);
+        }
+        __syncthreads();
+        uint32_t total;
+        {
+            const uint32_t b0 = threadIdx.x * (PF_NB / PF_TPB);
+            uint32_t sum = 0;
+            for (uint32_t q = 0; q < PF_NB / PF_TPB; q++) {
+                const uint32_t c = cnt[b0 + q];
+                kept[b0 + q] = (uint8_t)min(c, 14u);
+                sum += min(c, PGRC_BUCKET_CAP);
+            }
+            uint32_t off = psc_block_scan(sum, scan_tmp, &total);
+            for (uint32_t q = 0; q < PF_NB / PF_TPB; q++) {
+                const uint32_t c = min((uint32_t)kept[b0 + q], PGRC_BUCKET_CAP);
+                cnt[b0 + q] = off;
+                off += c;
+            }
+        }
+        __syncthreads();
+        for (uint64_t c0 = s; c0 < e; c0 += PF_TPB) {
+            const uint64_t x = c0 + threadIdx.x;
+            const uint32_t b = x < e ? (keys[x] & cbmask) - r0 : 0xFFFFFFFFu;
+            const bool valid = b < PF_NB;
+            ckey[threadIdx.x] = valid ? b : 0xFFFFFFFFu;
+            const uint32_t snap = valid ? (fill[b >> 2] >> (8u * (b & 3u))) & 0xFFu : 0u;   // placed by earlier chunks
+            __syncthreads();
+            if (valid) {
+                const uint32_t kc = kept[b];
+                uint32_t r = 0;
+                bool keep = true;
+                if (kc <= PGRC_BUCKET_CAP) {
+                    r = (atomicAdd(&fill[b >> 2], 1u << (8u * (b & 3u))) >> (8u * (b & 3u))) & 0xFFu;
+                } else if (snap >= PGRC_BUCKET_CAP) {
+                    keep = false;
+                } else {
+                    uint32_t before = 0;                       // same-bucket records earlier in this chunk
+                    for (uint32_t y = 0; y < threadIdx.x; y++) before += ckey[y] == b;
+                    r = snap + before;
+                    keep = r < PGRC_BUCKET_CAP;
+                    if (keep) atomicAdd(&fill[b >> 2], 1u << (8u * (b & 3u)));
+                }
+                if (keep) ent[out + cnt[b] + r] = vals[x];
+            }
+            __syncthreads();
+        }
+        for (uint32_t b = threadIdx.x; b < PF_NB; b += PF_TPB) {
+            const uint32_t c = min((uint32_t)kept[b], PGRC_BUCKET_CAP);
+            ulonglong2 hd = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
+            if (c) {
+                uint64_t *q = ent + out + cnt[b];
+                uint64_t v0 = q[0], v1 = c > 1 ? q[1] : 0;
+                if (c == 2) {
+                    if (v1 < v0) { const uint64_t t = v0; v0 = v1; v1 = t; q[0] = v0; q[1] = v1; }
+                } else if (c > 2) {
+                    for (uint32_t i = 1; i < c; i++) {          // insertion sort of <= 13 values, in place
+                        const uint64_t x = q[i];
+                        uint32_t j = i;
+                        while (j > 0 && q[j - 1] > x) { q[j] = q[j - 1]; j--; }
+                        q[j] = x;
+                    }
+                    v0 = q[0];
+                }
+                hd.x = v0;
+                if (c == 2) hd.y = v1;
+                else if (c > 2) {
+                    hd.x |= HEAD_OVF;
+                    hd.y = (out + cnt[b] + 1) | ((uint64_t)c << 56);    // entries 1.. at ent[base + j - 1]
+                }
+            }
+            head[((uint64_t)p << cb) + r0 + b] = hd;
+        }
+        out += total;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- drivers
+
+uint32_t pgrc_ps_partition_bits(uint32_t hbits) { return hbits > PS_CB + 16u ? hbits - 16u : PS_CB; }
+
+bool pgrc_ps_applicable(const pgrc_match_ctx *c, uint32_t hbits) {
+    return hbits >= PS_CB + 2 && hbits <= 31 && c->npos > 0 && c->npos < 0xFFFFF000ull && c->cp.k1 <= 16 && c->cp.K <= 56;
+}
+
+// The hand-written front end: records straight from the text, two stable scatter passes over the bucket bits
+// [cb, hbits).  Output in c->d_skey[1] / c->d_sval[1] (sorted by partition, position order inside); c->d_sval[0] is free.
+int pgrc_ps_scatter_front(pgrc_match_ctx *c, int strand, uint32_t hbits, uint32_t cb) {
+    const uint32_t K = (uint32_t)c->cp.K, k1 = (uint32_t)c->cp.k1;
+    const uint64_t hs = c->cp.hash_size, n = c->npos;
+    PsPlan pl;
+    pl.hbits = hbits;
+    pl.b1 = (hbits - cb) / 2;
+    pl.b2 = hbits - cb - pl.b1;
+    pl.n = n;
+    pl.ntiles = (n + PS_TILE - 1) / PS_TILE;
+    const uint32_t D = 1u << pl.b2;                                       // b2 >= b1
+    int e;
+    for (int k = 0; k < 2; k++)
+        if ((e = pgrc_buf_ensure(c, c->d_skey[k], (n + 16) * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, c->d_sval[k], (n + 16) * sizeof(uint64_t)))) return e;
+    const uint64_t ncnt = (uint64_t)D * pl.ntiles;
+    const uint64_t nbs = (ncnt + PSC_EPB - 1) / PSC_EPB + 1;
+    if ((e = pgrc_buf_ensure(c, c->d_sorttmp, (ncnt + nbs) * sizeof(uint32_t) + 256))) return e;
+    uint32_t *cnt = (uint32_t *)c->d_sorttmp.p, *bsum = cnt + ncnt;
+    uint32_t *kA = (uint32_t *)c->d_skey[0].p, *kB = (uint32_t *)c->d_skey[1].p;
+    uint64_t *vA = (uint64_t *)c->d_sval[0].p, *vB = (uint64_t *)c->d_sval[1].p;
+    GenArgs g;
+    g.pg = (const uint32_t *)c->pg2[strand].p;
+    g.pg_words_alloc = c->pg_words + PGRC_PG_PAD_WORDS;
+    g.npos = n;
+    g.k1 = k1;
+    g.K = K;
+    g.mask = (uint32_t)(hs - 1);
+    const uint32_t grid = (uint32_t)pl.ntiles;
+    const uint32_t sh1 = cb, sh2 = cb + pl.b1;
+    // pass 1: text -> A; pass 2: A -> B
+    hipLaunchKernelGGL(k_ps_hist_gen, dim3(grid), dim3(PS_TPB), 0, c->stream, g, sh1, (1u << pl.b1) - 1u, pl.ntiles, cnt);
+    if ((e = ps_scan(c, cnt, ((uint64_t)1 << pl.b1) * pl.ntiles, bsum))) return e;
+    hipLaunchKernelGGL(k_ps_scatter_gen, dim3(grid), dim3(PS_TPB), 0, c->stream, g, sh1, pl.b1, pl.ntiles, (const uint32_t *)cnt, kA, vA);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(k_ps_hist_keys, dim3(grid), dim3(PS_TPB), 0, c->stream, (const uint32_t *)kA, n, sh2, (1u << pl.b2) - 1u, pl.ntiles, cnt);
+    if ((e = ps_scan(c, cnt, ncnt, bsum))) return e;
+    hipLaunchKernelGGL(k_ps_scatter_keys, dim3(grid), dim3(PS_TPB), 0, c->stream, (const uint32_t *)kA, (const uint64_t *)vA, n, sh2, pl.b2,
+                       pl.ntiles, (const uint32_t *)cnt, kB, vB);
+    HIP_TRY(c, hipGetLastError());
+    return PGRC_OK;
+}
+
+// records sorted by their bucket bits [cb, hbits) (position order inside) -> ent[] (d_ent) and all bucket heads
+int pgrc_ps_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uint64_t *d_vals, uint32_t hbits, uint32_t cb, uint64_t *d_ent) {
+    const uint64_t n = c->npos;
+    const uint32_t np = 1u << (hbits - cb);
+    int e;
+    if ((e = pgrc_buf_ensure(c, c->d_sorttmp, (3ull * (np + 2)) * sizeof(uint32_t) + 256))) return e;
+    uint32_t *pst = (uint32_t *)c->d_sorttmp.p, *pst2 = pst + np + 2, *slow = pst2 + np + 2;
+    HIP_TRY(c, hipMemsetAsync(pst, 0xFF, (size_t)(np + 1) * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(slow, 0, (size_t)np * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_ps_bounds, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 65536ull * 4)), dim3(256), 0, c->stream, d_keys, n, cb, pst);
+    hipLaunchKernelGGL(k_ps_bounds_fill, dim3((np + 256) / 256), dim3(256), 0, c->stream, (const uint32_t *)pst, np, (uint32_t)n, pst2);
+    const char *gen = getenv("PGRC_INDEX_FINISH");   // "general": the general finish kernel for every partition (tests)
+    if (gen && !strcmp(gen, "general")) {
+        hipLaunchKernelGGL(k_ps_finish, dim3(np), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, (const uint32_t *)pst2, cb, d_ent,
+                           (ulonglong2 *)c->d_head.p, (const uint32_t *)nullptr);
+    } else {
+        // registers per thread sized for the mean partition (uniform hash values); whatever is larger is flagged
+        const uint64_t need = n / np + n / np / 4 + 512;
+        // block shape: 1024 threads x 8 records (16 for larger partitions: tables beyond 2^29 buckets), two 4096-bucket
+        // rounds.  Measured at C3 (index build per strand, tools/ab_finish_cfg.sh in the round-2 history): 512 x 16: 15.1 ms,
+        // 256 x 32: 16.0, 256 x 32 with 2048-bucket rounds: 16.8, 512 x 16 with 2048-bucket rounds: 16.4, 1024 x 8: 13.5.
+#define PFF_LAUNCH(E, TPB, SB, CAP)                                                                                       \
+        hipLaunchKernelGGL((k_ps_finish_fast<E, TPB, SB, CAP>), dim3(np), dim3(TPB), 0, c->stream, d_keys, d_vals,         \
+                           (const uint32_t *)pst2, cb, d_ent, (ulonglong2 *)c->d_head.p, slow)
+        if (need <= 8192) PFF_LAUNCH(8, 1024, 12, 4096);
+        else PFF_LAUNCH(16, 1024, 12, 4096);
+#undef PFF_LAUNCH
+        hipLaunchKernelGGL(k_ps_finish, dim3(np), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, (const uint32_t *)pst2, cb, d_ent,
+                           (ulonglong2 *)c->d_head.p, (const uint32_t *)slow);
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->ent_ptr = d_ent;
+    return PGRC_OK;
+}

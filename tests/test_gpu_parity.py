@@ -63,6 +63,39 @@ def test_index_bucket_cap_on_low_complexity_text():
     assert np.array_equal(c, cumm) and np.array_equal(p, positions)
 
 
+@pytest.mark.parametrize("variant", ["hybrid", "own", "rocprim", "hybrid+general", "own+general"])
+def test_index_build_variants(monkeypatch, variant):
+    """The three ways the records get grouped by bucket (copmem.hip: library sort of the top bits + in-LDS finish; the
+    hand-written scatter passes + the same finish; round 1's full library sort) and both finish kernels give the
+    serial reference index -- on a uniform text with realistic partition sizes, and on repeats / low-complexity tracts
+    whose buckets overflow the 13-entry cap and whose partitions overflow the fast kernel."""
+    from pgrc_amd import MatchContext
+    sort, _, fin = variant.partition("+")
+    if sort != "hybrid":
+        monkeypatch.setenv("PGRC_INDEX_SORT", sort)
+    if fin:
+        monkeypatch.setenv("PGRC_INDEX_FINISH", fin)
+    rng = np.random.default_rng(11)
+    texts = []
+    pg, _ = make_inputs(40_000_000, 1, 100, seed=3)           # 8 M samples over 2048 partitions
+    texts.append((pg, 38))
+    lowc = rng.choice(list(b"ACGT"), size=3_000_000).astype(np.uint8)
+    lowc[100_000:700_000] = ord("A")                          # one bucket with 120 k records
+    lowc[1_000_000:1_400_000] = np.resize(np.frombuffer(b"ACGTTG", dtype=np.uint8), 400_000)
+    lowc[2_000_000:2_600_000] = lowc[1_000_000:1_600_000]     # a long repeat: many buckets with 2 entries
+    texts.append((lowc, 38))
+    texts.append((lowc[:1_500_000], 45))
+    for pg, seed_len in texts:
+        _, cumm, positions = orc.oracle_index(pg, seed_len)
+        ctx = MatchContext(100, seed_len, 2, 0, "c")
+        ctx.set_pg_ascii(pg)
+        for strand in (0, 1):
+            if strand:
+                _, cumm, positions = orc.oracle_index(revcomp(pg), seed_len)
+            c, p = ctx.export_index(strand)
+            assert np.array_equal(c, cumm) and np.array_equal(p, positions), (variant, pg.size, seed_len, strand)
+
+
 CASES = [
     # L, seed, M, mode, G, n
     (100, 38, 50, "c", 400000, 20000),
