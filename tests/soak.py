@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """One-off randomized soak (not part of the suite): HIP path vs oracle on many random small configurations of both the
-read matcher (modes c/d/i/e) and the text matcher.  usage: python tests/soak.py [seconds] [seed]"""
+read matcher (modes c/d/i/e; reads handed over as ASCII rows or as the reference's packed LQ + N sets; one device or a
+matcher over 2-5 shards; every index-build variant) with the export streams of every case, and of the text matcher.
+usage: python tests/soak.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -13,6 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle as orc  # noqa: E402
 from mem_util import mem_sweep_texts  # noqa: E402
 from util import gpu_match, make_inputs  # noqa: E402
+import export_util as xu  # noqa: E402
 
 
 def main():
@@ -41,11 +44,47 @@ def main():
         seed = int(rng.integers(0, 1 << 30))
         pg, reads = make_inputs(G, n, L, seed=seed, n_with_n=nn, pool_div=int(rng.choice([8, 64])), tandem_every=int(rng.choice([0, 2, 64])))
         o = orc.oracle_match(mode, pg, reads, seed_len, kmax, kmin, rev)
-        g = gpu_match(mode, pg, reads, seed_len, kmax, kmin, rev)
+        shards = int(rng.integers(2, 6)) if rng.random() < 0.3 else 0
+        packed = bool(rng.random() < 0.5)
+        variant = str(rng.choice(["", "", "own", "rocprim"]))
+        finish = "general" if rng.random() < 0.3 else ""
+        for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish)):
+            if val:
+                os.environ[key] = val
+            else:
+                os.environ.pop(key, None)
+        g = gpu_match(mode, pg, reads, seed_len, kmax, kmin, rev, devices=[0] * shards if shards else None,
+                      n_nset=nn if packed else None)
+        what = dict(mode=mode, L=L, seed_len=seed_len, M=M, kmin=kmin, G=G, n=n, nn=nn, rev=rev, seed=seed, shards=shards,
+                    packed=packed, variant=variant, finish=finish)
         for k in ("pos", "rc", "mism", "hist"):
             if not np.array_equal(np.asarray(g[k]), np.asarray(o[k])):
-                print("READS MISMATCH", dict(mode=mode, L=L, seed_len=seed_len, M=M, kmin=kmin, G=G, n=n, nn=nn, rev=rev, seed=seed), k, flush=True)
+                print("READS MISMATCH", what, k, flush=True)
                 sys.exit(1)
+        # --- export streams of this result (single-device contexts), Pg order with a random reads list and original order
+        if not shards:
+            h = int(rng.integers(0, max(1, (G - L) // 40)))
+            off = rng.integers(0, 80, size=h).astype(np.uint8)
+            while h and int(off.astype(np.int64).sum()) > G - L:
+                off = off[: off.size // 2]
+                h = off.size
+            total = h + n
+            perm = rng.permutation(total).astype(np.uint32)
+            case = {"pg": pg, "reads": reads, "n_n": nn, "L": L, "list_off": off, "list_org": perm[:h].copy(),
+                    "list_rc": (rng.random(h) < 0.5).astype(np.uint8) if rng.random() < 0.7 else None,
+                    "read_org": np.concatenate([np.sort(perm[h:h + n - nn]), np.sort(perm[h + n - nn:])]).astype(np.uint32), "total": total}
+            res = {k: g[k] for k in ("pos", "rc", "mism")}
+            pair, byte_mode = bool(rng.random() < 0.5), bool(rng.random() < 0.7)
+            order = xu.stable_order(res["pos"])
+            want = xu.oracle_export_pg_order(case, res, order, pair_file=pair, byte_mode=byte_mode)
+            got = g["ctx"].export_pg_order(order, off, case["list_org"], case["list_rc"], case["read_org"], pair, byte_mode)
+            er, eo = xu.original_order_entries(case["read_org"], res["mism"] != 255, total, pair, n - nn)
+            want2 = xu.oracle_export_entries(case, res, er, eo, pair_file=pair, byte_mode=byte_mode)
+            got2 = g["ctx"].export_entries(er, eo, pair, byte_mode)
+            for k in xu.STREAMS:
+                if not np.array_equal(got[k], want[k]) or not np.array_equal(got2[k], want2[k]):
+                    print("EXPORT MISMATCH", what, dict(h=h, pair=pair, byte_mode=byte_mode), k, flush=True)
+                    sys.exit(1)
         n_reads_cases += 1
         # --- text matcher
         target = int(rng.choice([24, 28, 33, 38, 45, 45, 45, 50, 64, 90, 130, 255]))
