@@ -17,9 +17,12 @@ def _have_e2e():
     return orc.have_ref() and hasattr(orc.ref(), "pgrc_ref_encode")
 
 
-def _run(tmp_path, case, cpu_only):
+def _run(tmp_path, case, cpu_only, devices=None):
     env = dict(os.environ)
     env.pop("PGRC_REF_VERBOSE", None)
+    env.pop("PGRC_DEVICES", None)
+    if devices:
+        env["PGRC_DEVICES"] = devices
     if cpu_only:
         env["PGRC_E2E_CPU_ONLY"] = "1"
     p = subprocess.run([sys.executable, os.path.join(HERE, "e2e_dropin.py"), str(tmp_path), case], env=env,
@@ -50,3 +53,16 @@ def test_archive_identical_with_gpu_matcher(tmp_path, case):
     assert r["roundtrip"], r
     if case not in ("se_modeD", "se_modeI", "se_exact"):     # (those match nothing: the sum-set quirk)
         assert r["gpu_device_exports"] >= 1 and r["cpu_device_exports"] == 0, r   # the export streams came from the device
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["se", "pe_order"])
+def test_archive_identical_with_a_matcher_over_two_logical_devices(tmp_path, case):
+    """PGRC_DEVICES=0,0: HipReadsMatcher builds ONE matcher over two shards (pgrc_match_create_multi; on a box with
+    two GPUs: PGRC_DEVICES=0,1 and a RCCL all-gather).  Same archive, byte for byte; the export of such a context
+    takes the inherited loop fed by the bulk mismatch lists."""
+    if not _have_e2e():
+        pytest.skip("oracle/_ref was built without the encoder harness")
+    r = _run(tmp_path, case, cpu_only=False, devices="0,0")
+    assert r["gpu_gpu_calls"] >= 1 and r["identical"] and r["roundtrip"], r
+    assert r["gpu_device_exports"] == 0 and r["gpu_bulk_updates"] > 1000, r

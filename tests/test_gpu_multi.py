@@ -46,6 +46,21 @@ def test_sharded_matcher_equals_single_device(mode, k):
             assert ca[key] == cb[key], key                   # the same work, only split
 
 
+def test_more_shards_than_reads_and_no_reads_at_all():
+    pg, reads = make_inputs(80000, 3, 100, seed=12)
+    o = orc.oracle_match("c", pg, reads, 38, 2, 0)
+    g = gpu_match("c", pg, reads, 38, 2, 0, devices=[0] * 8)       # 2, 1 and 0 reads per shard
+    assert_same_results(g, o, "3 reads over 8 shards")
+    assert [s[2] for s in g["ctx"].shards()] == [2, 1, 0, 0, 0, 0, 0, 0]
+    cum, codes, offs = g["ctx"].extract_mismatches()
+    assert cum.size == 4 and int(cum[-1]) == int(g["mism"][g["mism"] != 255].sum())
+    for mode in ("c", "d"):
+        e = gpu_match(mode, pg, reads[:0], 38, 2, 0, devices=[0, 0])
+        assert e["pos"].size == 0 and e["matched"] == 0 and int(e["hist"].sum()) == 0
+        e = gpu_match(mode, pg, reads[:0], 38, 2, 0)
+        assert e["pos"].size == 0 and e["matched"] == 0
+
+
 def test_sharded_streamed_uploads_cross_shard_boundaries():
     L = 150
     pg, reads = make_inputs(200000, 5003, L, seed=77, n_with_n=211)
