@@ -165,3 +165,25 @@ def original_order_entries(read_org, matched, total, pair_file_mode, n_lq):
                 er.append(i)
                 eo.append(o)
     return np.array(er, dtype=np.uint32), np.array(eo, dtype=np.uint32)
+
+
+# ---- committed golden fixtures of the export (tests/golden/make_golden_export.py)
+
+def load_export_golden(name):
+    """-> (case, paired-file rule, reference results, reference order, {pg|org: stream bytes})"""
+    import hashlib
+    import json
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    m = json.load(open(os.path.join(gold, "manifest_export.json")))[name]
+    case = export_case(**m["kw"])
+    h = hashlib.sha256()
+    for k in ("pg", "reads", "list_off", "list_org", "list_rc", "read_org"):
+        h.update(np.ascontiguousarray(case[k]).tobytes())
+    assert h.hexdigest() == m["inputs_sha256"], "generator drifted"
+    z = np.load(os.path.join(gold, name + ".npz"))
+    res = {"pos": z["pos"], "rc": z["rc"], "mism": z["mism"]}
+    streams = {tag: {k: z[f"{tag}_{k}"].tobytes() for k in STREAMS} for tag in ("pg", "org")}
+    return case, m["paired_file_rule"], m["kmax"], res, z["order"], streams
+
+
+EXPORT_GOLDEN = ("export_se", "export_pe_pairfile", "export_short_list", "export_L250")

@@ -60,3 +60,24 @@ def test_gpu_mem_match_reproduces_reference_output(name):
     for (dis, rc), want in expected.items():
         got = m.matchTexts(orc.mem_dest(src, other, dis, rc), dis, rc, ml)
         assert np.array_equal(got, want), (name, dis, rc)
+
+
+# ---- row f1: export streams against the committed reference output
+
+import export_util as xu  # noqa: E402
+
+
+@pytest.mark.parametrize("name", xu.EXPORT_GOLDEN)
+def test_gpu_export_reproduces_reference_streams(name):
+    case, pair, kmax, res, order, gold = xu.load_export_golden(name)
+    g = gpu_match("c", case["pg"], case["reads"], 38, kmax, 0, n_nset=case["n_n"])
+    for k in ("pos", "rc", "mism"):
+        assert np.array_equal(g[k], res[k]), k
+    got = xu.stream_bytes(g["ctx"].export_pg_order(order, case["list_off"], case["list_org"], case["list_rc"], case["read_org"], pair, True))
+    for k in xu.STREAMS:
+        assert got[k] == gold["pg"][k], (name, k)
+    n = case["reads"].shape[0]
+    er, eo = xu.original_order_entries(case["read_org"], res["mism"] != 255, case["total"], pair, n - case["n_n"])
+    got = xu.stream_bytes(g["ctx"].export_entries(er, eo, pair, True))
+    for k in xu.STREAMS:
+        assert got[k] == gold["org"][k], (name, "original order", k)

@@ -134,3 +134,25 @@ def test_oracle_mem_match_reproduces_reference_output(name):
     for (dis, rc), want in expected.items():
         got = orc.oracle_mem_match(src, orc.mem_dest(src, other, dis, rc), dis, rc, tl, ml)
         assert len(want) > 5 and np.array_equal(got, want), (name, dis, rc)
+
+
+# ---- row f1: the export streams of the reference (tests/golden/export_*.npz)
+
+import export_util as xu  # noqa: E402
+
+
+@pytest.mark.parametrize("name", xu.EXPORT_GOLDEN)
+def test_oracle_export_reproduces_reference_streams(name):
+    case, pair, kmax, res, order, gold = xu.load_export_golden(name)
+    # the committed match results are what the oracle computes for these inputs
+    o = orc.oracle_match("c", case["pg"], case["reads"], 38, kmax, 0)
+    for k in ("pos", "rc", "mism"):
+        assert np.array_equal(o[k], res[k]), k
+    got = xu.stream_bytes(xu.oracle_export_pg_order(case, res, order, pair_file=pair))
+    for k in xu.STREAMS:
+        assert got[k] == gold["pg"][k], (name, k)
+    n = case["reads"].shape[0]
+    er, eo = xu.original_order_entries(case["read_org"], res["mism"] != 255, case["total"], pair, n - case["n_n"])
+    got = xu.stream_bytes(xu.oracle_export_entries(case, res, er, eo, pair_file=pair))
+    for k in xu.STREAMS:
+        assert got[k] == gold["org"][k], (name, "original order", k)
