@@ -75,7 +75,8 @@ int pgrc_match_create(const pgrc_match_params *params, pgrc_match_ctx **out);
  * 1/n of the text handed to pgrc_match_set_pg_ascii and ONE all-gather (RCCL over xGMI; peer copies when a device is
  * listed twice, which only makes sense for rehearsals on a smaller box) replicates the packed text, every device
  * builds the index and matches its reads, results land in the caller's arrays at the shard offsets and the
- * histograms are summed.  params->device is ignored; n_devices in [1, 32].  pgrc_match_set_stream,
+ * histograms are summed; the export streams are made on the first device (the shards' results and reads are
+ * gathered there).  params->device is ignored; n_devices in [1, 32].  pgrc_match_set_stream,
  * pgrc_match_set_reads_device and pgrc_match_get_results_device need a single-device context. */
 int pgrc_match_create_multi(const pgrc_match_params *params, int32_t n_devices, const int32_t *devices,
                             pgrc_match_ctx **out);

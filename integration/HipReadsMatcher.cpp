@@ -290,7 +290,6 @@ namespace PgTools {
     bool HipReadsMatcher::deviceExportPossible(SeparatedPseudoGenome *sPg) const {
         if (getenv("PGRC_HOST_EXPORT")) return false;                    // A/B knob: the inherited export
         if (!uploaded || deviceReads != readsCount || readsCount == 0) return false;
-        if (pgrc_match_shard_count(ctx) != 1) return false;
         if (SeparatedPseudoGenomePersistence::enableReadPositionRepresentation ||
             !SeparatedPseudoGenomePersistence::enableRevOffsetMismatchesRepresentation)
             return false;

@@ -78,8 +78,9 @@ namespace PgTools {
         // the mismatch lists and their reverse-offset coding come from the device as whole streams
         // (pgrc_match_export_pg_order / pgrc_match_export_entries) and go into the builder's destinations in one
         // write each, instead of seven stream writes per entry.  Whatever the device path does not cover (a reads
-        // list that carries mismatches, the position / plain-offset representations of PgRC.cpp:158-162, several
-        // devices) takes the inherited export with the bulk mismatch lists.
+        // list that carries mismatches, the position / plain-offset representations of PgRC.cpp:158-162) takes the
+        // inherited export with the bulk mismatch lists.  A matcher over several devices exports from its first
+        // device (the library gathers the shards' results and reads there).
         void exportMatchesInPgOrderOnDevice(SeparatedPseudoGenome *sPg, ostream &pgrcOut, uint8_t compressionLevel,
                                             const string &outPgPrefix, IndexesMapping *orgIndexesMapping,
                                             bool pairFileMode, bool revComplPairFile);

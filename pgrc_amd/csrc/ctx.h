@@ -160,6 +160,8 @@ int pgrc_multi_export_pg(pgrc_match_ctx *f, int strand, uint32_t *words);
 int pgrc_multi_set_profiling(pgrc_match_ctx *f, int enabled);
 int pgrc_multi_get_counters(pgrc_match_ctx *f, pgrc_match_counters *out);
 void pgrc_multi_destroy(pgrc_match_ctx *f);
+struct PgrcShardView { pgrc_match_ctx *ctx; uint64_t lo, hi; };     // one shard of a multi-device context: reads [lo, hi)
+std::vector<PgrcShardView> pgrc_multi_shards(pgrc_match_ctx *f);
 
 // pack.hip
 int pgrc_launch_pack_ascii(pgrc_match_ctx *c, const uint8_t *d_ascii, uint64_t count, uint32_t *d_words,

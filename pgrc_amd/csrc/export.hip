@@ -435,16 +435,101 @@ static int export_pg_order(pgrc_match_ctx *c, const pgrc_export_pg_order_args *x
     return PGRC_OK;
 }
 
+// A multi-device context exports from ONE device: the per-read results, the packed reads and the side list of reads with
+// N of every shard are gathered (peer copies) into the layout of a single-device context on the first shard's device,
+// whose copy of the text serves; the export kernels then run on that view.  C3 over 8 devices: 0.9 GB of results and
+// 3.5 GB of reads travel once.
+namespace {
+struct GatheredView {
+    pgrc_match_ctx view;
+    DevBuf reads, nflag, nidx, nascii, pos, rc, mism;
+    ~GatheredView() {
+        for (DevBuf *b : {&reads, &nflag, &nidx, &nascii, &pos, &rc, &mism}) pgrc_buf_free(*b);
+    }
+    int build(pgrc_match_ctx *f) {
+        const std::vector<PgrcShardView> sh = pgrc_multi_shards(f);
+        pgrc_match_ctx *c0 = sh[0].ctx;
+        PgrcDeviceScope scope(c0->device);
+        if (!scope.ok) { f->err = "hipSetDevice failed"; return PGRC_E_NO_DEVICE; }
+        const uint64_t n = f->n, stride = (n + 63) & ~63ull;
+        const uint32_t nw = c0->nw, L = c0->prm.read_len;
+        uint64_t nn = 0;
+        for (const PgrcShardView &s : sh) nn += s.ctx->n_nreads;
+        int e;
+        auto fail = [&](int code) { f->err = c0->err; return code; };
+        if ((e = pgrc_buf_ensure(c0, reads, (size_t)nw * std::max<uint64_t>(stride, 64) * 4)) || (e = pgrc_buf_ensure(c0, pos, n * 8)) ||
+            (e = pgrc_buf_ensure(c0, rc, n)) || (e = pgrc_buf_ensure(c0, mism, n)) || (e = pgrc_buf_ensure(c0, nflag, n)) ||
+            (e = pgrc_buf_ensure(c0, nidx, nn * 4)) || (e = pgrc_buf_ensure(c0, nascii, nn * L)))
+            return fail(e);
+        hipError_t he = hipMemsetAsync(nflag.p, 0, n ? n : 1, c0->stream);
+        uint64_t nat = 0;
+        std::vector<uint32_t> idx;
+        for (const PgrcShardView &s : sh) {
+            const uint64_t cnt = s.hi - s.lo;
+            if (!cnt || he != hipSuccess) continue;
+            pgrc_match_ctx *c = s.ctx;
+            {   // whatever the shard still has in flight
+                PgrcDeviceScope cs(c->device);
+                he = hipStreamSynchronize(c->stream);
+            }
+            if (he == hipSuccess) he = hipMemcpyAsync((uint64_t *)pos.p + s.lo, c->d_pos.p, cnt * 8, hipMemcpyDefault, c0->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync((uint8_t *)rc.p + s.lo, c->d_rc.p, cnt, hipMemcpyDefault, c0->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync((uint8_t *)mism.p + s.lo, c->d_mism.p, cnt, hipMemcpyDefault, c0->stream);
+            // word-major reads: row w of the shard (pitch = its stride) into columns [lo, hi) of row w of the view
+            if (he == hipSuccess)
+                he = hipMemcpy2DAsync((uint32_t *)reads.p + s.lo, stride * 4, c->reads2, c->stride * 4, cnt * 4, nw, hipMemcpyDefault, c0->stream);
+            if (c->n_nreads && he == hipSuccess) {
+                he = hipMemcpyAsync((uint8_t *)nflag.p + s.lo, c->nread_flag.p, cnt, hipMemcpyDefault, c0->stream);
+                if (he == hipSuccess) he = hipMemcpyAsync((uint8_t *)nascii.p + nat * L, c->nread_ascii.p, c->n_nreads * L, hipMemcpyDefault, c0->stream);
+                idx.resize(c->n_nreads);
+                if (he == hipSuccess) he = hipMemcpy(idx.data(), c->nread_idx.p, c->n_nreads * 4, hipMemcpyDefault);
+                for (uint32_t &v : idx) v += (uint32_t)s.lo;        // shard-local read index -> index in the whole set
+                if (he == hipSuccess) he = hipMemcpy((uint32_t *)nidx.p + nat, idx.data(), c->n_nreads * 4, hipMemcpyDefault);
+                nat += c->n_nreads;
+            }
+        }
+        if (he == hipSuccess) he = hipStreamSynchronize(c0->stream);
+        if (he != hipSuccess) { f->err = std::string("export: gathering the shards: ") + hipGetErrorString(he); return pgrc_hip_code(he); }
+        view.prm = c0->prm;
+        view.device = c0->device;
+        view.stream = c0->stream;
+        view.nw = nw;
+        view.n = n;
+        view.stride = stride;
+        view.reads2 = (const uint32_t *)reads.p;
+        view.n_nreads = nn;
+        view.nread_flag = nflag;      // (DevBuf copies: the view never frees anything, this object does)
+        view.nread_idx = nidx;
+        view.nread_ascii = nascii;
+        view.d_pos = pos;
+        view.d_rc = rc;
+        view.d_mism = mism;
+        view.pg2[0] = c0->pg2[0];
+        view.G = c0->G;
+        view.pg_words = c0->pg_words;
+        view.have_pg = view.have_reads = view.have_results = true;
+        return PGRC_OK;
+    }
+};
+}
+
 extern "C" int pgrc_match_export_pg_order(pgrc_match_ctx *c, const pgrc_export_pg_order_args *x, pgrc_export_streams *out) {
     if (!c || !x || !out || (x->n_matched && !x->order) || (x->list_count && (!x->list_off || !x->list_org_idx))) return PGRC_E_PARAM;
     memset(out, 0, sizeof *out);
-    if (c->multi) { c->err = "export_pg_order: single-device contexts only (the adapter falls back to per-entry mismatch lists)"; return PGRC_E_PARAM; }
     if (!c->have_results || !c->have_pg || !c->have_reads) { c->err = "export: run first"; return PGRC_E_STATE; }
     if (x->n_matched > c->n) { c->err = "export: more matched reads than reads"; return PGRC_E_PARAM; }
-    PGRC_ON_DEVICE(c);
+    GatheredView gv;
+    pgrc_match_ctx *w = c;
+    if (c->multi) {
+        int ge = gv.build(c);
+        if (ge) return ge;
+        w = &gv.view;
+    }
+    PgrcDeviceScope scope(w->device);
     Bufs b;
-    int e = export_pg_order(c, x, b, out);
+    int e = export_pg_order(w, x, b, out);
     b.release();
+    if (e && w != c) c->err = w->err;
     if (e) pgrc_match_free_export(out);
     return e;
 }
@@ -471,14 +556,21 @@ extern "C" int pgrc_match_export_entries(pgrc_match_ctx *c, const uint32_t *entr
                                          int32_t rev_compl_pair_file, int32_t byte_per_read_length, pgrc_export_streams *out) {
     if (!c || !out || (n_entries && (!entry_read || !entry_org_idx))) return PGRC_E_PARAM;
     memset(out, 0, sizeof *out);
-    if (c->multi) { c->err = "export_entries: single-device contexts only (the adapter falls back to per-entry mismatch lists)"; return PGRC_E_PARAM; }
     if (!c->have_results || !c->have_pg || !c->have_reads) { c->err = "export: run first"; return PGRC_E_STATE; }
     for (uint64_t k = 0; k < n_entries; k++)
         if (entry_read[k] != EX_NONE && entry_read[k] >= c->n) { c->err = "export_entries: read index out of range"; return PGRC_E_PARAM; }
-    PGRC_ON_DEVICE(c);
+    GatheredView gv;
+    pgrc_match_ctx *w = c;
+    if (c->multi) {
+        int ge = gv.build(c);
+        if (ge) return ge;
+        w = &gv.view;
+    }
+    PgrcDeviceScope scope(w->device);
     Bufs b;
-    int e = export_entries(c, entry_read, entry_org_idx, n_entries, rev_compl_pair_file, byte_per_read_length ? 1u : 2u, b, out);
+    int e = export_entries(w, entry_read, entry_org_idx, n_entries, rev_compl_pair_file, byte_per_read_length ? 1u : 2u, b, out);
     b.release();
+    if (e && w != c) c->err = w->err;
     if (e) pgrc_match_free_export(out);
     return e;
 }

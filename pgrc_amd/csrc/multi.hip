@@ -166,6 +166,14 @@ int pgrc_match_create_multi(const pgrc_match_params *p, int32_t n_devices, const
 
 } // extern "C"
 
+std::vector<PgrcShardView> pgrc_multi_shards(pgrc_match_ctx *f) {
+    std::vector<PgrcShardView> v;
+    pgrc_multi *m = f->multi;
+    for (size_t r = 0; r < m->child.size(); r++)
+        v.push_back({m->child[r], m->lo.empty() ? 0 : m->lo[r], m->lo.empty() ? 0 : m->hi[r]});
+    return v;
+}
+
 void pgrc_multi_destroy(pgrc_match_ctx *f) {
     pgrc_multi *m = f->multi;
     if (m) {

@@ -59,10 +59,10 @@ def test_archive_identical_with_gpu_matcher(tmp_path, case):
 @pytest.mark.parametrize("case", ["se", "pe_order"])
 def test_archive_identical_with_a_matcher_over_two_logical_devices(tmp_path, case):
     """PGRC_DEVICES=0,0: HipReadsMatcher builds ONE matcher over two shards (pgrc_match_create_multi; on a box with
-    two GPUs: PGRC_DEVICES=0,1 and a RCCL all-gather).  Same archive, byte for byte; the export of such a context
-    takes the inherited loop fed by the bulk mismatch lists."""
+    two GPUs: PGRC_DEVICES=0,1 and a RCCL all-gather).  Same archive, byte for byte; the export streams come from the
+    first device, where the library gathers the shards' results and reads."""
     if not _have_e2e():
         pytest.skip("oracle/_ref was built without the encoder harness")
     r = _run(tmp_path, case, cpu_only=False, devices="0,0")
     assert r["gpu_gpu_calls"] >= 1 and r["identical"] and r["roundtrip"], r
-    assert r["gpu_device_exports"] == 0 and r["gpu_bulk_updates"] > 1000, r
+    assert r["gpu_device_exports"] >= 1, r

@@ -76,7 +76,26 @@ def test_export_edge_cases():
     from pgrc_amd import MatchContext, PgrcMatchError
     many = MatchContext(100, 38, 33, 0, "c", devices=[0, 0])
     with pytest.raises(PgrcMatchError):
-        many.export_entries(none, none)
+        many.export_entries(none, none)             # nothing matched yet
+
+
+@pytest.mark.parametrize("name", ["se", "pe_pairfile", "L37"])
+def test_export_from_a_matcher_over_several_shards(name):
+    """a multi-device context exports from its first device after gathering the shards' results, reads and N side lists"""
+    case, pair = _case(name)
+    L = case["L"]
+    seed_len, kmax = (38 if L >= 100 else 24), L // 3
+    n = case["reads"].shape[0]
+    one = gpu_match("c", case["pg"], case["reads"], seed_len, kmax, 0, n_nset=case["n_n"])
+    many = gpu_match("c", case["pg"], case["reads"], seed_len, kmax, 0, n_nset=case["n_n"], devices=[0, 0, 0])
+    order = xu.stable_order(one["pos"])
+    a = one["ctx"].export_pg_order(order, case["list_off"], case["list_org"], case["list_rc"], case["read_org"], pair, True)
+    b = many["ctx"].export_pg_order(order, case["list_off"], case["list_org"], case["list_rc"], case["read_org"], pair, True)
+    er, eo = xu.original_order_entries(case["read_org"], one["mism"] != 255, case["total"], pair, n - case["n_n"])
+    a2 = one["ctx"].export_entries(er, eo, pair, True)
+    b2 = many["ctx"].export_entries(er, eo, pair, True)
+    for k in xu.STREAMS:
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a2[k], b2[k]), (name, k)
 
 
 @pytest.mark.parametrize("name", ["se", "pe_pairfile", "short_list", "no_list"])
