@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""One-off randomized soak at medium sizes (not part of the suite): texts of 5-80 Mbp and 0.2-2 M reads, so that the
+index build runs with realistic partition and tile counts (every PGRC_INDEX_SORT / PGRC_INDEX_FINISH variant), the match
+kernel with many waves in flight, and the sharded matcher with shards of real size.  HIP path vs oracle (mode c; the
+index itself is compared for a third of the cases).  usage: python tests/soak_medium.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle as orc  # noqa: E402
+from util import gpu_match, make_inputs  # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    t0 = time.time()
+    cases = 0
+    while time.time() - t0 < budget:
+        L = int(rng.choice([100, 100, 150, 150, 250, int(rng.integers(60, 256))]))
+        seed_len = int(rng.choice([38, 38, 38, 32, 45, min(L, 64), L]))
+        kmax = int(rng.choice([L // 50, L // 50, L // 25, L // 3]))
+        kmax = min(kmax, 247)
+        kmin = kmax if rng.random() < 0.15 else 0
+        G = int(rng.integers(5_000_000, 80_000_000))
+        n = int(rng.integers(200_000, 2_000_000))
+        nn = int(rng.integers(0, 20_000)) if rng.random() < 0.4 else 0
+        seed = int(rng.integers(0, 1 << 30))
+        pg, reads = make_inputs(G, n, L, seed=seed, n_with_n=nn, pool_div=int(rng.choice([8, 64])), tandem_every=int(rng.choice([0, 2, 64])),
+                                paired=bool(rng.random() < 0.3))
+        shards = int(rng.integers(2, 5)) if rng.random() < 0.3 else 0
+        variant = str(rng.choice(["", "", "own", "rocprim"]))
+        finish = "general" if rng.random() < 0.25 else ""
+        for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish)):
+            if val:
+                os.environ[key] = val
+            else:
+                os.environ.pop(key, None)
+        what = dict(L=L, seed_len=seed_len, kmax=kmax, kmin=kmin, G=G, n=n, nn=nn, seed=seed, shards=shards, variant=variant, finish=finish)
+        o = orc.oracle_match("c", pg, reads, seed_len, kmax, kmin, True, 16)
+        g = gpu_match("c", pg, reads, seed_len, kmax, kmin, True, devices=[0] * shards if shards else None)
+        for k in ("pos", "rc", "mism", "hist"):
+            if not np.array_equal(np.asarray(g[k]), np.asarray(o[k])):
+                print("MISMATCH", what, k, int((np.asarray(g[k]) != np.asarray(o[k])).sum()), flush=True)
+                sys.exit(1)
+        if cases % 3 == 0 and not shards:
+            _, cumm, positions = orc.oracle_index(pg, seed_len)
+            c, p = g["ctx"].export_index(0)
+            if not (np.array_equal(c, cumm) and np.array_equal(p, positions)):
+                print("INDEX MISMATCH", what, flush=True)
+                sys.exit(1)
+        del g
+        cases += 1
+        print(f"{cases} ok ({time.time() - t0:.0f} s) {what}", flush=True)
+    print(f"soak ok: {cases} medium cases, {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
