@@ -182,10 +182,6 @@ int pgrc_pg_alloc(pgrc_match_ctx *c, uint64_t G) {
         c->err = "pseudogenome of 2^40 symbols or more is not supported (entries keep 40 position bits)";
         return PGRC_E_PARAM;
     }
-    if (G + 256 >= (1ull << 32) && c->prm.mode != 'c') {
-        c->err = "modes d/i/e: pseudogenome below 4 Gi symbols only (mode c has the 64-bit-position variant)";
-        return PGRC_E_PARAM;
-    }
     if (G < c->prm.read_len) {
         c->err = "pseudogenome shorter than a read";
         return PGRC_E_PARAM;
@@ -298,6 +294,7 @@ static int begin_reads(pgrc_match_ctx *c, uint64_t n, bool own) {
     if (n >= (1ull << 32) - 1) { c->err = "reads count must stay below 2^32-1 (uint_reads_cnt_max, pg-config.h:21-22)"; return PGRC_E_PARAM; }
     c->n = n;
     c->n_nreads = 0;
+    c->h_nidx.clear();
     c->have_reads = false;
     int e;
     if (own) {
@@ -416,6 +413,7 @@ int pgrc_match_end_reads(pgrc_match_ctx *c) {
     PGRC_ON_DEVICE(c);
     int e;
     c->n_nreads = c->up_nidx.size();
+    c->h_nidx = c->up_nidx;
     if (c->n_nreads) {
         const uint32_t L = c->prm.read_len;
         if ((e = pgrc_buf_ensure(c, c->nread_idx, c->up_nidx.size() * sizeof(uint32_t)))) return e;

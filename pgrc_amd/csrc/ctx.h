@@ -62,6 +62,7 @@ struct pgrc_match_ctx {
     DevBuf nread_idx;       // u32[n_nreads] read index
     DevBuf nread_ascii;     // u8[n_nreads][read_len]
     DevBuf nread_flag;      // u8[n] 1 = handled by the byte path
+    std::vector<uint32_t> h_nidx; // host copy of nread_idx (ascending): modes d/i/e cut it per batch of reads
 
     // chunked upload state (pgrc_match_begin_reads / _append_ / _end_)
     bool up_open = false;

@@ -19,7 +19,10 @@
 // (rocPRIM device radix sort -- a plain library primitive) so that each read's candidates come out in exactly the
 // reference's order (ascending text position, equal positions in descending part index); one thread per read then
 // replays the reference's sequential rule over its candidates with popcount Hamming on 2-bit words.
+#include <cstdlib>
 #include <cstring>
+
+#include <algorithm>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -61,6 +64,8 @@ struct SeedArgs {
     uint32_t L, m, P, cstride; // m = pattern length, P = parts, cstride = symbol stride inside a part (P for mode i)
     uint32_t mode;             // 'd', 'i', 'e'
     uint32_t kmax, kmin, strand;
+    uint64_t tbase;            // first window start of the text segment being scanned (hit records keep 32-bit offsets from it)
+    uint64_t ibase;            // first read of the batch (reads / result pointers are already offset; nidx holds set-wide indexes)
     uint64_t *tkeys;
     uint32_t *theads;
     uint64_t tmask;
@@ -109,7 +114,7 @@ __global__ void __launch_bounds__(256) k_seed_insert_ascii(const SeedArgs a) {
     if (x >= a.nn * a.P) return;
     const uint64_t t = x / a.P;
     const uint32_t j = (uint32_t)(x % a.P);
-    const uint64_t i = a.nidx[t];
+    const uint64_t i = a.nidx[t] - a.ibase;
     const uint8_t *row = a.nascii + t * a.L;
     const uint32_t off = part_offset(a, j);
     uint32_t h0 = 0, h1 = 0;
@@ -136,6 +141,7 @@ __global__ void __launch_bounds__(256) k_seed_insert_ascii(const SeedArgs a) {
 #define SCAN_B 8
 __global__ void __launch_bounds__(SCAN_TPB)
 k_seed_scan(const SeedArgs a, uint64_t nwin, uint64_t pg_words_alloc, unsigned long long *cursor, uint64_t *hits, uint64_t cap) {
+    // windows [a.tbase, nwin) of the text: one segment of fewer than 2^32 window starts
     __shared__ uint32_t tile[SCAN_TILE_WORDS];
     __shared__ uint64_t lbuf[SCAN_TPB / 64][SCAN_WCAP];
     __shared__ uint32_t wtotal[SCAN_TPB / 64];
@@ -145,7 +151,7 @@ k_seed_scan(const SeedArgs a, uint64_t nwin, uint64_t pg_words_alloc, unsigned l
     const uint32_t cs = a.cstride, m = a.m;
     const uint32_t groups = SCAN_TPB / cs;               // runs of SCAN_R * cs consecutive starts, one thread per phase
     const uint32_t per_block = groups * cs * SCAN_R;
-    const uint64_t b0 = (uint64_t)blockIdx.x * per_block;
+    const uint64_t b0 = a.tbase + (uint64_t)blockIdx.x * per_block;
     const uint64_t w0 = b0 >> 4;
     const uint32_t need = (uint32_t)(((b0 & 15) + per_block + (uint64_t)m * cs + 15) >> 4) + 1;   // <= SCAN_TILE_WORDS
     for (uint32_t w = threadIdx.x; w < need; w += SCAN_TPB) tile[w] = (w0 + w < pg_words_alloc) ? a.pg[w0 + w] : 0u;
@@ -230,7 +236,7 @@ k_seed_scan(const SeedArgs a, uint64_t nwin, uint64_t pg_words_alloc, unsigned l
                     const uint32_t j = e % a.P;
                     const uint64_t shift = part_offset(a, j);
                     // ReadsMatchers.cpp:308-309 / :375-376 and :311-312 / :378-379
-                    if (shift <= t && t - shift + a.L <= a.G) { emit = true; rec = (i << 36) | (t << 4) | (15u - j); }
+                    if (shift <= t && t - shift + a.L <= a.G) { emit = true; rec = (i << 36) | ((t - a.tbase) << 4) | (15u - j); }
                 }
                 const unsigned long long mk = __ballot(emit);
                 if (mk) {
@@ -334,11 +340,11 @@ k_seed_hamming(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhi
     const uint64_t hkey = hits[x];
     const uint64_t i = hkey >> 36;
     if (x == 0 || (hits[x - 1] >> 36) != i) rstart[i] = x;
-    const uint64_t tp = (hkey >> 4) & 0xFFFFFFFFull;
+    const uint64_t tp = a.tbase + ((hkey >> 4) & 0xFFFFFFFFull);
     const uint32_t j = 15u - (uint32_t)(hkey & 15u);
     const uint64_t p = tp - part_offset(a, j);
     uint32_t mm;
-    if (a.nflag && a.nflag[i]) mm = hamming_vs_text_n(a, i, lower_bound_u32(a.nidx, a.nn, (uint32_t)i), p);   // a read with N
+    if (a.nflag && a.nflag[i]) mm = hamming_vs_text_n(a, i, lower_bound_u32(a.nidx, a.nn, (uint32_t)(i + a.ibase)), p);   // a read with N
     else mm = hamming_vs_text(a, i, p);
     mmv[x] = (uint8_t)min(mm, 255u);
 }
@@ -366,7 +372,7 @@ k_seed_replay(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhit
             heavy[atomicAdd(nheavy, 1ull)] = (uint32_t)i;
             return;
         }
-        const uint64_t tp = (hkey >> 4) & 0xFFFFFFFFull;
+        const uint64_t tp = a.tbase + ((hkey >> 4) & 0xFFFFFFFFull);
         const uint32_t j = 15u - (uint32_t)(hkey & 15u);
         const uint64_t p = tp - part_offset(a, j);
         const uint64_t cand = a.strand ? a.G - (p + a.L) : p;
@@ -424,7 +430,7 @@ k_seed_replay_heavy(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_
                 const uint64_t hkey = hits[xi];
                 mine = (hkey >> 36) == i;
                 if (mine) {
-                    const uint64_t tp = (hkey >> 4) & 0xFFFFFFFFull;
+                    const uint64_t tp = a.tbase + ((hkey >> 4) & 0xFFFFFFFFull);
                     const uint32_t j = 15u - (uint32_t)(hkey & 15u);
                     const uint64_t p = tp - part_offset(a, j);
                     cand = a.strand ? a.G - (p + a.L) : p;
@@ -461,38 +467,15 @@ __global__ void __launch_bounds__(256) k_seed_table_init(uint64_t *keys, uint32_
     }
 }
 
-int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
-    const uint32_t L = c->prm.read_len;
-    const char mode = c->prm.mode;
-    SeedArgs a;
-    a.L = L;
-    a.mode = (uint32_t)mode;
-    a.P = (mode == 'e') ? 1u : L / c->prm.seed_len;   // targetMismatches + 1 (ReadsMatchers.cpp:236)
-    a.m = (mode == 'e') ? L : c->prm.seed_len;
-    a.cstride = (mode == 'i') ? a.P : 1u;
+// One batch of reads (fewer than 2^28: the hit records keep 28 bits for the read) against both strands, the text
+// scanned in segments of fewer than 2^32 window starts (32 bits for the position inside the segment).  A read's
+// candidates come in ascending text position, so segment after segment with the per-read state carried in the result
+// arrays IS the reference's sequential scan; reads are independent, so batch after batch is its loop over the reads.
+static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, int first_strand, int last_strand) {
     const uint64_t span = (uint64_t)a.m * a.cstride;  // extent of a text window
-    if (a.P == 0 || a.P > 15) { c->err = "modes d/i: 1..15 seed parts supported"; return PGRC_E_PARAM; }
-    if (c->n >= (1ull << 28)) { c->err = "modes d/i/e: fewer than 2^28 reads per call"; return PGRC_E_PARAM; }
-    a.pg = nullptr;
-    a.G = c->G;
-    a.reads = c->reads2;
-    a.n = c->n;
-    a.stride = c->stride;
-    a.nflag = c->n_nreads ? (const uint8_t *)c->nread_flag.p : nullptr;
-    a.nidx = (const uint32_t *)c->nread_idx.p;
-    a.nascii = (const uint8_t *)c->nread_ascii.p;
-    a.nn = c->n_nreads;
-    a.nwr = (L + 15) / 16;
-    a.nmask = nullptr;
-    a.kmax = c->prm.max_mismatches;
-    a.kmin = c->prm.min_mismatches;
-    a.pos = (uint64_t *)c->d_pos.p;
-    a.rc = (uint8_t *)c->d_rc.p;
-    a.mism = (uint8_t *)c->d_mism.p;
-    if (c->n == 0) return PGRC_OK;
-
+    const uint32_t L = a.L;
     // read-part table
-    const uint64_t nent = c->n * a.P;
+    const uint64_t nent = a.n * a.P;
     uint64_t tsize = 1024;
     while (tsize < 2 * nent) tsize <<= 1;   // (4 * nent was tried: -1 % time for twice the memory)
     int e;
@@ -504,30 +487,29 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
     a.theads = (uint32_t *)c->s_vals.p;
     a.tmask = tsize - 1;
     a.next = (uint32_t *)c->s_tab.p;
-    if (c->n_nreads) {
-        if ((e = pgrc_buf_ensure(c, c->s_nmask, c->n_nreads * a.nwr * sizeof(uint16_t)))) return e;
+    if (a.nn) {
+        if ((e = pgrc_buf_ensure(c, c->s_nmask, a.nn * a.nwr * sizeof(uint16_t)))) return e;
         a.nmask = (const uint16_t *)c->s_nmask.p;
-        hipLaunchKernelGGL(k_seed_nmask, dim3((uint32_t)((c->n_nreads * a.nwr + 255) / 256)), dim3(256), 0, c->stream, a.nascii, c->n_nreads, L,
+        hipLaunchKernelGGL(k_seed_nmask, dim3((uint32_t)((a.nn * a.nwr + 255) / 256)), dim3(256), 0, c->stream, a.nascii, a.nn, L,
                            a.nwr, (uint16_t *)c->s_nmask.p);
     }
     hipLaunchKernelGGL(k_seed_table_init, dim3(4096), dim3(256), 0, c->stream, a.tkeys, a.theads, tsize);
     hipLaunchKernelGGL(k_seed_insert, dim3((uint32_t)((nent + 255) / 256)), dim3(256), 0, c->stream, a);
-    if (c->n_nreads)
-        hipLaunchKernelGGL(k_seed_insert_ascii, dim3((uint32_t)((c->n_nreads * a.P + 255) / 256)), dim3(256), 0, c->stream, a);
+    if (a.nn)
+        hipLaunchKernelGGL(k_seed_insert_ascii, dim3((uint32_t)((a.nn * a.P + 255) / 256)), dim3(256), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
 
     unsigned long long *cursor = (unsigned long long *)c->s_tmp.p;
     for (int pass = first_strand; pass <= last_strand; pass++) {
-        if (pass == 1) {
-            if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) return e;
-            c->have_rc = true;
-        }
         a.pg = (const uint32_t *)c->pg2[pass].p;
         a.strand = (uint32_t)pass;
         if (c->G < span) continue; // no window fits (the reference's scan loops are empty / undefined there)
-        const uint64_t nwin = c->G - span + 1;
+        const uint64_t nwin_all = c->G - span + 1;
         const uint32_t per_block = (SCAN_TPB / a.cstride) * a.cstride * SCAN_R;
-        const uint32_t grid = (uint32_t)((nwin + per_block - 1) / per_block);
+        for (uint64_t w0 = 0; w0 < nwin_all; w0 += seg_windows) {
+        a.tbase = w0;
+        const uint64_t nwin = std::min(nwin_all, w0 + seg_windows);      // this segment: window starts [w0, nwin)
+        const uint32_t grid = (uint32_t)((nwin - w0 + per_block - 1) / per_block);
         // hit buffer: a guess (two hits per indexed part, or whatever an earlier pass needed); exact size on overflow
         uint64_t cap = std::max<uint64_t>(2 * nent + 4096, c->s_hits.bytes / sizeof(uint64_t));
         unsigned long long nhits = 0;
@@ -544,11 +526,9 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
                                                             // (growing these multi-GB buffers again costs more than the pass itself)
         }
         if (nhits == 0) continue;
-        int ibits = 1, tbits = 1;                           // only the key bits that can be set take part in the sort
-        while ((1ull << ibits) < c->n) ibits++;
-        while ((1ull << tbits) < c->G) tbits++;
+        int ibits = 1;                                      // only the key bits that can be set take part in the sort
+        while ((1ull << ibits) < a.n) ibits++;
         const int end_bit = 36 + ibits;
-        (void)tbits;
         size_t temp_bytes = 0;
         HIP_TRY(c, rocprim::radix_sort_keys(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)cap, 0, end_bit, c->stream));
         // scratch lives in the context (grow-only): no hipMalloc / hipFree (= device synchronisation) per pass
@@ -556,16 +536,16 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
         if ((e = pgrc_buf_ensure(c, sorted, cap * sizeof(uint64_t)))) return e;       // sized like the hit buffer: no regrow
         if ((e = pgrc_buf_ensure(c, temp, temp_bytes))) return e;
         if ((e = pgrc_buf_ensure(c, c->s_mm, cap))) return e;
-        if ((e = pgrc_buf_ensure(c, c->s_rstart, c->n * sizeof(uint64_t)))) return e;
-        if ((e = pgrc_buf_ensure(c, c->s_heavy, c->n * sizeof(uint32_t)))) return e;
+        if ((e = pgrc_buf_ensure(c, c->s_rstart, a.n * sizeof(uint64_t)))) return e;
+        if ((e = pgrc_buf_ensure(c, c->s_heavy, a.n * sizeof(uint32_t)))) return e;
         hipError_t he = rocprim::radix_sort_keys(temp.p, temp_bytes, (uint64_t *)c->s_hits.p, (uint64_t *)sorted.p, (size_t)nhits, 0, end_bit, c->stream);
-        if (he == hipSuccess) he = hipMemsetAsync(c->s_rstart.p, 0xFF, c->n * sizeof(uint64_t), c->stream);
+        if (he == hipSuccess) he = hipMemsetAsync(c->s_rstart.p, 0xFF, a.n * sizeof(uint64_t), c->stream);
         unsigned long long *nheavy = cursor + 1;
         if (he == hipSuccess) he = hipMemsetAsync(nheavy, 0, sizeof(unsigned long long), c->stream);
         if (he == hipSuccess) {
             hipLaunchKernelGGL(k_seed_hamming, dim3((uint32_t)((nhits + 255) / 256)), dim3(256), 0, c->stream, a,
                                (const uint64_t *)sorted.p, (uint64_t)nhits, (uint8_t *)c->s_mm.p, (uint64_t *)c->s_rstart.p);
-            hipLaunchKernelGGL(k_seed_replay, dim3((uint32_t)((c->n + 255) / 256)), dim3(256), 0, c->stream, a,
+            hipLaunchKernelGGL(k_seed_replay, dim3((uint32_t)((a.n + 255) / 256)), dim3(256), 0, c->stream, a,
                                (const uint64_t *)sorted.p, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p,
                                (uint32_t *)c->s_heavy.p, nheavy);
             hipLaunchKernelGGL(k_seed_replay_heavy, dim3((uint32_t)c->num_cus * 8u), dim3(256), 0, c->stream, a,
@@ -575,8 +555,59 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
         }
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) { c->err = std::string("seed-index pass: ") + hipGetErrorString(he); return PGRC_E_DEVICE; }
-        c->ctr.searched[pass] = c->n;
-        c->ctr.candidates[pass] = nhits;
+        c->ctr.candidates[pass] += nhits;
+        }
+        c->ctr.searched[pass] += a.n;
+    }
+    return PGRC_OK;
+}
+
+int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
+    const uint32_t L = c->prm.read_len;
+    const char mode = c->prm.mode;
+    SeedArgs a;
+    a.L = L;
+    a.mode = (uint32_t)mode;
+    a.P = (mode == 'e') ? 1u : L / c->prm.seed_len;   // targetMismatches + 1 (ReadsMatchers.cpp:236)
+    a.m = (mode == 'e') ? L : c->prm.seed_len;
+    a.cstride = (mode == 'i') ? a.P : 1u;
+    if (a.P == 0 || a.P > 15) { c->err = "modes d/i: 1..15 seed parts supported"; return PGRC_E_PARAM; }
+    a.pg = nullptr;
+    a.G = c->G;
+    a.stride = c->stride;
+    a.nwr = (L + 15) / 16;
+    a.nmask = nullptr;
+    a.kmax = c->prm.max_mismatches;
+    a.kmin = c->prm.min_mismatches;
+    a.tbase = 0;
+    if (c->n == 0) return PGRC_OK;
+    int e;
+    if (last_strand >= 1) {
+        if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) return e;
+        c->have_rc = true;
+    }
+    // limits of the 64-bit hit record (read 28 bits | position in the segment 32 bits | part 4 bits); the knobs force
+    // small batches / segments so that tests cover the loops on small inputs
+    uint64_t batch = (1ull << 28) - 1, seg = (1ull << 32) - 65536;
+    if (const char *k = getenv("PGRC_SEED_READ_BATCH")) batch = std::max<uint64_t>(1, strtoull(k, nullptr, 10));
+    if (const char *k = getenv("PGRC_SEED_SEGMENT")) seg = std::max<uint64_t>(4096, strtoull(k, nullptr, 10));
+    const uint32_t *d_nidx = (const uint32_t *)c->nread_idx.p;
+    for (uint64_t r0 = 0; r0 < c->n; r0 += batch) {
+        const uint64_t r1 = std::min(c->n, r0 + batch);
+        a.ibase = r0;
+        a.n = r1 - r0;
+        a.reads = c->reads2 + r0;                      // word-major: word w of read i at reads[w * stride + i]
+        a.pos = (uint64_t *)c->d_pos.p + r0;
+        a.rc = (uint8_t *)c->d_rc.p + r0;
+        a.mism = (uint8_t *)c->d_mism.p + r0;
+        // the batch's part of the side list of reads with N (indexes ascending)
+        const auto nlo = std::lower_bound(c->h_nidx.begin(), c->h_nidx.end(), (uint32_t)r0) - c->h_nidx.begin();
+        const auto nhi = std::lower_bound(c->h_nidx.begin(), c->h_nidx.end(), (uint32_t)std::min<uint64_t>(r1, 0xFFFFFFFFull)) - c->h_nidx.begin();
+        a.nn = (uint64_t)(nhi - nlo);
+        a.nflag = a.nn ? (const uint8_t *)c->nread_flag.p + r0 : nullptr;
+        a.nidx = d_nidx + nlo;
+        a.nascii = (const uint8_t *)c->nread_ascii.p + (uint64_t)nlo * L;
+        if ((e = seedidx_batch(c, a, seg, first_strand, last_strand))) return e;
     }
     return PGRC_OK;
 }

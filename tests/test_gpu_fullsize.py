@@ -192,7 +192,7 @@ def test_c4_full_size_eight_shards(c3world):
     assert end == n and np.array_equal(total_hist, hist)
 
 
-def _full_size_run(n, L, G, seed_len, kmax, sample):
+def _full_size_run(n, L, G, seed_len, kmax, sample, also_mode=None):
     """inputs generated in HBM, one run over all n reads, properties, and the first `sample` reads against the checker
     on the whole text"""
     g = synth.pg_params(G, seed=12345)
@@ -217,6 +217,19 @@ def _full_size_run(n, L, G, seed_len, kmax, sample):
     r = _check("c", pg, reads, seed_len, kmax)
     for k, v in (("pos", pos), ("rc", rc), ("mism", mism)):
         assert np.array_equal(v[:sample], r[k]), k
+    if also_mode:
+        # a read-side seed-index mode on the same inputs: reported alignments are real, every read mode c matched exactly
+        # is matched exactly (every part of such a read hits at its occurrence)
+        cx = MatchContext(L, seed_len, kmax, 0, also_mode)
+        cx.set_pg_packed_device(d_pg.data_ptr(), G)
+        cx.set_reads_device(d_rd.data_ptr(), n, stride, keep=d_rd)
+        cx.init_results()
+        cx.run(True)
+        p2, r2, m2, h2, mt2 = cx.get_results()
+        _bookkeeping(n, G, L, kmax, p2, r2, m2, h2, mt2)
+        assert (m2 == 0)[mism == 0].all() and mt2 >= 0.85 * n
+        _alignments_are_real(pg, reads, p2[:sample], r2[:sample], m2[:sample])
+        assert int((p2[m2 != 255] >= np.uint64(2**32)).sum()) > 100_000
     return ctx, pos, mism
 
 
@@ -234,8 +247,9 @@ def test_c5_shard_full_size():
 
 def test_p64_full_size():
     """A text of 4.4 Gbp (>= 4 Gi symbols): the reference's u64 index branch (CopMEMMatcher.cpp:579-586), here the
-    64-bit-position kernels, at a size where positions really leave 32 bits."""
-    ctx, pos, mism = _full_size_run(50_000_000, 150, 4_400_000_000, 38, 3, 50_000)
+    64-bit-position kernels, at a size where positions really leave 32 bits; mode d on the same inputs scans the text in
+    two segments."""
+    ctx, pos, mism = _full_size_run(50_000_000, 150, 4_400_000_000, 38, 3, 50_000, also_mode="d")
     assert int((pos[mism != 255] >= np.uint64(2**32)).sum()) > 100_000
 
 

@@ -96,6 +96,28 @@ def test_index_build_variants(monkeypatch, variant):
             assert np.array_equal(c, cumm) and np.array_equal(p, positions), (variant, pg.size, seed_len, strand)
 
 
+@pytest.mark.parametrize("mode", ["d", "i", "e"])
+def test_seedindex_text_segments_and_read_batches(monkeypatch, mode):
+    """Modes d / i / e scan a text of 2^32 or more symbols in segments of fewer than 2^32 window starts and take 2^28 or
+    more reads in batches (the 64-bit hit record keeps 32 + 28 bits); the knobs force both loops on a small input:
+    segment after segment, batch after batch must be the reference's one sequential scan."""
+    L = 100
+    pg, reads = make_inputs(150_000, 5000, L, seed=77, n_with_n=300, pool_div=64, tandem_every=2)
+    seed_len, kmax = (L, 0) if mode == "e" else (38, 2)
+    o = orc.oracle_match(mode, pg, reads, seed_len, kmax, 0)
+    for seg, batch in ((4096, None), (None, 700), (10_000, 1300), (65_536, 4700)):
+        if seg:
+            monkeypatch.setenv("PGRC_SEED_SEGMENT", str(seg))
+        else:
+            monkeypatch.delenv("PGRC_SEED_SEGMENT", raising=False)
+        if batch:
+            monkeypatch.setenv("PGRC_SEED_READ_BATCH", str(batch))
+        else:
+            monkeypatch.delenv("PGRC_SEED_READ_BATCH", raising=False)
+        assert_same_results(gpu_match(mode, pg, reads, seed_len, kmax, 0), o, f"mode {mode} segment {seg} batch {batch}")
+        assert_same_results(gpu_match(mode, pg, reads, seed_len, kmax, 0, devices=[0, 0]), o, f"mode {mode}, 2 shards, segment {seg} batch {batch}")
+
+
 CASES = [
     # L, seed, M, mode, G, n
     (100, 38, 50, "c", 400000, 20000),
