@@ -23,10 +23,12 @@
 //
 // All integer work, bound by the random head gathers (one per window): no MFMA.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -368,21 +370,40 @@ struct Replay {
     uint64_t skip, nmain;                        // probes jumped over after a hit; probes of the main loop (whole blocks of 256)
     // history of the probes that ended with a jump: (probe, order of the entry that caused it, 1 = recorded a match)
     struct Jump { uint64_t t; uint32_t order; uint32_t accepted; };
-    std::vector<Jump> jumps;
+    // the jumps recorded so far, in probe order: the finished chunks' lists (none empty, ascending) and the list of the
+    // chunk being replayed
+    std::vector<const std::vector<Jump> *> hist;
+    const std::vector<Jump> *cur = nullptr;
     int lookup_err = 0;
 
     uint64_t block_of(uint64_t t) const { return t < nmain ? t / 256 : nmain / 256 + 1; }   // the tail loop is one block
-    // was probe t visited, given the jumps recorded so far (all of them at probes < t)?
+    static bool jump_lt(const Jump &j, uint64_t v) { return j.t < v; }
+    // the list that holds the latest jump at a probe < t (or <= t), if any
+    const std::vector<Jump> *list_for(uint64_t t, bool inclusive) const {
+        if (cur && !cur->empty() && (inclusive ? cur->front().t <= t : cur->front().t < t)) return cur;
+        size_t lo = 0, hi = hist.size();                 // first list whose first jump lies beyond t
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            const uint64_t f = hist[mid]->front().t;
+            if (inclusive ? f <= t : f < t) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo ? hist[lo - 1] : nullptr;
+    }
+    // was probe t visited, given the jumps recorded so far?
     bool examined(uint64_t t) const {
         // only the latest jump before t can still cover it (jumps are skip probes long, and recorded in order)
-        auto it = std::lower_bound(jumps.begin(), jumps.end(), t, [](const Jump &j, uint64_t v) { return j.t < v; });
-        if (it == jumps.begin()) return true;
+        const std::vector<Jump> *v = list_for(t, false);
+        if (!v) return true;
+        auto it = std::lower_bound(v->begin(), v->end(), t, jump_lt);     // > begin: the list's first jump is before t
         --it;
         return !(block_of(it->t) == block_of(t) && t <= it->t + skip);
     }
     const Jump *jump_at(uint64_t t) const {
-        auto it = std::lower_bound(jumps.begin(), jumps.end(), t, [](const Jump &j, uint64_t v) { return j.t < v; });
-        return (it != jumps.end() && it->t == t) ? &*it : nullptr;
+        const std::vector<Jump> *v = list_for(t, true);
+        if (!v) return nullptr;
+        auto it = std::lower_bound(v->begin(), v->end(), t, jump_lt);
+        return (it != v->end() && it->t == t) ? &*it : nullptr;
     }
     // the bucket of a destination window, from the device (rare path)
     int bucket(uint64_t q, uint64_t *pos) {
@@ -700,7 +721,15 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     }
     (void)hipEventElapsedTime(&m->ctr.ms_probe, ev[0], ev[1]);
 
-    // ---- 4. the sequential rules, over the events only
+    // ---- 4. the sequential rules, over the events only.
+    // The scan is sequential for two reasons: a jump skips the next windows -- but never beyond its block of 256 windows
+    // (main loop), so blocks are independent there -- and rule (b) looks at the LAST match recorded, which carries from
+    // block to block.  The events are therefore cut into chunks at block boundaries and replayed by several host
+    // threads speculatively (incoming last match: none); then the chunks are resolved in order: a chunk whose true
+    // incoming match cannot reach into it (it ends before the chunk's first window) keeps its speculative result, the
+    // others are replayed again with the right incoming state, round after round until nothing changes (one round when
+    // no match straddles a chunk boundary; the chain is at worst sequential).  Chunks holding an event whose side
+    // context lies outside a text (the stale-register walk needs the whole jump history) run in order on one thread.
     const auto th0 = std::chrono::steady_clock::now();
     Replay rp;
     rp.m = m; rp.dest = dest; rp.N2 = N2; rp.dest_is_src = dest_is_src != 0; rp.rev_compl = rev_compl != 0;
@@ -712,56 +741,194 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
         if (lim > K + block) nb = (lim - K - block + block - 1) / block;
         rp.nmain = nb * 256;
     }
-    std::vector<pgrc_text_match> res;
-    bool have_last = false;
-    pgrc_text_match last{0, 0, 0};
-    uint64_t i = 0;
-    while (i < nev) {
-        const uint64_t t = hk[i] >> 4;
-        uint64_t jend = i;
-        while (jend < nev && (hk[jend] >> 4) == t) jend++;
-        // probes come in ascending order: only the latest jump can still cover this one (Replay::examined, the
-        // general form, is for the walk-back of the stale registers)
-        const bool visited = rp.jumps.empty() || !(rp.block_of(rp.jumps.back().t) == rp.block_of(t) && t <= rp.jumps.back().t + rp.skip);
-        if (visited) {
-            const uint64_t q = t * k2;
-            for (uint64_t x = i; x < jend; x++) {
-                const uint64_t p = hp[x];
-                const uint32_t order = (uint32_t)(hk[x] & 15u);
-                // (b) the window lies inside the previous match, on its diagonal (:393-399)
-                if (have_last && q - p == last.pos_dest - last.pos_src && q + K < last.pos_dest + last.length) {
-                    rp.jumps.push_back({t, order, 0u});
-                    break;
-                }
-                // (c) side contexts (:401-404); registers whose 4 bytes lie outside a text keep their previous value
-                const uint32_t fl = hf[x];
-                bool pass;
-                if ((fl & 15u) == 15u) {
-                    pass = (fl & (MF_L_EQ | MF_R_EQ)) != 0;
-                } else {
-                    m->ctr.stale_lookups++;
-                    const uint32_t l1 = (fl & MF_L1_OK) ? le32(m->src + p - m->LK2) : rp.stale_src_reg(true, t, order);
-                    const uint32_t r1 = (fl & MF_R1_OK) ? le32(m->src + p + m->KLK24) : rp.stale_src_reg(false, t, order);
-                    const uint32_t l2 = (fl & MF_L2_OK) ? le32(dest + q - m->LK2) : 0u;   // windows below LK2 come first: still the initial 0
-                    const uint32_t r2 = (fl & MF_R2_OK) ? le32(dest + q + m->KLK24) : rp.stale_r2(t);
-                    pass = r1 == r2 || l1 == l2;
-                    if (rp.lookup_err) { m->err = "bucket lookup failed"; return PGRC_E_DEVICE; }
-                }
-                if (!pass) continue;
-                // (d) long enough?  right - p1 > minMatchLength with right - p1 = length + 1 (:413)
-                const uint64_t mstart = hrs[hr[x]], mlen = hre[hr[x]] - mstart;
-                if (mlen + 1 > (uint64_t)min_len) {
-                    last.pos_src = mstart;
-                    last.length = mlen;
-                    last.pos_dest = q - (p - mstart);
-                    have_last = true;
-                    res.push_back(last);
-                    rp.jumps.push_back({t, order, 1u});
-                    break;
+    struct ChunkRun {
+        uint64_t i0 = 0, i1 = 0;
+        bool barrier = false;                    // holds an event that may need the stale-register walk: sequential only
+        std::vector<pgrc_text_match> res;
+        std::vector<Replay::Jump> jumps;
+        bool in_have = false, out_have = false;  // incoming match this run assumed / last match recorded inside the chunk
+        pgrc_text_match in_last{0, 0, 0}, out_last{0, 0, 0};
+    };
+    // events [i0, i1) with the incoming last match `in`; seq: the run may meet stale events and then walks the jump
+    // history of everything before the chunk (rp.hist) and its own jumps so far (rp.cur)
+    auto replay_chunk = [&](ChunkRun &ck, bool in_have, const pgrc_text_match &in, bool seq) -> int {
+        ck.res.clear();
+        ck.jumps.clear();
+        ck.in_have = in_have;
+        ck.in_last = in;
+        ck.out_have = false;
+        std::vector<Replay::Jump> &jumps = ck.jumps;
+        if (seq) rp.cur = &ck.jumps;
+        bool have_last = in_have;
+        pgrc_text_match last = in;
+        uint64_t i = ck.i0;
+        while (i < ck.i1) {
+            const uint64_t t = hk[i] >> 4;
+            uint64_t jend = i;
+            while (jend < ck.i1 && (hk[jend] >> 4) == t) jend++;
+            // probes come in ascending order and a chunk starts with a new block: only the chunk's own latest jump can
+            // still cover this one (Replay::examined, the general form, is for the walk-back of the stale registers)
+            const bool visited = jumps.empty() || !(rp.block_of(jumps.back().t) == rp.block_of(t) && t <= jumps.back().t + rp.skip);
+            if (visited) {
+                const uint64_t q = t * k2;
+                for (uint64_t x = i; x < jend; x++) {
+                    const uint64_t p = hp[x];
+                    const uint32_t order = (uint32_t)(hk[x] & 15u);
+                    // (b) the window lies inside the previous match, on its diagonal (:393-399)
+                    if (have_last && q - p == last.pos_dest - last.pos_src && q + K < last.pos_dest + last.length) {
+                        jumps.push_back({t, order, 0u});
+                        break;
+                    }
+                    // (c) side contexts (:401-404); registers whose 4 bytes lie outside a text keep their previous value
+                    const uint32_t fl = hf[x];
+                    bool pass;
+                    if ((fl & 15u) == 15u) {
+                        pass = (fl & (MF_L_EQ | MF_R_EQ)) != 0;
+                    } else {
+                        if (!seq) return -1;             // (cannot happen: such chunks are barriers)
+                        m->ctr.stale_lookups++;
+                        const uint32_t l1 = (fl & MF_L1_OK) ? le32(m->src + p - m->LK2) : rp.stale_src_reg(true, t, order);
+                        const uint32_t r1 = (fl & MF_R1_OK) ? le32(m->src + p + m->KLK24) : rp.stale_src_reg(false, t, order);
+                        const uint32_t l2 = (fl & MF_L2_OK) ? le32(dest + q - m->LK2) : 0u;   // windows below LK2 come first: still the initial 0
+                        const uint32_t r2 = (fl & MF_R2_OK) ? le32(dest + q + m->KLK24) : rp.stale_r2(t);
+                        pass = r1 == r2 || l1 == l2;
+                        if (rp.lookup_err) return -2;
+                    }
+                    if (!pass) continue;
+                    // (d) long enough?  right - p1 > minMatchLength with right - p1 = length + 1 (:413)
+                    const uint64_t mstart = hrs[hr[x]], mlen = hre[hr[x]] - mstart;
+                    if (mlen + 1 > (uint64_t)min_len) {
+                        last.pos_src = mstart;
+                        last.length = mlen;
+                        last.pos_dest = q - (p - mstart);
+                        have_last = true;
+                        ck.out_have = true;
+                        ck.out_last = last;
+                        ck.res.push_back(last);
+                        jumps.push_back({t, order, 1u});
+                        break;
+                    }
                 }
             }
+            i = jend;
         }
-        i = jend;
+        return 0;
+    };
+    // chunks: cut where the block of 256 windows changes
+    std::vector<ChunkRun> chunks;
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        const char *knob = getenv("PGRC_MEM_REPLAY_THREADS");                         // test / A-B knob (1 = one sequential chunk)
+        const uint64_t nthreads = knob ? (uint64_t)std::max(1, atoi(knob)) : std::min<uint64_t>(16, hw ? hw : 1);
+        const char *cknob = getenv("PGRC_MEM_REPLAY_CHUNK");                          // test knob: events per chunk
+        const uint64_t target = cknob ? (uint64_t)std::max(1, atoi(cknob))
+                                      : (nthreads <= 1 || nev < 200000 ? nev + 1 : std::max<uint64_t>(50000, nev / (4 * nthreads)));
+        uint64_t i0 = 0;
+        while (i0 < nev) {
+            uint64_t i1 = std::min<uint64_t>(nev, i0 + target);
+            while (i1 < nev && rp.block_of(hk[i1] >> 4) == rp.block_of(hk[i1 - 1] >> 4)) i1++;
+            ChunkRun ck;
+            ck.i0 = i0;
+            ck.i1 = i1;
+            chunks.push_back(std::move(ck));
+            i0 = i1;
+        }
+        const bool single = chunks.size() <= 1;
+        // run `ids` on the thread pool; a chunk is first scanned for stale-capable events (those make it a barrier)
+        auto run_parallel = [&](const std::vector<size_t> &ids, const std::vector<std::pair<bool, pgrc_text_match>> &inc) {
+            std::atomic<size_t> next{0};
+            auto worker = [&]() {
+                for (;;) {
+                    const size_t w = next.fetch_add(1);
+                    if (w >= ids.size()) break;
+                    ChunkRun &ck = chunks[ids[w]];
+                    (void)replay_chunk(ck, inc[w].first, inc[w].second, false);
+                }
+            };
+            const size_t nt = std::min<size_t>(nthreads, ids.size());
+            std::vector<std::thread> th;
+            for (size_t k = 1; k < nt; k++) th.emplace_back(worker);
+            worker();
+            for (auto &t : th) t.join();
+        };
+        if (single) {
+            for (ChunkRun &ck : chunks) ck.barrier = true;
+        } else {
+            // barriers: any event whose four side contexts are not all inside the texts
+            std::atomic<size_t> next{0};
+            auto scan = [&]() {
+                for (;;) {
+                    const size_t w = next.fetch_add(1);
+                    if (w >= chunks.size()) break;
+                    ChunkRun &ck = chunks[w];
+                    for (uint64_t x = ck.i0; x < ck.i1; x++)
+                        if ((hf[x] & 15u) != 15u) { ck.barrier = true; break; }
+                }
+            };
+            {
+                std::vector<std::thread> th;
+                for (size_t k = 1; k < std::min<size_t>(nthreads, chunks.size()); k++) th.emplace_back(scan);
+                scan();
+                for (auto &t : th) t.join();
+            }
+            std::vector<size_t> ids;
+            for (size_t k = 0; k < chunks.size(); k++)
+                if (!chunks[k].barrier) ids.push_back(k);
+            run_parallel(ids, std::vector<std::pair<bool, pgrc_text_match>>(ids.size(), {false, pgrc_text_match{0, 0, 0}}));
+        }
+        // resolve in order
+        auto reaches = [&](bool have, const pgrc_text_match &l, const ChunkRun &ck) {
+            return have && (hk[ck.i0] >> 4) * k2 + K < l.pos_dest + l.length;   // rule (b) could fire inside the chunk
+        };
+        auto same = [](bool ha, const pgrc_text_match &a, bool hb, const pgrc_text_match &b) {
+            return ha == hb && (!ha || (a.pos_src == b.pos_src && a.length == b.length && a.pos_dest == b.pos_dest));
+        };
+        bool cur_have = false;
+        pgrc_text_match cur{0, 0, 0};
+        size_t k = 0;
+        while (k < chunks.size()) {
+            if (chunks[k].barrier) {
+                const int rcx = replay_chunk(chunks[k], cur_have, cur, true);
+                rp.cur = nullptr;
+                if (rcx) { m->err = "bucket lookup failed"; return PGRC_E_DEVICE; }
+                if (!chunks[k].jumps.empty()) rp.hist.push_back(&chunks[k].jumps);
+                if (chunks[k].out_have) { cur_have = true; cur = chunks[k].out_last; }
+                k++;
+                continue;
+            }
+            size_t k2e = k;
+            while (k2e < chunks.size() && !chunks[k2e].barrier) k2e++;
+            for (;;) {      // rounds over [k, k2e)
+                std::vector<size_t> ids;
+                std::vector<std::pair<bool, pgrc_text_match>> inc;
+                bool h = cur_have;
+                pgrc_text_match l = cur;
+                for (size_t x = k; x < k2e; x++) {
+                    const bool eh = reaches(h, l, chunks[x]);
+                    if (!same(eh, l, chunks[x].in_have, chunks[x].in_last)) {
+                        ids.push_back(x);
+                        inc.push_back({eh, eh ? l : pgrc_text_match{0, 0, 0}});
+                    }
+                    if (chunks[x].out_have) { h = true; l = chunks[x].out_last; }
+                }
+                if (ids.empty()) {
+                    cur_have = h;
+                    cur = l;
+                    break;
+                }
+                run_parallel(ids, inc);
+            }
+            for (size_t x = k; x < k2e; x++)
+                if (!chunks[x].jumps.empty()) rp.hist.push_back(&chunks[x].jumps);
+            k = k2e;
+        }
+    }
+    std::vector<pgrc_text_match> res;
+    {
+        size_t total = 0;
+        for (const ChunkRun &ck : chunks) total += ck.res.size();
+        res.reserve(total);
+        for (const ChunkRun &ck : chunks) res.insert(res.end(), ck.res.begin(), ck.res.end());
     }
     m->ctr.ms_host = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - th0).count();
     if (!res.empty()) {

@@ -60,7 +60,8 @@ def main():
         ctr = m.counters()
         rec = {"dest_len": int(dest.size), "dest_is_src": dis, "rev_compl": rc, "matches": int(len(gm)),
                "matched_symbols": int(gm[:, 1].sum()) if len(gm) else 0, "gpu_s": gpu_s,
-               "gpu_windows_per_s": ctr["probes"] / gpu_s, "counters": ctr}
+               "gpu_windows_per_s": ctr["probes"] / gpu_s, "counters": ctr,
+               "digest": __import__("hashlib").sha256(np.ascontiguousarray(gm).tobytes()).hexdigest()[:16]}
         print(json.dumps({case: rec}), flush=True)
         if not a.no_reference:
             t = time.perf_counter()

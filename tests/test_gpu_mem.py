@@ -114,6 +114,20 @@ def test_mem_long_matches():
             assert np.array_equal(g, orc.ref_mem_match(src, d, dest_is_src, rev_compl))
 
 
+@pytest.mark.parametrize("chunk,threads", [(1, 4), (37, 3), (500, 8), (5000, 2)])
+def test_mem_parallel_replay_of_the_sequential_rules(monkeypatch, chunk, threads):
+    """The host replay cuts the events into chunks at block boundaries, replays them speculatively on several threads and
+    resolves the last-match dependency in rounds (mem.hip, step 4).  Tiny chunks force every path on small inputs: long
+    matches that straddle many chunks (rounds), texts with stale-register events (barrier chunks), low complexity."""
+    monkeypatch.setenv("PGRC_MEM_REPLAY_CHUNK", str(chunk))
+    monkeypatch.setenv("PGRC_MEM_REPLAY_THREADS", str(threads))
+    for seed, with_n, lowc in ((0, False, False), (1, True, True), (2, False, True)):
+        src, other = make_pair(seed, with_n=with_n, low_complexity=lowc)
+        assert check(src, other, what=f"chunk {chunk} seed {seed}") > 100
+    test_mem_long_matches()
+    test_mem_matches_touching_the_text_ends_and_stale_registers()
+
+
 def test_mem_event_buffer_regrows(monkeypatch):
     """more events than the first guess of the event buffer: the probe pass is rerun with the exact size"""
     monkeypatch.setenv("PGRC_MEM_EVENT_CAP", "7")
