@@ -34,6 +34,48 @@ int main(int argc, char **argv) {
         printf("matched %llu of %llu, exact %llu, digest %016llx\n", (unsigned long long)matched, (unsigned long long)n,
                (unsigned long long)hist[0], (unsigned long long)fnv);
     }
+    /* the round-2 entry points from plain C: one matcher over two shards (both on device 0), reads handed over in the
+     * reference's ACGT packing (4 symbols per byte, first symbol most significant), the export streams */
+    {
+        pgrc_match_ctx *two = NULL;
+        const int32_t devs[2] = {0, 0};
+        const uint32_t pb = (L + 3) / 4;
+        uint8_t *rows = (uint8_t *)calloc(n, pb), *rc2 = (uint8_t *)malloc(n), *mism2 = (uint8_t *)malloc(n);
+        uint64_t *pos2 = (uint64_t *)malloc(n * sizeof(uint64_t)), hist2[256], matched2 = 0, i;
+        uint32_t *entry_read = (uint32_t *)malloc(n * sizeof(uint32_t)), *entry_org = (uint32_t *)malloc(n * sizeof(uint32_t)), x;
+        pgrc_export_streams st;
+        uint64_t mm = 0;
+        for (i = 0; i < n; i++)
+            for (x = 0; x < L; x++) {
+                const char ch = reads[i * L + x];
+                const uint32_t code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u;
+                rows[i * pb + x / 4] |= (uint8_t)(code << (2 * (3 - x % 4)));
+            }
+        if ((e = pgrc_match_create_multi(&prm, 2, devs, &two))) { fprintf(stderr, "create_multi: %d %s\n", e, pgrc_match_last_error(NULL)); return 5; }
+        if ((e = pgrc_match_set_pg_ascii(two, pg, G)) || (e = pgrc_match_begin_reads(two, n)) ||
+            (e = pgrc_match_append_reads_packed(two, rows, n / 3, 4)) ||
+            (e = pgrc_match_append_reads_packed(two, rows + (n / 3) * pb, n - n / 3, 4)) || (e = pgrc_match_end_reads(two)) ||
+            (e = pgrc_match_init_results(two)) || (e = pgrc_match_run(two, 1)) ||
+            (e = pgrc_match_get_results(two, pos2, rc2, mism2, hist2, &matched2))) {
+            fprintf(stderr, "multi error %d: %s\n", e, pgrc_match_last_error(two));
+            return 6;
+        }
+        if (pgrc_match_shard_count(two) != 2 || matched2 != matched || memcmp(pos, pos2, n * sizeof(uint64_t)) || memcmp(rc, rc2, n) ||
+            memcmp(mism, mism2, n) || memcmp(hist, hist2, sizeof hist)) {
+            fprintf(stderr, "two shards disagree with one device\n");
+            return 7;
+        }
+        for (i = 0; i < n; i++) { entry_read[i] = (uint32_t)i; entry_org[i] = (uint32_t)i; mm += mism[i] == 255 ? 0 : mism[i]; }
+        if ((e = pgrc_match_export_entries(two, entry_read, entry_org, n, 0, 1, &st))) {
+            fprintf(stderr, "export error %d: %s\n", e, pgrc_match_last_error(two));
+            return 8;
+        }
+        if (st.n_entries != n || st.n_mismatches != mm || st.off_width != 1) { fprintf(stderr, "export counts\n"); return 9; }
+        printf("two shards agree; export: %llu entries, %llu mismatches\n", (unsigned long long)st.n_entries, (unsigned long long)st.n_mismatches);
+        pgrc_match_free_export(&st);
+        pgrc_match_destroy(two);
+        free(rows); free(rc2); free(mism2); free(pos2); free(entry_read); free(entry_org);
+    }
     pgrc_match_destroy(ctx);
     free(pg); free(reads); free(pos); free(rc); free(mism);
     return 0;

@@ -438,6 +438,8 @@ def test_c_consumer_of_the_abi(tmp_path):
     for p, m, c in zip(o["pos"].tolist(), o["mism"].tolist(), o["rc"].tolist()):
         fnv = ((fnv ^ p ^ (m << 56) ^ (c << 48)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert f"matched {o['matched']} of 4000, exact {int(o['hist'][0])}, digest {fnv:016x}" in r.stdout
+    mm = int(o["mism"][o["mism"] != 255].astype(np.int64).sum())
+    assert f"two shards agree; export: 4000 entries, {mm} mismatches" in r.stdout   # create_multi, packed appends, export from C
 
 
 @pytest.mark.parametrize("L,seed_len,M,shortcut", [(100, 38, 50, False), (150, 38, 3, False), (250, 45, 20, True), (64, 32, 10, False)])
