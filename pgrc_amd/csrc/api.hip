@@ -2,6 +2,8 @@
 // pseudogenome and the reads, the two-pass driver (DefaultReadsMatcher::matchConstantLengthReads,
 // matching/ReadsMatchers.cpp:162-172) and result retrieval.  No CPU fallback exists: every compute
 // entry point needs a HIP device.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -25,6 +27,7 @@ int pgrc_buf_ensure(pgrc_match_ctx *c, DevBuf &b, size_t bytes) {
         return pgrc_hip_code(e);
     }
     b.bytes = bytes;
+    if (getenv("PGRC_DEBUG_ALLOC")) fprintf(stderr, "pgrc alloc ctx %p buf %p: %zu bytes at %p\n", (void *)c, (void *)&b, bytes, b.p);
     return PGRC_OK;
 }
 

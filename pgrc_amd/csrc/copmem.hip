@@ -338,6 +338,14 @@ __device__ __forceinline__ uint32_t hash_fp_window(const uint32_t w0, const uint
 #ifndef PROBE_AHEAD
 #define PROBE_AHEAD 1       // probing lanes fetch the next seed's bucket head together with their own
 #endif
+#ifdef MATCH_WAVES_PER_EU     // experiments only (tools/variants.sh): the compiler's own choice is 6 for L <= 160
+#define MATCH_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(MATCH_WAVES_PER_EU)))
+#else
+#define MATCH_OCCUPANCY_ATTR
+#endif
+#ifndef MATCH_STAGE
+#define MATCH_STAGE 32      // reads a wave stages in LDS per burst of full-line loads (k_copmem_match_sm, STAGE)
+#endif
 #ifndef MATCH_CHUNK
 #define MATCH_CHUNK 1024u // reads a wave reserves per visit to the global work counter (256 / 512 / 1024: step +0 / -0.2 / -0.4 %)
 #endif
@@ -351,8 +359,8 @@ __device__ __forceinline__ uint32_t hash_fp_window(const uint32_t w0, const uint
 // exhausted.  The per-read sequence of events is untouched.
 // POS64: text positions need more than 32 bits (Pg >= 4 Gi symbols: the reference's u64 index branch,
 // CopMEMMatcher.cpp:579-586); otherwise positions are kept in one register.
-template <int NW, int KQ, bool POS64>
-__global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a) {
+template <int NW, int KQ, bool POS64, int STAGE = 0>
+__global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match_sm(const MatchArgs a) {
     typedef typename std::conditional<POS64, uint64_t, uint32_t>::type pos_t;
     constexpr pos_t POS_NONE = (pos_t)~(pos_t)0;
     constexpr uint32_t EPOCH_BITS = POS64 ? 13u : 16u; // POS64 keeps position bits 32..39 next to the counts
@@ -360,6 +368,13 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
     __shared__ uint32_t fpm_tab[SM_MAX_SEEDS];
     __shared__ uint2 vcache[VC_SLOTS][MATCH_TPB]; // {position, head count | tail count << 8 | epoch << 16}
     __shared__ uint32_t rd_lds[NW][MATCH_TPB];    // the read itself: only needed when a window is verified
+    // STAGE > 0 (experiment): the next STAGE reads of the wave's chunk are fetched with full-line loads into LDS and
+    // refilling lanes take their read from there instead of loading it themselves
+    constexpr int SW = STAGE > 0 ? STAGE : 1;
+    __shared__ uint32_t stg[MATCH_TPB / 64][NW][SW];
+    __shared__ uint8_t stg_c[MATCH_TPB / 64][SW], stg_f[MATCH_TPB / 64][SW];
+    const uint32_t wv = threadIdx.x >> 6;
+    uint32_t wbeg = 0, wend = 0, wnext = 0;      // the staged window and the next read of it to hand out (wave-uniform)
     hash_lut_init(lut);
     const int H = ((int)a.L / 8) * 8;
     const uint32_t nseeds = (a.L - a.K) / a.k2 + 1; // seeds s = 0, k2, ... with s + K <= L
@@ -422,7 +437,19 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                 cnext = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base, a.n));
                 cend = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base + MATCH_CHUNK, a.n));
             }
-            const uint32_t avail = cend - cnext;
+            if (STAGE > 0 && wnext == wend && cnext != cend) {    // the window is used up: stage the chunk's next reads
+                const uint32_t nst = min((uint32_t)SW, cend - cnext);
+                wbeg = wnext = cnext;
+                wend = cnext = __builtin_amdgcn_readfirstlane(cnext + nst);
+                if (lane < nst) {
+#pragma unroll
+                    for (int k = 0; k < NW; k++) stg[wv][k][lane] = a.reads[(uint64_t)k * a.stride + wbeg + lane];
+                    stg_c[wv][lane] = a.mism[wbeg + lane];
+                    stg_f[wv][lane] = a.nflag ? a.nflag[wbeg + lane] : (uint8_t)0;
+                }
+                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // a wave's LDS accesses are served in order
+            }
+            const uint32_t avail = STAGE > 0 ? wend - wnext : cend - cnext;
             if (avail == 0) {
                 if (mode == M_NEED) mode = M_DEAD;               // the read set is exhausted
             } else {
@@ -430,12 +457,14 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                 const uint32_t take = min((uint32_t)__popcll(need), avail);
                 bool started = false;
                 if (mode == M_NEED && rank < take) {
-                    idx = cnext + rank;
-                    cin = a.mism[idx];
-                    const bool skip = (a.nflag && a.nflag[idx]) || cin <= a.kmin; // ReadsMatchers.cpp:430; 'N' reads: byte path
+                    const uint32_t sj = wnext - wbeg + rank;
+                    idx = STAGE > 0 ? wbeg + sj : cnext + rank;
+                    cin = STAGE > 0 ? stg_c[wv][sj] : a.mism[idx];
+                    const bool skip = (STAGE > 0 ? stg_f[wv][sj] != 0 : (a.nflag && a.nflag[idx])) || cin <= a.kmin; // ReadsMatchers.cpp:430; 'N' reads: byte path
                     if (!skip) {
 #pragma unroll
-                        for (int k = 0; k < NW; k++) rd_lds[k][threadIdx.x] = sh[k] = a.reads[(uint64_t)k * a.stride + idx];
+                        for (int k = 0; k < NW; k++)
+                            rd_lds[k][threadIdx.x] = sh[k] = STAGE > 0 ? stg[wv][k][sj] : a.reads[(uint64_t)k * a.stride + idx];
                         st.limit = (cin < a.kmax) ? cin - 1u : a.kmax;   // :488-489
                         st.falses = 0;
                         st.cur = cin;
@@ -456,7 +485,8 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_sm(const MatchArgs a
                         mode = M_PROBE;
                     }
                 }
-                cnext = __builtin_amdgcn_readfirstlane(cnext + take);
+                if (STAGE > 0) wnext = __builtin_amdgcn_readfirstlane(wnext + take);
+                else cnext = __builtin_amdgcn_readfirstlane(cnext + take);
                 n_search += (uint32_t)__popcll(__ballot(started));
             }
         }
@@ -791,13 +821,22 @@ static void launch_match(pgrc_match_ctx *c, const MatchArgs &a) {
     const char *f64 = getenv("PGRC_FORCE_POS64"); // test knob: run the 64-bit-position kernel on a small text
     const bool pos64 = c->G + 256 >= (1ull << 32) || (f64 && f64[0] == '1');
     const bool k28 = a.K == 28;                   // the default seed: compile-time hash loop
+    // PGRC_MATCH_STAGE=0: every refilling lane loads its own read (A/B knob; staged is 1.8 % faster on C3, same context)
+    const char *sg = getenv("PGRC_MATCH_STAGE");
+    const bool staged = !(sg && sg[0] == '0');
+#define PGRC_LAUNCH_MATCH(KQ_, P64_)                                                                                              \
+    do {                                                                                                                          \
+        if (staged) hipLaunchKernelGGL((k_copmem_match_sm<NW, KQ_, P64_, MATCH_STAGE>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a); \
+        else hipLaunchKernelGGL((k_copmem_match_sm<NW, KQ_, P64_, 0>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);       \
+    } while (0)
     if (pos64) {
-        if (k28) hipLaunchKernelGGL((k_copmem_match_sm<NW, 7, true>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
-        else hipLaunchKernelGGL((k_copmem_match_sm<NW, 0, true>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
+        if (k28) PGRC_LAUNCH_MATCH(7, true);
+        else PGRC_LAUNCH_MATCH(0, true);
     } else {
-        if (k28) hipLaunchKernelGGL((k_copmem_match_sm<NW, 7, false>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
-        else hipLaunchKernelGGL((k_copmem_match_sm<NW, 0, false>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
+        if (k28) PGRC_LAUNCH_MATCH(7, false);
+        else PGRC_LAUNCH_MATCH(0, false);
     }
+#undef PGRC_LAUNCH_MATCH
 }
 
 int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {

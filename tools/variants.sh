@@ -5,7 +5,8 @@
 set -eu
 cd "$(dirname "$0")/.."
 V=pgrc_amd/variants
-declare -A DEFS=( [base]="" [noahead]="-DPROBE_AHEAD=0" [chunk256]="-DMATCH_CHUNK=256u" [vc8]="-DVC_BITS=3" )
+declare -A DEFS=( [base]="" [w7]="-DMATCH_WAVES_PER_EU=7" [w8]="-DMATCH_WAVES_PER_EU=8" [w5]="-DMATCH_WAVES_PER_EU=5" [vc8]="-DVC_BITS=3" [vc2]="-DVC_BITS=1" [noahead]="-DPROBE_AHEAD=0" [chunk256]="-DMATCH_CHUNK=256u" )
+ORDER="${VARIANTS:-base w7 w8 vc8}"
 if [ "${1:-build}" = build ]; then
   mkdir -p $V
   for v in "${!DEFS[@]}"; do
@@ -15,7 +16,7 @@ if [ "${1:-build}" = build ]; then
   done
 else
   for rep in 1 2 3; do
-    for v in base noahead chunk256 vc8; do
+    for v in $ORDER; do
       PGRC_MATCH_LIB=$PWD/$V/libpgrc_match_$v.so python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); p=d['phases_ms']; print('$v', round(d['ms_per_step'],1), round(p['match_fwd'],1), round(p['match_rc'],1), d['counters']['verifies'])"
     done
