@@ -197,7 +197,7 @@ def main():
                          "kernel_ms": ms, "algorithmic_bytes": alg_bytes,
                          "kernel_bytes": kernel_bytes, "achieved_kernel_bytes": kernel_gbs,
                          "frac_kernel_bytes": kernel_gbs / HBM_PEAK_GBS,
-                         "limiter": "random 64-B line requests (one per bucket head / entry pair / text window)",
+                         "limiter": "random accesses (one per bucket head / entry pair / text window): each costs a 64-B line request and an address translation; the chip serves ~48 G lines/s and the UTCL2s ~43 G translations/s (DESIGN.md 9)",
                          "random_gathers": gathers, "gather_rate_G_per_s": gather_rate,
                          "gather_ceiling_G_per_s": GATHER_CEILING_GPS, "gather_frac": gather_rate / GATHER_CEILING_GPS},
             "phases_ms": {"index_fwd": ctr["ms_index"][0], "match_fwd": ctr["ms_match"][0], "index_rc": ctr["ms_index"][1],

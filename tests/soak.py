@@ -51,7 +51,9 @@ def main():
         # modes d / i / e: small text segments and read batches now and then (the loops a >= 4 Gi text / >= 2^28 reads take)
         seg = str(int(rng.integers(4096, 40000))) if mode != "c" and rng.random() < 0.4 else ""
         batch = str(int(rng.integers(1, 1500))) if mode != "c" and rng.random() < 0.4 else ""
-        for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish), ("PGRC_SEED_SEGMENT", seg), ("PGRC_SEED_READ_BATCH", batch)):
+        stage = "0" if rng.random() < 0.2 else ""        # the match kernel without staged refills
+        for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish), ("PGRC_SEED_SEGMENT", seg), ("PGRC_SEED_READ_BATCH", batch),
+                         ("PGRC_MATCH_STAGE", stage)):
             if val:
                 os.environ[key] = val
             else:
@@ -59,7 +61,7 @@ def main():
         g = gpu_match(mode, pg, reads, seed_len, kmax, kmin, rev, devices=[0] * shards if shards else None,
                       n_nset=nn if packed else None)
         what = dict(mode=mode, L=L, seed_len=seed_len, M=M, kmin=kmin, G=G, n=n, nn=nn, rev=rev, seed=seed, shards=shards,
-                    packed=packed, variant=variant, finish=finish, seg=seg, batch=batch)
+                    packed=packed, variant=variant, finish=finish, seg=seg, batch=batch, stage=stage)
         for k in ("pos", "rc", "mism", "hist"):
             if not np.array_equal(np.asarray(g[k]), np.asarray(o[k])):
                 print("READS MISMATCH", what, k, flush=True)

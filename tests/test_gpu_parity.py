@@ -158,6 +158,19 @@ def test_copmem_forward_only_and_ragged_sizes():
         assert_same_results(g, o, f"n={n}")
 
 
+@pytest.mark.parametrize("stage", ["", "0"])
+def test_copmem_staged_refills_window_edges(monkeypatch, stage):
+    """The match kernel hands out reads from a 32-read window staged in LDS per wave (1024-read chunks): read counts
+    around both sizes, reads with N inside the windows, both passes; PGRC_MATCH_STAGE=0 is the unstaged path."""
+    if stage:
+        monkeypatch.setenv("PGRC_MATCH_STAGE", stage)
+    for n, nn in ((31, 0), (32, 3), (33, 0), (1023, 40), (1024, 0), (1025, 1), (2080, 0), (70001, 900)):
+        pg, reads = make_inputs(120000, n, 100, seed=900 + n, n_with_n=nn)
+        o = orc.oracle_match("c", pg, reads, 38, 33, 0)
+        g = gpu_match("c", pg, reads, 38, 33, 0)
+        assert_same_results(g, o, f"n={n} nn={nn} stage={stage!r}")
+
+
 def test_copmem_reads_hanging_over_pg_ends_and_repeats():
     pg, reads = make_inputs(60000, 4000, 100, seed=5, pool_div=64)
     # reads that overlap the Pg ends: their seeds hit but the window is rejected (:517-520)
