@@ -48,16 +48,18 @@ static double rate(const void *tab, size_t bytes) {
 int main(int argc, char **argv) {
     const size_t bytes = (size_t)((argc > 1 ? atof(argv[1]) : 8.6) * (1ull << 30)) & ~((size_t)(2u << 20) - 1);
     const int ntab = argc > 2 ? atoi(argv[2]) : 8;
+    const bool contig = argc > 3 && argv[3][0] == 'c';   // physically contiguous tables (hipDeviceMallocContiguous)
     hipMalloc(&g_out, 64);
     printf("table bytes %zu\n", bytes);
     // some unrelated allocations first, as a real process has (text, reads)
     void *pre1, *pre2;
     hipMalloc(&pre1, 800ull << 20); hipMalloc(&pre2, 4ull << 30);
-    printf("-- hipMalloc, one after another (all kept)\n");
+    printf("-- %s, one after another (all kept)\n", contig ? "hipExtMallocWithFlags(contiguous)" : "hipMalloc");
     std::vector<void *> tabs;
     for (int i = 0; i < ntab; i++) {
         void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) { printf("alloc %d failed\n", i); break; }
+        const hipError_t ae = contig ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous) : hipMalloc(&p, bytes);
+        if (ae != hipSuccess) { printf("alloc %d failed: %s\n", i, hipGetErrorString(ae)); (void)hipGetLastError(); break; }
         hipMemset(p, 0, bytes);
         tabs.push_back(p);
         // an allocate/free pair in between, as the index build's sort buffers are
