@@ -218,6 +218,18 @@ void pgrc_or_index_free(pgrc_or_index *idx) {
     idx->positions = NULL;
 }
 
+/* Test switch, off by default (= the reference's loops).  On: the per-read query stops as soon as the HIP kernel's
+ * early-stop rule says that nothing can be accepted any more (pgrc_amd/csrc/copmem.hip, "Early stop"): a check of that
+ * rule itself -- tests/test_early_stop_rule.py runs this restatement both ways and expects identical results. */
+static int g_early_stop = 0;
+static uint64_t g_probes = 0;
+void pgrc_or_set_early_stop(int on) { g_early_stop = on; }
+uint64_t pgrc_or_probe_count(int reset) {
+    uint64_t v = __atomic_load_n(&g_probes, __ATOMIC_RELAXED);
+    if (reset) __atomic_store_n(&g_probes, 0, __ATOMIC_RELAXED);
+    return v;
+}
+
 /* CopMEMMatcher.cpp:483-566 (processApproxMatchQueryTight) */
 uint64_t pgrc_or_copmem_match_read(const pgrc_or_index *idx, const char *pg, const char *read,
                                    uint32_t read_len, uint8_t kmax, uint8_t kmin, uint8_t *cnt,
@@ -231,10 +243,22 @@ uint64_t pgrc_or_copmem_match_read(const pgrc_or_index *idx, const char *pg, con
     const uint64_t budget = (uint64_t)((read_len + 1 - (uint32_t)K) / (uint32_t)k2); /* :496-498 */
     uint64_t falses = 0, cands = 0;
     uint64_t best = PGRC_OR_NOT_MATCHED_POS;
+    /* early-stop bookkeeping (only read when g_early_stop is set) */
+    const uint32_t k1 = (uint32_t)idx->p.k1;
+    const uint32_t rper = ((uint32_t)K + k1 * (uint32_t)k2 - 1) / (k1 * (uint32_t)k2) * k1;
+    uint32_t rq = 0, rclean = 0, probes = 0;
+    int rdirty = 0;
     for (uint32_t s = 0; s + (uint32_t)K < read_len + 1; s += (uint32_t)k2) { /* :503 */
+        if (s) { /* the previous seed is done */
+            if (rq == k1 - 1) { rclean += rdirty ? 0 : 1; rdirty = 0; }
+            rq = (rq + 1 == rper) ? 0 : rq + 1;
+            if (g_early_stop && rclean > limit) break;
+        }
+        probes++;
         uint32_t h = pgrc_or_copmem_hash(K, read + s) & mask;
         uint32_t lo = idx->cumm[h], hi = idx->cumm[h + 1];
         if (lo == hi) continue;
+        if (rq < k1 && (hi - lo >= PGRC_OR_BUCKET_CAP || (budget < falses && hi > lo + PGRC_OR_TRUNC_BUCKET))) rdirty = 1;
         if (budget < falses && hi > lo + PGRC_OR_TRUNC_BUCKET) hi = lo + PGRC_OR_TRUNC_BUCKET; /* :510-514 */
         for (uint32_t j = lo; j < hi; j++) {
             uint64_t sp = idx->positions[j];
@@ -257,6 +281,7 @@ uint64_t pgrc_or_copmem_match_read(const pgrc_or_index *idx, const char *pg, con
             if (m <= kmin) { /* :556-559 */
                 if (falses_out) *falses_out += falses;
                 if (cand_out) *cand_out += cands;
+                __atomic_fetch_add(&g_probes, probes, __ATOMIC_RELAXED);
                 return best;
             }
             limit = (uint8_t)(m - 1);                       /* :560 */
@@ -264,6 +289,7 @@ uint64_t pgrc_or_copmem_match_read(const pgrc_or_index *idx, const char *pg, con
     }
     if (falses_out) *falses_out += falses;
     if (cand_out) *cand_out += cands;
+    __atomic_fetch_add(&g_probes, probes, __ATOMIC_RELAXED);
     return best;
 }
 

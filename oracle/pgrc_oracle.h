@@ -70,6 +70,10 @@ void pgrc_or_index_free(pgrc_or_index *idx);
  * 255 = unmatched).  Returns the match position in the indexed text or
  * PGRC_OR_NOT_MATCHED_POS.  *falses receives this read's false-candidate
  * count (currentFalseMatchCount, incl. the double-counted tail rejects). */
+/* test switch (default 0 = the reference's loops): stop a read once the HIP kernel's early-stop rule holds; and the
+ * number of seed probes executed since the last reset */
+void pgrc_or_set_early_stop(int on);
+uint64_t pgrc_or_probe_count(int reset);
 uint64_t pgrc_or_copmem_match_read(const pgrc_or_index *idx, const char *pg, const char *read,
                                    uint32_t read_len, uint8_t kmax, uint8_t kmin, uint8_t *cnt,
                                    uint64_t *falses, uint64_t *candidates);

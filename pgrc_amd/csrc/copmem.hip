@@ -280,6 +280,7 @@ struct MatchArgs {
     unsigned long long *counters; // [0] searched [1] candidates [2] probes
     unsigned long long *work;     // global read cursor of the persistent match kernel
     uint32_t L, K, k2, mask, kmax, kmin, strand;
+    uint32_t k1, early;           // sampling step of the index; early = 1: stop a read once nothing can be accepted any more
 };
 
 #define MATCH_TPB 256
@@ -357,6 +358,20 @@ __device__ __forceinline__ uint32_t hash_fp_window(const uint32_t w0, const uint
 // next one of its wave's chunk (ranks by ballot/popcount, no atomics; a wave reserves MATCH_CHUNK reads at a time
 // from one global counter), so every resident lane always has a gather in flight until the read set is
 // exhausted.  The per-read sequence of events is untouched.
+// Early stop (round 2).  The reference probes every seed of a read even when nothing can be accepted any more; the
+// result is the same if the read stops there, and when that is can be proven from what the probes have seen.  The index
+// samples every k1-th text position and the read is probed every k2-th symbol (coprime), so an alignment at text
+// position p is found through exactly the seeds s with (p + s) % k1 == 0, and k1 consecutive seeds hold one seed of
+// every such class.  Call k1 consecutive probes a ROUND, start one every rper = ceil(K / (k1 k2)) k1 seeds (the windows
+// of one class in two rounds are then >= K symbols apart: disjoint), and call a round CLEAN if every one of its buckets
+// was complete: fewer than 13 entries (nothing dropped by the cap at build time, CopMEMMatcher.cpp:156-159) and not cut
+// to 4 by the falses budget (:510-514).  An alignment with m mismatches leaves at least one of any m + 1 disjoint
+// windows of its class untouched; that window hashes to the bucket holding p + s, so in a clean round the alignment is
+// LOOKED AT -- and accepted if m <= limit at that time (the fingerprint filter and the verify cache are exact).  Limits
+// only fall, and an accepted alignment with m mismatches lowers the limit to m - 1.  Hence: after rclean clean rounds
+// no alignment with <= rclean - 1 mismatches exists that has not been accepted, and once rclean > limit no later
+// candidate can pass `m <= limit`: (cur, best) are final.  Unmatched 150-bp reads at k <= 3 stop after seed 50 of 62,
+// a read waiting for an exact match (limit 0) after 5 seeds.  PGRC_EARLY_STOP=0 restores the full loops.
 // POS64: text positions need more than 32 bits (Pg >= 4 Gi symbols: the reference's u64 index branch,
 // CopMEMMatcher.cpp:579-586); otherwise positions are kept in one register.
 template <int NW, int KQ, bool POS64, int STAGE = 0>
@@ -401,6 +416,10 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
     uint32_t cin = 0, epoch = 0;
     uint32_t cnext = 0, cend = 0; // this wave's reserved range of reads (wave-uniform: kept in SGPRs)
     uint32_t si = 0;              // seed index: s = si * k2
+    // Early stop (exact, see the comment at the kernel): rounds of k1 consecutive seeds, a round every rper seeds
+    const uint32_t rper = (a.K + a.k1 * a.k2 - 1u) / (a.k1 * a.k2) * a.k1;
+    uint32_t rq = 0, rclean = 0;  // seed index inside the current period; rounds whose probes all saw complete buckets
+    bool rdirty = false;          // the current round had a capped or truncated bucket
     pos_t lo = 0;          // index into ent[] (as many entries as sampled positions: 32 bits unless POS64)
     uint32_t nb = 0, j = 0, fp_read = 0;
     pos_t cand_p = 0;
@@ -471,6 +490,9 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
                         st.best = POS_NONE;
                         st.done = false;
                         si = 0;
+                        rq = 0;
+                        rclean = 0;
+                        rdirty = false;
                         has_pend = false;
 #if PROBE_AHEAD
                         have_n = false;
@@ -581,6 +603,8 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
             }
             nb = cnt;
             if (st.falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET); // :510-514
+            // not every sampled position with this hash is looked at: the bucket was capped at build time or is cut here
+            if (rq < a.k1 && (cnt >= PGRC_BUCKET_CAP || nb < cnt)) rdirty = true;
             has_pend = cnt == 2 && nb > 1; // entry 1 of a two-entry bucket sits in the head
             pend_e = hx.y;
             lo = (pos_t)(hx.y & W1_BASE_MASK); // count >= 3: entries 1.. live at ent[lo + j - 1]
@@ -590,6 +614,11 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
         auto advance = [&]() {                                       // to the next seed of this read
             si++;
             has_pend = false;
+            if (rq == a.k1 - 1u) {                                   // a round is behind this read
+                rclean += rdirty ? 0u : 1u;
+                rdirty = false;
+            }
+            rq = (rq + 1u == rper) ? 0u : rq + 1u;
 #pragma unroll
             for (int k = 0; k < NW - 1; k++) sh[k] = funnel_r(sh[k], sh[k + 1], sbits);
             sh[NW - 1] >>= sbits;
@@ -626,9 +655,12 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
             if (got2) {
                 if (next == M_ADV) {                                 // empty bucket: the next seed's head is here already
                     advance();
-                    fp_read = fp2;
-                    second_probe = true;
-                    take_head(hd2);
+                    if (a.early && rclean > st.limit) next = M_NEED; // ... but nothing can be accepted any more
+                    else {
+                        fp_read = fp2;
+                        second_probe = true;
+                        take_head(hd2);
+                    }
                 } else {                                             // keep it for when this lane reaches that seed
                     hdn = hd2;
                     fpn = fp2;
@@ -639,7 +671,7 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
         }
         if (next == M_ADV) {
             advance();
-            next = (si < nseeds) ? M_PROBE : M_NEED;
+            next = (si < nseeds && !(a.early && rclean > st.limit)) ? M_PROBE : M_NEED;
         }
         // work counters, wave-wide (scalar popcounts instead of five per-lane registers)
         n_probe += (uint32_t)__popcll(__ballot(m0 == M_PROBE)) + (uint32_t)__popcll(__ballot(second_probe));
@@ -862,6 +894,11 @@ int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
     a.kmax = c->prm.max_mismatches;
     a.kmin = c->prm.min_mismatches;
     a.strand = (uint32_t)strand;
+    a.k1 = (uint32_t)c->cp.k1;
+    {
+        const char *es = getenv("PGRC_EARLY_STOP");       // 0: every read probes all its seeds (A/B runs, tests)
+        a.early = (es && es[0] == '0') ? 0u : 1u;
+    }
     // The reads with N (a percent or two, one lane each, latency-bound) start first on a side stream and run beside the
     // main kernel, whose persistent blocks simply take the remaining slots; the two kernels write disjoint reads.
     if (c->n_nreads) {

@@ -50,6 +50,9 @@ def oracle():
         lib.pgrc_or_copmem_match_read.argtypes = [C.POINTER(Index), _P, _P, C.c_uint32, C.c_uint8, C.c_uint8,
                                                   C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         lib.pgrc_or_copmem_match_read.restype = C.c_uint64
+        lib.pgrc_or_set_early_stop.argtypes = [C.c_int]
+        lib.pgrc_or_probe_count.argtypes = [C.c_int]
+        lib.pgrc_or_probe_count.restype = C.c_uint64
         lib.pgrc_or_match_copmem.argtypes = [_P, C.c_uint64, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint8,
                                              C.c_uint8, C.c_int, C.c_int, C.c_int, C.POINTER(Result)]
         lib.pgrc_or_match_seedindex.argtypes = [C.c_char, _P, C.c_uint64, _P, C.c_uint64, C.c_uint32, C.c_uint32,
@@ -123,8 +126,16 @@ def _pack_result(r, pos, rc, mism):
             "searched": list(r.searched), "candidates": list(r.candidates), "falses": list(r.falses)}
 
 
-def oracle_match(mode, pg, reads, seed_len, kmax, kmin, rev_compl=True, threads=8, state=None):
-    """mode in 'c','d','i','e'. pg: uint8[G] ASCII, reads: uint8[n, L] ASCII."""
+def oracle_match(mode, pg, reads, seed_len, kmax, kmin, rev_compl=True, threads=8, state=None, early_stop=False):
+    """mode in 'c','d','i','e'. pg: uint8[G] ASCII, reads: uint8[n, L] ASCII.
+    early_stop (mode c): the HIP kernel's early-stop rule instead of the reference's full loops -- same results, the
+    work counters (candidates) are then the kernel's."""
+    if early_stop:
+        oracle().pgrc_or_set_early_stop(1)
+        try:
+            return oracle_match(mode, pg, reads, seed_len, kmax, kmin, rev_compl, threads, state)
+        finally:
+            oracle().pgrc_or_set_early_stop(0)
     pg = np.ascontiguousarray(pg, dtype=np.uint8)
     reads = np.ascontiguousarray(reads, dtype=np.uint8)
     n, L = reads.shape

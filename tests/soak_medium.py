@@ -36,12 +36,14 @@ def main():
         shards = int(rng.integers(2, 5)) if rng.random() < 0.3 else 0
         variant = str(rng.choice(["", "", "own", "rocprim"]))
         finish = "general" if rng.random() < 0.25 else ""
-        for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish)):
+        early = "0" if rng.random() < 0.2 else ""        # the match kernel probing every seed of every read
+        stage = "0" if rng.random() < 0.2 else ""        # ... and without staged refills
+        for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish), ("PGRC_EARLY_STOP", early), ("PGRC_MATCH_STAGE", stage)):
             if val:
                 os.environ[key] = val
             else:
                 os.environ.pop(key, None)
-        what = dict(L=L, seed_len=seed_len, kmax=kmax, kmin=kmin, G=G, n=n, nn=nn, seed=seed, shards=shards, variant=variant, finish=finish)
+        what = dict(L=L, seed_len=seed_len, kmax=kmax, kmin=kmin, G=G, n=n, nn=nn, seed=seed, shards=shards, variant=variant, finish=finish, early=early, stage=stage)
         o = orc.oracle_match("c", pg, reads, seed_len, kmax, kmin, True, 16)
         g = gpu_match("c", pg, reads, seed_len, kmax, kmin, True, devices=[0] * shards if shards else None)
         for k in ("pos", "rc", "mism", "hist"):

@@ -1,6 +1,8 @@
 """Parity tests proper: the HIP path (through the C ABI) against the CPU oracle -- and against the
 real reference where oracle/_ref is present -- on the same seeded inputs.  Bit-exact: positions,
 RC flags, mismatch counts, histogram, matched count, index arrays, mismatch lists."""
+import os
+
 import numpy as np
 import pytest
 
@@ -143,7 +145,19 @@ def test_copmem_parity(L, seed_len, M, mode, G, n):
     assert_same_results(g, o, f"L={L} seed={seed_len} M={M} {mode}")
     ctr = g["ctx"].counters()
     assert ctr["searched"] == o["searched"]
-    assert ctr["candidates"] == o["candidates"]
+    # the kernel stops a read once nothing can be accepted any more: its work counters are those of the oracle run
+    # with the same rule (tests/test_early_stop_rule.py shows the rule changes no result) ...
+    oe = orc.oracle_match("c", pg, reads, seed_len, kmax, kmin, early_stop=True)
+    assert_same_results(oe, o, "early-stop rule")
+    assert ctr["candidates"] == oe["candidates"]
+    # ... and with the rule switched off, the reference's
+    os.environ["PGRC_EARLY_STOP"] = "0"
+    try:
+        g0 = gpu_match("c", pg, reads, seed_len, kmax, kmin)
+    finally:
+        del os.environ["PGRC_EARLY_STOP"]
+    assert_same_results(g0, o, "full loops")
+    assert g0["ctx"].counters()["candidates"] == o["candidates"]
     if orc.have_ref():
         r = orc.ref_match("c", pg, reads, seed_len, kmax, kmin)
         assert_same_results(g, r, "vs real reference")
