@@ -201,7 +201,10 @@ def main():
                          "random_gathers": gathers, "gather_rate_G_per_s": gather_rate,
                          "gather_ceiling_G_per_s": GATHER_CEILING_GPS, "gather_frac": gather_rate / GATHER_CEILING_GPS},
             "phases_ms": {"index_fwd": ctr["ms_index"][0], "match_fwd": ctr["ms_match"][0], "index_rc": ctr["ms_index"][1],
-                          "match_rc": ctr["ms_match"][1], "other": ctr["ms_other"], "total_device": ctr["ms_total"]},
+                          "match_rc": ctr["ms_match"][1], "other": ctr["ms_other"], "total_device": ctr["ms_total"],
+                          # the screened schedule: both indexes first, then an exact-match screen on the RC
+                          # text, the forward pass, the RC pass; "screen" is that first launch (0 when the run did not take it)
+                          "screen": ctr["ms_screen"], "screened_schedule": bool(ctr["screened"])},
             "dist_backend": args.dist_backend if world > 1 else None,
             "counters": {k: ctr[k] for k in ("searched", "candidates", "probes", "entry_fetches", "verifies", "index_entries")},
         }

@@ -226,6 +226,11 @@ typedef struct {
     float ms_other;
     float ms_total;
     float ms_allgather;     /* multi-device contexts: the last all-gather of the packed text (host clock) */
+    /* two-pass runs of mode c with min_mismatches == 0: 1 = the run took the screened schedule (both indexes first, an
+     * exact-match screen on the RC text, then the two passes); ms_screen = the screen launch, its probes / candidates /
+     * fetches are counted with strand 1 */
+    uint32_t screened;
+    float ms_screen;
 } pgrc_match_counters;
 /* enable per-kernel HIP-event timing + work counters for subsequent runs */
 int pgrc_match_set_profiling(pgrc_match_ctx *ctx, int enabled);

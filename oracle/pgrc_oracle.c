@@ -230,15 +230,19 @@ uint64_t pgrc_or_probe_count(int reset) {
     return v;
 }
 
-/* CopMEMMatcher.cpp:483-566 (processApproxMatchQueryTight) */
-uint64_t pgrc_or_copmem_match_read(const pgrc_or_index *idx, const char *pg, const char *read,
-                                   uint32_t read_len, uint8_t kmax, uint8_t kmin, uint8_t *cnt,
-                                   uint64_t *falses_out, uint64_t *cand_out) {
+/* CopMEMMatcher.cpp:483-566 (processApproxMatchQueryTight).  The two extras serve the restatement of the HIP path's
+ * schedule further down and are neutral otherwise: only_exact starts the query at limit 0, early applies the
+ * early-stop rule, *by_rule reports that the rule (not the end of the seed list) ended the query. */
+static uint64_t match_read_ex(const pgrc_or_index *idx, const char *pg, const char *read,
+                              uint32_t read_len, uint8_t kmax, uint8_t kmin, uint8_t *cnt,
+                              uint64_t *falses_out, uint64_t *cand_out, int only_exact, int early, int *by_rule) {
     const int K = idx->p.K, k2 = idx->p.k2;
     const uint32_t mask = idx->p.hash_size - 1;
     const uint64_t G = idx->pg_len;
     uint8_t limit = kmax;
     if (*cnt < kmax) limit = (uint8_t)(*cnt - 1); /* :488-489 */
+    if (only_exact) limit = 0;
+    if (by_rule) *by_rule = 0;
     const uint32_t head = (read_len / 8) * 8;      /* :495 */
     const uint64_t budget = (uint64_t)((read_len + 1 - (uint32_t)K) / (uint32_t)k2); /* :496-498 */
     uint64_t falses = 0, cands = 0;
@@ -252,7 +256,10 @@ uint64_t pgrc_or_copmem_match_read(const pgrc_or_index *idx, const char *pg, con
         if (s) { /* the previous seed is done */
             if (rq == k1 - 1) { rclean += rdirty ? 0 : 1; rdirty = 0; }
             rq = (rq + 1 == rper) ? 0 : rq + 1;
-            if (g_early_stop && rclean > limit) break;
+            if (early && rclean > limit) {
+                if (by_rule) *by_rule = 1;
+                break;
+            }
         }
         probes++;
         uint32_t h = pgrc_or_copmem_hash(K, read + s) & mask;
@@ -291,6 +298,12 @@ uint64_t pgrc_or_copmem_match_read(const pgrc_or_index *idx, const char *pg, con
     if (cand_out) *cand_out += cands;
     __atomic_fetch_add(&g_probes, probes, __ATOMIC_RELAXED);
     return best;
+}
+
+uint64_t pgrc_or_copmem_match_read(const pgrc_or_index *idx, const char *pg, const char *read,
+                                   uint32_t read_len, uint8_t kmax, uint8_t kmin, uint8_t *cnt,
+                                   uint64_t *falses_out, uint64_t *cand_out) {
+    return match_read_ex(idx, pg, read, read_len, kmax, kmin, cnt, falses_out, cand_out, 0, g_early_stop, NULL);
 }
 
 static void result_init(pgrc_or_result *res, uint64_t n, int with_counts) {
@@ -376,6 +389,107 @@ int pgrc_or_match_copmem(const char *pg, uint64_t pg_len, const char *reads, uin
     }
     free(rcpg);
     (void)threads;
+    return 0;
+}
+
+/* ---- The HIP path's SCHEDULE for a two-pass run, restated on the CPU (a test of that schedule, not of the reference:
+ * tests/test_early_stop_rule.py expects it to equal pgrc_or_match_copmem on every input).  With kmin == 0:
+ *   K1  every read not yet matched exactly is screened on the RC text for an EXACT alignment (limit 0, early stop: one
+ *       clean round); it is flagged if one is found and twice the false candidates seen stay within the falses budget
+ *       (so no run of the real query, whose false counts are at most twice as high, could have cut a bucket before);
+ *   K2  forward pass: a flagged read only looks for an exact forward alignment (which would win: the RC pass skips
+ *       reads matched exactly).  Found within the budget -> final.  Proven absent by the early-stop rule -> the RC
+ *       alignment of K1 is final (whatever the forward pass would have found is worse, and the RC pass would then reach
+ *       that same first exact alignment).  Anything else -> the real forward query.  Unflagged reads: the real query;
+ *   K3  the real RC pass over what is still not matched exactly. */
+int pgrc_or_match_copmem_screened(const char *pg, uint64_t pg_len, const char *reads, uint64_t n,
+                                  uint32_t read_len, uint32_t seed_len, uint8_t kmax, uint8_t kmin,
+                                  int threads, int init, pgrc_or_result *res) {
+    if (init) result_init(res, n, 1);
+    if (threads < 1) threads = 1;
+    char *rcpg = (char *)malloc(pg_len + 1);
+    if (!rcpg) return 3;
+    memcpy(rcpg, pg, pg_len);
+    rcpg[pg_len] = 0;
+    pgrc_or_revcomp(rcpg, pg_len);
+    pgrc_or_index idxF, idxR;
+    int e = pgrc_or_index_build(pg, pg_len, seed_len, &idxF);
+    if (e) { free(rcpg); return e; }
+    e = pgrc_or_index_build(rcpg, pg_len, seed_len, &idxR);
+    if (e) { pgrc_or_index_free(&idxF); free(rcpg); return e; }
+    const uint64_t budget = (uint64_t)((read_len + 1 - (uint32_t)idxF.p.K) / (uint32_t)idxF.p.k2);
+    uint8_t *flag = (uint8_t *)calloc(n ? n : 1, 1);
+    uint64_t *scr = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+    const int screen = kmin == 0;
+    uint64_t searched0 = 0, searched1 = 0, cands0 = 0, cands1 = 0;
+    /* K1 */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads) reduction(+ : cands1)
+#endif
+    for (int64_t ii = 0; ii < (int64_t)n; ii++) {
+        const uint64_t i = (uint64_t)ii;
+        if (!screen || res->mism[i] <= kmin) continue;
+        uint8_t c = res->mism[i];
+        uint64_t f = 0, cd = 0;
+        const uint64_t p = match_read_ex(&idxR, rcpg, reads + i * (uint64_t)read_len, read_len, kmax, kmin, &c, &f, &cd, 1, 1, NULL);
+        cands1 += cd;
+        if (p != PGRC_OR_NOT_MATCHED_POS && c == 0 && 2 * f <= budget) { flag[i] = 1; scr[i] = p; }
+    }
+    /* K2 */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads) reduction(+ : searched0, cands0)
+#endif
+    for (int64_t ii = 0; ii < (int64_t)n; ii++) {
+        const uint64_t i = (uint64_t)ii;
+        if (res->mism[i] <= kmin) continue;
+        searched0++;
+        const char *rd = reads + i * (uint64_t)read_len;
+        if (flag[i]) {
+            uint8_t c = res->mism[i];
+            uint64_t f = 0, cd = 0;
+            int by_rule = 0;
+            const uint64_t p = match_read_ex(&idxF, pg, rd, read_len, kmax, kmin, &c, &f, &cd, 1, 1, &by_rule);
+            cands0 += cd;
+            if (p != PGRC_OR_NOT_MATCHED_POS && c == 0 && 2 * f <= budget) {
+                res->pos[i] = p; res->rc[i] = 0; res->mism[i] = 0;
+                continue;
+            }
+            if (p == PGRC_OR_NOT_MATCHED_POS && by_rule) {
+                res->pos[i] = pg_len - (scr[i] + read_len); res->rc[i] = 1; res->mism[i] = 0;
+                continue;
+            }
+        }
+        uint8_t c = res->mism[i];
+        uint64_t f = 0, cd = 0;
+        const uint64_t p = match_read_ex(&idxF, pg, rd, read_len, kmax, kmin, &c, &f, &cd, 0, 1, NULL);
+        cands0 += cd;
+        if (p != PGRC_OR_NOT_MATCHED_POS && c < res->mism[i]) { res->pos[i] = p; res->rc[i] = 0; res->mism[i] = c; }
+    }
+    /* K3 */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads) reduction(+ : searched1, cands1)
+#endif
+    for (int64_t ii = 0; ii < (int64_t)n; ii++) {
+        const uint64_t i = (uint64_t)ii;
+        if (res->mism[i] <= kmin) continue;
+        searched1++;
+        uint8_t c = res->mism[i];
+        uint64_t f = 0, cd = 0;
+        const uint64_t p = match_read_ex(&idxR, rcpg, reads + i * (uint64_t)read_len, read_len, kmax, kmin, &c, &f, &cd, 0, 1, NULL);
+        cands1 += cd;
+        if (p != PGRC_OR_NOT_MATCHED_POS && c < res->mism[i]) { res->pos[i] = pg_len - (p + read_len); res->rc[i] = 1; res->mism[i] = c; }
+    }
+    memset(res->hist, 0, sizeof res->hist);
+    res->matched = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        res->hist[res->mism[i]]++;
+        res->matched += res->mism[i] != PGRC_OR_NOT_MATCHED_CNT;
+    }
+    res->searched[0] = searched0; res->searched[1] = searched1;
+    res->candidates[0] = cands0; res->candidates[1] = cands1;   /* [1] = K1 + K3 */
+    free(flag); free(scr); free(rcpg);
+    pgrc_or_index_free(&idxF);
+    pgrc_or_index_free(&idxR);
     return 0;
 }
 

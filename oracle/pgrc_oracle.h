@@ -102,6 +102,11 @@ typedef struct {
 int pgrc_or_match_copmem(const char *pg, uint64_t pg_len, const char *reads, uint64_t n,
                          uint32_t read_len, uint32_t seed_len, uint8_t kmax, uint8_t kmin,
                          int rev_compl_pg, int threads, int init, pgrc_or_result *res);
+/* the HIP path's schedule for a two-pass run (exact-match screen on the RC text first), restated: must equal
+ * pgrc_or_match_copmem(..., rev_compl_pg = 1, ...) on every input */
+int pgrc_or_match_copmem_screened(const char *pg, uint64_t pg_len, const char *reads, uint64_t n,
+                                  uint32_t read_len, uint32_t seed_len, uint8_t kmax, uint8_t kmin,
+                                  int threads, int init, pgrc_or_result *res);
 
 /* Modes 'e' (exact, ReadsMatchers.cpp:198-230), 'd' (:297-341), 'i' (:364-409)
  * over the read-side seed index (ConstantLengthPatternsOnTextHashMatcher.{h,cpp})

@@ -149,6 +149,7 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
     }
     DevBuf *bufs[] = {&c->pg2[0], &c->pg2[1], &c->reads_own, &c->nread_idx, &c->nread_ascii, &c->nread_flag, &c->d_pos,
                       &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_head, &c->d_skey[0], &c->d_skey[1], &c->d_sval[0], &c->d_sval[1], &c->d_sorttmp,
+                      &c->alt_head, &c->alt_skey[0], &c->alt_skey[1], &c->alt_sval[0], &c->alt_sval[1], &c->alt_sorttmp, &c->d_scr_pos, &c->d_scr_flag,
                       &c->s_keys, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp, &c->s_sorted, &c->s_sorttmp, &c->s_mm, &c->s_rstart, &c->s_heavy, &c->s_nmask};
     for (DevBuf *b : bufs) pgrc_buf_free(*b);
     for (DevBuf &b : c->up_nchunks) pgrc_buf_free(b);
@@ -495,6 +496,31 @@ int pgrc_match_set_results(pgrc_match_ctx *c, const uint64_t *pos, const uint8_t
     return PGRC_OK;
 }
 
+// the two sets of index buffers of the screened schedule swap roles
+static void swap_index_sets(pgrc_match_ctx *c) {
+    std::swap(c->d_head, c->alt_head);
+    for (int k = 0; k < 2; k++) {
+        std::swap(c->d_skey[k], c->alt_skey[k]);
+        std::swap(c->d_sval[k], c->alt_sval[k]);
+    }
+    std::swap(c->d_sorttmp, c->alt_sorttmp);
+    std::swap(c->ent_ptr, c->alt_ent_ptr);
+    std::swap(c->index_strand, c->alt_index_strand);
+}
+
+// Two-pass runs of mode c with min_mismatches == 0 take the screened schedule (copmem.hip, "Exact-match screen") unless
+// PGRC_SCREEN=0 or the second set of index buffers does not fit.
+static bool screen_wanted(const pgrc_match_ctx *c, int first, int last) {
+    if (c->prm.mode != 'c' || first != 0 || last != 1 || c->prm.min_mismatches != 0 || !c->n || c->screen_broken) return false;
+    const char *v = getenv("PGRC_SCREEN");     // 0: never, 1: whenever it applies; unset: where it pays
+    if (v && (v[0] == '0' || v[0] == '1')) return v[0] == '1';
+    // The screen is one more sweep over all reads (~5 probes each) and saves a read that matches the other strand exactly
+    // the forward query it would lose: with fewer than ~48 seeds per read (L = 100: 37) the two about cancel
+    // (profiles/r02_screen_ab.txt: C2 +2.6 %, C3 -12 %).
+    const uint32_t K = (uint32_t)c->cp.K, k2 = (uint32_t)c->cp.k2;
+    return k2 && c->prm.read_len >= K && (c->prm.read_len - K) / k2 + 1 >= 48u;
+}
+
 static int run_passes(pgrc_match_ctx *c, int first, int last) {
     if (!c) return PGRC_E_PARAM;
     if (c->multi) return pgrc_multi_run(c, first, last);
@@ -508,7 +534,53 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
     int evi = 0;
     auto mark = [&]() { if (prof) (void)hipEventRecord(c->ev[evi], c->stream); evi++; };
     mark(); // 0
-    if (c->prm.mode == 'c') {
+    bool screened = screen_wanted(c, first, last);
+    if (screened && ((e = pgrc_buf_ensure(c, c->d_scr_pos, c->n * sizeof(uint64_t))) || (e = pgrc_buf_ensure(c, c->d_scr_flag, c->n)))) {
+        if (e != PGRC_E_ALLOC) return e;
+        (void)hipGetLastError();
+        c->screen_broken = true;
+        screened = false;
+    }
+    if (screened) {
+        if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) return e;
+        c->have_rc = true;
+        mark(); // 1
+        if ((e = pgrc_copmem_build_index(c, 0))) return e;
+        mark(); // 2
+        swap_index_sets(c);
+        e = pgrc_copmem_build_index(c, 1);
+        if (e == PGRC_E_ALLOC) {
+            // no room for both indexes: free what the second set got, and run the passes in the reference's order
+            (void)hipGetLastError();
+            DevBuf *part[] = {&c->d_head, &c->d_skey[0], &c->d_skey[1], &c->d_sval[0], &c->d_sval[1], &c->d_sorttmp};
+            for (DevBuf *b : part) pgrc_buf_free(*b);
+            c->ent_ptr = nullptr;
+            c->index_strand = -1;
+            swap_index_sets(c);
+            c->screen_broken = true;
+            screened = false;
+            mark(); // 3
+            if ((e = pgrc_copmem_match_pass(c, 0))) return e;
+            mark(); // 4
+            if ((e = pgrc_copmem_build_index(c, 1))) return e;
+            mark(); // 5
+            if ((e = pgrc_copmem_match_pass(c, 1))) return e;
+            mark(); // 6
+            first = 2;  // (event layout: see the timing below)
+        } else {
+            if (e) return e;
+            mark(); // 3
+            HIP_TRY(c, hipMemsetAsync(c->d_scr_flag.p, 0, c->n, c->stream));
+            if ((e = pgrc_copmem_match_phase(c, 1, 1))) return e;          // screen on the RC text
+            mark(); // 4
+            swap_index_sets(c);
+            if ((e = pgrc_copmem_match_phase(c, 0, 2))) return e;          // forward pass honouring the flags
+            mark(); // 5
+            swap_index_sets(c);
+            if ((e = pgrc_copmem_match_phase(c, 1, 0))) return e;          // RC pass over what is left
+            mark(); // 6
+        }
+    } else if (c->prm.mode == 'c') {
         for (int pass = first; pass <= last; pass++) {
             if (pass == 1) {
                 // PgHelpers::reverseComplementInPlace(pgPtr), ReadsMatchers.cpp:168 -- rebuilt every run like the reference
@@ -528,6 +600,8 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
     mark();
     uint64_t ctr[16];
     HIP_TRY(c, hipMemcpy(ctr, c->d_counters.p, sizeof ctr, hipMemcpyDeviceToHost));
+    uint64_t scr[8];
+    HIP_TRY(c, hipMemcpy(scr, (const uint64_t *)c->d_counters.p + 24, sizeof scr, hipMemcpyDeviceToHost));
     for (int s = 0; s < 2 && c->prm.mode == 'c'; s++) {      // (modes d/i/e: pgrc_seedidx_run filled searched / candidates)
         c->ctr.searched[s] = ctr[8 * s + 0];
         c->ctr.candidates[s] = ctr[8 * s + 1];
@@ -535,10 +609,32 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
         c->ctr.entry_fetches[s] = ctr[8 * s + 3];
         c->ctr.verifies[s] = ctr[8 * s + 4];
     }
+    if (screened) {                  // the screen ran on the RC text: its work counts with that strand's (not "searched")
+        c->ctr.candidates[1] += scr[1];
+        c->ctr.probes[1] += scr[2];
+        c->ctr.entry_fetches[1] += scr[3];
+        c->ctr.verifies[1] += scr[4];
+        c->ctr.screened = 1;
+    }
     if (prof) {
         HIP_TRY(c, hipEventSynchronize(c->ev[evi - 1]));
         float ms = 0;
-        if (c->prm.mode == 'c') {
+        if (c->prm.mode == 'c' && (screened || first == 2)) {
+            // events: 1 start of the forward index, 2 its end; then (screened) RC index, screen, forward match, RC match
+            //         or (fallback) forward match, RC index, RC match
+            auto span = [&](int x, int y) { float t = 0; (void)hipEventElapsedTime(&t, c->ev[x], c->ev[y]); return t; };
+            c->ctr.ms_index[0] = span(1, 2);
+            if (screened) {
+                c->ctr.ms_index[1] = span(2, 3);
+                c->ctr.ms_screen = span(3, 4);
+                c->ctr.ms_match[0] = span(4, 5);
+                c->ctr.ms_match[1] = span(5, 6);
+            } else {
+                c->ctr.ms_match[0] = span(3, 4);
+                c->ctr.ms_index[1] = span(4, 5);
+                c->ctr.ms_match[1] = span(5, 6);
+            }
+        } else if (c->prm.mode == 'c') {
             int b = 1;
             for (int pass = first; pass <= last; pass++, b += 3) {
                 (void)hipEventElapsedTime(&ms, c->ev[b], c->ev[b + 1]);
@@ -549,7 +645,7 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
         }
         (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[evi - 1]);
         c->ctr.ms_total = ms;
-        c->ctr.ms_other = ms - c->ctr.ms_index[0] - c->ctr.ms_index[1] - c->ctr.ms_match[0] - c->ctr.ms_match[1];
+        c->ctr.ms_other = ms - c->ctr.ms_index[0] - c->ctr.ms_index[1] - c->ctr.ms_match[0] - c->ctr.ms_match[1] - c->ctr.ms_screen;
     }
     return PGRC_OK;
 }

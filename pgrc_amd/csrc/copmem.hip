@@ -281,6 +281,11 @@ struct MatchArgs {
     unsigned long long *work;     // global read cursor of the persistent match kernel
     uint32_t L, K, k2, mask, kmax, kmin, strand;
     uint32_t k1, early;           // sampling step of the index; early = 1: stop a read once nothing can be accepted any more
+    // the screened schedule of a two-pass run (see "Exact-match screen" at the kernel): phase 0 = a plain pass,
+    // 1 = screen (RC text, exact alignments only, flags and positions to scr_*), 2 = forward pass that honours the flags
+    uint32_t phase;
+    uint64_t *scr_pos;
+    uint8_t *scr_flag;
 };
 
 #define MATCH_TPB 256
@@ -372,6 +377,20 @@ __device__ __forceinline__ uint32_t hash_fp_window(const uint32_t w0, const uint
 // no alignment with <= rclean - 1 mismatches exists that has not been accepted, and once rclean > limit no later
 // candidate can pass `m <= limit`: (cur, best) are final.  Unmatched 150-bp reads at k <= 3 stop after seed 50 of 62,
 // a read waiting for an exact match (limit 0) after 5 seeds.  PGRC_EARLY_STOP=0 restores the full loops.
+// Exact-match screen (round 2).  In a two-pass run a read that matches the OTHER strand exactly still pays a whole
+// forward query to learn that the forward strand has nothing better.  With both indexes alive the run is scheduled as
+//   phase 1  every read not yet matched exactly looks on the RC text for an EXACT alignment only (limit 0: one clean
+//            round); found, and twice its false-candidate count within the falses budget -> flagged, position kept.
+//            (A query at a higher limit counts at most twice as many falses over the same candidates, so no run of the
+//            real RC query could have cut a bucket before reaching that alignment: it would accept the same one.)
+//   phase 2  the forward pass; a flagged read again looks for an exact alignment only.  Found within the budget: final
+//            (the real forward query reaches the same alignment, and the RC pass skips exactly matched reads).  Proven
+//            absent by the early-stop rule: whatever the real forward query finds has >= 1 mismatch, the real RC query
+//            then returns phase 1's alignment: written as the final result here.  Otherwise (budget exceeded, no clean
+//            round) the lane simply starts the read again as a real query.  Unflagged reads: the real query.
+//   phase 0  (RC pass) unchanged: reads matched exactly are skipped.
+// Only with min_mismatches == 0.  oracle/pgrc_oracle.c restates this schedule (pgrc_or_match_copmem_screened) and
+// tests/test_early_stop_rule.py expects it to equal the reference's two passes on every input.
 // POS64: text positions need more than 32 bits (Pg >= 4 Gi symbols: the reference's u64 index branch,
 // CopMEMMatcher.cpp:579-586); otherwise positions are kept in one register.
 template <int NW, int KQ, bool POS64, int STAGE = 0>
@@ -420,6 +439,7 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
     const uint32_t rper = (a.K + a.k1 * a.k2 - 1u) / (a.k1 * a.k2) * a.k1;
     uint32_t rq = 0, rclean = 0;  // seed index inside the current period; rounds whose probes all saw complete buckets
     bool rdirty = false;          // the current round had a capped or truncated bucket
+    bool spec = false;            // this read only looks for an exact alignment (phases 1 and 2 of the screened schedule)
     pos_t lo = 0;          // index into ent[] (as many entries as sampled positions: 32 bits unless POS64)
     uint32_t nb = 0, j = 0, fp_read = 0;
     pos_t cand_p = 0;
@@ -464,7 +484,7 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
 #pragma unroll
                     for (int k = 0; k < NW; k++) stg[wv][k][lane] = a.reads[(uint64_t)k * a.stride + wbeg + lane];
                     stg_c[wv][lane] = a.mism[wbeg + lane];
-                    stg_f[wv][lane] = a.nflag ? a.nflag[wbeg + lane] : (uint8_t)0;
+                    stg_f[wv][lane] = (uint8_t)((a.nflag ? a.nflag[wbeg + lane] : 0) | (a.phase == 2u ? (a.scr_flag[wbeg + lane] & 1u) << 1 : 0u));
                 }
                 __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // a wave's LDS accesses are served in order
             }
@@ -479,12 +499,15 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
                     const uint32_t sj = wnext - wbeg + rank;
                     idx = STAGE > 0 ? wbeg + sj : cnext + rank;
                     cin = STAGE > 0 ? stg_c[wv][sj] : a.mism[idx];
-                    const bool skip = (STAGE > 0 ? stg_f[wv][sj] != 0 : (a.nflag && a.nflag[idx])) || cin <= a.kmin; // ReadsMatchers.cpp:430; 'N' reads: byte path
+                    const uint32_t rflags = STAGE > 0 ? (uint32_t)stg_f[wv][sj]
+                                                      : (uint32_t)((a.nflag ? a.nflag[idx] : 0) | (a.phase == 2u ? (a.scr_flag[idx] & 1u) << 1 : 0u));
+                    const bool skip = (rflags & 1u) || cin <= a.kmin; // ReadsMatchers.cpp:430; 'N' reads: byte path
                     if (!skip) {
 #pragma unroll
                         for (int k = 0; k < NW; k++)
                             rd_lds[k][threadIdx.x] = sh[k] = STAGE > 0 ? stg[wv][k][sj] : a.reads[(uint64_t)k * a.stride + idx];
-                        st.limit = (cin < a.kmax) ? cin - 1u : a.kmax;   // :488-489
+                        spec = a.phase == 1u || (rflags & 2u);           // exact alignments only (the screened schedule)
+                        st.limit = spec ? 0u : (cin < a.kmax) ? cin - 1u : a.kmax;   // :488-489
                         st.falses = 0;
                         st.cur = cin;
                         st.best = POS_NONE;
@@ -624,6 +647,7 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
             sh[NW - 1] >>= sbits;
         };
         bool second_probe = false;
+        bool ended_rule = false;      // the early-stop rule (not the end of the seed list) ends this read in this iteration
         if (m0 == M_VERIFY) {
             uint32_t pw[PWN];
             const uint32_t b = ((uint32_t)cand_p & 15u) * 2u;
@@ -655,8 +679,10 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
             if (got2) {
                 if (next == M_ADV) {                                 // empty bucket: the next seed's head is here already
                     advance();
-                    if (a.early && rclean > st.limit) next = M_NEED; // ... but nothing can be accepted any more
-                    else {
+                    if (a.early && rclean > st.limit) {              // ... but nothing can be accepted any more
+                        next = M_NEED;
+                        ended_rule = true;
+                    } else {
                         fp_read = fp2;
                         second_probe = true;
                         take_head(hd2);
@@ -671,7 +697,8 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
         }
         if (next == M_ADV) {
             advance();
-            next = (si < nseeds && !(a.early && rclean > st.limit)) ? M_PROBE : M_NEED;
+            ended_rule = a.early && rclean > st.limit;
+            next = (si < nseeds && !ended_rule) ? M_PROBE : M_NEED;
         }
         // work counters, wave-wide (scalar popcounts instead of five per-lane registers)
         n_probe += (uint32_t)__popcll(__ballot(m0 == M_PROBE)) + (uint32_t)__popcll(__ballot(second_probe));
@@ -679,8 +706,42 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
         n_ver += (uint32_t)__popcll(__ballot(m0 == M_VERIFY));
         n_cand += (uint32_t)__popcll(__ballot(ncand_it >= 1)) + (uint32_t)__popcll(__ballot(ncand_it >= 2));
         if (next == M_NEED && m0 <= M_VERIFY) {
-            // this read is finished (ReadsMatchers.cpp:437-447)
-            if (st.best != POS_NONE && st.cur < cin) {
+            if (spec) {
+                // the screened schedule: an exact alignment, found with so few false candidates that no real query
+                // could have cut a bucket on its way to it?
+                const bool exact = st.done && st.cur == 0u && 2u * st.falses <= budget;
+                if (a.phase == 1u) {
+                    a.scr_flag[idx] = exact ? (uint8_t)1 : (uint8_t)0;
+                    if (exact) a.scr_pos[idx] = (uint64_t)st.best;
+                } else if (exact) {                                  // forward exact: final
+                    a.pos[idx] = (uint64_t)st.best;
+                    a.rc[idx] = 0;
+                    a.mism[idx] = 0;
+                } else if (!st.done && ended_rule) {                 // no forward exact exists: phase 1's RC alignment is final
+                    a.pos[idx] = a.G - (a.scr_pos[idx] + a.L);
+                    a.rc[idx] = 1;
+                    a.mism[idx] = 0;
+                } else {                                             // undecided: the real query, from the first seed
+                    spec = false;
+                    st.limit = (cin < a.kmax) ? cin - 1u : a.kmax;
+                    st.falses = 0;
+                    st.cur = cin;
+                    st.best = POS_NONE;
+                    st.done = false;
+                    si = 0;
+                    rq = 0;
+                    rclean = 0;
+                    rdirty = false;
+                    has_pend = false;
+#if PROBE_AHEAD
+                    have_n = false;
+#endif
+#pragma unroll
+                    for (int k = 0; k < NW; k++) sh[k] = rd_lds[k][threadIdx.x];
+                    next = M_PROBE;
+                }
+            } else if (st.best != POS_NONE && st.cur < cin) {
+                // this read is finished (ReadsMatchers.cpp:437-447)
                 a.pos[idx] = a.strand ? a.G - ((uint64_t)st.best + a.L) : (uint64_t)st.best;
                 a.rc[idx] = (uint8_t)a.strand;
                 a.mism[idx] = (uint8_t)st.cur;
@@ -871,7 +932,10 @@ static void launch_match(pgrc_match_ctx *c, const MatchArgs &a) {
 #undef PGRC_LAUNCH_MATCH
 }
 
-int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
+int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) { return pgrc_copmem_match_phase(c, strand, 0); }
+
+// phase: 0 = a plain pass; 1 / 2 = the screen and the flag-honouring forward pass of the screened schedule (kernel comment)
+int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase) {
     if (c->n == 0) return PGRC_OK;
     MatchArgs a;
     a.pg = (const uint32_t *)c->pg2[strand].p;
@@ -885,8 +949,12 @@ int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
     a.pos = (uint64_t *)c->d_pos.p;
     a.rc = (uint8_t *)c->d_rc.p;
     a.mism = (uint8_t *)c->d_mism.p;
-    a.counters = (unsigned long long *)c->d_counters.p + 8 * strand;
-    a.work = (unsigned long long *)c->d_counters.p + 16 + strand;
+    a.counters = (unsigned long long *)c->d_counters.p + (phase == 1 ? 24 : 8 * strand);   // the screen counts apart
+    a.work = (unsigned long long *)c->d_counters.p + (phase == 1 ? 18 : 16 + strand);
+    a.phase = (uint32_t)phase;
+    a.scr_pos = (uint64_t *)c->d_scr_pos.p;
+    a.scr_flag = (uint8_t *)c->d_scr_flag.p;
+    if (phase && (!a.scr_pos || !a.scr_flag)) { c->err = "screened schedule without its buffers"; return PGRC_E_STATE; }
     a.L = c->prm.read_len;
     a.K = (uint32_t)c->cp.K;
     a.k2 = (uint32_t)c->cp.k2;
@@ -901,7 +969,8 @@ int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
     }
     // The reads with N (a percent or two, one lane each, latency-bound) start first on a side stream and run beside the
     // main kernel, whose persistent blocks simply take the remaining slots; the two kernels write disjoint reads.
-    if (c->n_nreads) {
+    const bool with_n = c->n_nreads && phase != 1;   // (the screen only flags reads; reads with N are never flagged)
+    if (with_n) {
         if (!c->side_stream) {   // stream and both events, or nothing
             hipStream_t st = nullptr;
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -937,6 +1006,6 @@ int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) {
         return PGRC_E_PARAM;
     }
     HIP_TRY(c, hipGetLastError());
-    if (c->n_nreads) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_ev[1], 0));   // the pass ends when both kernels have
+    if (with_n) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_ev[1], 0));   // the pass ends when both kernels have
     return PGRC_OK;
 }

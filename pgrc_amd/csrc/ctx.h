@@ -84,6 +84,13 @@ struct pgrc_match_ctx {
     DevBuf d_skey[2], d_sval[2], d_sorttmp; // (bucket, entry) records: radix sort ping-pong + rocPRIM scratch (grow-only)
     const uint64_t *ent_ptr = nullptr;  // the sorted entries (one of d_sval[]): ent[] of the match kernel
     int index_strand = -1;  // which strand the buffers currently describe
+    // the screened schedule of a two-pass run (copmem.hip, "Exact-match screen") keeps both strands' indexes: a second
+    // set of index buffers that swaps roles with the first, and per read the flag / position the screen found
+    DevBuf alt_head, alt_skey[2], alt_sval[2], alt_sorttmp;
+    const uint64_t *alt_ent_ptr = nullptr;
+    int alt_index_strand = -1;
+    DevBuf d_scr_pos, d_scr_flag;
+    bool screen_broken = false;         // no room for the second set: the passes run as the reference orders them
 
     // read-side seed index (modes d / i / e)
     DevBuf s_keys, s_vals, s_tab, s_hits, s_tmp;
@@ -186,6 +193,7 @@ bool pgrc_ps_applicable(const pgrc_match_ctx *c, uint32_t hbits);
 int pgrc_ps_scatter_front(pgrc_match_ctx *c, int strand, uint32_t hbits, uint32_t cb);
 int pgrc_ps_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uint64_t *d_vals, uint32_t hbits, uint32_t cb, uint64_t *d_ent);
 int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand);
+int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase);
 int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_positions, uint64_t *count);
 
 // seedidx.hip (modes d / i / e)

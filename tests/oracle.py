@@ -51,6 +51,8 @@ def oracle():
                                                   C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         lib.pgrc_or_copmem_match_read.restype = C.c_uint64
         lib.pgrc_or_set_early_stop.argtypes = [C.c_int]
+        lib.pgrc_or_match_copmem_screened.argtypes = [_P, C.c_uint64, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint8,
+                                                      C.c_uint8, C.c_int, C.c_int, C.POINTER(Result)]
         lib.pgrc_or_probe_count.argtypes = [C.c_int]
         lib.pgrc_or_probe_count.restype = C.c_uint64
         lib.pgrc_or_match_copmem.argtypes = [_P, C.c_uint64, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint8,
@@ -152,6 +154,22 @@ def oracle_match(mode, pg, reads, seed_len, kmax, kmin, rev_compl=True, threads=
     else:
         e = oracle().pgrc_or_match_seedindex(mode.encode(), _ptr(pg), pg.size, _ptr(reads), n, L, seed_len, kmax, kmin,
                                              1 if rev_compl else 0, C.byref(r))
+    if e:
+        raise RuntimeError(f"oracle returned {e}")
+    return _pack_result(r, pos, rc, mism)
+
+
+def oracle_match_screened(pg, reads, seed_len, kmax, kmin, threads=8, state=None):
+    """Mode c, both strands, in the HIP path's schedule (exact-match screen first): see pgrc_or_match_copmem_screened."""
+    pg = np.ascontiguousarray(pg, dtype=np.uint8)
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    n, L = reads.shape
+    r, pos, rc, mism = _new_result(n)
+    init = 1
+    if state is not None:
+        pos[:], rc[:], mism[:] = state
+        init = 0
+    e = oracle().pgrc_or_match_copmem_screened(_ptr(pg), pg.size, _ptr(reads), n, L, seed_len, kmax, kmin, threads, init, C.byref(r))
     if e:
         raise RuntimeError(f"oracle returned {e}")
     return _pack_result(r, pos, rc, mism)

@@ -24,6 +24,15 @@ def _both(pg, reads, seed_len, kmax, kmin, rev=True):
     for k in ("pos", "rc", "mism", "hist"):
         assert np.array_equal(np.asarray(full[k]), np.asarray(early[k])), k
     assert full["matched"] == early["matched"]
+    if rev:
+        # ... and the HIP path's schedule of a two-pass run (exact-match screen on the RC text first)
+        lib.pgrc_or_probe_count(1)
+        scr = orc.oracle_match_screened(pg, reads, seed_len, kmax, kmin)
+        p_scr = lib.pgrc_or_probe_count(1)
+        for k in ("pos", "rc", "mism", "hist"):
+            assert np.array_equal(np.asarray(full[k]), np.asarray(scr[k])), ("screened", k)
+        assert full["matched"] == scr["matched"]
+        _both.last_screened = p_scr
     return p_full, p_early
 
 

@@ -144,20 +144,33 @@ def test_copmem_parity(L, seed_len, M, mode, G, n):
     g = gpu_match("c", pg, reads, seed_len, kmax, kmin)
     assert_same_results(g, o, f"L={L} seed={seed_len} M={M} {mode}")
     ctr = g["ctx"].counters()
-    assert ctr["searched"] == o["searched"]
-    # the kernel stops a read once nothing can be accepted any more: its work counters are those of the oracle run
-    # with the same rule (tests/test_early_stop_rule.py shows the rule changes no result) ...
+    # The kernel stops a read once nothing can be accepted any more, and a two-pass run with kmin == 0 screens the reads
+    # for exact RC alignments first: its work counters are those of the oracle's restatement of that rule / schedule
+    # (tests/test_early_stop_rule.py shows on the CPU that neither changes a result) ...
     oe = orc.oracle_match("c", pg, reads, seed_len, kmax, kmin, early_stop=True)
     assert_same_results(oe, o, "early-stop rule")
-    assert ctr["candidates"] == oe["candidates"]
-    # ... and with the rule switched off, the reference's
-    os.environ["PGRC_EARLY_STOP"] = "0"
-    try:
-        g0 = gpu_match("c", pg, reads, seed_len, kmax, kmin)
-    finally:
-        del os.environ["PGRC_EARLY_STOP"]
-    assert_same_results(g0, o, "full loops")
-    assert g0["ctx"].counters()["candidates"] == o["candidates"]
+    legs = [({"PGRC_SCREEN": "0"}, oe, 0), ({"PGRC_SCREEN": "0", "PGRC_EARLY_STOP": "0"}, o, 0)]
+    if kmin == 0:
+        osc = orc.oracle_match_screened(pg, reads, seed_len, kmax, kmin)
+        assert_same_results(osc, o, "screened schedule")
+        legs.append(({"PGRC_SCREEN": "1"}, osc, 1))
+    else:
+        osc = None
+        assert ctr["screened"] == 0
+    want = osc if ctr["screened"] else oe            # (the library screens by itself where it pays: long reads)
+    assert ctr["searched"] == want["searched"] and ctr["candidates"] == want["candidates"]
+    # ... with the screen switched off, the early-stop oracle's; with both off, the reference's; forced on, the schedule's
+    for knobs, want, screened in legs:
+        os.environ.update(knobs)
+        try:
+            g0 = gpu_match("c", pg, reads, seed_len, kmax, kmin)
+        finally:
+            for k in knobs:
+                del os.environ[k]
+        assert_same_results(g0, o, str(knobs))
+        c0 = g0["ctx"].counters()
+        assert c0["screened"] == screened, knobs
+        assert c0["searched"] == want["searched"] and c0["candidates"] == want["candidates"], knobs
     if orc.have_ref():
         r = orc.ref_match("c", pg, reads, seed_len, kmax, kmin)
         assert_same_results(g, r, "vs real reference")
@@ -264,6 +277,64 @@ def test_two_phase_continuation():
     assert np.array_equal(m.readMismatchesCount, o2["mism"])
     assert np.array_equal(m.readMatchRC.astype(np.uint8), o2["rc"])
     assert np.array_equal(bitmap, o2["mism"] <= 254)
+
+
+@pytest.mark.parametrize("screen", ["0", "1"])
+def test_screened_schedule_hard_cases(monkeypatch, screen):
+    """The screened schedule of a two-pass run (exact-match screen on the RC text first) where its side conditions
+    bite: low-complexity text (capped buckets, falses budgets running out: flagged reads fall back to the real query),
+    reads that match both strands exactly (reverse-palindromic inserts), reads with N, a run that continues from an
+    earlier phase's results, and a sharded matcher.  Results against the reference-order oracle, work counters against
+    the oracle's restatement of the schedule."""
+    from pgrc_amd import MatchContext
+    monkeypatch.setenv("PGRC_SCREEN", screen)
+    rng = np.random.default_rng(17)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    # (a) low-complexity text
+    unit = rng.choice(acgt, size=37)
+    pg = np.tile(unit, 3000)[:100000].copy()
+    flips = rng.integers(0, pg.size, size=600)
+    pg[flips] = rng.choice(acgt, size=flips.size)
+    _, reads = make_inputs(100000, 3000, 100, seed=3)
+    for i, st in enumerate(rng.integers(0, pg.size - 100, size=2000)):
+        reads[i] = pg[st:st + 100]
+        for _ in range(int(rng.integers(0, 4))):
+            reads[i, int(rng.integers(0, 100))] = rng.choice(acgt)
+    for i, st in enumerate(rng.integers(0, pg.size - 100, size=800)):          # ... and reads from its other strand
+        reads[2000 + i] = revcomp(pg[st:st + 100])
+        for _ in range(int(rng.integers(0, 3))):
+            reads[2000 + i, int(rng.integers(0, 100))] = rng.choice(acgt)
+    # (b) a text with reverse-palindromic stretches: reads from them match both strands exactly
+    pg2, reads2 = make_inputs(150000, 4000, 100, seed=8, n_with_n=150)
+    for k in range(40):
+        half = rng.choice(acgt, size=100)
+        pal = np.concatenate([half, np.array([comp[int(x)] for x in half[::-1]], dtype=np.uint8)])
+        at = 1000 + 3000 * k
+        pg2[at:at + 200] = pal
+        reads2[k] = pal[50:150]
+        reads2[40 + k] = pal[20:120]
+    for name, (P, R, kmax) in {"lowcomplexity": (pg, reads, 5), "lowcomplexity_k2": (pg, reads, 2), "palindromes": (pg2, reads2, 2)}.items():
+        o = orc.oracle_match("c", P, R, 38, kmax, 0)
+        g = gpu_match("c", P, R, 38, kmax, 0)
+        assert_same_results(g, o, name)
+        ctr = g["ctx"].counters()
+        assert ctr["screened"] == int(screen)
+        want = orc.oracle_match_screened(P, R, 38, kmax, 0) if screen == "1" else orc.oracle_match("c", P, R, 38, kmax, 0, early_stop=True)
+        if name != "palindromes":        # (reads with N go the byte path: the main kernel's counters leave them out)
+            assert ctr["searched"] == want["searched"] and ctr["candidates"] == want["candidates"], name
+        g3 = gpu_match("c", P, R, 38, kmax, 0, devices=[0, 0, 0])
+        assert_same_results(g3, o, name + " (3 shards)")
+    # (c) continuing from an earlier phase (set_results): exact phase first, then k <= 2 with min 0
+    o1 = orc.oracle_match("c", pg2, reads2, 100, 0, 0)
+    o2 = orc.oracle_match("c", pg2, reads2, 38, 2, 0, state=(o1["pos"], o1["rc"], o1["mism"]))
+    ctx = MatchContext(100, 38, 2, 0, "c")
+    ctx.set_pg_ascii(pg2)
+    ctx.set_reads_ascii(reads2)
+    ctx.set_results(o1["pos"], o1["rc"], o1["mism"])
+    ctx.run(True)
+    pos, rc, mism, hist, matched = ctx.get_results()
+    assert np.array_equal(pos, o2["pos"]) and np.array_equal(rc, o2["rc"]) and np.array_equal(mism, o2["mism"])
 
 
 def test_device_generators_equal_host_generators():
