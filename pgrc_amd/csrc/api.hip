@@ -147,6 +147,11 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
         (void)hipEventDestroy(c->side_ev[0]);
         (void)hipEventDestroy(c->side_ev[1]);
     }
+    if (c->build_stream) {
+        (void)hipStreamDestroy(c->build_stream);
+        (void)hipEventDestroy(c->build_ev[0]);
+        (void)hipEventDestroy(c->build_ev[1]);
+    }
     DevBuf *bufs[] = {&c->pg2[0], &c->pg2[1], &c->reads_own, &c->nread_idx, &c->nread_ascii, &c->nread_flag, &c->d_pos,
                       &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_head, &c->d_skey[0], &c->d_skey[1], &c->d_sval[0], &c->d_sval[1], &c->d_sorttmp,
                       &c->alt_head, &c->alt_skey[0], &c->alt_skey[1], &c->alt_sval[0], &c->alt_sval[1], &c->alt_sorttmp, &c->d_scr_pos, &c->d_scr_flag,
@@ -545,10 +550,32 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
         if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) return e;
         c->have_rc = true;
         mark(); // 1
+        // both builds at once on two streams (they share nothing but the bandwidth; PGRC_BUILD_STREAMS=1: in turn)
+        const char *bs = getenv("PGRC_BUILD_STREAMS");
+        bool two = !(bs && bs[0] == '1');
+        if (two && !c->build_stream) {
+            hipError_t he = hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking);
+            for (int k = 0; k < 2 && he == hipSuccess; k++) he = hipEventCreateWithFlags(&c->build_ev[k], hipEventDisableTiming);
+            if (he != hipSuccess) { (void)hipGetLastError(); c->build_stream = nullptr; two = false; }
+        }
+        hipStream_t main_stream = c->stream;
+        if (two) {
+            HIP_TRY(c, hipEventRecord(c->build_ev[0], main_stream));             // the RC text is ready
+            HIP_TRY(c, hipStreamWaitEvent(c->build_stream, c->build_ev[0], 0));
+        }
         if ((e = pgrc_copmem_build_index(c, 0))) return e;
-        mark(); // 2
+        if (!two) mark(); // 2
         swap_index_sets(c);
+        if (two) c->stream = c->build_stream;
         e = pgrc_copmem_build_index(c, 1);
+        c->stream = main_stream;
+        if (two) {
+            if (hipEventRecord(c->build_ev[1], c->build_stream) != hipSuccess || hipStreamWaitEvent(main_stream, c->build_ev[1], 0) != hipSuccess) {
+                c->err = "index build streams";
+                return PGRC_E_DEVICE;
+            }
+            mark(); // 2: both indexes (ms_index[0] is then the pair, ms_index[1] ~ 0)
+        }
         if (e == PGRC_E_ALLOC) {
             // no room for both indexes: free what the second set got, and run the passes in the reference's order
             (void)hipGetLastError();

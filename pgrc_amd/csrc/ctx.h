@@ -91,6 +91,8 @@ struct pgrc_match_ctx {
     int alt_index_strand = -1;
     DevBuf d_scr_pos, d_scr_flag;
     bool screen_broken = false;         // no room for the second set: the passes run as the reference orders them
+    hipStream_t build_stream = nullptr; // the RC index is built beside the forward one (screened schedule)
+    hipEvent_t build_ev[2]{};
 
     // read-side seed index (modes d / i / e)
     DevBuf s_keys, s_vals, s_tab, s_hits, s_tmp;

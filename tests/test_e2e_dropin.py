@@ -17,12 +17,13 @@ def _have_e2e():
     return orc.have_ref() and hasattr(orc.ref(), "pgrc_ref_encode")
 
 
-def _run(tmp_path, case, cpu_only, devices=None):
+def _run(tmp_path, case, cpu_only, devices=None, extra_env=None):
     env = dict(os.environ)
     env.pop("PGRC_REF_VERBOSE", None)
     env.pop("PGRC_DEVICES", None)
     if devices:
         env["PGRC_DEVICES"] = devices
+    env.update(extra_env or {})
     if cpu_only:
         env["PGRC_E2E_CPU_ONLY"] = "1"
     p = subprocess.run([sys.executable, os.path.join(HERE, "e2e_dropin.py"), str(tmp_path), case], env=env,
@@ -66,3 +67,14 @@ def test_archive_identical_with_a_matcher_over_two_logical_devices(tmp_path, cas
     r = _run(tmp_path, case, cpu_only=False, devices="0,0")
     assert r["gpu_gpu_calls"] >= 1 and r["identical"] and r["roundtrip"], r
     assert r["gpu_device_exports"] >= 1, r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["se", "pe_order"])
+def test_archive_identical_with_the_screened_schedule_forced(tmp_path, case):
+    """PGRC_SCREEN=1: the two-pass runs of the encoder take the screened schedule (exact-match screen on the RC text first)
+    although its 100-bp reads are below the length where the library picks it by itself.  Same archive, byte for byte."""
+    if not _have_e2e():
+        pytest.skip("oracle/_ref was built without the encoder harness")
+    r = _run(tmp_path, case, cpu_only=False, extra_env={"PGRC_SCREEN": "1"})
+    assert r["gpu_gpu_calls"] >= 1 and r["identical"] and r["roundtrip"], r
