@@ -519,6 +519,8 @@ static bool screen_wanted(const pgrc_match_ctx *c, int first, int last) {
     if (c->prm.mode != 'c' || first != 0 || last != 1 || c->prm.min_mismatches != 0 || !c->n || c->screen_broken) return false;
     const char *v = getenv("PGRC_SCREEN");     // 0: never, 1: whenever it applies; unset: where it pays
     if (v && (v[0] == '0' || v[0] == '1')) return v[0] == '1';
+    const char *es = getenv("PGRC_EARLY_STOP");
+    if (es && es[0] == '0') return false;       // (the screen's proofs of absence ARE the early-stop rule)
     // The screen is one more sweep over all reads (~5 probes each) and saves a read that matches the other strand exactly
     // the forward query it would lose: with fewer than ~48 seeds per read (L = 100: 37) the two about cancel
     // (profiles/r02_screen_ab.txt: C2 +2.6 %, C3 -12 %).
