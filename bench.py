@@ -212,7 +212,9 @@ def main():
                           "match_rc": ctr["ms_match"][1], "other": ctr["ms_other"], "total_device": ctr["ms_total"],
                           # the screened schedule: both indexes first, then an exact-match screen on the RC
                           # text, the forward pass, the RC pass; "screen" is that first launch (0 when the run did not take it)
-                          "screen": ctr["ms_screen"], "screened_schedule": bool(ctr["screened"])},
+                          "screen": ctr["ms_screen"], "screened_schedule": bool(ctr["screened"]),
+                          "index_note": ("both index builds run at once on two streams: index_fwd is the pair, index_rc ~ 0"
+                                         if ctr["screened"] and ctr["ms_index"][1] < 0.1 * ctr["ms_index"][0] else None)},
             "dist_backend": args.dist_backend if world > 1 else None,
             "counters": {k: ctr[k] for k in ("searched", "candidates", "probes", "entry_fetches", "verifies", "index_entries")},
         }
