@@ -229,8 +229,11 @@ typedef struct {
     /* two-pass runs of mode c with min_mismatches == 0: 1 = the run took the screened schedule (both indexes first, an
      * exact-match screen on the RC text, then the two passes); ms_screen = the screen launch, its probes / candidates /
      * fetches are counted with strand 1 */
-    uint32_t screened;
+    uint32_t screened;      /* 2 = one query per read over both strands (the dual kernel): ms_screen = that launch, its
+                             * work is counted with strand 0, ms_match[] = the two ordinary passes over what it left
+                             * undecided (redo_reads) and the reads with N */
     float ms_screen;
+    uint64_t redo_reads;
 } pgrc_match_counters;
 /* enable per-kernel HIP-event timing + work counters for subsequent runs */
 int pgrc_match_set_profiling(pgrc_match_ctx *ctx, int enabled);

@@ -392,6 +392,148 @@ int pgrc_or_match_copmem(const char *pg, uint64_t pg_len, const char *reads, uin
     return 0;
 }
 
+/* ---- One query over BOTH strands at once (the HIP path's dual kernel), restated on the CPU: a test of that scheme, not
+ * of the reference (tests/test_early_stop_rule.py expects pgrc_or_match_copmem_dual == pgrc_or_match_copmem).  kmin == 0.
+ * Every seed probes the forward and the RC table (same hash); each strand is a query of its own whose limit is
+ * additionally capped by what the other strand has found: forward by the RC count (a forward alignment only matters if
+ * it is at least as good), RC by the forward count - 1 (it must be strictly better).  Each strand stops by the
+ * early-stop rule against its capped limit.  Why this gives the reference's result: a query under ANY sequence of
+ * limits that never falls below the smallest count m_min among its candidates accepts the FIRST candidate with m_min
+ * (earlier accepted ones have larger counts, so the limit is still >= m_min when it comes) and nothing after it -- the
+ * reference's final alignment; the caps never fall below the counts that still matter.  All of it presupposes that no
+ * run cuts a bucket by the falses budget: U bounds the falses of any run over the candidates seen so far (1 for a
+ * candidate whose head count alone exceeds the starting limit, else 2); U > budget at a seed start -> the read is
+ * done again in the reference's order (return 1). */
+typedef struct { int limit; uint32_t cur; uint64_t best; uint64_t U; uint32_t rclean; int rdirty, active, found; } dual_side;
+
+static int dual_query(const pgrc_or_index *idx[2], const char *text[2], const char *read, uint32_t read_len,
+                      uint8_t kmax, uint8_t cin, int *strand_out, uint64_t *pos_out, uint8_t *m_out, uint64_t cands[2]) {
+    const int K = idx[0]->p.K, k2 = idx[0]->p.k2;
+    const uint32_t k1 = (uint32_t)idx[0]->p.k1;
+    const uint32_t mask = idx[0]->p.hash_size - 1;
+    const uint64_t G = idx[0]->pg_len;
+    const uint32_t head = (read_len / 8) * 8;
+    const uint64_t budget = (uint64_t)((read_len + 1 - (uint32_t)K) / (uint32_t)k2);
+    const int L0 = cin < kmax ? (int)cin - 1 : (int)kmax;
+    const uint32_t rper = ((uint32_t)K + k1 * (uint32_t)k2 - 1) / (k1 * (uint32_t)k2) * k1;
+    dual_side sd[2];
+    for (int x = 0; x < 2; x++) { sd[x].limit = L0; sd[x].cur = cin; sd[x].best = PGRC_OR_NOT_MATCHED_POS; sd[x].U = 0; sd[x].rclean = 0; sd[x].rdirty = 0; sd[x].active = 1; sd[x].found = 0; }
+    uint32_t rq = 0, probes = 0;
+#define DUAL_EFF(x) ((x) == 0 ? (sd[1].found && (int)sd[1].cur < sd[0].limit ? (int)sd[1].cur : sd[0].limit) \
+                              : (sd[0].found && (int)sd[0].cur - 1 < sd[1].limit ? (int)sd[0].cur - 1 : sd[1].limit))
+    for (uint32_t s = 0; s + (uint32_t)K < read_len + 1; s += (uint32_t)k2) {
+        if (s) {
+            for (int x = 0; x < 2; x++)
+                if (rq == k1 - 1) { sd[x].rclean += sd[x].rdirty ? 0 : 1; sd[x].rdirty = 0; }
+            rq = (rq + 1 == rper) ? 0 : rq + 1;
+            for (int x = 0; x < 2; x++)
+                if (sd[x].active && (int)sd[x].rclean > DUAL_EFF(x)) sd[x].active = 0;
+        }
+        if (!sd[0].active && !sd[1].active) break;
+        const uint32_t h = pgrc_or_copmem_hash(K, read + s) & mask;
+        int fwd_exact = 0;
+        for (int x = 0; x < 2 && !fwd_exact; x++) {
+            if (!sd[x].active) continue;
+            if (sd[x].U > budget) { __atomic_fetch_add(&g_probes, probes, __ATOMIC_RELAXED); return 1; }
+            probes++;
+            const uint32_t lo = idx[x]->cumm[h], hi = idx[x]->cumm[h + 1];
+            if (lo == hi) continue;
+            if (rq < k1 && hi - lo >= PGRC_OR_BUCKET_CAP) sd[x].rdirty = 1;
+            for (uint32_t j = lo; j < hi; j++) {
+                const uint64_t sp = idx[x]->positions[j];
+                if ((uint64_t)s > sp) continue;
+                if (sp - s + read_len > G) continue;
+                const char *t = text[x] + (sp - s);
+                cands[x]++;
+                uint32_t mh = 0, mt = 0;
+                for (uint32_t i = 0; i < head; i++) mh += (read[i] != t[i]);
+                for (uint32_t i = head; i < read_len; i++) mt += (read[i] != t[i]);
+                sd[x].U += ((int)mh > L0) ? 1 : 2;
+                const int m = (int)(mh + mt);
+                if (m > DUAL_EFF(x)) continue;
+                sd[x].cur = (uint32_t)m;
+                sd[x].best = sp - s;
+                sd[x].found = 1;
+                sd[x].limit = m - 1;
+                if (m == 0) {                      /* m <= kmin: this strand's query returns */
+                    sd[x].active = 0;
+                    if (x == 0) fwd_exact = 1;     /* ... and the RC pass would skip the read */
+                    break;
+                }
+            }
+        }
+        if (fwd_exact) break;
+    }
+#undef DUAL_EFF
+    __atomic_fetch_add(&g_probes, probes, __ATOMIC_RELAXED);
+    if (sd[0].found && sd[0].cur == 0) { *strand_out = 0; *pos_out = sd[0].best; *m_out = 0; return 0; }
+    if (sd[1].found && sd[1].cur < (sd[0].found ? sd[0].cur : (uint32_t)cin)) { *strand_out = 1; *pos_out = sd[1].best; *m_out = (uint8_t)sd[1].cur; return 0; }
+    if (sd[0].found) { *strand_out = 0; *pos_out = sd[0].best; *m_out = (uint8_t)sd[0].cur; return 0; }
+    *strand_out = -1;
+    return 0;
+}
+
+int pgrc_or_match_copmem_dual(const char *pg, uint64_t pg_len, const char *reads, uint64_t n,
+                              uint32_t read_len, uint32_t seed_len, uint8_t kmax, uint8_t kmin,
+                              int threads, int init, pgrc_or_result *res, uint64_t *aborted_out) {
+    if (kmin != 0) return 2;
+    if (init) result_init(res, n, 1);
+    if (threads < 1) threads = 1;
+    char *rcpg = (char *)malloc(pg_len + 1);
+    if (!rcpg) return 3;
+    memcpy(rcpg, pg, pg_len);
+    rcpg[pg_len] = 0;
+    pgrc_or_revcomp(rcpg, pg_len);
+    pgrc_or_index idxF, idxR;
+    int e = pgrc_or_index_build(pg, pg_len, seed_len, &idxF);
+    if (e) { free(rcpg); return e; }
+    e = pgrc_or_index_build(rcpg, pg_len, seed_len, &idxR);
+    if (e) { pgrc_or_index_free(&idxF); free(rcpg); return e; }
+    const pgrc_or_index *idx[2] = {&idxF, &idxR};
+    const char *text[2] = {pg, rcpg};
+    uint64_t searched = 0, cands0 = 0, cands1 = 0, aborted = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads) reduction(+ : searched, cands0, cands1, aborted)
+#endif
+    for (int64_t ii = 0; ii < (int64_t)n; ii++) {
+        const uint64_t i = (uint64_t)ii;
+        if (res->mism[i] <= kmin) continue;
+        searched++;
+        const char *rd = reads + i * (uint64_t)read_len;
+        int strand = -1;
+        uint64_t pos = 0, cd[2] = {0, 0};
+        uint8_t m = 0;
+        if (!dual_query(idx, text, rd, read_len, kmax, res->mism[i], &strand, &pos, &m, cd)) {
+            cands0 += cd[0]; cands1 += cd[1];
+            if (strand >= 0) { res->pos[i] = strand ? pg_len - (pos + read_len) : pos; res->rc[i] = (uint8_t)strand; res->mism[i] = m; }
+            continue;
+        }
+        aborted++;
+        cands0 += cd[0]; cands1 += cd[1];
+        for (int pass = 0; pass < 2; pass++) {            /* the reference's order */
+            if (res->mism[i] <= kmin) break;
+            uint8_t c = res->mism[i];
+            uint64_t f = 0, cdd = 0;
+            const uint64_t p = match_read_ex(idx[pass], text[pass], rd, read_len, kmax, kmin, &c, &f, &cdd, 0, 1, NULL);
+            if (pass) cands1 += cdd; else cands0 += cdd;
+            if (p != PGRC_OR_NOT_MATCHED_POS && c < res->mism[i]) { res->pos[i] = pass ? pg_len - (p + read_len) : p; res->rc[i] = (uint8_t)pass; res->mism[i] = c; }
+        }
+    }
+    memset(res->hist, 0, sizeof res->hist);
+    res->matched = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        res->hist[res->mism[i]]++;
+        res->matched += res->mism[i] != PGRC_OR_NOT_MATCHED_CNT;
+    }
+    res->searched[0] = searched; res->searched[1] = 0;
+    res->candidates[0] = cands0; res->candidates[1] = cands1;
+    if (aborted_out) *aborted_out = aborted;
+    free(rcpg);
+    pgrc_or_index_free(&idxF);
+    pgrc_or_index_free(&idxR);
+    return 0;
+}
+
 /* ---- The HIP path's SCHEDULE for a two-pass run, restated on the CPU (a test of that schedule, not of the reference:
  * tests/test_early_stop_rule.py expects it to equal pgrc_or_match_copmem on every input).  With kmin == 0:
  *   K1  every read not yet matched exactly is screened on the RC text for an EXACT alignment (limit 0, early stop: one

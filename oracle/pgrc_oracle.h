@@ -102,6 +102,12 @@ typedef struct {
 int pgrc_or_match_copmem(const char *pg, uint64_t pg_len, const char *reads, uint64_t n,
                          uint32_t read_len, uint32_t seed_len, uint8_t kmax, uint8_t kmin,
                          int rev_compl_pg, int threads, int init, pgrc_or_result *res);
+/* one query over both strands at once (the HIP path's dual kernel), restated: must equal
+ * pgrc_or_match_copmem(..., rev_compl_pg = 1, ...) on every input; kmin must be 0; *aborted = reads redone in the
+ * reference's order because the falses bound exceeded the budget */
+int pgrc_or_match_copmem_dual(const char *pg, uint64_t pg_len, const char *reads, uint64_t n,
+                              uint32_t read_len, uint32_t seed_len, uint8_t kmax, uint8_t kmin,
+                              int threads, int init, pgrc_or_result *res, uint64_t *aborted);
 /* the HIP path's schedule for a two-pass run (exact-match screen on the RC text first), restated: must equal
  * pgrc_or_match_copmem(..., rev_compl_pg = 1, ...) on every input */
 int pgrc_or_match_copmem_screened(const char *pg, uint64_t pg_len, const char *reads, uint64_t n,

@@ -528,6 +528,20 @@ static bool screen_wanted(const pgrc_match_ctx *c, int first, int last) {
     return k2 && c->prm.read_len >= K && (c->prm.read_len - K) / k2 + 1 >= 48u;
 }
 
+// ... and, when they apply, rather ONE query per read over both strands (copmem.hip, "The dual kernel"); PGRC_DUAL=0: never
+static bool dual_wanted(const pgrc_match_ctx *c, int first, int last) {
+    if (c->prm.mode != 'c' || first != 0 || last != 1 || c->prm.min_mismatches != 0 || !c->n || c->screen_broken) return false;
+    const char *v = getenv("PGRC_DUAL");
+    if (v && v[0] == '0') return false;
+    const char *es = getenv("PGRC_EARLY_STOP");
+    const char *sc = getenv("PGRC_SCREEN");
+    if ((es && es[0] == '0') || (sc && (sc[0] == '0' || sc[0] == '1'))) return false;   // the older schedules were asked for
+    if (v && v[0] == '1') return true;
+    // short reads: too few seeds to save, and the fixed cost of the extra launches shows (C2, 37 seeds: +19 %)
+    const uint32_t K = (uint32_t)c->cp.K, k2 = (uint32_t)c->cp.k2;
+    return k2 && c->prm.read_len >= K && (c->prm.read_len - K) / k2 + 1 >= 48u;
+}
+
 static int run_passes(pgrc_match_ctx *c, int first, int last) {
     if (!c) return PGRC_E_PARAM;
     if (c->multi) return pgrc_multi_run(c, first, last);
@@ -541,7 +555,8 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
     int evi = 0;
     auto mark = [&]() { if (prof) (void)hipEventRecord(c->ev[evi], c->stream); evi++; };
     mark(); // 0
-    bool screened = screen_wanted(c, first, last);
+    const bool dual = dual_wanted(c, first, last);
+    bool screened = dual || screen_wanted(c, first, last);
     if (screened && ((e = pgrc_buf_ensure(c, c->d_scr_pos, c->n * sizeof(uint64_t))) || (e = pgrc_buf_ensure(c, c->d_scr_flag, c->n)))) {
         if (e != PGRC_E_ALLOC) return e;
         (void)hipGetLastError();
@@ -600,6 +615,16 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
             if (e) return e;
             mark(); // 3
             HIP_TRY(c, hipMemsetAsync(c->d_scr_flag.p, 0, c->n, c->stream));
+            if (dual) {
+                if ((e = pgrc_copmem_match_dual(c))) return e;             // one query per read over both strands
+                mark(); // 4
+                swap_index_sets(c);
+                if ((e = pgrc_copmem_match_phase(c, 0, 4))) return e;      // what it left undecided, and the reads with N:
+                mark(); // 5
+                swap_index_sets(c);
+                if ((e = pgrc_copmem_match_phase(c, 1, 4))) return e;      // the two passes in the reference's order
+                mark(); // 6
+            } else {
             if ((e = pgrc_copmem_match_phase(c, 1, 1))) return e;          // screen on the RC text
             mark(); // 4
             swap_index_sets(c);
@@ -608,6 +633,7 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
             swap_index_sets(c);
             if ((e = pgrc_copmem_match_phase(c, 1, 0))) return e;          // RC pass over what is left
             mark(); // 6
+            }
         }
     } else if (c->prm.mode == 'c') {
         for (int pass = first; pass <= last; pass++) {
@@ -638,7 +664,15 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
         c->ctr.entry_fetches[s] = ctr[8 * s + 3];
         c->ctr.verifies[s] = ctr[8 * s + 4];
     }
-    if (screened) {                  // the screen ran on the RC text: its work counts with that strand's (not "searched")
+    if (screened && dual) {          // the dual kernel's work counts with strand 0
+        c->ctr.searched[0] += scr[0];
+        c->ctr.candidates[0] += scr[1];
+        c->ctr.probes[0] += scr[2];
+        c->ctr.entry_fetches[0] += scr[3];
+        c->ctr.verifies[0] += scr[4];
+        c->ctr.redo_reads = scr[5];
+        c->ctr.screened = 2;
+    } else if (screened) {           // the screen ran on the RC text: its work counts with that strand's (not "searched")
         c->ctr.candidates[1] += scr[1];
         c->ctr.probes[1] += scr[2];
         c->ctr.entry_fetches[1] += scr[3];

@@ -282,7 +282,8 @@ struct MatchArgs {
     uint32_t L, K, k2, mask, kmax, kmin, strand;
     uint32_t k1, early;           // sampling step of the index; early = 1: stop a read once nothing can be accepted any more
     // the screened schedule of a two-pass run (see "Exact-match screen" at the kernel): phase 0 = a plain pass,
-    // 1 = screen (RC text, exact alignments only, flags and positions to scr_*), 2 = forward pass that honours the flags
+    // 1 = screen (RC text, exact alignments only, flags and positions to scr_*), 2 = forward pass that honours the flags,
+    // 4 = a plain pass over the reads flagged in scr_flag only (what the dual kernel left undecided)
     uint32_t phase;
     uint64_t *scr_pos;
     uint8_t *scr_flag;
@@ -480,11 +481,17 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
                 const uint32_t nst = min((uint32_t)SW, cend - cnext);
                 wbeg = wnext = cnext;
                 wend = cnext = __builtin_amdgcn_readfirstlane(cnext + nst);
+                uint32_t wf = 0;
+                if (lane < nst) wf = (uint32_t)((a.nflag ? a.nflag[wbeg + lane] : 0) | (a.phase == 2u || a.phase == 4u ? (a.scr_flag[wbeg + lane] & 1u) << 1 : 0u));
+                // phase 4 only works on flagged reads: a window without any is handed out unloaded (all its reads skip)
+                const bool load_rows = a.phase != 4u || __any(lane < nst && (wf & 2u));
                 if (lane < nst) {
+                    if (load_rows) {
 #pragma unroll
-                    for (int k = 0; k < NW; k++) stg[wv][k][lane] = a.reads[(uint64_t)k * a.stride + wbeg + lane];
-                    stg_c[wv][lane] = a.mism[wbeg + lane];
-                    stg_f[wv][lane] = (uint8_t)((a.nflag ? a.nflag[wbeg + lane] : 0) | (a.phase == 2u ? (a.scr_flag[wbeg + lane] & 1u) << 1 : 0u));
+                        for (int k = 0; k < NW; k++) stg[wv][k][lane] = a.reads[(uint64_t)k * a.stride + wbeg + lane];
+                        stg_c[wv][lane] = a.mism[wbeg + lane];
+                    } else stg_c[wv][lane] = 0;       // (count 0 <= min_mismatches: skipped)
+                    stg_f[wv][lane] = (uint8_t)wf;
                 }
                 __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // a wave's LDS accesses are served in order
             }
@@ -500,13 +507,14 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
                     idx = STAGE > 0 ? wbeg + sj : cnext + rank;
                     cin = STAGE > 0 ? stg_c[wv][sj] : a.mism[idx];
                     const uint32_t rflags = STAGE > 0 ? (uint32_t)stg_f[wv][sj]
-                                                      : (uint32_t)((a.nflag ? a.nflag[idx] : 0) | (a.phase == 2u ? (a.scr_flag[idx] & 1u) << 1 : 0u));
-                    const bool skip = (rflags & 1u) || cin <= a.kmin; // ReadsMatchers.cpp:430; 'N' reads: byte path
+                                                      : (uint32_t)((a.nflag ? a.nflag[idx] : 0) | (a.phase == 2u || a.phase == 4u ? (a.scr_flag[idx] & 1u) << 1 : 0u));
+                    // ReadsMatchers.cpp:430; 'N' reads: byte path; phase 4: only what the dual kernel left undecided
+                    const bool skip = (rflags & 1u) || cin <= a.kmin || (a.phase == 4u && !(rflags & 2u));
                     if (!skip) {
 #pragma unroll
                         for (int k = 0; k < NW; k++)
                             rd_lds[k][threadIdx.x] = sh[k] = STAGE > 0 ? stg[wv][k][sj] : a.reads[(uint64_t)k * a.stride + idx];
-                        spec = a.phase == 1u || (rflags & 2u);           // exact alignments only (the screened schedule)
+                        spec = a.phase == 1u || (a.phase == 2u && (rflags & 2u));   // exact alignments only (the screened schedule)
                         st.limit = spec ? 0u : (cin < a.kmax) ? cin - 1u : a.kmax;   // :488-489
                         st.falses = 0;
                         st.cur = cin;
@@ -904,6 +912,400 @@ k_copmem_match_n(const MatchArgs a, const uint32_t *__restrict__ nidx, const uin
     }
 }
 
+// ----------------------------------------------------------------------------- one query over both strands
+
+// The dual kernel: a two-pass run (min_mismatches == 0) as ONE query per read over both strands' indexes.  A read
+// window hashes to the same bucket number in both tables, so every seed probes the forward and the RC head together
+// (two gathers in flight); the forward bucket's entries are judged first, then the RC bucket's.  Each strand is a
+// query of its own whose limit is additionally capped by what the other strand has found -- forward by the RC count (a
+// forward alignment only matters if it is at least as good), RC by the forward count - 1 (it must be strictly better) --
+// and each stops by the early-stop rule against its capped limit.  Why the result is the reference's (all forward
+// seeds, then all RC seeds): a query under ANY sequence of limits that never falls below the smallest count m_min among
+// its candidates accepts the FIRST candidate with m_min and nothing after it, which is the reference's final
+// alignment; the caps never fall below the counts that still matter.  All of it presupposes that no run would have cut
+// a bucket by the falses budget: U bounds the falses of any run over the candidates seen so far (1 for a candidate
+// whose head count -- or already its fingerprint -- exceeds the starting limit, else 2); U > budget when a bucket is
+// opened -> the read is flagged (redo) and goes through the two passes in the reference's order afterwards.
+// oracle/pgrc_oracle.c restates the scheme (pgrc_or_match_copmem_dual); tests/test_early_stop_rule.py expects it to
+// equal the reference's two passes on every input.
+struct DualArgs {
+    const uint32_t *pg[2];        // packed text, forward and reverse complement
+    uint64_t G;
+    const uint32_t *reads;
+    uint64_t n, stride;
+    const uint8_t *nflag;         // reads with N: the byte path of the ordinary passes
+    const ulonglong2 *head[2];
+    const uint64_t *ent[2];
+    uint64_t *pos;
+    uint8_t *rc;
+    uint8_t *mism;
+    uint8_t *redo;                // [n] 1 = undecided here
+    unsigned long long *counters; // [0] searched [1] candidates [2] heads probed [3] entry fetches [4] verifies [5] redo
+    unsigned long long *work;
+    uint32_t L, K, k1, k2, mask, kmax;
+};
+
+template <int NW, int KQ, bool POS64>
+__global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_dual(const DualArgs a) {
+    typedef typename std::conditional<POS64, uint64_t, uint32_t>::type pos_t;
+    constexpr pos_t POS_NONE = (pos_t)~(pos_t)0;
+    constexpr uint32_t EPOCH_BITS = POS64 ? 12u : 15u;   // one bit less than the single-strand kernel: the strand is part of the tag
+    constexpr int SW = MATCH_STAGE;
+    __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
+    __shared__ uint32_t fpm_tab[SM_MAX_SEEDS];
+    __shared__ uint2 vcache[VC_SLOTS][MATCH_TPB];
+    __shared__ uint32_t rd_lds[NW][MATCH_TPB];
+    __shared__ uint32_t stg[MATCH_TPB / 64][NW][SW];
+    __shared__ uint8_t stg_c[MATCH_TPB / 64][SW], stg_f[MATCH_TPB / 64][SW];
+    __shared__ ulonglong2 hdR_lds[MATCH_TPB];    // the RC head of a lane's current seed, waiting for the forward bucket to finish
+    const uint32_t wv = threadIdx.x >> 6;
+    uint32_t wbeg = 0, wend = 0, wnext = 0;
+    hash_lut_init(lut);
+    const int H = ((int)a.L / 8) * 8;
+    const uint32_t nseeds = (a.L - a.K) / a.k2 + 1;
+    for (uint32_t t = threadIdx.x; t < nseeds && t < SM_MAX_SEEDS; t += blockDim.x)
+        fpm_tab[t] = fp_head_mask(a.K, t * a.k2, (uint32_t)H);
+#pragma unroll
+    for (int k = 0; k < VC_SLOTS; k++) vcache[k][threadIdx.x] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t n_search = 0, n_cand = 0, n_probe = 0, n_ent = 0, n_ver = 0, n_redo = 0;
+    uint32_t sh[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) sh[k] = 0u;
+    const uint32_t budget = (a.L + 1u - a.K) / a.k2;
+    const uint32_t sbits = 2u * a.k2;
+    const uint32_t rper = (a.K + a.k1 * a.k2 - 1u) / (a.k1 * a.k2) * a.k1;
+
+    enum { M_PROBE = 0, M_ENTRY = 1, M_VERIFY = 2, M_NEED = 3, M_ADV = 4, M_DEAD = 5 };
+    enum { F_ACT0 = 1, F_ACT1 = 2, F_FOUND0 = 4, F_FOUND1 = 8, F_DIRTY0 = 16, F_DIRTY1 = 32, F_REDO = 64, F_FWDEXACT = 128 };
+    uint32_t mode = M_NEED;
+    uint32_t idx = 0, cin = 0, epoch = 0;
+    uint32_t cnext = 0, cend = 0;
+    uint32_t si = 0, rq = 0;
+    // per strand (0 forward, 1 RC): own limit (-1 once an exact alignment is accepted), best count and position,
+    // bound on the falses of any run, clean rounds
+    int lim0 = 0, lim1 = 0, L0 = 0;
+    uint32_t cur0 = 0, cur1 = 0, U0 = 0, U1 = 0, rcl0 = 0, rcl1 = 0, fl = 0;
+    pos_t best0 = POS_NONE, best1 = POS_NONE;
+    uint32_t x = 0;               // the strand whose bucket is being gone through
+    pos_t lo = 0;
+    uint32_t nb = 0, j = 0, fp_read = 0;
+    pos_t cand_p = 0;
+    uint64_t pend_e = 0;
+    bool has_pend = false;
+    constexpr int PWN = ((NW + 1 + 3) / 4) * 4;
+
+    // the limit a candidate of strand s is judged against: its own, capped by what the other strand has found
+    auto eff = [&](uint32_t s) -> int {
+        if (s == 0u) return (fl & F_FOUND1) ? min(lim0, (int)cur1) : lim0;
+        return (fl & F_FOUND0) ? min(lim1, (int)cur0 - 1) : lim1;
+    };
+
+    for (;;) {
+        // ---- refill (as in k_copmem_match_sm, staged)
+        const unsigned long long need = __ballot(mode == M_NEED);
+        if (need) {
+            if (cnext == cend) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(a.work, (unsigned long long)MATCH_CHUNK);
+                base = __shfl(base, 0, 64);
+                cnext = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base, a.n));
+                cend = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base + MATCH_CHUNK, a.n));
+            }
+            if (wnext == wend && cnext != cend) {
+                const uint32_t nst = min((uint32_t)SW, cend - cnext);
+                wbeg = wnext = cnext;
+                wend = cnext = __builtin_amdgcn_readfirstlane(cnext + nst);
+                if (lane < nst) {
+#pragma unroll
+                    for (int k = 0; k < NW; k++) stg[wv][k][lane] = a.reads[(uint64_t)k * a.stride + wbeg + lane];
+                    stg_c[wv][lane] = a.mism[wbeg + lane];
+                    stg_f[wv][lane] = a.nflag ? a.nflag[wbeg + lane] : (uint8_t)0;
+                }
+                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            const uint32_t avail = wend - wnext;
+            if (avail == 0) {
+                if (mode == M_NEED) mode = M_DEAD;
+            } else {
+                const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                const uint32_t take = min((uint32_t)__popcll(need), avail);
+                bool started = false;
+                if (mode == M_NEED && rank < take) {
+                    const uint32_t sj = wnext - wbeg + rank;
+                    idx = wbeg + sj;
+                    cin = stg_c[wv][sj];
+                    if (!stg_f[wv][sj] && cin != 0u) {               // ReadsMatchers.cpp:430 with min_mismatches == 0
+#pragma unroll
+                        for (int k = 0; k < NW; k++) rd_lds[k][threadIdx.x] = sh[k] = stg[wv][k][sj];
+                        L0 = (cin < a.kmax) ? (int)cin - 1 : (int)a.kmax;   // :488-489
+                        lim0 = lim1 = L0;
+                        cur0 = cur1 = cin;
+                        best0 = best1 = POS_NONE;
+                        U0 = U1 = 0;
+                        rcl0 = rcl1 = 0;
+                        fl = F_ACT0 | F_ACT1;
+                        si = 0;
+                        rq = 0;
+                        has_pend = false;
+                        epoch = (epoch + 1u) & ((1u << EPOCH_BITS) - 1u);
+                        if (epoch == 0) {
+#pragma unroll
+                            for (int k = 0; k < VC_SLOTS; k++) vcache[k][threadIdx.x] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+                            epoch = 1;
+                        }
+                        started = true;
+                        mode = M_PROBE;
+                    }
+                }
+                wnext = __builtin_amdgcn_readfirstlane(wnext + take);
+                n_search += (uint32_t)__popcll(__ballot(started));
+            }
+        }
+        if (!__any(mode != M_DEAD)) break;
+
+        const uint32_t m0 = mode;
+        // ---- this iteration's loads
+        ulonglong2 hdF = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
+        uint64_t v = 0;
+        bool counted_ent = false;
+        uint32_t ncand_it = 0, nprobe_it = 0;
+        if (m0 == M_PROBE) {
+            const uint32_t h = hash_fp_window<KQ>(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
+                                                  NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
+            ulonglong2 hr = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
+            if (fl & F_ACT0) hdF = a.head[0][h];
+            if (fl & F_ACT1) hr = a.head[1][h];
+            hdR_lds[threadIdx.x] = hr;
+            nprobe_it = ((fl & F_ACT0) ? 1u : 0u) + ((fl & F_ACT1) ? 1u : 0u);
+        } else if (m0 == M_ENTRY) {
+            if (has_pend) {
+                v = pend_e;
+                has_pend = false;
+            } else {
+                const U64x2A8 q = *reinterpret_cast<const U64x2A8 *>((x ? a.ent[1] : a.ent[0]) + lo + j - 1);
+                v = q.x;
+                pend_e = q.y;
+                has_pend = j + 1 < nb;
+                counted_ent = true;
+            }
+        }
+        // ---- consume
+        uint32_t next = m0;
+        bool bdone = false;           // the current strand's bucket is finished
+        // a verified alignment of the current strand (head count mh, tail count mt)
+        auto judge = [&](uint32_t mh, uint32_t mt, pos_t p) {
+            const uint32_t u = ((int)mh > L0) ? 1u : 2u;
+            const int m = (int)(mh + mt);
+            if (x == 0u) U0 += u; else U1 += u;
+            if (m > eff(x)) return;
+            if (x == 0u) { cur0 = (uint32_t)m; best0 = p; lim0 = m - 1; fl |= F_FOUND0; }
+            else { cur1 = (uint32_t)m; best1 = p; lim1 = m - 1; fl |= F_FOUND1; }
+            if (m == 0) {                                            // m <= min_mismatches: this strand's query returns
+                fl &= ~(x == 0u ? (uint32_t)F_ACT0 : (uint32_t)F_ACT1);
+                if (x == 0u) fl |= F_FWDEXACT;                       // ... and the RC pass would skip the read
+            }
+        };
+        // what follows an examined entry
+        auto after_entry = [&]() {
+            if (fl & F_FWDEXACT) next = M_NEED;
+            else if (!(fl & (x == 0u ? (uint32_t)F_ACT0 : (uint32_t)F_ACT1))) bdone = true;   // an exact RC alignment: that query is over
+            else if (j < nb) next = M_ENTRY;
+            else bdone = true;
+        };
+        auto take_entry = [&](const uint64_t e) {
+            const uint32_t s = si * a.k2;
+            const uint64_t sp = e >> PGRC_FP_BITS;
+            if ((uint64_t)s <= sp && sp - s + a.L <= a.G) {          // :517-520
+                ncand_it++;
+                const pos_t p = (pos_t)(sp - s);
+                const uint32_t xr = ((uint32_t)e ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
+                const int fpc = __popc((xr | (xr >> 1)) & fpm_tab[si]);   // a lower bound of the head count
+                if (fpc > eff(x)) {
+                    const uint32_t u = (fpc > L0) ? 1u : 2u;
+                    if (x == 0u) U0 += u; else U1 += u;
+                } else {
+                    const uint2 cv = vcache[((uint32_t)p * 0x9E3779B1u + x) >> (32 - VC_BITS)][threadIdx.x];
+                    const bool hit = POS64 ? (cv.x == (uint32_t)p && (cv.y >> 20) == epoch && ((cv.y >> 19) & 1u) == x &&
+                                              ((cv.y >> 11) & 0xFFu) == (uint32_t)((uint64_t)p >> 32))
+                                           : (cv.x == (uint32_t)p && (cv.y >> 17) == epoch && ((cv.y >> 16) & 1u) == x);
+                    if (hit) judge(cv.y & 0xFFu, (cv.y >> 8) & (POS64 ? 0x7u : 0xFFu), p);
+                    else {
+                        cand_p = p;
+                        next = M_VERIFY;
+                        return;
+                    }
+                }
+            }
+            after_entry();
+        };
+        // open the bucket of strand x for the current seed
+        auto open_bucket = [&](const ulonglong2 hx) {
+            if ((x == 0u ? U0 : U1) > budget) {                      // some run could have cut a bucket by now: not decidable here
+                fl |= F_REDO;
+                next = M_NEED;
+                return;
+            }
+            const uint32_t cnt = head_count(hx);
+            if (!cnt) {
+                bdone = true;
+                return;
+            }
+            nb = cnt;
+            if (rq < a.k1 && cnt >= PGRC_BUCKET_CAP) fl |= (x == 0u ? (uint32_t)F_DIRTY0 : (uint32_t)F_DIRTY1);
+            has_pend = cnt == 2;
+            pend_e = hx.y;
+            lo = (pos_t)(hx.y & W1_BASE_MASK);
+            j = 1;
+            take_entry(hx.x & ENT_MASK);
+        };
+        if (m0 == M_VERIFY) {
+            uint32_t pw[PWN];
+            const uint32_t *src = (x ? a.pg[1] : a.pg[0]) + (cand_p >> 4);   // the text is padded: PWN words are always in bounds
+#pragma unroll
+            for (int k = 0; k < PWN; k += 4) {
+                const u32x4 q = reinterpret_cast<const U32x4A4 *>(src + k)->v;
+                pw[k] = q.x; pw[k + 1] = q.y; pw[k + 2] = q.z; pw[k + 3] = q.w;
+            }
+            const uint32_t b = ((uint32_t)cand_p & 15u) * 2u;
+            uint32_t mh = 0, mt = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const uint32_t tw = funnel_r(pw[k], pw[k + 1], b);
+                const uint32_t rw = rd_lds[k][threadIdx.x];
+                mh += mism2(tw, rw, sym_mask(k, 0, H));
+                mt += mism2(tw, rw, sym_mask(k, H, (int)a.L));
+            }
+            vcache[((uint32_t)cand_p * 0x9E3779B1u + x) >> (32 - VC_BITS)][threadIdx.x] =
+                make_uint2((uint32_t)cand_p, POS64 ? (mh | (mt << 8) | ((uint32_t)((uint64_t)cand_p >> 32) << 11) | (x << 19) | (epoch << 20))
+                                                   : (mh | (mt << 8) | (x << 16) | (epoch << 17)));
+            judge(mh, mt, cand_p);
+            after_entry();
+        } else if (m0 == M_ENTRY) {
+            j++;
+            take_entry(v);
+        } else if (m0 == M_PROBE) {
+            x = (fl & F_ACT0) ? 0u : 1u;
+            open_bucket(x == 0u ? hdF : hdR_lds[threadIdx.x]);
+        }
+        // the forward bucket is done: the RC head of the same seed waits in LDS
+        if (bdone && x == 0u && (fl & F_ACT1)) {
+            bdone = false;
+            x = 1u;
+            open_bucket(hdR_lds[threadIdx.x]);
+        }
+        if (bdone) next = M_ADV;
+        if (next == M_ADV) {                                         // to the next seed
+            si++;
+            has_pend = false;
+            if (rq == a.k1 - 1u) {                                   // a round is behind this read
+                rcl0 += (fl & F_DIRTY0) ? 0u : 1u;
+                rcl1 += (fl & F_DIRTY1) ? 0u : 1u;
+                fl &= ~(uint32_t)(F_DIRTY0 | F_DIRTY1);
+            }
+            rq = (rq + 1u == rper) ? 0u : rq + 1u;
+#pragma unroll
+            for (int k = 0; k < NW - 1; k++) sh[k] = funnel_r(sh[k], sh[k + 1], sbits);
+            sh[NW - 1] >>= sbits;
+            if ((fl & F_ACT0) && (int)rcl0 > eff(0u)) fl &= ~(uint32_t)F_ACT0;   // nothing acceptable is left on that strand
+            if ((fl & F_ACT1) && (int)rcl1 > eff(1u)) fl &= ~(uint32_t)F_ACT1;
+            next = (si < nseeds && (fl & (F_ACT0 | F_ACT1))) ? M_PROBE : M_NEED;
+        }
+        n_probe += (uint32_t)__popcll(__ballot(nprobe_it >= 1)) + (uint32_t)__popcll(__ballot(nprobe_it >= 2));
+        n_ent += (uint32_t)__popcll(__ballot(counted_ent));
+        n_ver += (uint32_t)__popcll(__ballot(m0 == M_VERIFY));
+        n_cand += (uint32_t)__popcll(__ballot(ncand_it >= 1)) + (uint32_t)__popcll(__ballot(ncand_it >= 2));
+        const bool fin = next == M_NEED && m0 <= M_VERIFY;
+        if (fin) {
+            // the read is finished: forward wins ties, RC must be strictly better (ReadsMatchers.cpp:437-447, both passes)
+            if (fl & F_REDO) a.redo[idx] = 1;
+            else if ((fl & F_FOUND1) && !((fl & F_FOUND0) && cur0 <= cur1)) {
+                a.pos[idx] = a.G - ((uint64_t)best1 + a.L);
+                a.rc[idx] = 1;
+                a.mism[idx] = (uint8_t)cur1;
+            } else if (fl & F_FOUND0) {
+                a.pos[idx] = (uint64_t)best0;
+                a.rc[idx] = 0;
+                a.mism[idx] = (uint8_t)cur0;
+            }
+        }
+        n_redo += (uint32_t)__popcll(__ballot(fin && (fl & F_REDO) != 0u));
+        mode = next;
+    }
+    if (a.counters && lane == 0) {
+        atomicAdd(&a.counters[0], (unsigned long long)n_search);
+        atomicAdd(&a.counters[1], (unsigned long long)n_cand);
+        atomicAdd(&a.counters[2], (unsigned long long)n_probe);
+        atomicAdd(&a.counters[3], (unsigned long long)n_ent);
+        atomicAdd(&a.counters[4], (unsigned long long)n_ver);
+        atomicAdd(&a.counters[5], (unsigned long long)n_redo);
+    }
+}
+
+template <int NW>
+static void launch_dual(pgrc_match_ctx *c, const DualArgs &a) {
+    const uint64_t want = (a.n + MATCH_TPB - 1) / MATCH_TPB;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)c->num_cus * 8u);
+    const char *f64 = getenv("PGRC_FORCE_POS64");
+    const bool pos64 = c->G + 256 >= (1ull << 32) || (f64 && f64[0] == '1');
+    const bool k28 = a.K == 28;
+    if (pos64) {
+        if (k28) hipLaunchKernelGGL((k_copmem_match_dual<NW, 7, true>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_copmem_match_dual<NW, 0, true>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+    } else {
+        if (k28) hipLaunchKernelGGL((k_copmem_match_dual<NW, 7, false>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_copmem_match_dual<NW, 0, false>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+    }
+}
+
+// The dual kernel over all reads without N: the ACTIVE index set must describe the RC strand, the alternate set the
+// forward strand (api.hip builds them in that order); undecided reads are flagged in d_scr_flag for the two ordinary
+// passes that follow (phase 4).
+int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
+    if (c->n == 0) return PGRC_OK;
+    if (c->index_strand != 1 || c->alt_index_strand != 0 || !c->ent_ptr || !c->alt_ent_ptr || !c->d_scr_flag.p) {
+        c->err = "dual kernel without both indexes";
+        return PGRC_E_STATE;
+    }
+    DualArgs a;
+    a.pg[0] = (const uint32_t *)c->pg2[0].p;
+    a.pg[1] = (const uint32_t *)c->pg2[1].p;
+    a.G = c->G;
+    a.reads = c->reads2;
+    a.n = c->n;
+    a.stride = c->stride;
+    a.nflag = c->n_nreads ? (const uint8_t *)c->nread_flag.p : nullptr;
+    a.head[0] = (const ulonglong2 *)c->alt_head.p;
+    a.head[1] = (const ulonglong2 *)c->d_head.p;
+    a.ent[0] = c->alt_ent_ptr;
+    a.ent[1] = c->ent_ptr;
+    a.pos = (uint64_t *)c->d_pos.p;
+    a.rc = (uint8_t *)c->d_rc.p;
+    a.mism = (uint8_t *)c->d_mism.p;
+    a.redo = (uint8_t *)c->d_scr_flag.p;
+    a.counters = (unsigned long long *)c->d_counters.p + 24;
+    a.work = (unsigned long long *)c->d_counters.p + 18;
+    a.L = c->prm.read_len;
+    a.K = (uint32_t)c->cp.K;
+    a.k1 = (uint32_t)c->cp.k1;
+    a.k2 = (uint32_t)c->cp.k2;
+    a.mask = c->cp.hash_size - 1;
+    a.kmax = c->prm.max_mismatches;
+    switch (c->nw) {
+#define CASE_NW(N) case N: launch_dual<N>(c, a); break;
+        CASE_NW(2) CASE_NW(3) CASE_NW(4) CASE_NW(5) CASE_NW(6) CASE_NW(7) CASE_NW(8) CASE_NW(9)
+        CASE_NW(10) CASE_NW(11) CASE_NW(12) CASE_NW(13) CASE_NW(14) CASE_NW(15) CASE_NW(16)
+#undef CASE_NW
+    default:
+        c->err = "unsupported read length for mode c";
+        return PGRC_E_PARAM;
+    }
+    HIP_TRY(c, hipGetLastError());
+    return PGRC_OK;
+}
+
 template <int NW>
 static void launch_match(pgrc_match_ctx *c, const MatchArgs &a) {
     // persistent grid: what the chip can hold (8 blocks of 4 waves per CU is the register/LDS limit at most)
@@ -954,7 +1356,7 @@ int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase) {
     a.phase = (uint32_t)phase;
     a.scr_pos = (uint64_t *)c->d_scr_pos.p;
     a.scr_flag = (uint8_t *)c->d_scr_flag.p;
-    if (phase && (!a.scr_pos || !a.scr_flag)) { c->err = "screened schedule without its buffers"; return PGRC_E_STATE; }
+    if (phase && (!a.scr_flag || (phase != 4 && !a.scr_pos))) { c->err = "screened schedule without its buffers"; return PGRC_E_STATE; }
     a.L = c->prm.read_len;
     a.K = (uint32_t)c->cp.K;
     a.k2 = (uint32_t)c->cp.k2;

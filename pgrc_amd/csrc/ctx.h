@@ -196,6 +196,7 @@ int pgrc_ps_scatter_front(pgrc_match_ctx *c, int strand, uint32_t hbits, uint32_
 int pgrc_ps_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uint64_t *d_vals, uint32_t hbits, uint32_t cb, uint64_t *d_ent);
 int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand);
 int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase);
+int pgrc_copmem_match_dual(pgrc_match_ctx *c);
 int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_positions, uint64_t *count);
 
 // seedidx.hip (modes d / i / e)

@@ -51,6 +51,8 @@ def oracle():
                                                   C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         lib.pgrc_or_copmem_match_read.restype = C.c_uint64
         lib.pgrc_or_set_early_stop.argtypes = [C.c_int]
+        lib.pgrc_or_match_copmem_dual.argtypes = [_P, C.c_uint64, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint8,
+                                                  C.c_uint8, C.c_int, C.c_int, C.POINTER(Result), C.POINTER(C.c_uint64)]
         lib.pgrc_or_match_copmem_screened.argtypes = [_P, C.c_uint64, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint8,
                                                       C.c_uint8, C.c_int, C.c_int, C.POINTER(Result)]
         lib.pgrc_or_probe_count.argtypes = [C.c_int]
@@ -173,6 +175,26 @@ def oracle_match_screened(pg, reads, seed_len, kmax, kmin, threads=8, state=None
     if e:
         raise RuntimeError(f"oracle returned {e}")
     return _pack_result(r, pos, rc, mism)
+
+
+def oracle_match_dual(pg, reads, seed_len, kmax, threads=8, state=None):
+    """Mode c, both strands, kmin 0, as ONE query over both strands per read (pgrc_or_match_copmem_dual).
+    The returned dict also has 'aborted': reads that fell back to the reference's order."""
+    pg = np.ascontiguousarray(pg, dtype=np.uint8)
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    n, L = reads.shape
+    r, pos, rc, mism = _new_result(n)
+    init = 1
+    if state is not None:
+        pos[:], rc[:], mism[:] = state
+        init = 0
+    ab = C.c_uint64(0)
+    e = oracle().pgrc_or_match_copmem_dual(_ptr(pg), pg.size, _ptr(reads), n, L, seed_len, kmax, 0, threads, init, C.byref(r), C.byref(ab))
+    if e:
+        raise RuntimeError(f"oracle returned {e}")
+    out = _pack_result(r, pos, rc, mism)
+    out["aborted"] = int(ab.value)
+    return out
 
 
 def oracle_index(pg, seed_len):

@@ -53,9 +53,10 @@ def main():
         batch = str(int(rng.integers(1, 1500))) if mode != "c" and rng.random() < 0.4 else ""
         stage = "0" if rng.random() < 0.2 else ""        # the match kernel without staged refills
         early = "0" if rng.random() < 0.25 else ""       # ... probing every seed of every read (no early stop)
-        screen = str(rng.choice(["", "0", "1", "1"]))       # ... the two passes in the reference's order (no exact-match screen)
+        dual = str(rng.choice(["", "1", "1", "0"]))         # one query per read over both strands: forced / where it pays / never
+        screen = str(rng.choice(["", "", "0", "1"]))       # "" = the dual kernel where it applies       # ... the two passes in the reference's order (no exact-match screen)
         for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish), ("PGRC_SEED_SEGMENT", seg), ("PGRC_SEED_READ_BATCH", batch),
-                         ("PGRC_MATCH_STAGE", stage), ("PGRC_EARLY_STOP", early), ("PGRC_SCREEN", screen)):
+                         ("PGRC_MATCH_STAGE", stage), ("PGRC_EARLY_STOP", early), ("PGRC_SCREEN", screen), ("PGRC_DUAL", dual)):
             if val:
                 os.environ[key] = val
             else:
@@ -63,7 +64,7 @@ def main():
         g = gpu_match(mode, pg, reads, seed_len, kmax, kmin, rev, devices=[0] * shards if shards else None,
                       n_nset=nn if packed else None)
         what = dict(mode=mode, L=L, seed_len=seed_len, M=M, kmin=kmin, G=G, n=n, nn=nn, rev=rev, seed=seed, shards=shards,
-                    packed=packed, variant=variant, finish=finish, seg=seg, batch=batch, stage=stage, early=early, screen=screen)
+                    packed=packed, variant=variant, finish=finish, seg=seg, batch=batch, stage=stage, early=early, screen=screen, dual=dual)
         for k in ("pos", "rc", "mism", "hist"):
             if not np.array_equal(np.asarray(g[k]), np.asarray(o[k])):
                 print("READS MISMATCH", what, k, flush=True)

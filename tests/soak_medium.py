@@ -38,13 +38,14 @@ def main():
         finish = "general" if rng.random() < 0.25 else ""
         early = "0" if rng.random() < 0.2 else ""        # the match kernel probing every seed of every read
         stage = "0" if rng.random() < 0.2 else ""        # ... and without staged refills
-        screen = str(rng.choice(["", "0", "1", "1"]))       # ... and the two passes in the reference's order (no exact-match screen)
-        for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish), ("PGRC_EARLY_STOP", early), ("PGRC_MATCH_STAGE", stage), ("PGRC_SCREEN", screen)):
+        dual = str(rng.choice(["", "1", "1", "0"]))         # one query per read over both strands: forced / where it pays / never
+        screen = str(rng.choice(["", "", "0", "1"]))       # "" = the dual kernel where it applies       # ... and the two passes in the reference's order (no exact-match screen)
+        for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish), ("PGRC_EARLY_STOP", early), ("PGRC_MATCH_STAGE", stage), ("PGRC_SCREEN", screen), ("PGRC_DUAL", dual)):
             if val:
                 os.environ[key] = val
             else:
                 os.environ.pop(key, None)
-        what = dict(L=L, seed_len=seed_len, kmax=kmax, kmin=kmin, G=G, n=n, nn=nn, seed=seed, shards=shards, variant=variant, finish=finish, early=early, stage=stage, screen=screen)
+        what = dict(L=L, seed_len=seed_len, kmax=kmax, kmin=kmin, G=G, n=n, nn=nn, seed=seed, shards=shards, variant=variant, finish=finish, early=early, stage=stage, screen=screen, dual=dual)
         o = orc.oracle_match("c", pg, reads, seed_len, kmax, kmin, True, 16)
         g = gpu_match("c", pg, reads, seed_len, kmax, kmin, True, devices=[0] * shards if shards else None)
         for k in ("pos", "rc", "mism", "hist"):

@@ -33,6 +33,15 @@ def _both(pg, reads, seed_len, kmax, kmin, rev=True):
             assert np.array_equal(np.asarray(full[k]), np.asarray(scr[k])), ("screened", k)
         assert full["matched"] == scr["matched"]
         _both.last_screened = p_scr
+        if kmin == 0:
+            # ... and ONE query over both strands at once (the dual kernel's scheme)
+            lib.pgrc_or_probe_count(1)
+            du = orc.oracle_match_dual(pg, reads, seed_len, kmax)
+            _both.last_dual = lib.pgrc_or_probe_count(1)
+            _both.last_aborted = du["aborted"]
+            for k in ("pos", "rc", "mism", "hist"):
+                assert np.array_equal(np.asarray(full[k]), np.asarray(du[k])), ("dual", k)
+            assert full["matched"] == du["matched"]
     return p_full, p_early
 
 

@@ -151,14 +151,21 @@ def test_copmem_parity(L, seed_len, M, mode, G, n):
     assert_same_results(oe, o, "early-stop rule")
     legs = [({"PGRC_SCREEN": "0"}, oe, 0), ({"PGRC_SCREEN": "0", "PGRC_EARLY_STOP": "0"}, o, 0)]
     if kmin == 0:
+        legs.append(({"PGRC_DUAL": "1"}, None, 2))
+    if kmin == 0:
         osc = orc.oracle_match_screened(pg, reads, seed_len, kmax, kmin)
         assert_same_results(osc, o, "screened schedule")
         legs.append(({"PGRC_SCREEN": "1"}, osc, 1))
     else:
         osc = None
         assert ctr["screened"] == 0
-    want = osc if ctr["screened"] else oe            # (the library screens by itself where it pays: long reads)
-    assert ctr["searched"] == want["searched"] and ctr["candidates"] == want["candidates"]
+    if ctr["screened"] == 2:                         # the default for kmin == 0: ONE query per read over both strands
+        od = orc.oracle_match_dual(pg, reads, seed_len, kmax)
+        assert_same_results(od, o, "dual scheme (oracle restatement)")
+        assert ctr["redo_reads"] <= n // 4 + 50      # (reads whose falses bound exceeded the budget took the two passes)
+    else:
+        want = osc if ctr["screened"] else oe
+        assert ctr["searched"] == want["searched"] and ctr["candidates"] == want["candidates"]
     # ... with the screen switched off, the early-stop oracle's; with both off, the reference's; forced on, the schedule's
     for knobs, want, screened in legs:
         os.environ.update(knobs)
@@ -170,7 +177,8 @@ def test_copmem_parity(L, seed_len, M, mode, G, n):
         assert_same_results(g0, o, str(knobs))
         c0 = g0["ctx"].counters()
         assert c0["screened"] == screened, knobs
-        assert c0["searched"] == want["searched"] and c0["candidates"] == want["candidates"], knobs
+        if want is not None:
+            assert c0["searched"] == want["searched"] and c0["candidates"] == want["candidates"], knobs
     if orc.have_ref():
         r = orc.ref_match("c", pg, reads, seed_len, kmax, kmin)
         assert_same_results(g, r, "vs real reference")
@@ -279,7 +287,7 @@ def test_two_phase_continuation():
     assert np.array_equal(bitmap, o2["mism"] <= 254)
 
 
-@pytest.mark.parametrize("screen", ["0", "1"])
+@pytest.mark.parametrize("screen", ["0", "1", "dual"])
 def test_screened_schedule_hard_cases(monkeypatch, screen):
     """The screened schedule of a two-pass run (exact-match screen on the RC text first) where its side conditions
     bite: low-complexity text (capped buckets, falses budgets running out: flagged reads fall back to the real query),
@@ -287,7 +295,10 @@ def test_screened_schedule_hard_cases(monkeypatch, screen):
     earlier phase's results, and a sharded matcher.  Results against the reference-order oracle, work counters against
     the oracle's restatement of the schedule."""
     from pgrc_amd import MatchContext
-    monkeypatch.setenv("PGRC_SCREEN", screen)
+    if screen != "dual":
+        monkeypatch.setenv("PGRC_SCREEN", screen)
+    else:                                # the dual kernel, one query per read over both strands (forced: these reads are short)
+        monkeypatch.setenv("PGRC_DUAL", "1")
     rng = np.random.default_rng(17)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     comp = {65: 84, 67: 71, 71: 67, 84: 65}
@@ -319,9 +330,11 @@ def test_screened_schedule_hard_cases(monkeypatch, screen):
         g = gpu_match("c", P, R, 38, kmax, 0)
         assert_same_results(g, o, name)
         ctr = g["ctx"].counters()
-        assert ctr["screened"] == int(screen)
+        assert ctr["screened"] == (2 if screen == "dual" else int(screen))
         want = orc.oracle_match_screened(P, R, 38, kmax, 0) if screen == "1" else orc.oracle_match("c", P, R, 38, kmax, 0, early_stop=True)
-        if name != "palindromes":        # (reads with N go the byte path: the main kernel's counters leave them out)
+        if screen == "dual":
+            assert_same_results(orc.oracle_match_dual(P, R, 38, kmax), o, name + " (oracle restatement of the dual scheme)")
+        elif name != "palindromes":      # (reads with N go the byte path: the main kernel's counters leave them out)
             assert ctr["searched"] == want["searched"] and ctr["candidates"] == want["candidates"], name
         g3 = gpu_match("c", P, R, 38, kmax, 0, devices=[0, 0, 0])
         assert_same_results(g3, o, name + " (3 shards)")
