@@ -144,20 +144,29 @@ def main():
         # the 10-B result; per executed seed probe one 8-B bucket range; per verified candidate a 4-B position
         # and the (L/4 + 1)-B text window.
         rb = (L + 3) // 4
+        schedule = {0: "two passes", 1: "screened", 2: "dual"}[ctr["screened"]]
         dom = 0 if ctr["ms_match"][0] >= ctr["ms_match"][1] else 1
-        alg_bytes = ctr["searched"][dom] * (rb + 10) + ctr["probes"][dom] * 8 + ctr["candidates"][dom] * (5 + rb)
-        ms = ctr["ms_match"][dom]
+        if schedule == "dual":
+            # one launch does a read's query over both strands; the two ordinary passes after it only see
+            # the reads it left undecided: the dual kernel is the dominant one
+            kc = ctr["dual"]
+            ms = ctr["ms_screen"]
+            kname = "k_copmem_match_dual"
+        else:
+            kc = {k: ctr[k][dom] for k in ("searched", "probes", "candidates", "entry_fetches", "verifies")}
+            ms = ctr["ms_match"][dom]
+            kname = "k_copmem_match" + ("(fwd)" if dom == 0 else "(rc)")
+        alg_bytes = kc["searched"] * (rb + 10) + kc["probes"] * 8 + kc["candidates"] * (5 + rb)
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         # random 64-B line requests issued by that launch: one per probed bucket head, one per fetched entry pair,
         # and per verified text window the lines a (L/4)-byte window at a random 4-B offset spans on average
         # (tools/ubench: the chip sustains ~51 G independent random requests per second, whatever their width)
-        gathers = int(ctr["probes"][dom] + ctr["entry_fetches"][dom] + ctr["verifies"][dom] * (1.0 + max(rb - 4, 0) / 64.0))
+        gathers = int(kc["probes"] + kc["entry_fetches"] + kc["verifies"] * (1.0 + max(rb - 4, 0) / 64.0))
         gather_rate = gathers / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         # the bytes THIS kernel's algorithm needs (its fingerprints reject 99.9 % of the false candidates without
         # touching the text, so the reference's text-window bytes above are mostly never moved): a 16-B head per
         # probe, 16 B per fetched entry pair, a window only per VERIFIED candidate, the read and the result
-        kernel_bytes = (ctr["probes"][dom] * 16 + ctr["entry_fetches"][dom] * 16 + ctr["verifies"][dom] * (5 + rb) +
-                        ctr["searched"][dom] * (rb + 10))
+        kernel_bytes = kc["probes"] * 16 + kc["entry_fetches"] * 16 + kc["verifies"] * (5 + rb) + kc["searched"] * (rb + 10)
         kernel_gbs = kernel_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         # HBM traffic of that launch from the PMC counters (FETCH_SIZE + WRITE_SIZE): they cannot be read from inside
         # this process, so the value comes from the committed separate `rocprofv3 --pmc` passes of this very command
@@ -169,10 +178,11 @@ def main():
         if world == 1 and os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                per = tj.get("per_step", 2)        # match launches per step when the profile was taken: 3 = screen, fwd, rc
-                if per != (3 if ctr["screened"] else 2):
+                # the profile names the schedule it was taken under and lists that step's match launches in order:
+                # "two passes": fwd, rc; "screened": screen, fwd, rc; "dual": dual kernel, fwd, rc (the two redo passes)
+                if tj.get("schedule", "two passes") != schedule:
                     raise KeyError("profile taken under another schedule")
-                traffic = tj["dispatches"][dom + (1 if per == 3 else 0)]["hbm_bytes"]
+                traffic = tj["dispatches"][0 if schedule == "dual" else dom + (1 if schedule == "screened" else 0)]["hbm_bytes"]
                 traffic_src = os.path.relpath(tp, ROOT)
             except Exception:
                 traffic = None
@@ -197,11 +207,11 @@ def main():
                        "parallelism": f"reads sharded x{world}, Pg replicated" + (" (1 all-gather/step)" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_copmem_match" + ("(fwd)" if dom == 0 else "(rc)"),
+                         "kernel": kname, "schedule": schedule,
                          "kernel_ms": ms, "algorithmic_bytes": alg_bytes,
                          # every launch of the match kernel in a step (the screened schedule has three: screen, forward
                          # pass, RC pass) and their mean -- what `rocprofv3 --stats` reports as the kernel's average
-                         "match_launches_ms": ([ctr["ms_screen"]] if ctr["screened"] else []) + list(ctr["ms_match"]),
+                         "match_launches_ms": ([ctr["ms_screen"]] if ctr["screened"] else []) + list(ctr["ms_match"]),   # (screen or dual kernel first)
                          "match_launches_mean_ms": (ctr["ms_screen"] + sum(ctr["ms_match"])) / (3 if ctr["screened"] else 2),
                          "kernel_bytes": kernel_bytes, "achieved_kernel_bytes": kernel_gbs,
                          "frac_kernel_bytes": kernel_gbs / HBM_PEAK_GBS,
@@ -212,11 +222,14 @@ def main():
                           "match_rc": ctr["ms_match"][1], "other": ctr["ms_other"], "total_device": ctr["ms_total"],
                           # the screened schedule: both indexes first, then an exact-match screen on the RC
                           # text, the forward pass, the RC pass; "screen" is that first launch (0 when the run did not take it)
-                          "screen": ctr["ms_screen"], "screened_schedule": bool(ctr["screened"]),
+                          "screen": ctr["ms_screen"], "screened_schedule": bool(ctr["screened"]), "schedule": schedule,
+                          "schedule_note": {"dual": "'screen' is the dual kernel (every read, both strands at once); match_fwd / match_rc are the two ordinary passes over the reads it left undecided",
+                                            "screened": "'screen' = exact-match screen on the RC text, then the forward and the RC pass",
+                                            "two passes": None}[schedule],
                           "index_note": ("both index builds run at once on two streams: index_fwd is the pair, index_rc ~ 0"
                                          if ctr["screened"] and ctr["ms_index"][1] < 0.1 * ctr["ms_index"][0] else None)},
             "dist_backend": args.dist_backend if world > 1 else None,
-            "counters": {k: ctr[k] for k in ("searched", "candidates", "probes", "entry_fetches", "verifies", "index_entries")},
+            "counters": {k: ctr[k] for k in ("searched", "candidates", "probes", "entry_fetches", "verifies", "index_entries", "dual", "redo_reads")},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

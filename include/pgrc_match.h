@@ -230,10 +230,12 @@ typedef struct {
      * exact-match screen on the RC text, then the two passes); ms_screen = the screen launch, its probes / candidates /
      * fetches are counted with strand 1 */
     uint32_t screened;      /* 2 = one query per read over both strands (the dual kernel): ms_screen = that launch, its
-                             * work is counted with strand 0, ms_match[] = the two ordinary passes over what it left
-                             * undecided (redo_reads) and the reads with N */
+                             * work is in dual[], ms_match[] = the two ordinary passes over what it left undecided
+                             * (redo_reads) and the reads with N */
     float ms_screen;
     uint64_t redo_reads;
+    uint64_t dual[5];       /* screened == 2: the dual kernel's own searched / candidates / heads probed / entry fetches /
+                             * verifies (the per-strand counters above then describe the two ordinary passes after it) */
 } pgrc_match_counters;
 /* enable per-kernel HIP-event timing + work counters for subsequent runs */
 int pgrc_match_set_profiling(pgrc_match_ctx *ctx, int enabled);

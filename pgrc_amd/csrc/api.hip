@@ -664,12 +664,8 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
         c->ctr.entry_fetches[s] = ctr[8 * s + 3];
         c->ctr.verifies[s] = ctr[8 * s + 4];
     }
-    if (screened && dual) {          // the dual kernel's work counts with strand 0
-        c->ctr.searched[0] += scr[0];
-        c->ctr.candidates[0] += scr[1];
-        c->ctr.probes[0] += scr[2];
-        c->ctr.entry_fetches[0] += scr[3];
-        c->ctr.verifies[0] += scr[4];
+    if (screened && dual) {
+        for (int k = 0; k < 5; k++) c->ctr.dual[k] = scr[k];
         c->ctr.redo_reads = scr[5];
         c->ctr.screened = 2;
     } else if (screened) {           // the screen ran on the RC text: its work counts with that strand's (not "searched")
