@@ -402,7 +402,7 @@ int pgrc_or_match_copmem(const char *pg, uint64_t pg_len, const char *reads, uin
  * (earlier accepted ones have larger counts, so the limit is still >= m_min when it comes) and nothing after it -- the
  * reference's final alignment; the caps never fall below the counts that still matter.  All of it presupposes that no
  * run cuts a bucket by the falses budget: U bounds the falses of any run over the candidates seen so far (1 for a
- * candidate whose head count alone exceeds the starting limit, else 2); U > budget at a seed start -> the read is
+ * candidate whose head count alone exceeds the starting limit or that has no mismatch in the tail, else 2); U > budget at a seed start -> the read is
  * done again in the reference's order (return 1). */
 typedef struct { int limit; uint32_t cur; uint64_t best; uint64_t U; uint32_t rclean; int rdirty, active, found; } dual_side;
 
@@ -448,7 +448,7 @@ static int dual_query(const pgrc_or_index *idx[2], const char *text[2], const ch
                 uint32_t mh = 0, mt = 0;
                 for (uint32_t i = 0; i < head; i++) mh += (read[i] != t[i]);
                 for (uint32_t i = head; i < read_len; i++) mt += (read[i] != t[i]);
-                sd[x].U += ((int)mh > L0) ? 1 : 2;
+                sd[x].U += ((int)mh > L0 || mt == 0) ? 1 : 2;   /* no tail mismatch: head reject (1) or accepted (0), never 2 */
                 const int m = (int)(mh + mt);
                 if (m > DUAL_EFF(x)) continue;
                 sd[x].cur = (uint32_t)m;

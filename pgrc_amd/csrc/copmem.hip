@@ -924,7 +924,7 @@ k_copmem_match_n(const MatchArgs a, const uint32_t *__restrict__ nidx, const uin
 // its candidates accepts the FIRST candidate with m_min and nothing after it, which is the reference's final
 // alignment; the caps never fall below the counts that still matter.  All of it presupposes that no run would have cut
 // a bucket by the falses budget: U bounds the falses of any run over the candidates seen so far (1 for a candidate
-// whose head count -- or already its fingerprint -- exceeds the starting limit, else 2); U > budget when a bucket is
+// whose head count -- or already its fingerprint -- exceeds the starting limit or whose tail is clean, else 2); U > budget when a bucket is
 // opened -> the read is flagged (redo) and goes through the two passes in the reference's order afterwards.
 // oracle/pgrc_oracle.c restates the scheme (pgrc_or_match_copmem_dual); tests/test_early_stop_rule.py expects it to
 // equal the reference's two passes on every input.
@@ -1097,7 +1097,9 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_dual(const DualArgs 
         bool bdone = false;           // the current strand's bucket is finished
         // a verified alignment of the current strand (head count mh, tail count mt)
         auto judge = [&](uint32_t mh, uint32_t mt, pos_t p) {
-            const uint32_t u = ((int)mh > L0) ? 1u : 2u;
+            // what any run can count for this candidate: 1 if the head alone exceeds every limit a run can have, or if the
+            // tail is clean (then it is a head reject or an acceptance), else 2 (a tail reject is counted twice)
+            const uint32_t u = ((int)mh > L0 || mt == 0u) ? 1u : 2u;
             const int m = (int)(mh + mt);
             if (x == 0u) U0 += u; else U1 += u;
             if (m > eff(x)) return;
