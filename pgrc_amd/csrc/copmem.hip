@@ -283,10 +283,14 @@ struct MatchArgs {
     uint32_t k1, early;           // sampling step of the index; early = 1: stop a read once nothing can be accepted any more
     // the screened schedule of a two-pass run (see "Exact-match screen" at the kernel): phase 0 = a plain pass,
     // 1 = screen (RC text, exact alignments only, flags and positions to scr_*), 2 = forward pass that honours the flags,
-    // 4 = a plain pass over the reads flagged in scr_flag only (what the dual kernel left undecided)
+    // 4 = a plain pass over the reads of `list` only (what the dual kernel left undecided)
     uint32_t phase;
     uint64_t *scr_pos;
     uint8_t *scr_flag;
+    // a pass over a LIST of reads (what the dual kernel left undecided) instead of all of them: the indices and, on the
+    // device, their number
+    const uint32_t *list;
+    const unsigned long long *list_n;
 };
 
 #define MATCH_TPB 256
@@ -408,8 +412,10 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
     constexpr int SW = STAGE > 0 ? STAGE : 1;
     __shared__ uint32_t stg[MATCH_TPB / 64][NW][SW];
     __shared__ uint8_t stg_c[MATCH_TPB / 64][SW], stg_f[MATCH_TPB / 64][SW];
+    __shared__ uint32_t stg_i[MATCH_TPB / 64][SW];   // list mode: which read sits in a staged slot
     const uint32_t wv = threadIdx.x >> 6;
     uint32_t wbeg = 0, wend = 0, wnext = 0;      // the staged window and the next read of it to hand out (wave-uniform)
+    const uint64_t n_items = a.list ? (uint64_t)*a.list_n : a.n;   // reads, or entries of the list
     hash_lut_init(lut);
     const int H = ((int)a.L / 8) * 8;
     const uint32_t nseeds = (a.L - a.K) / a.k2 + 1; // seeds s = 0, k2, ... with s + K <= L
@@ -471,27 +477,25 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
         const unsigned long long need = __ballot(mode == M_NEED);
         if (need) {
             if (cnext == cend) { // reserve another chunk (one atomic per wave and MATCH_CHUNK reads)
+                // (a list is short and its reads are heavy -- repeat families --: small chunks, or most waves get nothing)
+                const unsigned long long chunk = a.list ? 64ull : (unsigned long long)MATCH_CHUNK;
                 unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(a.work, (unsigned long long)MATCH_CHUNK);
+                if (lane == 0) base = atomicAdd(a.work, chunk);
                 base = __shfl(base, 0, 64);
-                cnext = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base, a.n));
-                cend = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base + MATCH_CHUNK, a.n));
+                cnext = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base, n_items));
+                cend = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base + chunk, n_items));
             }
             if (STAGE > 0 && wnext == wend && cnext != cend) {    // the window is used up: stage the chunk's next reads
                 const uint32_t nst = min((uint32_t)SW, cend - cnext);
                 wbeg = wnext = cnext;
                 wend = cnext = __builtin_amdgcn_readfirstlane(cnext + nst);
-                uint32_t wf = 0;
-                if (lane < nst) wf = (uint32_t)((a.nflag ? a.nflag[wbeg + lane] : 0) | (a.phase == 2u || a.phase == 4u ? (a.scr_flag[wbeg + lane] & 1u) << 1 : 0u));
-                // phase 4 only works on flagged reads: a window without any is handed out unloaded (all its reads skip)
-                const bool load_rows = a.phase != 4u || __any(lane < nst && (wf & 2u));
                 if (lane < nst) {
-                    if (load_rows) {
+                    const uint32_t ri = a.list ? a.list[wbeg + lane] : wbeg + lane;   // (a listed read is gathered, not streamed)
 #pragma unroll
-                        for (int k = 0; k < NW; k++) stg[wv][k][lane] = a.reads[(uint64_t)k * a.stride + wbeg + lane];
-                        stg_c[wv][lane] = a.mism[wbeg + lane];
-                    } else stg_c[wv][lane] = 0;       // (count 0 <= min_mismatches: skipped)
-                    stg_f[wv][lane] = (uint8_t)wf;
+                    for (int k = 0; k < NW; k++) stg[wv][k][lane] = a.reads[(uint64_t)k * a.stride + ri];
+                    stg_c[wv][lane] = a.mism[ri];
+                    stg_f[wv][lane] = (uint8_t)((a.nflag ? a.nflag[ri] : 0) | (a.phase == 2u ? (a.scr_flag[ri] & 1u) << 1 : 0u));
+                    stg_i[wv][lane] = ri;
                 }
                 __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // a wave's LDS accesses are served in order
             }
@@ -504,12 +508,11 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
                 bool started = false;
                 if (mode == M_NEED && rank < take) {
                     const uint32_t sj = wnext - wbeg + rank;
-                    idx = STAGE > 0 ? wbeg + sj : cnext + rank;
+                    idx = STAGE > 0 ? stg_i[wv][sj] : (a.list ? a.list[cnext + rank] : cnext + rank);
                     cin = STAGE > 0 ? stg_c[wv][sj] : a.mism[idx];
                     const uint32_t rflags = STAGE > 0 ? (uint32_t)stg_f[wv][sj]
-                                                      : (uint32_t)((a.nflag ? a.nflag[idx] : 0) | (a.phase == 2u || a.phase == 4u ? (a.scr_flag[idx] & 1u) << 1 : 0u));
-                    // ReadsMatchers.cpp:430; 'N' reads: byte path; phase 4: only what the dual kernel left undecided
-                    const bool skip = (rflags & 1u) || cin <= a.kmin || (a.phase == 4u && !(rflags & 2u));
+                                                      : (uint32_t)((a.nflag ? a.nflag[idx] : 0) | (a.phase == 2u ? (a.scr_flag[idx] & 1u) << 1 : 0u));
+                    const bool skip = (rflags & 1u) || cin <= a.kmin;   // ReadsMatchers.cpp:430; 'N' reads: byte path
                     if (!skip) {
 #pragma unroll
                         for (int k = 0; k < NW; k++)
@@ -939,7 +942,8 @@ struct DualArgs {
     uint64_t *pos;
     uint8_t *rc;
     uint8_t *mism;
-    uint8_t *redo;                // [n] 1 = undecided here
+    uint32_t *redo;               // the reads left undecided here: their indices ...
+    unsigned long long *redo_n;   // ... and how many
     unsigned long long *counters; // [0] searched [1] candidates [2] heads probed [3] entry fetches [4] verifies [5] redo
     unsigned long long *work;
     uint32_t L, K, k1, k2, mask, kmax;
@@ -1222,8 +1226,8 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_dual(const DualArgs 
         const bool fin = next == M_NEED && m0 <= M_VERIFY;
         if (fin) {
             // the read is finished: forward wins ties, RC must be strictly better (ReadsMatchers.cpp:437-447, both passes)
-            if (fl & F_REDO) a.redo[idx] = 1;
-            else if ((fl & F_FOUND1) && !((fl & F_FOUND0) && cur0 <= cur1)) {
+            if (fl & F_REDO) {
+            } else if ((fl & F_FOUND1) && !((fl & F_FOUND0) && cur0 <= cur1)) {
                 a.pos[idx] = a.G - ((uint64_t)best1 + a.L);
                 a.rc[idx] = 1;
                 a.mism[idx] = (uint8_t)cur1;
@@ -1233,7 +1237,16 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_dual(const DualArgs 
                 a.mism[idx] = (uint8_t)cur0;
             }
         }
-        n_redo += (uint32_t)__popcll(__ballot(fin && (fl & F_REDO) != 0u));
+        {   // undecided reads go on the list of the two ordinary passes (one atomic per wave and iteration)
+            const unsigned long long rb = __ballot(fin && (fl & F_REDO) != 0u);
+            if (rb) {
+                unsigned long long at = 0;
+                if (lane == (uint32_t)__ffsll((long long)rb) - 1u) at = atomicAdd(a.redo_n, (unsigned long long)__popcll(rb));
+                at = __shfl(at, __ffsll((long long)rb) - 1, 64);
+                if (fin && (fl & F_REDO)) a.redo[at + (uint32_t)__popcll(rb & ((1ull << lane) - 1ull))] = idx;
+                n_redo += (uint32_t)__popcll(rb);
+            }
+        }
         mode = next;
     }
     if (a.counters && lane == 0) {
@@ -1267,7 +1280,7 @@ static void launch_dual(pgrc_match_ctx *c, const DualArgs &a) {
 // passes that follow (phase 4).
 int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     if (c->n == 0) return PGRC_OK;
-    if (c->index_strand != 1 || c->alt_index_strand != 0 || !c->ent_ptr || !c->alt_ent_ptr || !c->d_scr_flag.p) {
+    if (c->index_strand != 1 || c->alt_index_strand != 0 || !c->ent_ptr || !c->alt_ent_ptr || !c->d_scr_pos.p) {
         c->err = "dual kernel without both indexes";
         return PGRC_E_STATE;
     }
@@ -1286,7 +1299,8 @@ int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     a.pos = (uint64_t *)c->d_pos.p;
     a.rc = (uint8_t *)c->d_rc.p;
     a.mism = (uint8_t *)c->d_mism.p;
-    a.redo = (uint8_t *)c->d_scr_flag.p;
+    a.redo = (uint32_t *)c->d_scr_pos.p;
+    a.redo_n = (unsigned long long *)c->d_counters.p + 19;
     a.counters = (unsigned long long *)c->d_counters.p + 24;
     a.work = (unsigned long long *)c->d_counters.p + 18;
     a.L = c->prm.read_len;
@@ -1358,7 +1372,13 @@ int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase) {
     a.phase = (uint32_t)phase;
     a.scr_pos = (uint64_t *)c->d_scr_pos.p;
     a.scr_flag = (uint8_t *)c->d_scr_flag.p;
-    if (phase && (!a.scr_flag || (phase != 4 && !a.scr_pos))) { c->err = "screened schedule without its buffers"; return PGRC_E_STATE; }
+    if (phase && (!a.scr_flag || !a.scr_pos)) { c->err = "screened schedule without its buffers"; return PGRC_E_STATE; }
+    a.list = nullptr;
+    a.list_n = nullptr;
+    if (phase == 4) {                 // the reads the dual kernel listed (it kept the list where the screen keeps its positions)
+        a.list = (const uint32_t *)c->d_scr_pos.p;
+        a.list_n = (const unsigned long long *)c->d_counters.p + 19;
+    }
     a.L = c->prm.read_len;
     a.K = (uint32_t)c->cp.K;
     a.k2 = (uint32_t)c->cp.k2;
