@@ -555,6 +555,7 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
     int evi = 0;
     auto mark = [&]() { if (prof) (void)hipEventRecord(c->ev[evi], c->stream); evi++; };
     mark(); // 0
+    bool fallback_layout = false;
     const bool dual = dual_wanted(c, first, last);
     bool screened = dual || screen_wanted(c, first, last);
     if (screened && ((e = pgrc_buf_ensure(c, c->d_scr_pos, c->n * sizeof(uint64_t))) || (e = pgrc_buf_ensure(c, c->d_scr_flag, c->n)))) {
@@ -584,7 +585,8 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
         if (!two) mark(); // 2
         swap_index_sets(c);
         if (two) c->stream = c->build_stream;
-        e = pgrc_copmem_build_index(c, 1);
+        // (PGRC_TEST_NO_SECOND_INDEX: tests take the out-of-memory road below without exhausting the device)
+        e = getenv("PGRC_TEST_NO_SECOND_INDEX") ? PGRC_E_ALLOC : pgrc_copmem_build_index(c, 1);
         c->stream = main_stream;
         if (two) {
             if (hipEventRecord(c->build_ev[1], c->build_stream) != hipSuccess || hipStreamWaitEvent(main_stream, c->build_ev[1], 0) != hipSuccess) {
@@ -596,6 +598,7 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
         if (e == PGRC_E_ALLOC) {
             // no room for both indexes: free what the second set got, and run the passes in the reference's order
             (void)hipGetLastError();
+            if (two) (void)hipStreamSynchronize(c->build_stream);   // (nothing of a half-started build may still be running)
             DevBuf *part[] = {&c->d_head, &c->d_skey[0], &c->d_skey[1], &c->d_sval[0], &c->d_sval[1], &c->d_sorttmp};
             for (DevBuf *b : part) pgrc_buf_free(*b);
             c->ent_ptr = nullptr;
@@ -610,7 +613,7 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
             mark(); // 5
             if ((e = pgrc_copmem_match_pass(c, 1))) return e;
             mark(); // 6
-            first = 2;  // (event layout: see the timing below)
+            fallback_layout = true;  // (events: see the timing below)
         } else {
             if (e) return e;
             mark(); // 3
@@ -625,14 +628,14 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
                 if ((e = pgrc_copmem_match_phase(c, 1, 4))) return e;      // the two passes in the reference's order
                 mark(); // 6
             } else {
-            if ((e = pgrc_copmem_match_phase(c, 1, 1))) return e;          // screen on the RC text
-            mark(); // 4
-            swap_index_sets(c);
-            if ((e = pgrc_copmem_match_phase(c, 0, 2))) return e;          // forward pass honouring the flags
-            mark(); // 5
-            swap_index_sets(c);
-            if ((e = pgrc_copmem_match_phase(c, 1, 0))) return e;          // RC pass over what is left
-            mark(); // 6
+                if ((e = pgrc_copmem_match_phase(c, 1, 1))) return e;      // screen on the RC text
+                mark(); // 4
+                swap_index_sets(c);
+                if ((e = pgrc_copmem_match_phase(c, 0, 2))) return e;      // forward pass honouring the flags
+                mark(); // 5
+                swap_index_sets(c);
+                if ((e = pgrc_copmem_match_phase(c, 1, 0))) return e;      // RC pass over what is left
+                mark(); // 6
             }
         }
     } else if (c->prm.mode == 'c') {
@@ -678,7 +681,7 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
     if (prof) {
         HIP_TRY(c, hipEventSynchronize(c->ev[evi - 1]));
         float ms = 0;
-        if (c->prm.mode == 'c' && (screened || first == 2)) {
+        if (c->prm.mode == 'c' && (screened || fallback_layout)) {
             // events: 1 start of the forward index, 2 its end; then (screened) RC index, screen, forward match, RC match
             //         or (fallback) forward match, RC index, RC match
             auto span = [&](int x, int y) { float t = 0; (void)hipEventElapsedTime(&t, c->ev[x], c->ev[y]); return t; };

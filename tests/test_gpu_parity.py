@@ -350,6 +350,30 @@ def test_screened_schedule_hard_cases(monkeypatch, screen):
     assert np.array_equal(pos, o2["pos"]) and np.array_equal(rc, o2["rc"]) and np.array_equal(mism, o2["mism"])
 
 
+def test_two_index_schedules_fall_back_when_the_second_index_does_not_fit(monkeypatch):
+    """PGRC_TEST_NO_SECOND_INDEX makes the build of the second index set report out-of-memory: the run must free what it
+    got, take the two passes in the reference's order, and stay on them for later runs of the context."""
+    from pgrc_amd import MatchContext
+    pg, reads = make_inputs(300000, 6000, 150, seed=77, n_with_n=100)
+    o = orc.oracle_match("c", pg, reads, 38, 3, 0)
+    monkeypatch.setenv("PGRC_TEST_NO_SECOND_INDEX", "1")
+    ctx = MatchContext(150, 38, 3, 0, "c")
+    ctx.set_profiling(True)
+    ctx.set_pg_ascii(pg)
+    ctx.set_reads_ascii(reads)
+    for run in range(2):
+        if run == 1:
+            monkeypatch.delenv("PGRC_TEST_NO_SECOND_INDEX")      # the context remembers
+        ctx.init_results()
+        ctx.run(True)
+        pos, rc, mism, hist, matched = ctx.get_results()
+        assert np.array_equal(pos, o["pos"]) and np.array_equal(rc, o["rc"]) and np.array_equal(mism, o["mism"]), run
+        assert ctx.counters()["screened"] == 0
+    g = gpu_match("c", pg, reads, 38, 3, 0)                        # a fresh context takes the dual kernel again
+    assert g["ctx"].counters()["screened"] == 2
+    assert_same_results(g, o, "fresh context")
+
+
 def test_device_generators_equal_host_generators():
     import torch
     from pgrc_amd import MatchContext, synth
