@@ -928,7 +928,8 @@ k_copmem_match_n(const MatchArgs a, const uint32_t *__restrict__ nidx, const uin
 // alignment; the caps never fall below the counts that still matter.  All of it presupposes that no run would have cut
 // a bucket by the falses budget: U bounds the falses of any run over the candidates seen so far (1 for a candidate
 // whose head count -- or already its fingerprint -- exceeds the starting limit or whose tail is clean, else 2); U > budget when a bucket is
-// opened -> the read is flagged (redo) and goes through the two passes in the reference's order afterwards.
+// opened -> the lane does that read again in the reference's order, right here (F_SEQ: the real forward query with its
+// falses count and bucket truncation, then the real RC query from its result) -- hidden behind the other lanes.
 // oracle/pgrc_oracle.c restates the scheme (pgrc_or_match_copmem_dual); tests/test_early_stop_rule.py expects it to
 // equal the reference's two passes on every input.
 struct DualArgs {
@@ -950,7 +951,8 @@ struct DualArgs {
 };
 
 template <int NW, int KQ, bool POS64>
-__global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_dual(const DualArgs a) {
+__global__ void __launch_bounds__(MATCH_TPB) __attribute__((amdgpu_waves_per_eu(NW <= 10 ? 5 : 4)))   // (97 registers without the hint: 4 waves)
+k_copmem_match_dual(const DualArgs a) {
     typedef typename std::conditional<POS64, uint64_t, uint32_t>::type pos_t;
     constexpr pos_t POS_NONE = (pos_t)~(pos_t)0;
     constexpr uint32_t EPOCH_BITS = POS64 ? 12u : 15u;   // one bit less than the single-strand kernel: the strand is part of the tag
@@ -983,7 +985,10 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_dual(const DualArgs 
     const uint32_t rper = (a.K + a.k1 * a.k2 - 1u) / (a.k1 * a.k2) * a.k1;
 
     enum { M_PROBE = 0, M_ENTRY = 1, M_VERIFY = 2, M_NEED = 3, M_ADV = 4, M_DEAD = 5 };
-    enum { F_ACT0 = 1, F_ACT1 = 2, F_FOUND0 = 4, F_FOUND1 = 8, F_DIRTY0 = 16, F_DIRTY1 = 32, F_REDO = 64, F_FWDEXACT = 128 };
+    // F_SEQ: the falses bound ran out: the lane does this read again in the reference's order, right here (forward query
+    // with its real falses count and bucket truncation, then -- F_SEQ1 -- the RC query from the forward result)
+    enum { F_ACT0 = 1, F_ACT1 = 2, F_FOUND0 = 4, F_FOUND1 = 8, F_DIRTY0 = 16, F_DIRTY1 = 32, F_REDO = 64, F_FWDEXACT = 128,
+           F_SEQ = 256, F_SEQ1 = 512 };
     uint32_t mode = M_NEED;
     uint32_t idx = 0, cin = 0, epoch = 0;
     uint32_t cnext = 0, cend = 0;
@@ -1003,6 +1008,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_dual(const DualArgs 
 
     // the limit a candidate of strand s is judged against: its own, capped by what the other strand has found
     auto eff = [&](uint32_t s) -> int {
+        if (fl & F_SEQ) return s == 0u ? lim0 : lim1;                // the reference's order: no coupling
         if (s == 0u) return (fl & F_FOUND1) ? min(lim0, (int)cur1) : lim0;
         return (fl & F_FOUND0) ? min(lim1, (int)cur0 - 1) : lim1;
     };
@@ -1076,6 +1082,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_dual(const DualArgs 
         uint64_t v = 0;
         bool counted_ent = false;
         uint32_t ncand_it = 0, nprobe_it = 0;
+        bool n_redo_it = false;
         if (m0 == M_PROBE) {
             const uint32_t h = hash_fp_window<KQ>(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
                                                   NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
@@ -1101,11 +1108,17 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_dual(const DualArgs 
         bool bdone = false;           // the current strand's bucket is finished
         // a verified alignment of the current strand (head count mh, tail count mt)
         auto judge = [&](uint32_t mh, uint32_t mt, pos_t p) {
-            // what any run can count for this candidate: 1 if the head alone exceeds every limit a run can have, or if the
-            // tail is clean (then it is a head reject or an acceptance), else 2 (a tail reject is counted twice)
-            const uint32_t u = ((int)mh > L0 || mt == 0u) ? 1u : 2u;
             const int m = (int)(mh + mt);
-            if (x == 0u) U0 += u; else U1 += u;
+            if (fl & F_SEQ) {                                        // the real count of CopMEMMatcher.cpp:536-551
+                const int lm = eff(x);
+                const uint32_t u = ((int)mh > lm) ? 1u : (m > lm) ? 2u : 0u;
+                if (x == 0u) U0 += u; else U1 += u;
+            } else {
+                // what any run can count for this candidate: 1 if the head alone exceeds every limit a run can have, or if
+                // the tail is clean (then it is a head reject or an acceptance), else 2 (a tail reject is counted twice)
+                const uint32_t u = ((int)mh > L0 || mt == 0u) ? 1u : 2u;
+                if (x == 0u) U0 += u; else U1 += u;
+            }
             if (m > eff(x)) return;
             if (x == 0u) { cur0 = (uint32_t)m; best0 = p; lim0 = m - 1; fl |= F_FOUND0; }
             else { cur1 = (uint32_t)m; best1 = p; lim1 = m - 1; fl |= F_FOUND1; }
@@ -1130,7 +1143,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_dual(const DualArgs 
                 const uint32_t xr = ((uint32_t)e ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
                 const int fpc = __popc((xr | (xr >> 1)) & fpm_tab[si]);   // a lower bound of the head count
                 if (fpc > eff(x)) {
-                    const uint32_t u = (fpc > L0) ? 1u : 2u;
+                    const uint32_t u = ((fl & F_SEQ) || fpc > L0) ? 1u : 2u;   // (sequential: a certain head reject)
                     if (x == 0u) U0 += u; else U1 += u;
                 } else {
                     const uint2 cv = vcache[((uint32_t)p * 0x9E3779B1u + x) >> (32 - VC_BITS)][threadIdx.x];
@@ -1149,8 +1162,8 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_dual(const DualArgs 
         };
         // open the bucket of strand x for the current seed
         auto open_bucket = [&](const ulonglong2 hx) {
-            if ((x == 0u ? U0 : U1) > budget) {                      // some run could have cut a bucket by now: not decidable here
-                fl |= F_REDO;
+            if (!(fl & F_SEQ) && (x == 0u ? U0 : U1) > budget) {     // some run could have cut a bucket by now: not decidable
+                fl |= F_REDO;                                        // this way -> the read again, in the reference's order
                 next = M_NEED;
                 return;
             }
@@ -1160,8 +1173,9 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_dual(const DualArgs 
                 return;
             }
             nb = cnt;
-            if (rq < a.k1 && cnt >= PGRC_BUCKET_CAP) fl |= (x == 0u ? (uint32_t)F_DIRTY0 : (uint32_t)F_DIRTY1);
-            has_pend = cnt == 2;
+            if ((fl & F_SEQ) && (x == 0u ? U0 : U1) > budget) nb = min(nb, PGRC_TRUNC_BUCKET);   // :510-514
+            if (rq < a.k1 && (cnt >= PGRC_BUCKET_CAP || nb < cnt)) fl |= (x == 0u ? (uint32_t)F_DIRTY0 : (uint32_t)F_DIRTY1);
+            has_pend = cnt == 2 && nb > 1;
             pend_e = hx.y;
             lo = (pos_t)(hx.y & W1_BASE_MASK);
             j = 1;
@@ -1219,6 +1233,25 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_dual(const DualArgs 
             if ((fl & F_ACT1) && (int)rcl1 > eff(1u)) fl &= ~(uint32_t)F_ACT1;
             next = (si < nseeds && (fl & (F_ACT0 | F_ACT1))) ? M_PROBE : M_NEED;
         }
+        // ---- the reference's order for a read whose falses bound ran out: restart it as a forward query, then an RC query
+        if (next == M_NEED && m0 <= M_VERIFY && (((fl & F_REDO) != 0u) || ((fl & (F_SEQ | F_SEQ1 | F_FWDEXACT)) == F_SEQ))) {
+            const bool second = (fl & F_SEQ) != 0u;                  // the forward query just ended: now the RC query
+            const uint32_t c1 = (second && (fl & F_FOUND0)) ? cur0 : cin;   // what the RC query has to beat (:488-489)
+            if (!second) {
+                lim0 = L0; cur0 = cin; best0 = POS_NONE; U0 = 0; rcl0 = 0;
+                fl = F_SEQ | F_ACT0;
+                n_redo_it = true;
+            } else {
+                lim1 = (c1 < a.kmax) ? (int)c1 - 1 : (int)a.kmax; cur1 = c1; best1 = POS_NONE; U1 = 0; rcl1 = 0;
+                fl = (fl & (F_FOUND0 | F_SEQ)) | F_SEQ1 | F_ACT1;
+            }
+            si = 0;
+            rq = 0;
+            has_pend = false;
+#pragma unroll
+            for (int kk = 0; kk < NW; kk++) sh[kk] = rd_lds[kk][threadIdx.x];
+            next = M_PROBE;
+        }
         n_probe += (uint32_t)__popcll(__ballot(nprobe_it >= 1)) + (uint32_t)__popcll(__ballot(nprobe_it >= 2));
         n_ent += (uint32_t)__popcll(__ballot(counted_ent));
         n_ver += (uint32_t)__popcll(__ballot(m0 == M_VERIFY));
@@ -1226,8 +1259,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_dual(const DualArgs 
         const bool fin = next == M_NEED && m0 <= M_VERIFY;
         if (fin) {
             // the read is finished: forward wins ties, RC must be strictly better (ReadsMatchers.cpp:437-447, both passes)
-            if (fl & F_REDO) {
-            } else if ((fl & F_FOUND1) && !((fl & F_FOUND0) && cur0 <= cur1)) {
+            if ((fl & F_FOUND1) && !((fl & F_FOUND0) && cur0 <= cur1)) {
                 a.pos[idx] = a.G - ((uint64_t)best1 + a.L);
                 a.rc[idx] = 1;
                 a.mism[idx] = (uint8_t)cur1;
@@ -1237,16 +1269,7 @@ __global__ void __launch_bounds__(MATCH_TPB) k_copmem_match_dual(const DualArgs 
                 a.mism[idx] = (uint8_t)cur0;
             }
         }
-        {   // undecided reads go on the list of the two ordinary passes (one atomic per wave and iteration)
-            const unsigned long long rb = __ballot(fin && (fl & F_REDO) != 0u);
-            if (rb) {
-                unsigned long long at = 0;
-                if (lane == (uint32_t)__ffsll((long long)rb) - 1u) at = atomicAdd(a.redo_n, (unsigned long long)__popcll(rb));
-                at = __shfl(at, __ffsll((long long)rb) - 1, 64);
-                if (fin && (fl & F_REDO)) a.redo[at + (uint32_t)__popcll(rb & ((1ull << lane) - 1ull))] = idx;
-                n_redo += (uint32_t)__popcll(rb);
-            }
-        }
+        n_redo += (uint32_t)__popcll(__ballot(n_redo_it));
         mode = next;
     }
     if (a.counters && lane == 0) {
