@@ -282,15 +282,10 @@ struct MatchArgs {
     uint32_t L, K, k2, mask, kmax, kmin, strand;
     uint32_t k1, early;           // sampling step of the index; early = 1: stop a read once nothing can be accepted any more
     // the screened schedule of a two-pass run (see "Exact-match screen" at the kernel): phase 0 = a plain pass,
-    // 1 = screen (RC text, exact alignments only, flags and positions to scr_*), 2 = forward pass that honours the flags,
-    // 4 = a plain pass over the reads of `list` only (what the dual kernel left undecided)
+    // 1 = screen (RC text, exact alignments only, flags and positions to scr_*), 2 = forward pass that honours the flags
     uint32_t phase;
     uint64_t *scr_pos;
     uint8_t *scr_flag;
-    // a pass over a LIST of reads (what the dual kernel left undecided) instead of all of them: the indices and, on the
-    // device, their number
-    const uint32_t *list;
-    const unsigned long long *list_n;
 };
 
 #define MATCH_TPB 256
@@ -412,10 +407,8 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
     constexpr int SW = STAGE > 0 ? STAGE : 1;
     __shared__ uint32_t stg[MATCH_TPB / 64][NW][SW];
     __shared__ uint8_t stg_c[MATCH_TPB / 64][SW], stg_f[MATCH_TPB / 64][SW];
-    __shared__ uint32_t stg_i[MATCH_TPB / 64][SW];   // list mode: which read sits in a staged slot
     const uint32_t wv = threadIdx.x >> 6;
     uint32_t wbeg = 0, wend = 0, wnext = 0;      // the staged window and the next read of it to hand out (wave-uniform)
-    const uint64_t n_items = a.list ? (uint64_t)*a.list_n : a.n;   // reads, or entries of the list
     hash_lut_init(lut);
     const int H = ((int)a.L / 8) * 8;
     const uint32_t nseeds = (a.L - a.K) / a.k2 + 1; // seeds s = 0, k2, ... with s + K <= L
@@ -477,25 +470,21 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
         const unsigned long long need = __ballot(mode == M_NEED);
         if (need) {
             if (cnext == cend) { // reserve another chunk (one atomic per wave and MATCH_CHUNK reads)
-                // (a list is short and its reads are heavy -- repeat families --: small chunks, or most waves get nothing)
-                const unsigned long long chunk = a.list ? 64ull : (unsigned long long)MATCH_CHUNK;
                 unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(a.work, chunk);
+                if (lane == 0) base = atomicAdd(a.work, (unsigned long long)MATCH_CHUNK);
                 base = __shfl(base, 0, 64);
-                cnext = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base, n_items));
-                cend = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base + chunk, n_items));
+                cnext = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base, a.n));
+                cend = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base + MATCH_CHUNK, a.n));
             }
             if (STAGE > 0 && wnext == wend && cnext != cend) {    // the window is used up: stage the chunk's next reads
                 const uint32_t nst = min((uint32_t)SW, cend - cnext);
                 wbeg = wnext = cnext;
                 wend = cnext = __builtin_amdgcn_readfirstlane(cnext + nst);
                 if (lane < nst) {
-                    const uint32_t ri = a.list ? a.list[wbeg + lane] : wbeg + lane;   // (a listed read is gathered, not streamed)
 #pragma unroll
-                    for (int k = 0; k < NW; k++) stg[wv][k][lane] = a.reads[(uint64_t)k * a.stride + ri];
-                    stg_c[wv][lane] = a.mism[ri];
-                    stg_f[wv][lane] = (uint8_t)((a.nflag ? a.nflag[ri] : 0) | (a.phase == 2u ? (a.scr_flag[ri] & 1u) << 1 : 0u));
-                    stg_i[wv][lane] = ri;
+                    for (int k = 0; k < NW; k++) stg[wv][k][lane] = a.reads[(uint64_t)k * a.stride + wbeg + lane];
+                    stg_c[wv][lane] = a.mism[wbeg + lane];
+                    stg_f[wv][lane] = (uint8_t)((a.nflag ? a.nflag[wbeg + lane] : 0) | (a.phase == 2u ? (a.scr_flag[wbeg + lane] & 1u) << 1 : 0u));
                 }
                 __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // a wave's LDS accesses are served in order
             }
@@ -508,7 +497,7 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
                 bool started = false;
                 if (mode == M_NEED && rank < take) {
                     const uint32_t sj = wnext - wbeg + rank;
-                    idx = STAGE > 0 ? stg_i[wv][sj] : (a.list ? a.list[cnext + rank] : cnext + rank);
+                    idx = STAGE > 0 ? wbeg + sj : cnext + rank;
                     cin = STAGE > 0 ? stg_c[wv][sj] : a.mism[idx];
                     const uint32_t rflags = STAGE > 0 ? (uint32_t)stg_f[wv][sj]
                                                       : (uint32_t)((a.nflag ? a.nflag[idx] : 0) | (a.phase == 2u ? (a.scr_flag[idx] & 1u) << 1 : 0u));
@@ -943,8 +932,6 @@ struct DualArgs {
     uint64_t *pos;
     uint8_t *rc;
     uint8_t *mism;
-    uint32_t *redo;               // the reads left undecided here: their indices ...
-    unsigned long long *redo_n;   // ... and how many
     unsigned long long *counters; // [0] searched [1] candidates [2] heads probed [3] entry fetches [4] verifies [5] redo
     unsigned long long *work;
     uint32_t L, K, k1, k2, mask, kmax;
@@ -1299,8 +1286,7 @@ static void launch_dual(pgrc_match_ctx *c, const DualArgs &a) {
 }
 
 // The dual kernel over all reads without N: the ACTIVE index set must describe the RC strand, the alternate set the
-// forward strand (api.hip builds them in that order); undecided reads are flagged in d_scr_flag for the two ordinary
-// passes that follow (phase 4).
+// forward strand (api.hip builds them in that order).  The reads with N follow in two ordinary passes (phase 4).
 int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     if (c->n == 0) return PGRC_OK;
     if (c->index_strand != 1 || c->alt_index_strand != 0 || !c->ent_ptr || !c->alt_ent_ptr || !c->d_scr_pos.p) {
@@ -1322,8 +1308,6 @@ int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     a.pos = (uint64_t *)c->d_pos.p;
     a.rc = (uint8_t *)c->d_rc.p;
     a.mism = (uint8_t *)c->d_mism.p;
-    a.redo = (uint32_t *)c->d_scr_pos.p;
-    a.redo_n = (unsigned long long *)c->d_counters.p + 19;
     a.counters = (unsigned long long *)c->d_counters.p + 24;
     a.work = (unsigned long long *)c->d_counters.p + 18;
     a.L = c->prm.read_len;
@@ -1375,7 +1359,8 @@ static void launch_match(pgrc_match_ctx *c, const MatchArgs &a) {
 
 int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) { return pgrc_copmem_match_phase(c, strand, 0); }
 
-// phase: 0 = a plain pass; 1 / 2 = the screen and the flag-honouring forward pass of the screened schedule (kernel comment)
+// phase: 0 = a plain pass; 1 / 2 = the screen and the flag-honouring forward pass of the screened schedule (kernel comment);
+// 4 = after the dual kernel: only the reads with N (the byte-path kernel), in the strand order of the two passes
 int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase) {
     if (c->n == 0) return PGRC_OK;
     MatchArgs a;
@@ -1396,12 +1381,7 @@ int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase) {
     a.scr_pos = (uint64_t *)c->d_scr_pos.p;
     a.scr_flag = (uint8_t *)c->d_scr_flag.p;
     if (phase && (!a.scr_flag || !a.scr_pos)) { c->err = "screened schedule without its buffers"; return PGRC_E_STATE; }
-    a.list = nullptr;
-    a.list_n = nullptr;
-    if (phase == 4) {                 // the reads the dual kernel listed (it kept the list where the screen keeps its positions)
-        a.list = (const uint32_t *)c->d_scr_pos.p;
-        a.list_n = (const unsigned long long *)c->d_counters.p + 19;
-    }
+
     a.L = c->prm.read_len;
     a.K = (uint32_t)c->cp.K;
     a.k2 = (uint32_t)c->cp.k2;
@@ -1443,6 +1423,7 @@ int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase) {
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->side_ev[1], c->side_stream));
     }
+    if (phase != 4)                  // (phase 4: the dual kernel has done every read without N)
     switch (c->nw) {
 #define CASE_NW(N) case N: launch_match<N>(c, a); break;
         CASE_NW(2) CASE_NW(3) CASE_NW(4) CASE_NW(5) CASE_NW(6) CASE_NW(7) CASE_NW(8) CASE_NW(9)
