@@ -191,13 +191,27 @@ typedef struct {
     int32_t byte_per_read_length; /* PgHelpers::bytePerReadLengthMode */
 } pgrc_export_pg_order_args;
 int pgrc_match_export_pg_order(pgrc_match_ctx *ctx, const pgrc_export_pg_order_args *args, pgrc_export_streams *out);
-/* exportMatchesInOriginalOrder: the caller walks the original read order (the :616-667 loops) and lists the entries:
+/* exportMatchesInOriginalOrder for a caller-made entry list (pgrc_match_export_original_order makes the list itself):
  * entry_read[k] = the read entry k describes, or UINT32_MAX for a filler entry (position 0, no mismatches);
  * entry_org_idx[k] = its original index.  Offsets are the entries' own positions (every entry starts from a fresh
  * DefaultReadsListEntry(0), :655-667). */
 int pgrc_match_export_entries(pgrc_match_ctx *ctx, const uint32_t *entry_read, const uint32_t *entry_org_idx,
                               uint64_t n_entries, int32_t rev_compl_pair_file, int32_t byte_per_read_length,
                               pgrc_export_streams *out);
+/* exportMatchesInOriginalOrder with the entry list made by the library (ReadsMatchers.cpp:597-675): one entry per
+ * original read index in [0, reads_total_count) -- the matched read that carries it, or a filler (position 0, no
+ * mismatches) for an index none of the matcher's reads carries; an index carried by an UNMATCHED read gets no entry.
+ * With pair_file_mode all even indexes come first, then all odd ones (:625-667).  read_org_idx[i] =
+ * IndexesMapping::getReadOriginalIndex(i) for every read of the matcher; the indexes must be distinct and below
+ * reads_total_count (PGRC_E_PARAM otherwise). */
+typedef struct {
+    const uint32_t *read_org_idx;
+    uint64_t reads_total_count;   /* IndexesMapping::getReadsTotalCount() */
+    int32_t pair_file_mode;
+    int32_t rev_compl_pair_file;
+    int32_t byte_per_read_length;
+} pgrc_export_original_order_args;
+int pgrc_match_export_original_order(pgrc_match_ctx *ctx, const pgrc_export_original_order_args *args, pgrc_export_streams *out);
 void pgrc_match_free_export(pgrc_export_streams *streams);
 
 /* ---- introspection (tests, bench) ---- */
@@ -236,6 +250,8 @@ typedef struct {
     uint64_t redo_reads;
     uint64_t dual[5];       /* screened == 2: the dual kernel's own searched / candidates / heads probed / entry fetches /
                              * verifies (the per-strand counters above then describe the two ordinary passes after it) */
+    uint32_t schedule_downgraded; /* 1 = the second index set (or the screen's arrays) did not fit in device memory: this
+                             * context runs the two passes in turn until another text / read set is handed over */
 } pgrc_match_counters;
 /* enable per-kernel HIP-event timing + work counters for subsequent runs */
 int pgrc_match_set_profiling(pgrc_match_ctx *ctx, int enabled);

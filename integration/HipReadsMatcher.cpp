@@ -24,6 +24,8 @@
 
 #include "HipReadsMatcher.h"
 
+#include <numeric>
+
 #include "pgrc_match.h"
 #include "readsset/PackedConstantLengthReadsSet.h"
 
@@ -393,82 +395,44 @@ namespace PgTools {
             return;
         }
         deviceExports++;
-        // the walk of ReadsMatchers.cpp:600-667 over the original read order, listing the entries instead of writing them
-        const uint_reads_cnt_std readsTotalCount = orgIndexesMapping->getReadsTotalCount();
-        std::vector<uint_pg_len_max> orgIdx2pgPos(readsTotalCount, -1);
-        ExtendedReadsListWithConstantAccessOption *const pgRl = sPg->getReadsList();
-        uint_pg_len_max pos = 0;
-        for (uint_reads_cnt_std i = 0; i < pgRl->readsCount; i++) {
-            pos += pgRl->off[i];
-            orgIdx2pgPos[pgRl->orgIdx[i]] = pos;
+        // What the reference's walk over the original read order (ReadsMatchers.cpp:600-667) produces, without the walk:
+        // the entry list is a table over the original indexes and is made on the device
+        // (pgrc_match_export_original_order); the host keeps only the caller-visible side effect, the reads list's
+        // `pos` by original index (:603-610, :663, :673).
+        ExtendedReadsListWithConstantAccessOption *const list = sPg->getReadsList();
+        const uint64_t allReads = orgIndexesMapping->getReadsTotalCount();
+        std::vector<uint_pg_len_max> pgPosOfOrg(allReads, (uint_pg_len_max) -1);
+        {
+            // entries already on the pseudogenome: position = running sum of the offset deltas
+            const size_t listed = list->readsCount;
+            std::vector<uint_pg_len_max> listPos(listed);
+            std::inclusive_scan(list->off.begin(), list->off.begin() + listed, listPos.begin(), std::plus<uint_pg_len_max>(),
+                                (uint_pg_len_max) 0);
+            #pragma omp parallel for
+            for (size_t k = 0; k < listed; k++)
+                pgPosOfOrg[list->orgIdx[k]] = listPos[k];
         }
-        pgRl->off.clear();
-        pgRl->orgIdx.clear();
-        SeparatedPseudoGenomeOutputBuilder *builder = this->createSeparatedPseudoGenomeOutputBuilder(sPg);
         std::vector<uint32_t> readOrg(readsCount);
         #pragma omp parallel for
-        for (uint_reads_cnt_max i = 0; i < readsCount; i++)
+        for (uint_reads_cnt_max i = 0; i < readsCount; i++) {
             readOrg[i] = orgIndexesMapping->getReadOriginalIndex(i);
-        std::vector<uint32_t> entryRead, entryOrg;
-        entryRead.reserve(readsTotalCount);
-        entryOrg.reserve(readsTotalCount);
-        {
-            PhaseLog log("export: entry list in original order");
-            uint_reads_cnt_max nI_start = readsCount;
-            int64_t curOrgIdx = 0;
-            for (uint_reads_cnt_std i = 0; i < readsCount; i++) {
-                const uint_reads_cnt_max oIdx = readOrg[i];
-                if (curOrgIdx > oIdx) {
-                    nI_start = i;
-                    break;
-                }
-                curOrgIdx = oIdx;
-            }
-            const uint8_t parts = pairFileMode ? 2 : 1;
-            const int inc = parts;
-            for (uint8_t p = 0; p < parts; p++) {
-                curOrgIdx = p - inc;
-                uint_reads_cnt_max lqI = 0;
-                uint_reads_cnt_max nI = nI_start;
-                while (lqI < nI_start || nI < readsCount) {
-                    uint_reads_cnt_max matchIdx;
-                    uint_reads_cnt_max oIdx;
-                    do {
-                        matchIdx = readsCount;
-                        if (lqI < nI_start)
-                            matchIdx = lqI;
-                        if (nI < readsCount && (lqI == nI_start || readOrg[nI] < readOrg[lqI]))
-                            matchIdx = nI++;
-                        else
-                            lqI++;
-                        if (matchIdx == readsCount)
-                            break;
-                        oIdx = readOrg[matchIdx];
-                    } while (parts != 1 && (oIdx % parts != p));
-                    if (matchIdx == readsCount)
-                        break;
-                    while ((curOrgIdx += inc) < oIdx) {
-                        entryRead.push_back(UINT32_MAX);
-                        entryOrg.push_back((uint32_t) curOrgIdx);
-                    }
-                    if (readMatchPos[matchIdx] != NOT_MATCHED_POSITION) {
-                        entryRead.push_back((uint32_t) matchIdx);
-                        entryOrg.push_back((uint32_t) oIdx);
-                        orgIdx2pgPos[oIdx] = readMatchPos[matchIdx];
-                    }
-                }
-                while ((curOrgIdx += inc) < readsTotalCount) {
-                    entryRead.push_back(UINT32_MAX);
-                    entryOrg.push_back((uint32_t) curOrgIdx);
-                }
-            }
+            if (readMatchPos[i] != NOT_MATCHED_POSITION)
+                pgPosOfOrg[readOrg[i]] = readMatchPos[i];
         }
+        // the builder must not see the old list's offsets / indexes (the reference drops them before it creates one)
+        list->orgIdx.clear();
+        list->off.clear();
+        SeparatedPseudoGenomeOutputBuilder *builder = this->createSeparatedPseudoGenomeOutputBuilder(sPg);
         {
-            PhaseLog log("export: streams from the device");
+            PhaseLog log("export: entry list and streams from the device");
+            pgrc_export_original_order_args a;
+            a.read_org_idx = readOrg.data();
+            a.reads_total_count = allReads;
+            a.pair_file_mode = pairFileMode ? 1 : 0;
+            a.rev_compl_pair_file = revComplPairFile ? 1 : 0;
+            a.byte_per_read_length = PgHelpers::bytePerReadLengthMode ? 1 : 0;
             pgrc_export_streams st;
-            failOn(pgrc_match_export_entries(ctx, entryRead.data(), entryOrg.data(), entryRead.size(),
-                                             revComplPairFile ? 1 : 0, PgHelpers::bytePerReadLengthMode ? 1 : 0, &st),
-                   "export_entries");
+            failOn(pgrc_match_export_original_order(ctx, &a, &st), "export_original_order");
             pgrc_export_streams_view v{&st};
             appendStreams(builder, v);
             pgrc_match_free_export(&st);
@@ -477,7 +441,7 @@ namespace PgTools {
         builder->build(outPgPrefix);
         builder->compressedBuild(pgrcOut, compressionLevel, true);
         delete (builder);
-        sPg->getReadsList()->pos = std::move(orgIdx2pgPos);
+        list->pos = std::move(pgPosOfOrg);
     }
 
     void HipReadsMatcher::executeMatching(bool revCompMode) {

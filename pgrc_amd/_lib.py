@@ -39,7 +39,8 @@ class Counters(C.Structure):
     _fields_ = [("searched", C.c_uint64 * 2), ("candidates", C.c_uint64 * 2), ("probes", C.c_uint64 * 2),
                 ("entry_fetches", C.c_uint64 * 2), ("verifies", C.c_uint64 * 2), ("index_entries", C.c_uint64 * 2), ("ms_index", C.c_float * 2), ("ms_match", C.c_float * 2),
                 ("ms_other", C.c_float), ("ms_total", C.c_float), ("ms_allgather", C.c_float),
-                ("screened", C.c_uint32), ("ms_screen", C.c_float), ("redo_reads", C.c_uint64), ("dual", C.c_uint64 * 5)]
+                ("screened", C.c_uint32), ("ms_screen", C.c_float), ("redo_reads", C.c_uint64), ("dual", C.c_uint64 * 5),
+                ("schedule_downgraded", C.c_uint32)]
 
 
 class SynthPg(C.Structure):
@@ -61,6 +62,11 @@ class ExportStreams(C.Structure):   # pgrc_export_streams
 class ExportPgOrderArgs(C.Structure):   # pgrc_export_pg_order_args
     _fields_ = [("order", C.c_void_p), ("n_matched", C.c_uint64), ("read_org_idx", C.c_void_p), ("list_off", C.c_void_p),
                 ("list_org_idx", C.c_void_p), ("list_rev_comp", C.c_void_p), ("list_count", C.c_uint64),
+                ("rev_compl_pair_file", C.c_int32), ("byte_per_read_length", C.c_int32)]
+
+
+class ExportOriginalOrderArgs(C.Structure):   # pgrc_export_original_order_args
+    _fields_ = [("read_org_idx", C.c_void_p), ("reads_total_count", C.c_uint64), ("pair_file_mode", C.c_int32),
                 ("rev_compl_pair_file", C.c_int32), ("byte_per_read_length", C.c_int32)]
 
 
@@ -106,6 +112,7 @@ _PROTOS = [
     ("pgrc_match_extract_mismatches", C.c_int, [_P, _P, _P, _P, _P]),
     ("pgrc_match_export_pg_order", C.c_int, [_P, C.POINTER(ExportPgOrderArgs), C.POINTER(ExportStreams)]),
     ("pgrc_match_export_entries", C.c_int, [_P, _P, _P, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(ExportStreams)]),
+    ("pgrc_match_export_original_order", C.c_int, [_P, C.POINTER(ExportOriginalOrderArgs), C.POINTER(ExportStreams)]),
     ("pgrc_match_free_export", None, [C.POINTER(ExportStreams)]),
     ("pgrc_match_copmem_params", C.c_int, [C.c_uint32, C.c_uint64, C.POINTER(CopmemParams)]),
     ("pgrc_match_export_index", C.c_int, [_P, C.c_int, _P, _P, C.POINTER(C.c_uint64)]),

@@ -195,6 +195,7 @@ int pgrc_pg_alloc(pgrc_match_ctx *c, uint64_t G) {
         c->err = "pseudogenome shorter than a read";
         return PGRC_E_PARAM;
     }
+    if (G != c->G) c->screen_broken = false;     // another text: the second index set may fit now
     c->G = G;
     c->pg_words = (G + 15) / 16;
     const size_t bytes = (c->pg_words + PGRC_PG_PAD_WORDS) * sizeof(uint32_t);
@@ -301,6 +302,7 @@ static int alloc_results(pgrc_match_ctx *c, uint64_t n) {
 
 static int begin_reads(pgrc_match_ctx *c, uint64_t n, bool own) {
     if (n >= (1ull << 32) - 1) { c->err = "reads count must stay below 2^32-1 (uint_reads_cnt_max, pg-config.h:21-22)"; return PGRC_E_PARAM; }
+    if (n != c->n) c->screen_broken = false;     // another read set: the screen's per-read arrays may fit now
     c->n = n;
     c->n_nreads = 0;
     c->h_nidx.clear();
@@ -678,6 +680,7 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
         c->ctr.verifies[1] += scr[4];
         c->ctr.screened = 1;
     }
+    c->ctr.schedule_downgraded = c->screen_broken ? 1u : 0u;
     if (prof) {
         HIP_TRY(c, hipEventSynchronize(c->ev[evi - 1]));
         float ms = 0;

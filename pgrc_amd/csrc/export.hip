@@ -139,6 +139,7 @@ struct ExportArgs {
     uint32_t *eread;              // the matched read an entry describes, EX_NONE for an old entry / a filler
     uint32_t *eorg;
     uint8_t *erc, *emc;
+    uint32_t *errflag;            // set when `order` names a read without a match
 };
 
 // first index in a[0, n) with a[i] >= x (UPPER: a[i] > x)
@@ -159,6 +160,7 @@ __device__ __forceinline__ uint64_t bound(const uint64_t *__restrict__ a, uint64
 __global__ void __launch_bounds__(256) k_export_place_new(const ExportArgs a) {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.m; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t i = a.order[j];
+        if (a.mism[i] == PGRC_NOT_MATCHED_CNT) atomicOr(a.errflag, 1u);     // (its position is all ones: nothing below dereferences it)
         const uint64_t p = a.pos[i];
         const uint64_t before = bound<false>(a.lpos, a.h, p);
         const uint64_t r = j + before;
@@ -214,6 +216,49 @@ k_export_fill_entries(const uint32_t *__restrict__ eread, uint64_t ne, const uin
         epos[r] = real ? pos[i] : 0ull;
         erc[r] = real ? rc[i] : 0;
         emc[r] = real ? mism[i] : 0;
+    }
+}
+
+// ---- original-order export: the entry list made on the device ----
+// exportMatchesInOriginalOrder writes one entry per ORIGINAL read index that is not an unmatched read of this matcher:
+// a matched read's entry, or a filler (position 0) for an index the matcher does not hold -- all even indexes first,
+// then all odd ones, when the two files of a pair are interleaved (pairFileMode).  Here that is a table over the
+// original indexes: every read of the matcher claims its index (k_oo_claim), every slot of the class-major order looks
+// its index up (k_oo_keep), an exclusive scan of the kept slots numbers the entries (k_oo_entries).
+#define EX_SKIP 0xFFFFFFFEu        // an original index held by an UNMATCHED read: no entry at all
+
+__global__ void __launch_bounds__(256)
+k_oo_claim(const uint32_t *__restrict__ read_org, uint64_t n, const uint8_t *__restrict__ mism, uint64_t total,
+           uint32_t *__restrict__ owner, uint32_t *__restrict__ errflag) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t o = read_org[i];
+        if (o >= total) { atomicOr(errflag, 1u); continue; }
+        const uint32_t was = atomicExch(&owner[o], mism[i] != PGRC_NOT_MATCHED_CNT ? (uint32_t)i : EX_SKIP);
+        if (was != EX_NONE) atomicOr(errflag, 2u);          // two reads with one original index
+    }
+}
+
+// slot q of the output order -> original index: class c = indexes congruent c modulo `parts`, classes in turn
+__device__ __forceinline__ uint64_t oo_slot_org(uint64_t q, uint64_t total, uint32_t parts) {
+    if (parts == 1) return q;
+    const uint64_t evens = (total + 1) >> 1;
+    return q < evens ? 2 * q : 2 * (q - evens) + 1;
+}
+
+__global__ void __launch_bounds__(256)
+k_oo_keep(const uint32_t *__restrict__ owner, uint64_t total, uint32_t parts, uint8_t *__restrict__ keep) {
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x)
+        keep[q] = owner[oo_slot_org(q, total, parts)] != EX_SKIP;
+}
+
+__global__ void __launch_bounds__(256)
+k_oo_entries(const uint32_t *__restrict__ owner, const uint8_t *__restrict__ keep, const uint64_t *__restrict__ rank, uint64_t total,
+             uint32_t parts, uint32_t *__restrict__ eread, uint32_t *__restrict__ eorg) {
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
+        if (!keep[q]) continue;
+        const uint64_t o = oo_slot_org(q, total, parts);
+        eread[rank[q]] = owner[o];                            // EX_NONE = filler
+        eorg[rank[q]] = (uint32_t)o;
     }
 }
 
@@ -312,9 +357,9 @@ extern "C" void pgrc_match_free_export(pgrc_export_streams *s) {
 
 namespace {
 struct Bufs {
-    DevBuf order, rorg, loff, lorg, lrc, lpos, epos, eread, eorg, erc, emc, off, mbase, sym, roff, bs;
+    DevBuf order, rorg, loff, lorg, lrc, lpos, epos, eread, eorg, erc, emc, off, mbase, sym, roff, bs, flag;
     void release() {
-        for (DevBuf *b : {&order, &rorg, &loff, &lorg, &lrc, &lpos, &epos, &eread, &eorg, &erc, &emc, &off, &mbase, &sym, &roff, &bs}) pgrc_buf_free(*b);
+        for (DevBuf *b : {&order, &rorg, &loff, &lorg, &lrc, &lpos, &epos, &eread, &eorg, &erc, &emc, &off, &mbase, &sym, &roff, &bs, &flag}) pgrc_buf_free(*b);
     }
 };
 }
@@ -417,6 +462,9 @@ static int export_pg_order(pgrc_match_ctx *c, const pgrc_export_pg_order_args *x
     a.eorg = (uint32_t *)b.eorg.p;
     a.erc = (uint8_t *)b.erc.p;
     a.emc = (uint8_t *)b.emc.p;
+    if ((e = pgrc_buf_ensure(c, b.flag, sizeof(uint32_t)))) return e;
+    HIP_TRY(c, hipMemsetAsync(b.flag.p, 0, sizeof(uint32_t), c->stream));
+    a.errflag = (uint32_t *)b.flag.p;
     if (m) hipLaunchKernelGGL(k_export_place_new, dim3(grid_for(m)), dim3(256), 0, c->stream, a);
     if (h) hipLaunchKernelGGL(k_export_place_old, dim3(grid_for(h)), dim3(256), 0, c->stream, a);
     if (ne) {
@@ -424,6 +472,10 @@ static int export_pg_order(pgrc_match_ctx *c, const pgrc_export_pg_order_args *x
         else hipLaunchKernelGGL(k_export_offsets<uint16_t>, dim3(grid_for(ne)), dim3(256), 0, c->stream, (const uint64_t *)b.epos.p, ne, (uint16_t *)b.off.p);
     }
     HIP_TRY(c, hipGetLastError());
+    uint32_t bad = 0;
+    HIP_TRY(c, hipMemcpyAsync(&bad, b.flag.p, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (bad) { c->err = "export_pg_order: order[] names a read without a match"; return PGRC_E_PARAM; }
     if ((e = finish_export(c, b, ne, x->rev_compl_pair_file, width, out))) return e;
     // the builder's lastWrittenPos: the position of the last entry written
     out->last_pos = 0;
@@ -518,6 +570,8 @@ extern "C" int pgrc_match_export_pg_order(pgrc_match_ctx *c, const pgrc_export_p
     memset(out, 0, sizeof *out);
     if (!c->have_results || !c->have_pg || !c->have_reads) { c->err = "export: run first"; return PGRC_E_STATE; }
     if (x->n_matched > c->n) { c->err = "export: more matched reads than reads"; return PGRC_E_PARAM; }
+    for (uint64_t j = 0; j < x->n_matched; j++)
+        if (x->order[j] >= c->n) { c->err = "export_pg_order: read index out of range"; return PGRC_E_PARAM; }
     GatheredView gv;
     pgrc_match_ctx *w = c;
     if (c->multi) {
@@ -534,10 +588,9 @@ extern "C" int pgrc_match_export_pg_order(pgrc_match_ctx *c, const pgrc_export_p
     return e;
 }
 
-static int export_entries(pgrc_match_ctx *c, const uint32_t *entry_read, const uint32_t *entry_org_idx, uint64_t ne, int pair_file,
-                          uint32_t width, Bufs &b, pgrc_export_streams *out) {
+// b.eread / b.eorg hold the entry list on the device: field arrays, offsets, mismatch streams
+static int export_entries_device(pgrc_match_ctx *c, uint64_t ne, int pair_file, uint32_t width, Bufs &b, pgrc_export_streams *out) {
     int e;
-    if ((e = upload(c, b.eread, entry_read, ne * sizeof(uint32_t))) || (e = upload(c, b.eorg, entry_org_idx, ne * sizeof(uint32_t)))) return e;
     if ((e = pgrc_buf_ensure(c, b.epos, ne * sizeof(uint64_t))) || (e = pgrc_buf_ensure(c, b.erc, ne)) || (e = pgrc_buf_ensure(c, b.emc, ne)) ||
         (e = pgrc_buf_ensure(c, b.off, ne * width)))
         return e;
@@ -550,6 +603,53 @@ static int export_entries(pgrc_match_ctx *c, const uint32_t *entry_read, const u
         HIP_TRY(c, hipGetLastError());
     }
     return finish_export(c, b, ne, pair_file, width, out);
+}
+
+static int export_entries(pgrc_match_ctx *c, const uint32_t *entry_read, const uint32_t *entry_org_idx, uint64_t ne, int pair_file,
+                          uint32_t width, Bufs &b, pgrc_export_streams *out) {
+    int e;
+    if ((e = upload(c, b.eread, entry_read, ne * sizeof(uint32_t))) || (e = upload(c, b.eorg, entry_org_idx, ne * sizeof(uint32_t)))) return e;
+    return export_entries_device(c, ne, pair_file, width, b, out);
+}
+
+// exportMatchesInOriginalOrder with the entry list made here (see k_oo_claim)
+static int export_original_order(pgrc_match_ctx *c, const pgrc_export_original_order_args *x, Bufs &b, pgrc_export_streams *out) {
+    const uint64_t total = x->reads_total_count;
+    const uint32_t parts = x->pair_file_mode ? 2u : 1u, width = x->byte_per_read_length ? 1u : 2u;
+    DevBuf owner, keep, rank, flag;
+    auto done = [&](int code) { pgrc_buf_free(owner); pgrc_buf_free(keep); pgrc_buf_free(rank); pgrc_buf_free(flag); return code; };
+    int e;
+    if ((e = upload(c, b.rorg, x->read_org_idx, c->n * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, owner, std::max<uint64_t>(total, 1) * sizeof(uint32_t))) ||
+        (e = pgrc_buf_ensure(c, keep, std::max<uint64_t>(total, 1))) || (e = pgrc_buf_ensure(c, rank, (total + 1) * sizeof(uint64_t))) ||
+        (e = pgrc_buf_ensure(c, flag, sizeof(uint32_t))))
+        return done(e);
+    hipError_t he = hipMemsetAsync(owner.p, 0xFF, std::max<uint64_t>(total, 1) * sizeof(uint32_t), c->stream);   // EX_NONE everywhere: fillers
+    if (he == hipSuccess) he = hipMemsetAsync(flag.p, 0, sizeof(uint32_t), c->stream);
+    if (he != hipSuccess) { c->err = std::string("export: ") + hipGetErrorString(he); return done(pgrc_hip_code(he)); }
+    if (c->n)
+        hipLaunchKernelGGL(k_oo_claim, dim3(grid_for(c->n)), dim3(256), 0, c->stream, (const uint32_t *)b.rorg.p, c->n, (const uint8_t *)c->d_mism.p,
+                           total, (uint32_t *)owner.p, (uint32_t *)flag.p);
+    if (total) hipLaunchKernelGGL(k_oo_keep, dim3(grid_for(total)), dim3(256), 0, c->stream, (const uint32_t *)owner.p, total, parts, (uint8_t *)keep.p);
+    if ((e = device_scan<uint8_t, false>(c, (const uint8_t *)keep.p, total, (uint64_t *)rank.p, b.bs))) return done(e);
+    uint64_t ne = 0;
+    uint32_t bad = 0;
+    he = hipMemcpyAsync(&ne, (const uint64_t *)rank.p + total, sizeof ne, hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    if (he != hipSuccess) { c->err = std::string("export: ") + hipGetErrorString(he); return done(pgrc_hip_code(he)); }
+    if (bad) {
+        c->err = (bad & 1u) ? "export_original_order: an original index is >= reads_total_count" : "export_original_order: two reads share one original index";
+        return done(PGRC_E_PARAM);
+    }
+    if ((e = pgrc_buf_ensure(c, b.eread, std::max<uint64_t>(ne, 1) * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, b.eorg, std::max<uint64_t>(ne, 1) * sizeof(uint32_t))))
+        return done(e);
+    if (total) {
+        hipLaunchKernelGGL(k_oo_entries, dim3(grid_for(total)), dim3(256), 0, c->stream, (const uint32_t *)owner.p, (const uint8_t *)keep.p,
+                           (const uint64_t *)rank.p, total, parts, (uint32_t *)b.eread.p, (uint32_t *)b.eorg.p);
+        he = hipGetLastError();
+        if (he != hipSuccess) { c->err = std::string("export: ") + hipGetErrorString(he); return done(pgrc_hip_code(he)); }
+    }
+    return done(export_entries_device(c, ne, x->rev_compl_pair_file, width, b, out));
 }
 
 extern "C" int pgrc_match_export_entries(pgrc_match_ctx *c, const uint32_t *entry_read, const uint32_t *entry_org_idx, uint64_t n_entries,
@@ -569,6 +669,27 @@ extern "C" int pgrc_match_export_entries(pgrc_match_ctx *c, const uint32_t *entr
     PgrcDeviceScope scope(w->device);
     Bufs b;
     int e = export_entries(w, entry_read, entry_org_idx, n_entries, rev_compl_pair_file, byte_per_read_length ? 1u : 2u, b, out);
+    b.release();
+    if (e && w != c) c->err = w->err;
+    if (e) pgrc_match_free_export(out);
+    return e;
+}
+
+extern "C" int pgrc_match_export_original_order(pgrc_match_ctx *c, const pgrc_export_original_order_args *x, pgrc_export_streams *out) {
+    if (!c || !x || !out || (c->n && !x->read_org_idx)) return PGRC_E_PARAM;
+    memset(out, 0, sizeof *out);
+    if (!c->have_results || !c->have_pg || !c->have_reads) { c->err = "export: run first"; return PGRC_E_STATE; }
+    if (x->reads_total_count >= EX_SKIP) { c->err = "export_original_order: too many original indexes"; return PGRC_E_PARAM; }
+    GatheredView gv;
+    pgrc_match_ctx *w = c;
+    if (c->multi) {
+        int ge = gv.build(c);
+        if (ge) return ge;
+        w = &gv.view;
+    }
+    PgrcDeviceScope scope(w->device);
+    Bufs b;
+    int e = export_original_order(w, x, b, out);
     b.release();
     if (e && w != c) c->err = w->err;
     if (e) pgrc_match_free_export(out);

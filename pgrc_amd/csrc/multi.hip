@@ -484,6 +484,7 @@ int pgrc_multi_get_counters(pgrc_match_ctx *f, pgrc_match_counters *out) {
         out->ms_screen = std::max(out->ms_screen, x.ms_screen);
         out->screened = std::max(out->screened, x.screened);
         out->redo_reads += x.redo_reads;
+        out->schedule_downgraded |= x.schedule_downgraded;
         for (int k = 0; k < 5; k++) out->dual[k] += x.dual[k];
     }
     out->ms_allgather = m->ms_allgather;

@@ -246,6 +246,18 @@ class MatchContext:
                                                int(rev_compl_pair_file), int(byte_per_read_length), C.byref(st)))
         return self._streams(st)
 
+    def export_original_order(self, read_org_idx, reads_total_count: int, pair_file_mode: bool = False,
+                              rev_compl_pair_file: bool = False, byte_per_read_length: bool = True) -> dict:
+        """exportMatchesInOriginalOrder's streams, entry list made on the device (see pgrc_match_export_original_order)."""
+        ro = np.ascontiguousarray(read_org_idx, dtype=np.uint32)
+        a = _lib.ExportOriginalOrderArgs()
+        a.read_org_idx, a.reads_total_count = ro.ctypes.data, int(reads_total_count)
+        a.pair_file_mode, a.rev_compl_pair_file = int(pair_file_mode), int(rev_compl_pair_file)
+        a.byte_per_read_length = int(byte_per_read_length)
+        st = _lib.ExportStreams()
+        self._ck(lib.pgrc_match_export_original_order(self._h, C.byref(a), C.byref(st)))
+        return self._streams(st)
+
     # ---- introspection
     def export_index(self, strand: int = 0):
         cnt = C.c_uint64(0)
@@ -272,6 +284,7 @@ class MatchContext:
                 "entry_fetches": list(c.entry_fetches), "verifies": list(c.verifies), "index_entries": list(c.index_entries), "ms_index": list(c.ms_index), "ms_match": list(c.ms_match),
                 "ms_other": c.ms_other, "ms_total": c.ms_total, "ms_allgather": c.ms_allgather,
                 "screened": c.screened, "ms_screen": c.ms_screen, "redo_reads": c.redo_reads,
+                "schedule_downgraded": c.schedule_downgraded,
                 "dual": dict(zip(("searched", "candidates", "probes", "entry_fetches", "verifies"), list(c.dual)))}
 
 

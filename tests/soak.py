@@ -89,8 +89,9 @@ def main():
             er, eo = xu.original_order_entries(case["read_org"], res["mism"] != 255, total, pair, n - nn)
             want2 = xu.oracle_export_entries(case, res, er, eo, pair_file=pair, byte_mode=byte_mode)
             got2 = g["ctx"].export_entries(er, eo, pair, byte_mode)
+            got3 = g["ctx"].export_original_order(case["read_org"], total, pair, pair, byte_mode)
             for k in xu.STREAMS:
-                if not np.array_equal(got[k], want[k]) or not np.array_equal(got2[k], want2[k]):
+                if not np.array_equal(got[k], want[k]) or not np.array_equal(got2[k], want2[k]) or not np.array_equal(got3[k], want2[k]):
                     print("EXPORT MISMATCH", what, dict(h=h, pair=pair, byte_mode=byte_mode), k, flush=True)
                     sys.exit(1)
         n_reads_cases += 1

@@ -17,22 +17,30 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 def _launch(tmp_path, world, backend, devices):
-    port = str(29600 + os.getpid() % 2000)
+    port = _free_port()
     procs = []
     for r in range(world):
-        out = str(tmp_path / f"rank{r}.npz")
-        procs.append((out, subprocess.Popen([sys.executable, os.path.join(HERE, "dist_child.py"), str(r), str(world), port,
-                                             backend, str(devices[r]), out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        out, log = str(tmp_path / f"rank{r}.npz"), open(tmp_path / f"rank{r}.log", "w")   # (a file, not a pipe: no rank can block on a full one)
+        procs.append((out, log, subprocess.Popen([sys.executable, os.path.join(HERE, "dist_child.py"), str(r), str(world), port,
+                                                  backend, str(devices[r]), out], stdout=log, stderr=subprocess.STDOUT)))
     outs = []
-    for out, p in procs:
+    for out, log, p in procs:
         try:
-            log, _ = p.communicate(timeout=600)
+            p.wait(timeout=600)
         except subprocess.TimeoutExpired:
-            for _, q in procs:
+            for _, _, q in procs:
                 q.kill()
             raise
-        assert p.returncode == 0, log[-3000:]
+        log.close()
+        assert p.returncode == 0, open(log.name).read()[-3000:]
         outs.append(np.load(out))
     return outs
 

@@ -58,6 +58,15 @@ def test_device_streams_equal_oracle_streams(name):
     got = g["ctx"].export_entries(er, eo, pair, True)
     for k in xu.STREAMS:
         assert np.array_equal(got[k], want[k]), (name, "entries", k)
+    # ... and with the entry list made on the device from the reads' original indexes alone
+    for byte_mode in (True, False):
+        want = xu.oracle_export_entries(case, res, er, eo, pair_file=pair, byte_mode=byte_mode)
+        for pair_mode in (False, True):       # pairFileMode (class-major order) is independent of the paired-file rule
+            er2, eo2 = xu.original_order_entries(case["read_org"], res["mism"] != 255, case["total"], pair_mode, n - case["n_n"])
+            want2 = want if pair_mode == pair else xu.oracle_export_entries(case, res, er2, eo2, pair_file=pair, byte_mode=byte_mode)
+            got = g["ctx"].export_original_order(case["read_org"], case["total"], pair_mode, pair, byte_mode)
+            for k in xu.STREAMS:
+                assert np.array_equal(got[k], want2[k]), (name, "original order on the device", byte_mode, pair_mode, k)
 
 
 def test_export_edge_cases():
@@ -74,6 +83,20 @@ def test_export_edge_cases():
     got = g["ctx"].export_entries(none, none)
     assert all(got[k].size == 0 for k in xu.STREAMS)
     from pgrc_amd import MatchContext, PgrcMatchError
+    # bad arguments come back as errors, not as device faults: an index beyond the read set, a read without a match in
+    # order[], original indexes out of range or used twice
+    n = case["reads"].shape[0]
+    unmatched = np.flatnonzero(res["mism"] == 255)
+    assert unmatched.size
+    for bad in (np.array([n], dtype=np.uint32), unmatched[:1].astype(np.uint32)):
+        with pytest.raises(PgrcMatchError):
+            g["ctx"].export_pg_order(bad, case["list_off"], case["list_org"], case["list_rc"], case["read_org"])
+    ro = case["read_org"].copy()
+    with pytest.raises(PgrcMatchError):
+        g["ctx"].export_original_order(ro, int(ro.max()))            # total too small
+    ro[1] = ro[0]
+    with pytest.raises(PgrcMatchError):
+        g["ctx"].export_original_order(ro, case["total"])            # two reads, one original index
     many = MatchContext(100, 38, 33, 0, "c", devices=[0, 0])
     with pytest.raises(PgrcMatchError):
         many.export_entries(none, none)             # nothing matched yet
@@ -94,8 +117,9 @@ def test_export_from_a_matcher_over_several_shards(name):
     er, eo = xu.original_order_entries(case["read_org"], one["mism"] != 255, case["total"], pair, n - case["n_n"])
     a2 = one["ctx"].export_entries(er, eo, pair, True)
     b2 = many["ctx"].export_entries(er, eo, pair, True)
+    c2 = many["ctx"].export_original_order(case["read_org"], case["total"], pair, pair, True)
     for k in xu.STREAMS:
-        assert np.array_equal(a[k], b[k]) and np.array_equal(a2[k], b2[k]), (name, k)
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a2[k], b2[k]) and np.array_equal(a2[k], c2[k]), (name, k)
 
 
 @pytest.mark.parametrize("name", ["se", "pe_pairfile", "short_list", "no_list"])

@@ -79,5 +79,7 @@ def test_gpu_export_reproduces_reference_streams(name):
     n = case["reads"].shape[0]
     er, eo = xu.original_order_entries(case["read_org"], res["mism"] != 255, case["total"], pair, n - case["n_n"])
     got = xu.stream_bytes(g["ctx"].export_entries(er, eo, pair, True))
+    dev = xu.stream_bytes(g["ctx"].export_original_order(case["read_org"], case["total"], pair, pair, True))
     for k in xu.STREAMS:
         assert got[k] == gold["org"][k], (name, "original order", k)
+        assert dev[k] == gold["org"][k], (name, "original order, entry list made on the device", k)

@@ -368,8 +368,16 @@ def test_two_index_schedules_fall_back_when_the_second_index_does_not_fit(monkey
         ctx.run(True)
         pos, rc, mism, hist, matched = ctx.get_results()
         assert np.array_equal(pos, o["pos"]) and np.array_equal(rc, o["rc"]) and np.array_equal(mism, o["mism"]), run
-        assert ctx.counters()["screened"] == 0
-    g = gpu_match("c", pg, reads, 38, 3, 0)                        # a fresh context takes the dual kernel again
+        assert ctx.counters()["screened"] == 0 and ctx.counters()["schedule_downgraded"] == 1
+    # another read set (or text) on the same context: the second set may fit now, so the schedule is tried again
+    ctx.set_reads_ascii(reads[:5000])
+    ctx.init_results()
+    ctx.run(True)
+    o5 = orc.oracle_match("c", pg, reads[:5000], 38, 3, 0)
+    pos, rc, mism, hist, matched = ctx.get_results()
+    assert np.array_equal(pos, o5["pos"]) and np.array_equal(rc, o5["rc"]) and np.array_equal(mism, o5["mism"])
+    assert ctx.counters()["screened"] == 2 and ctx.counters()["schedule_downgraded"] == 0
+    g = gpu_match("c", pg, reads, 38, 3, 0)                        # a fresh context takes the dual kernel
     assert g["ctx"].counters()["screened"] == 2
     assert_same_results(g, o, "fresh context")
 

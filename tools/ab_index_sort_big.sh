@@ -1,5 +1,7 @@
 #!/bin/bash
 # index build variants on the larger tables (C5 shard: 2^30 buckets, 620 M samples; P64: 4.4 Gbp text, 880 M samples)
+set -eu
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=${1:-gpurun_out/ab_index_big}
 mkdir -p $OUT
 for w in C5-shard P64; do

@@ -1,6 +1,8 @@
 #!/bin/bash
 # row f2: the host replay with one thread (PGRC_MEM_REPLAY_THREADS=1 = the sequential scan) vs the parallel speculative
 # replay, at the C3 pseudogenome size; the cases run twice in one process (the first call also grows the pinned mirrors).
+set -eu
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=${1:-gpurun_out/f2_replay}
 mkdir -p $OUT
 for t in 1 16; do

@@ -1,9 +1,10 @@
 #!/bin/bash
 # per-context counters of identical match kernels (why do contexts differ by up to 13 %?)
-set -u
+set -eu
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=${1:-gpurun_out/pmc_contexts}
 mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 i=0
 for grp in "TCP_UTCL1_LFIFO_FULL_sum TCP_UTCL1_STALL_LFIFO_NO_RES_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum" "GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE"; do
   i=$((i+1))

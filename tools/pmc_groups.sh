@@ -1,12 +1,13 @@
 #!/bin/bash
 # usage: tools/pmc_groups.sh <outdir> "<grp1>" "<grp2>" ... -- <bench args...>
-set -u
+set -eu
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$1; shift
 GROUPS_=()
 while [ "$1" != "--" ]; do GROUPS_+=("$1"); shift; done
 shift
 mkdir -p "$OUT"
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 i=0
 for grp in "${GROUPS_[@]}"; do
   i=$((i+1))
