@@ -164,14 +164,18 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     }
     int hbits = 0;
     while ((1ull << hbits) < hs) hbits++;
-    // How the records get grouped by bucket (all three give the serial reference index, byte for byte):
-    //   "hybrid" (default): record generation + the library's radix sort over the TOP bucket bits only (two 8-bit passes
-    //             instead of four), then one block per partition of 8192 buckets finishes counting, cap, order and
-    //             heads in LDS (idxsort.hip);
+    // How the records get grouped by bucket (all four give the serial reference index, byte for byte):
+    //   "sweep" (default): two hand-written one-sweep scatter passes over the TOP bucket bits that hash the text
+    //             themselves and shrink the records to 8 bytes (idxsweep.hip), then one block per partition of 8192
+    //             buckets finishes counting, cap, order and heads in LDS (idxsort.hip); no library call;
+    //   "hybrid" (round 2's default): record generation + the library's radix sort over the top bucket bits (two 8-bit
+    //             passes), then the same finish;
     //   "own":    the same finish behind hand-written scatter passes that hash the text themselves (no library call);
     //   "rocprim": round 1's path -- full library sort, streaming head kernel (also taken for 2^32 or more samples).
     const char *sel = getenv("PGRC_INDEX_SORT");
     const bool want_lib = sel && !strcmp(sel, "rocprim"), want_own = sel && !strcmp(sel, "own");
+    const bool want_sweep = !sel || !sel[0] || !strcmp(sel, "sweep");
+    if (want_sweep && pgrc_os_applicable(c, (uint32_t)hbits)) return pgrc_os_build_index(c, strand, (uint32_t)hbits);
     const bool partition = !want_lib && pgrc_ps_applicable(c, (uint32_t)hbits);
     const uint32_t cb = pgrc_ps_partition_bits((uint32_t)hbits);
     if (partition && want_own) {

@@ -84,6 +84,7 @@ struct pgrc_match_ctx {
     DevBuf d_skey[2], d_sval[2], d_sorttmp; // (bucket, entry) records: radix sort ping-pong + rocPRIM scratch (grow-only)
     const uint64_t *ent_ptr = nullptr;  // the sorted entries (one of d_sval[]): ent[] of the match kernel
     int index_strand = -1;  // which strand the buffers currently describe
+    bool os_lds_allowed = false;        // idxsweep.hip's kernels were granted their dynamic LDS on this context's device
     // the screened schedule of a two-pass run (copmem.hip, "Exact-match screen") keeps both strands' indexes: a second
     // set of index buffers that swaps roles with the first, and per read the flag / position the screen found
     DevBuf alt_head, alt_skey[2], alt_sval[2], alt_sorttmp;
@@ -194,6 +195,13 @@ uint32_t pgrc_ps_partition_bits(uint32_t hbits);
 bool pgrc_ps_applicable(const pgrc_match_ctx *c, uint32_t hbits);
 int pgrc_ps_scatter_front(pgrc_match_ctx *c, int strand, uint32_t hbits, uint32_t cb);
 int pgrc_ps_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uint64_t *d_vals, uint32_t hbits, uint32_t cb, uint64_t *d_ent);
+int pgrc_ps_finish_packed(pgrc_match_ctx *c, const uint64_t *d_recs, const uint32_t *d_pstart, uint32_t *d_slow, uint32_t np, uint32_t cb,
+                          uint32_t rec_sh, uint64_t *d_ent);
+uint64_t pgrc_ps_scan_blocks(uint64_t n);
+int pgrc_ps_scan_u32(pgrc_match_ctx *c, uint32_t *d_io, uint64_t n, uint32_t *d_bsum);
+// idxsweep.hip: the default front end (one-sweep scatter passes that hash the text themselves, 8-byte records)
+bool pgrc_os_applicable(const pgrc_match_ctx *c, uint32_t hbits);
+int pgrc_os_build_index(pgrc_match_ctx *c, int strand, uint32_t hbits);
 int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand);
 int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase);
 int pgrc_copmem_match_dual(pgrc_match_ctx *c);

@@ -113,7 +113,9 @@ __global__ void __launch_bounds__(PSC_TPB) k_psc_write(uint32_t *__restrict__ io
     }
 }
 
-// in place: counts -> exclusive prefix sums
+uint64_t pgrc_ps_scan_blocks(uint64_t n) { return (n + PSC_EPB - 1) / PSC_EPB; }
+
+// in place: counts -> exclusive prefix sums (d_bsum: pgrc_ps_scan_blocks(n) + 1 words of scratch)
 static int ps_scan(pgrc_match_ctx *c, uint32_t *d_io, uint64_t n, uint32_t *d_bsum) {
     const uint64_t nb = (n + PSC_EPB - 1) / PSC_EPB;
     hipLaunchKernelGGL(k_psc_sums, dim3((uint32_t)nb), dim3(PSC_TPB), 0, c->stream, (const uint32_t *)d_io, n, d_bsum);
@@ -122,6 +124,8 @@ static int ps_scan(pgrc_match_ctx *c, uint32_t *d_io, uint64_t n, uint32_t *d_bs
     HIP_TRY(c, hipGetLastError());
     return PGRC_OK;
 }
+
+int pgrc_ps_scan_u32(pgrc_match_ctx *c, uint32_t *d_io, uint64_t n, uint32_t *d_bsum) { return ps_scan(c, d_io, n, d_bsum); }
 
 // ---------------------------------------------------------------- record generation (one wave = 64 consecutive sampled positions)
 
@@ -336,9 +340,9 @@ __global__ void __launch_bounds__(256) k_ps_bounds_fill(const uint32_t *__restri
 //   1. count per bucket (LDS atomics; order is irrelevant for counting);
 //   2. kept = min(count, 13); exclusive scan -> where a bucket's entries go;
 //   3. placement: a record of a bucket with <= 13 entries takes the next free slot of its bucket (any order: step 4
-//      sorts); a record of an overflowing bucket gets the deterministic rank "entries placed by earlier chunks +
-//      same-bucket records before it in this chunk" and is dropped once that reaches 13 -- the serial build's
-//      `cumm[h] <= 12` cap (CopMEMMatcher.cpp:156-159);
+//      sorts); an over-full bucket keeps its 13 smallest entries -- the serial build's `cumm[h] <= 12` cap
+//      (CopMEMMatcher.cpp:156-159) -- found by 13 rounds of atomicMin, so the result does not depend on the order in
+//      which the records arrive (the one-sweep front end of idxsweep.hip does not keep them in position order);
 //   4. every bucket with >= 2 entries puts its <= 13 entries in ascending order (entry order = position order); the
 //      heads are built and streamed out as one contiguous run, the entries as another.
 // Fast kernel: the partition's records sit in registers (one load burst), entries are staged in LDS, nothing is
@@ -351,14 +355,24 @@ __global__ void __launch_bounds__(256) k_ps_bounds_fill(const uint32_t *__restri
 #define PFF_KEPT(w) (((w) >> 17) & 15u)
 #define PFF_FILL(w) (((w) >> 21) & 15u)
 
-template <int E, int PFF_TPB, int PFF_SUBBITS, int CAPI>
+// PACKED: the records are single 64-bit words (idxsweep.hip): bucket bits below cb | sampled position index t | fingerprint,
+// fmt.sh = bits of (t, fingerprint); `vals` is that array, `keys` is unused.
+struct PsRecFmt {
+    uint32_t sh, k1;
+};
+__device__ __forceinline__ void ps_unpack(const PsRecFmt f, uint64_t rec, uint32_t *k, uint64_t *v) {
+    const uint64_t tv = rec & ((1ull << f.sh) - 1ull);
+    *k = (uint32_t)(rec >> f.sh);
+    *v = (((tv >> PGRC_FP_BITS) * (uint64_t)f.k1) << PGRC_FP_BITS) | (tv & ((1ull << PGRC_FP_BITS) - 1ull));
+}
+
+template <int E, int PFF_TPB, int PFF_SUBBITS, int CAPI, bool PACKED>
 __global__ void __launch_bounds__(PFF_TPB)
 k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals, const uint32_t *__restrict__ pstart, uint32_t cb,
-                 uint64_t *__restrict__ ent, ulonglong2 *__restrict__ head, uint32_t *__restrict__ slow_flag) {
+                 uint64_t *__restrict__ ent, ulonglong2 *__restrict__ head, uint32_t *__restrict__ slow_flag, const PsRecFmt fmt) {
     constexpr uint32_t PFF_SUB = 1u << PFF_SUBBITS, PFF_CAP = (uint32_t)CAPI;
     __shared__ uint32_t pk[PFF_SUB + PFF_SUB / 16];
     __shared__ uint64_t entS[PFF_CAP];
-    __shared__ uint32_t ckey[PFF_TPB];
     __shared__ uint32_t scan_tmp[PFF_TPB / 64 + 1];
     __shared__ uint32_t flags[2];            // [0] a bucket of this round overflows, [1] bail out
     const uint32_t p = blockIdx.x;
@@ -372,8 +386,13 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
 #pragma unroll
     for (int i = 0; i < E; i++) {
         const uint64_t x = s + (uint64_t)i * PFF_TPB + threadIdx.x;
-        k[i] = x < e ? keys[x] : 0xFFFFFFFFu;
-        v[i] = x < e ? vals[x] : 0ull;
+        if (PACKED) {
+            ps_unpack(fmt, x < e ? vals[x] : 0ull, &k[i], &v[i]);
+            if (x >= e) k[i] = 0xFFFFFFFFu;
+        } else {
+            k[i] = x < e ? keys[x] : 0xFFFFFFFFu;
+            v[i] = x < e ? vals[x] : 0ull;
+        }
     }
     const uint32_t nb = 1u << cb, cbmask = nb - 1u;
     uint64_t out = s;                                         // where this round's entries start in ent[]
@@ -403,6 +422,8 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
 #pragma unroll
             for (uint32_t q = 0; q < PFF_SUB / PFF_TPB; q++) {
                 pk[PFF_PAD(b0 + q)] = off | (min(c[q], 14u) << 17);
+                if (c[q] > PGRC_BUCKET_CAP && total <= PFF_CAP)               // an over-full bucket: its slots start as "no entry yet" (step 3)
+                    for (uint32_t j = 0; j < PGRC_BUCKET_CAP; j++) entS[off + j] = ~0ull;
                 off += min(c[q], PGRC_BUCKET_CAP);
             }
             if (ovf) flags[0] = 1;
@@ -424,26 +445,32 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
                 }
             }
         } else {
-            for (int i = 0; i < E; i++) {                     // chunk i = 512 consecutive records
+            // Buckets with at most 13 records take any free slot as above.  An over-full bucket keeps its 13 SMALLEST
+            // entries (= positions: the serial build's `cumm[h] <= 12` cap, CopMEMMatcher.cpp:156-159) whatever order the
+            // records arrive in: 13 rounds of "the smallest entry not taken yet" (LDS atomicMin on slot r), which also
+            // leaves them in ascending order.
+            uint32_t live = 0;
+#pragma unroll
+            for (int i = 0; i < E; i++) {
                 const uint32_t b = (k[i] & cbmask) - r0;
-                const bool mine = k[i] != 0xFFFFFFFFu && b < PFF_SUB;
-                const uint32_t w0 = mine ? pk[PFF_PAD(b)] : 0u;     // state before this chunk
-                ckey[threadIdx.x] = mine ? b : 0xFFFFFFFFu;
-                __syncthreads();
-                if (mine) {
-                    if (PFF_KEPT(w0) <= PGRC_BUCKET_CAP) {
+                if (k[i] != 0xFFFFFFFFu && b < PFF_SUB) {
+                    if (PFF_KEPT(pk[PFF_PAD(b)]) <= PGRC_BUCKET_CAP) {
                         const uint32_t w = atomicAdd(&pk[PFF_PAD(b)], 1u << 21);
                         entS[PFF_OFF(w) + PFF_FILL(w)] = v[i];
-                    } else if (PFF_FILL(w0) < PGRC_BUCKET_CAP) {
-                        uint32_t before = 0;                  // same-bucket records earlier in this chunk
-                        for (uint32_t y = 0; y < threadIdx.x; y++) before += ckey[y] == b;
-                        const uint32_t r = PFF_FILL(w0) + before;
-                        if (r < PGRC_BUCKET_CAP) {
-                            entS[PFF_OFF(w0) + r] = v[i];
-                            atomicAdd(&pk[PFF_PAD(b)], 1u << 21);
-                        }
+                    } else {
+                        live |= 1u << i;
                     }
                 }
+            }
+            __syncthreads();
+            for (uint32_t r = 0; r < PGRC_BUCKET_CAP; r++) {
+#pragma unroll
+                for (int i = 0; i < E; i++)
+                    if ((live >> i) & 1u) atomicMin((unsigned long long *)&entS[PFF_OFF(pk[PFF_PAD((k[i] & cbmask) - r0)]) + r], (unsigned long long)v[i]);
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < E; i++)
+                    if (((live >> i) & 1u) && entS[PFF_OFF(pk[PFF_PAD((k[i] & cbmask) - r0)]) + r] == v[i]) live &= ~(1u << i);
                 __syncthreads();
             }
         }
@@ -483,104 +510,160 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
 }
 
 // The general kernel: any partition size, entries placed straight into ent[] and read back for the heads.  Runs only
-// for partitions the fast kernel flagged (slow_flag == nullptr: for all).  8192 buckets per round.
-#define PF_TPB 256
+// for the partitions the fast kernel flagged (`todo` = their list; nullptr: every partition), a persistent grid that
+// walks the list.  8192 buckets per round.  Three sweeps over the partition's records: count; place (buckets with at
+// most 13 records take any free slot); and, for over-full buckets, the selection of their 13 smallest entries:
+//   * the FIRST 13 records of such a bucket to arrive (any 13 will do) leave the largest of their position keys in
+//     tmax[bucket]: a record whose key is larger has 13 smaller ones before it and is out;
+//   * the remaining candidates (normally the bucket's first 13 records and a few neighbours: records arrive roughly in
+//     position order) are listed by index, and 13 rounds of "the smallest entry above the last round's" (atomicMin on
+//     slot r) over that short list fill the bucket's slots in ascending order.
+// Nothing depends on the order in which the records arrive.
+#define PF_TPB 512
 #define PF_NB 8192u
+#define PF_LIST 8192u
 
+template <bool PACKED>
 __global__ void __launch_bounds__(PF_TPB)
 k_ps_finish(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals, const uint32_t *__restrict__ pstart, uint32_t cb,
-            uint64_t *__restrict__ ent, ulonglong2 *__restrict__ head, const uint32_t *__restrict__ slow_flag) {
+            uint64_t *__restrict__ ent, ulonglong2 *__restrict__ head, const uint32_t *__restrict__ todo, const uint32_t *__restrict__ todo_count,
+            uint32_t np, const PsRecFmt fmt) {
     __shared__ uint32_t cnt[PF_NB];          // 1: count; from 2 on: first slot of the bucket (relative to this round's base)
     __shared__ uint8_t kept[PF_NB];          // min(count, 14): 14 = "more than 13"
-    __shared__ uint32_t fill[PF_NB / 4];     // entries placed so far, one byte per bucket
-    __shared__ uint32_t ckey[PF_TPB];
+    __shared__ uint32_t arrived[PF_NB];      // records of the bucket seen by the placement sweep
+    __shared__ uint32_t tmax[PF_NB];         // over-full buckets: largest position key among the first 13 arrivals
+    __shared__ uint32_t list[PF_LIST];       // candidates of the over-full buckets (record index in the partition)
     __shared__ uint32_t scan_tmp[PF_TPB / 64 + 1];
-    const uint32_t p = blockIdx.x;
-    if (slow_flag && !slow_flag[p]) return;
-    const uint64_t s = pstart[p], e = pstart[p + 1];
+    __shared__ uint32_t any_ovf, ncand;
+    const uint32_t nlist = todo ? *todo_count : np;
     const uint32_t nb = 1u << cb, cbmask = nb - 1u;
-    uint64_t out = s;
-    for (uint32_t r0 = 0; r0 < nb; r0 += PF_NB) {
-        for (uint32_t b = threadIdx.x; b < PF_NB; b += PF_TPB) cnt[b] = 0;
-        for (uint32_t b = threadIdx.x; b < PF_NB / 4; b += PF_TPB) fill[b] = 0;
-        __syncthreads();
-        for (uint64_t x = s + threadIdx.x; x < e; x += PF_TPB) {
-            const uint32_t b = (keys[x] & cbmask) - r0;
-            if (b < PF_NB) atomicAdd(&cnt[b], 1u);
-        }
-        __syncthreads();
-        uint32_t total;
-        {
-            const uint32_t b0 = threadIdx.x * (PF_NB / PF_TPB);
-            uint32_t sum = 0;
-            for (uint32_t q = 0; q < PF_NB / PF_TPB; q++) {
-                const uint32_t c = cnt[b0 + q];
-                kept[b0 + q] = (uint8_t)min(c, 14u);
-                sum += min(c, PGRC_BUCKET_CAP);
-            }
-            uint32_t off = psc_block_scan(sum, scan_tmp, &total);
-            for (uint32_t q = 0; q < PF_NB / PF_TPB; q++) {
-                const uint32_t c = min((uint32_t)kept[b0 + q], PGRC_BUCKET_CAP);
-                cnt[b0 + q] = off;
-                off += c;
-            }
-        }
-        __syncthreads();
-        for (uint64_t c0 = s; c0 < e; c0 += PF_TPB) {
-            const uint64_t x = c0 + threadIdx.x;
-            const uint32_t b = x < e ? (keys[x] & cbmask) - r0 : 0xFFFFFFFFu;
-            const bool valid = b < PF_NB;
-            ckey[threadIdx.x] = valid ? b : 0xFFFFFFFFu;
-            const uint32_t snap = valid ? (fill[b >> 2] >> (8u * (b & 3u))) & 0xFFu : 0u;   // placed by earlier chunks
+    auto record = [&](uint64_t x, uint32_t *k, uint64_t *v) {
+        if (PACKED) ps_unpack(fmt, vals[x], k, v);
+        else { *k = keys[x]; *v = vals[x]; }
+    };
+    auto poskey = [](uint64_t v) -> uint32_t { return (uint32_t)(v >> (PGRC_FP_BITS + 8u)); };   // position / 256: monotone in v
+    // entries other threads of the block placed (plain stores, or atomics that execute in the L2): read past this CU's L1
+    auto ld = [](const uint64_t *q) -> uint64_t { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    for (uint32_t li = blockIdx.x; li < nlist; li += gridDim.x) {
+        const uint32_t p = todo ? todo[li] : li;
+        const uint64_t s = pstart[p], e = pstart[p + 1];
+        uint64_t out = s;
+        for (uint32_t r0 = 0; r0 < nb; r0 += PF_NB) {
             __syncthreads();
-            if (valid) {
-                const uint32_t kc = kept[b];
-                uint32_t r = 0;
-                bool keep = true;
-                if (kc <= PGRC_BUCKET_CAP) {
-                    r = (atomicAdd(&fill[b >> 2], 1u << (8u * (b & 3u))) >> (8u * (b & 3u))) & 0xFFu;
-                } else if (snap >= PGRC_BUCKET_CAP) {
-                    keep = false;
-                } else {
-                    uint32_t before = 0;                       // same-bucket records earlier in this chunk
-                    for (uint32_t y = 0; y < threadIdx.x; y++) before += ckey[y] == b;
-                    r = snap + before;
-                    keep = r < PGRC_BUCKET_CAP;
-                    if (keep) atomicAdd(&fill[b >> 2], 1u << (8u * (b & 3u)));
+            for (uint32_t b = threadIdx.x; b < PF_NB; b += PF_TPB) { cnt[b] = 0; arrived[b] = 0; tmax[b] = 0; }
+            if (threadIdx.x == 0) { any_ovf = 0; ncand = 0; }
+            __syncthreads();
+            for (uint64_t x = s + threadIdx.x; x < e; x += PF_TPB) {
+                uint32_t k;
+                uint64_t v;
+                record(x, &k, &v);
+                const uint32_t b = (k & cbmask) - r0;
+                if (b < PF_NB) atomicAdd(&cnt[b], 1u);
+            }
+            __syncthreads();
+            uint32_t total;
+            {
+                const uint32_t b0 = threadIdx.x * (PF_NB / PF_TPB);
+                uint32_t sum = 0;
+                for (uint32_t q = 0; q < PF_NB / PF_TPB; q++) {
+                    const uint32_t c = cnt[b0 + q];
+                    kept[b0 + q] = (uint8_t)min(c, 14u);
+                    sum += min(c, PGRC_BUCKET_CAP);
                 }
-                if (keep) ent[out + cnt[b] + r] = vals[x];
-            }
-            __syncthreads();
-        }
-        for (uint32_t b = threadIdx.x; b < PF_NB; b += PF_TPB) {
-            const uint32_t c = min((uint32_t)kept[b], PGRC_BUCKET_CAP);
-            ulonglong2 hd = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
-            if (c) {
-                uint64_t *q = ent + out + cnt[b];
-                uint64_t v0 = q[0], v1 = c > 1 ? q[1] : 0;
-                if (c == 2) {
-                    if (v1 < v0) { const uint64_t t = v0; v0 = v1; v1 = t; q[0] = v0; q[1] = v1; }
-                } else if (c > 2) {
-                    for (uint32_t i = 1; i < c; i++) {          // insertion sort of <= 13 values, in place
-                        const uint64_t x = q[i];
-                        uint32_t j = i;
-                        while (j > 0 && q[j - 1] > x) { q[j] = q[j - 1]; j--; }
-                        q[j] = x;
+                uint32_t off = psc_block_scan(sum, scan_tmp, &total);
+                for (uint32_t q = 0; q < PF_NB / PF_TPB; q++) {
+                    cnt[b0 + q] = off;
+                    if (kept[b0 + q] > PGRC_BUCKET_CAP) {      // an over-full bucket: its 13 slots start as "no entry yet"
+                        for (uint32_t j = 0; j < PGRC_BUCKET_CAP; j++) ent[out + off + j] = ~0ull;
+                        any_ovf = 1;
                     }
-                    v0 = q[0];
-                }
-                hd.x = v0;
-                if (c == 2) hd.y = v1;
-                else if (c > 2) {
-                    hd.x |= HEAD_OVF;
-                    hd.y = (out + cnt[b] + 1) | ((uint64_t)c << 56);    // entries 1.. at ent[base + j - 1]
+                    off += min((uint32_t)kept[b0 + q], PGRC_BUCKET_CAP);
                 }
             }
-            head[((uint64_t)p << cb) + r0 + b] = hd;
+            __threadfence();
+            __syncthreads();
+            for (uint64_t x = s + threadIdx.x; x < e; x += PF_TPB) {
+                uint32_t k;
+                uint64_t v;
+                record(x, &k, &v);
+                const uint32_t b = (k & cbmask) - r0;
+                if (b < PF_NB) {
+                    const uint32_t r = atomicAdd(&arrived[b], 1u);
+                    if (kept[b] <= PGRC_BUCKET_CAP) ent[out + cnt[b] + r] = v;
+                    else if (r < PGRC_BUCKET_CAP) atomicMax(&tmax[b], poskey(v));
+                }
+            }
+            __syncthreads();
+            if (any_ovf) {
+                for (uint64_t x = s + threadIdx.x; x < e; x += PF_TPB) {
+                    uint32_t k;
+                    uint64_t v;
+                    record(x, &k, &v);
+                    const uint32_t b = (k & cbmask) - r0;
+                    if (b < PF_NB && kept[b] > PGRC_BUCKET_CAP && poskey(v) <= tmax[b]) {
+                        const uint32_t i = atomicAdd(&ncand, 1u);
+                        if (i < PF_LIST) list[i] = (uint32_t)(x - s);
+                    }
+                }
+                __syncthreads();
+                const bool listed = ncand <= PF_LIST;        // (else: sweep the whole partition in every round)
+                const uint64_t m = listed ? ncand : e - s;
+                for (uint32_t r = 0; r < PGRC_BUCKET_CAP; r++) {
+                    for (uint64_t i = threadIdx.x; i < m; i += PF_TPB) {
+                        const uint64_t x = s + (listed ? (uint64_t)list[i] : i);
+                        uint32_t k;
+                        uint64_t v;
+                        record(x, &k, &v);
+                        const uint32_t b = (k & cbmask) - r0;
+                        if (b < PF_NB && kept[b] > PGRC_BUCKET_CAP && poskey(v) <= tmax[b]) {
+                            uint64_t *slot = ent + out + cnt[b] + r;
+                            if (r == 0 || v > ld(slot - 1)) atomicMin((unsigned long long *)slot, (unsigned long long)v);
+                        }
+                    }
+                    __threadfence();
+                    __syncthreads();
+                }
+            }
+            __threadfence();
+            __syncthreads();
+            for (uint32_t b = threadIdx.x; b < PF_NB && r0 + b < nb; b += PF_TPB) {
+                const uint32_t c = min((uint32_t)kept[b], PGRC_BUCKET_CAP);
+                ulonglong2 hd = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
+                if (c) {
+                    uint64_t *q = ent + out + cnt[b];
+                    uint64_t v0 = ld(q), v1 = c > 1 ? ld(q + 1) : 0;
+                    if (c == 2) {
+                        if (v1 < v0) { const uint64_t t = v0; v0 = v1; v1 = t; q[0] = v0; q[1] = v1; }
+                    } else if (c > 2) {
+                        uint64_t w[PGRC_BUCKET_CAP];
+                        for (uint32_t i = 0; i < c; i++) w[i] = ld(q + i);
+                        for (uint32_t i = 1; i < c; i++) {      // insertion sort of <= 13 values
+                            const uint64_t x = w[i];
+                            uint32_t j = i;
+                            while (j > 0 && w[j - 1] > x) { w[j] = w[j - 1]; j--; }
+                            w[j] = x;
+                        }
+                        for (uint32_t i = 0; i < c; i++) q[i] = w[i];
+                        v0 = w[0];
+                    }
+                    hd.x = v0;
+                    if (c == 2) hd.y = v1;
+                    else if (c > 2) {
+                        hd.x |= HEAD_OVF;
+                        hd.y = (out + cnt[b] + 1) | ((uint64_t)c << 56);    // entries 1.. at ent[base + j - 1]
+                    }
+                }
+                head[((uint64_t)p << cb) + r0 + b] = hd;
+            }
+            out += total;
         }
-        out += total;
-        __syncthreads();
     }
+}
+
+// the partitions the fast kernel flagged, as a list (any order)
+__global__ void __launch_bounds__(256) k_ps_slow_list(const uint32_t *__restrict__ slow_flag, uint32_t np, uint32_t *__restrict__ list, uint32_t *__restrict__ count) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < np; p += gridDim.x * blockDim.x)
+        if (slow_flag[p]) list[atomicAdd(count, 1u)] = p;
 }
 
 // ---------------------------------------------------------------- drivers
@@ -634,37 +717,66 @@ int pgrc_ps_scatter_front(pgrc_match_ctx *c, int strand, uint32_t hbits, uint32_
     return PGRC_OK;
 }
 
-// records sorted by their bucket bits [cb, hbits) (position order inside) -> ent[] (d_ent) and all bucket heads
-int pgrc_ps_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uint64_t *d_vals, uint32_t hbits, uint32_t cb, uint64_t *d_ent) {
+// The finish of every partition.  pst2[0 .. np] = partition starts (device); slow = np flags + np + 1 words for the list
+// of flagged partitions (all zero).  packed_sh != 0: d_vals holds the 64-bit packed records of idxsweep.hip (d_keys
+// unused), packed_sh = bits of (t, fingerprint) in a record.
+static int ps_launch_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uint64_t *d_vals, const uint32_t *pst2, uint32_t *slow, uint32_t np,
+                            uint32_t cb, uint64_t *d_ent, uint32_t packed_sh) {
     const uint64_t n = c->npos;
-    const uint32_t np = 1u << (hbits - cb);
-    int e;
-    if ((e = pgrc_buf_ensure(c, c->d_sorttmp, (3ull * (np + 2)) * sizeof(uint32_t) + 256))) return e;
-    uint32_t *pst = (uint32_t *)c->d_sorttmp.p, *pst2 = pst + np + 2, *slow = pst2 + np + 2;
-    HIP_TRY(c, hipMemsetAsync(pst, 0xFF, (size_t)(np + 1) * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(slow, 0, (size_t)np * sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(k_ps_bounds, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 65536ull * 4)), dim3(256), 0, c->stream, d_keys, n, cb, pst);
-    hipLaunchKernelGGL(k_ps_bounds_fill, dim3((np + 256) / 256), dim3(256), 0, c->stream, (const uint32_t *)pst, np, (uint32_t)n, pst2);
+    PsRecFmt fmt;
+    fmt.sh = packed_sh;
+    fmt.k1 = (uint32_t)c->cp.k1;
+    const bool packed = packed_sh != 0;
+    uint32_t *todo = slow + np, *todo_count = todo + np;
+    ulonglong2 *head = (ulonglong2 *)c->d_head.p;
+    const uint32_t ggrid = std::min<uint32_t>(np, (uint32_t)c->num_cus * 2u);
     const char *gen = getenv("PGRC_INDEX_FINISH");   // "general": the general finish kernel for every partition (tests)
     if (gen && !strcmp(gen, "general")) {
-        hipLaunchKernelGGL(k_ps_finish, dim3(np), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, (const uint32_t *)pst2, cb, d_ent,
-                           (ulonglong2 *)c->d_head.p, (const uint32_t *)nullptr);
+        if (packed) hipLaunchKernelGGL(k_ps_finish<true>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, (const uint32_t *)nullptr, (const uint32_t *)nullptr, np, fmt);
+        else hipLaunchKernelGGL(k_ps_finish<false>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, (const uint32_t *)nullptr, (const uint32_t *)nullptr, np, fmt);
     } else {
         // registers per thread sized for the mean partition (uniform hash values); whatever is larger is flagged
         const uint64_t need = n / np + n / np / 4 + 512;
         // block shape: 1024 threads x 8 records (16 for larger partitions: tables beyond 2^29 buckets), two 4096-bucket
         // rounds.  Measured at C3 (index build per strand, tools/ab_finish_cfg.sh in the round-2 history): 512 x 16: 15.1 ms,
         // 256 x 32: 16.0, 256 x 32 with 2048-bucket rounds: 16.8, 512 x 16 with 2048-bucket rounds: 16.4, 1024 x 8: 13.5.
-#define PFF_LAUNCH(E, TPB, SB, CAP)                                                                                       \
-        hipLaunchKernelGGL((k_ps_finish_fast<E, TPB, SB, CAP>), dim3(np), dim3(TPB), 0, c->stream, d_keys, d_vals,         \
-                           (const uint32_t *)pst2, cb, d_ent, (ulonglong2 *)c->d_head.p, slow)
-        if (need <= 8192) PFF_LAUNCH(8, 1024, 12, 4096);
-        else PFF_LAUNCH(16, 1024, 12, 4096);
+#define PFF_LAUNCH(E, TPB, SB, CAP, PK)                                                                                   \
+        hipLaunchKernelGGL((k_ps_finish_fast<E, TPB, SB, CAP, PK>), dim3(np), dim3(TPB), 0, c->stream, d_keys, d_vals,     \
+                           pst2, cb, d_ent, head, slow, fmt)
+        if (packed) {
+            if (need <= 8192) PFF_LAUNCH(8, 1024, 12, 4096, true);
+            else PFF_LAUNCH(16, 1024, 12, 4096, true);
+        } else {
+            if (need <= 8192) PFF_LAUNCH(8, 1024, 12, 4096, false);
+            else PFF_LAUNCH(16, 1024, 12, 4096, false);
+        }
 #undef PFF_LAUNCH
-        hipLaunchKernelGGL(k_ps_finish, dim3(np), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, (const uint32_t *)pst2, cb, d_ent,
-                           (ulonglong2 *)c->d_head.p, (const uint32_t *)slow);
+        hipLaunchKernelGGL(k_ps_slow_list, dim3((np + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)slow, np, todo, todo_count);
+        if (packed) hipLaunchKernelGGL(k_ps_finish<true>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, (const uint32_t *)todo, (const uint32_t *)todo_count, np, fmt);
+        else hipLaunchKernelGGL(k_ps_finish<false>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, (const uint32_t *)todo, (const uint32_t *)todo_count, np, fmt);
     }
     HIP_TRY(c, hipGetLastError());
     c->ent_ptr = d_ent;
     return PGRC_OK;
+}
+
+// records sorted by their bucket bits [cb, hbits) -> ent[] (d_ent) and all bucket heads
+int pgrc_ps_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uint64_t *d_vals, uint32_t hbits, uint32_t cb, uint64_t *d_ent) {
+    const uint64_t n = c->npos;
+    const uint32_t np = 1u << (hbits - cb);
+    int e;
+    if ((e = pgrc_buf_ensure(c, c->d_sorttmp, (4ull * (np + 2)) * sizeof(uint32_t) + 256))) return e;
+    uint32_t *pst = (uint32_t *)c->d_sorttmp.p, *pst2 = pst + np + 2, *slow = pst2 + np + 2;
+    HIP_TRY(c, hipMemsetAsync(pst, 0xFF, (size_t)(np + 1) * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(slow, 0, (size_t)(2 * np + 1) * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_ps_bounds, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 65536ull * 4)), dim3(256), 0, c->stream, d_keys, n, cb, pst);
+    hipLaunchKernelGGL(k_ps_bounds_fill, dim3((np + 256) / 256), dim3(256), 0, c->stream, (const uint32_t *)pst, np, (uint32_t)n, pst2);
+    return ps_launch_finish(c, d_keys, d_vals, (const uint32_t *)pst2, slow, np, cb, d_ent, 0u);
+}
+
+// the same behind the one-sweep front end (idxsweep.hip): packed records, partition starts already known; d_slow = 2 np + 1
+// zeroed words
+int pgrc_ps_finish_packed(pgrc_match_ctx *c, const uint64_t *d_recs, const uint32_t *d_pstart, uint32_t *d_slow, uint32_t np, uint32_t cb,
+                          uint32_t rec_sh, uint64_t *d_ent) {
+    return ps_launch_finish(c, nullptr, d_recs, d_pstart, d_slow, np, cb, d_ent, rec_sh);
 }

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from golden_util import INDEX_CASES, MANIFEST, MATCH_CASES, cumm_to_sparse, load_case, load_index_case
+from golden_util import HARD_CASES, INDEX_CASES, MANIFEST, MATCH_CASES, cumm_to_sparse, load_case, load_hard_case, load_index_case
 from util import assert_same_results, gpu_match
 
 pytestmark = pytest.mark.gpu
@@ -13,6 +13,24 @@ def test_gpu_reproduces_reference_output(name):
     m, pg, reads, kind, sl, kmax, kmin, gold = load_case(name)
     g = gpu_match(kind, pg, reads, sl, kmax, kmin, m["rev_compl"])
     assert_same_results(g, gold, name)
+
+
+@pytest.mark.parametrize("schedule", ["default", "screen", "two_pass", "full_loops"])
+@pytest.mark.parametrize("name", HARD_CASES)
+def test_gpu_reproduces_reference_output_on_hard_inputs(monkeypatch, name, schedule):
+    """L = 150, seed 38 (the dual kernel is the default schedule here): repeat families, reverse palindromes, short-period
+    texts, reads from both strands, against the real reference's output -- under every schedule the library has."""
+    env = {"default": {}, "screen": {"PGRC_DUAL": "0"}, "two_pass": {"PGRC_DUAL": "0", "PGRC_SCREEN": "0"},
+           "full_loops": {"PGRC_EARLY_STOP": "0"}}[schedule]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    m, pg, reads, gold = load_hard_case(name)
+    g = gpu_match("c", pg, reads, m["seed_len"], m["kmax"], 0, True, n_nset=m["n_nset"] or None)
+    assert_same_results(g, gold, f"{name} [{schedule}]")
+    c = g["ctx"].counters()
+    assert c["screened"] == {"default": 2, "screen": 1, "two_pass": 0, "full_loops": 0}[schedule]
+    if schedule == "default" and ("repeat" in name or "period" in name):
+        assert c["redo_reads"] > 0          # the dual kernel met reads whose falses budget matters and redid them in order
 
 
 @pytest.mark.parametrize("name", INDEX_CASES)

@@ -65,16 +65,16 @@ def test_index_bucket_cap_on_low_complexity_text():
     assert np.array_equal(c, cumm) and np.array_equal(p, positions)
 
 
-@pytest.mark.parametrize("variant", ["hybrid", "own", "rocprim", "hybrid+general", "own+general"])
+@pytest.mark.parametrize("variant", ["sweep", "sweep+general", "hybrid", "own", "rocprim", "hybrid+general", "own+general"])
 def test_index_build_variants(monkeypatch, variant):
-    """The three ways the records get grouped by bucket (copmem.hip: library sort of the top bits + in-LDS finish; the
-    hand-written scatter passes + the same finish; round 1's full library sort) and both finish kernels give the
+    """The four ways the records get grouped by bucket (copmem.hip: the one-sweep scatter passes of idxsweep.hip, the
+    default; library sort of the top bits + in-LDS finish; round 2's scatter passes + the same finish; round 1's full
+    library sort) and both finish kernels give the
     serial reference index -- on a uniform text with realistic partition sizes, and on repeats / low-complexity tracts
     whose buckets overflow the 13-entry cap and whose partitions overflow the fast kernel."""
     from pgrc_amd import MatchContext
     sort, _, fin = variant.partition("+")
-    if sort != "hybrid":
-        monkeypatch.setenv("PGRC_INDEX_SORT", sort)
+    monkeypatch.setenv("PGRC_INDEX_SORT", sort)
     if fin:
         monkeypatch.setenv("PGRC_INDEX_FINISH", fin)
     rng = np.random.default_rng(11)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle as orc
-from golden_util import GOLD, INDEX_CASES, MATCH_CASES, cumm_to_sparse, load_case, load_index_case
+from golden_util import GOLD, HARD_CASES, INDEX_CASES, MATCH_CASES, cumm_to_sparse, load_case, load_hard_case, load_index_case
 from util import assert_same_results
 
 
@@ -17,6 +17,27 @@ def test_oracle_reproduces_reference_output(name):
     m, pg, reads, kind, sl, kmax, kmin, gold = load_case(name)
     o = orc.oracle_match(kind, pg, reads, sl, kmax, kmin, m["rev_compl"])
     assert_same_results(o, gold, name)
+
+
+@pytest.mark.parametrize("name", HARD_CASES)
+def test_oracle_and_its_restated_schedules_reproduce_reference_output_on_hard_inputs(name):
+    """L = 150, seed 38: repeat families, reverse palindromes, short-period texts, reads from both strands.  The oracle in
+    the reference's order, and its restatements of the HIP path's exact shortcuts (early stop; exact-match screen; one
+    query over both strands), all against the real reference's output."""
+    m, pg, reads, gold = load_hard_case(name)
+    lib = orc.oracle()
+    lib.pgrc_or_set_early_stop(0)
+    assert_same_results(orc.oracle_match("c", pg, reads, m["seed_len"], m["kmax"], 0, True), gold, name)
+    lib.pgrc_or_set_early_stop(1)
+    try:
+        assert_same_results(orc.oracle_match("c", pg, reads, m["seed_len"], m["kmax"], 0, True), gold, name + " early stop")
+    finally:
+        lib.pgrc_or_set_early_stop(0)
+    assert_same_results(orc.oracle_match_screened(pg, reads, m["seed_len"], m["kmax"], 0), gold, name + " screened")
+    du = orc.oracle_match_dual(pg, reads, m["seed_len"], m["kmax"])
+    assert_same_results(du, gold, name + " dual")
+    if "repeat" in name or "period" in name:
+        assert du["aborted"] > 0            # reads whose falses budget matters: redone in the reference's order
 
 
 @pytest.mark.parametrize("name", INDEX_CASES)
