@@ -253,6 +253,10 @@ typedef struct {
     uint32_t schedule_downgraded; /* 1 = the second index set (or the screen's arrays) did not fit in device memory: this
                              * context runs the two passes in turn until another text / read set is handed over */
 } pgrc_match_counters;
+/* flags[i] != 0: read i was one of `redo_reads` -- the dual kernel met a bucket it could not judge without the
+ * reference's own falses count and did the read again in the reference's order (tests and bench.py draw their parity
+ * samples from these reads).  n bytes; all zero when the last run did not take the dual kernel. */
+int pgrc_match_get_redo_flags(pgrc_match_ctx *ctx, uint8_t *flags);
 /* enable per-kernel HIP-event timing + work counters for subsequent runs */
 int pgrc_match_set_profiling(pgrc_match_ctx *ctx, int enabled);
 int pgrc_match_get_counters(pgrc_match_ctx *ctx, pgrc_match_counters *out);

@@ -56,6 +56,7 @@ namespace PgTools {
     uint64_t HipReadsMatcher::bulkUpdatesServed = 0;
     uint64_t HipReadsMatcher::packedHandOvers = 0;
     uint64_t HipReadsMatcher::deviceExports = 0;
+    uint64_t HipReadsMatcher::dualRuns = 0;
 
     HipReadsMatcher::HipReadsMatcher(char *pgPtr, const uint_pg_len_max pgLength, bool revComplPg,
                                      ConstantLengthReadsSetInterface *readsSet, uint32_t matchPrefixLength,
@@ -186,6 +187,8 @@ namespace PgTools {
             std::vector<uint8_t> rc(deviceReads);
             failOn(pgrc_match_get_results(ctx, readMatchPos.data(), rc.data(), readMismatchesCount.data(), hist,
                                           &matched), "get_results");
+            pgrc_match_counters ctr;
+            if (pgrc_match_get_counters(ctx, &ctr) == PGRC_OK && ctr.screened == 2) dualRuns++;
             // vector<bool> is bit-packed: threads may only share it along 64-bit word boundaries (the reference's own
             // parallel loop does not respect that, ReadsMatchers.cpp:426-446)
             const uint64_t chunk = 64u * 4096u, total = deviceReads;

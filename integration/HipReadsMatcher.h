@@ -98,6 +98,8 @@ namespace PgTools {
         static uint64_t bulkUpdatesServed;
         // uploads that took the reference's packed rows as they are (no getRead)
         static uint64_t packedHandOvers;
+        // device runs that took the dual kernel (one query per read over both strands; diagnostics / tests)
+        static uint64_t dualRuns;
     };
 }
 

@@ -346,6 +346,7 @@ extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const 
 extern "C" uint64_t pgrc_ref_bulk_updates() { return HipReadsMatcher::bulkUpdatesServed; }
 extern "C" uint64_t pgrc_ref_packed_handovers() { return HipReadsMatcher::packedHandOvers; }
 extern "C" uint64_t pgrc_ref_device_exports() { return HipReadsMatcher::deviceExports; }
+extern "C" uint64_t pgrc_ref_dual_runs() { return HipReadsMatcher::dualRuns; }
 // the adapter's position order (the reference's sort on (position, index) pairs) of a given result state
 extern "C" uint64_t pgrc_ref_position_order(const uint64_t *pos, uint64_t n, int omp_threads, uint32_t *order) {
     omp_set_num_threads(omp_threads);

@@ -757,6 +757,24 @@ int pgrc_match_get_counters(pgrc_match_ctx *c, pgrc_match_counters *out) {
     return PGRC_OK;
 }
 
+// introspection: which reads the dual kernel of the last run did again in the reference's order (flags[i] != 0)
+int pgrc_match_get_redo_flags(pgrc_match_ctx *c, uint8_t *flags) {
+    if (!c || !flags) return PGRC_E_PARAM;
+    if (c->multi) {
+        for (const PgrcShardView &sv : pgrc_multi_shards(c)) {
+            int e = pgrc_match_get_redo_flags(sv.ctx, flags + sv.lo);
+            if (e) { c->err = sv.ctx->err; return e; }
+        }
+        return PGRC_OK;
+    }
+    if (!c->have_results) { c->err = "get_redo_flags: run first"; return PGRC_E_STATE; }
+    if (c->ctr.screened != 2) { memset(flags, 0, c->n); return PGRC_OK; }     // no dual kernel in the last run: nothing was redone
+    PGRC_ON_DEVICE(c);
+    HIP_TRY(c, hipMemcpy(flags, c->d_scr_flag.p, c->n, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < c->n; i++) flags[i] = flags[i] >> 1;
+    return PGRC_OK;
+}
+
 int pgrc_match_extract_mismatches(pgrc_match_ctx *c, const uint8_t *reversed_flags, uint64_t *cum, uint8_t *codes,
                                   uint16_t *offsets) {
     if (!c || !cum) return PGRC_E_PARAM;

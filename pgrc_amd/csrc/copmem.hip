@@ -938,6 +938,7 @@ struct DualArgs {
     uint8_t *mism;
     unsigned long long *counters; // [0] searched [1] candidates [2] heads probed [3] entry fetches [4] verifies [5] redo
     unsigned long long *work;
+    uint8_t *redo_flag;           // per read: 2 = done again in the reference's order (F_SEQ); introspection only
     uint32_t L, K, k1, k2, mask, kmax;
 };
 
@@ -1232,6 +1233,7 @@ k_copmem_match_dual(const DualArgs a) {
                 lim0 = L0; cur0 = cin; best0 = POS_NONE; U0 = 0; rcl0 = 0;
                 fl = F_SEQ | F_ACT0;
                 n_redo_it = true;
+                a.redo_flag[idx] = 2;
             } else {
                 lim1 = (c1 < a.kmax) ? (int)c1 - 1 : (int)a.kmax; cur1 = c1; best1 = POS_NONE; U1 = 0; rcl1 = 0;
                 fl = (fl & (F_FOUND0 | F_SEQ)) | F_SEQ1 | F_ACT1;
@@ -1314,6 +1316,7 @@ int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     a.mism = (uint8_t *)c->d_mism.p;
     a.counters = (unsigned long long *)c->d_counters.p + 24;
     a.work = (unsigned long long *)c->d_counters.p + 18;
+    a.redo_flag = (uint8_t *)c->d_scr_flag.p;     // (zeroed by the caller; the screen's own use of it is another schedule)
     a.L = c->prm.read_len;
     a.K = (uint32_t)c->cp.K;
     a.k1 = (uint32_t)c->cp.k1;

@@ -350,15 +350,17 @@ __global__ void __launch_bounds__(256) k_ps_bounds_fill(const uint32_t *__restri
 // staging area: repeats and low-complexity text) are flagged and finished by the general kernel below.
 // TPB threads hold E records each; SUB = 2^SUBBITS buckets per round, CAP staged entries per round
 #define PFF_PAD(b) ((b) + ((b) >> 4))    // one pad word per 16: a thread's 8 consecutive words never share banks with its neighbours'
-// packed bucket word: bits 0-16 first slot, 17-20 kept (14 = more than 13), 21-24 placed so far
-#define PFF_OFF(w) ((w) & 0x1FFFFu)
-#define PFF_KEPT(w) (((w) >> 17) & 15u)
-#define PFF_FILL(w) (((w) >> 21) & 15u)
+// packed bucket word: bits 0-12 first slot in the staging area, 13-16 kept (14 = more than 13), 17-29 first slot among
+// the round's entries that go to ent[]
+#define PFF_OFF(w) ((w) & 0x1FFFu)
+#define PFF_KEPT(w) (((w) >> 13) & 15u)
+#define PFF_XOFF(w) ((w) >> 17)
 
 // PACKED: the records are single 64-bit words (idxsweep.hip): bucket bits below cb | sampled position index t | fingerprint,
 // fmt.sh = bits of (t, fingerprint); `vals` is that array, `keys` is unused.
 struct PsRecFmt {
     uint32_t sh, k1;
+    uint32_t dbg;                         // experiments (PGRC_OS_DBG): 8 = the fast kernel stores nothing, 16 = it loads nothing (made-up records)
 };
 __device__ __forceinline__ void ps_unpack(const PsRecFmt f, uint64_t rec, uint32_t *k, uint64_t *v) {
     const uint64_t tv = rec & ((1ull << f.sh) - 1ull);
@@ -366,65 +368,79 @@ __device__ __forceinline__ void ps_unpack(const PsRecFmt f, uint64_t rec, uint32
     *v = (((tv >> PGRC_FP_BITS) * (uint64_t)f.k1) << PGRC_FP_BITS) | (tv & ((1ull << PGRC_FP_BITS) - 1ull));
 }
 
+// Measured (C3, profiles/r03_index_pmc_before.txt): with two rounds of 4096 buckets the kernel issued ~1600 VALU and ~900
+// scalar instructions per wave and partition -- every round walks all of a thread's records and 64-bit entry arithmetic was
+// redone at each use -- and the SIMDs were busy with them for more than half of its 5 ms; memory was not the limit (storing
+// nothing saves 0.6 ms, prefetching the next partition's records into registers nothing).  Hence: ONE round over the
+// partition's 2^cb buckets (the counters and a staging area for 6144 entries fit in 84 KB: the register count allows one
+// block per CU anyway), bucket and entry of every record computed once, and a persistent grid.
 template <int E, int PFF_TPB, int PFF_SUBBITS, int CAPI, bool PACKED>
 __global__ void __launch_bounds__(PFF_TPB)
-k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals, const uint32_t *__restrict__ pstart, uint32_t cb,
+k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals, const uint32_t *__restrict__ pstart, uint32_t cb, uint32_t np,
                  uint64_t *__restrict__ ent, ulonglong2 *__restrict__ head, uint32_t *__restrict__ slow_flag, const PsRecFmt fmt) {
-    constexpr uint32_t PFF_SUB = 1u << PFF_SUBBITS, PFF_CAP = (uint32_t)CAPI;
+    constexpr uint32_t PFF_SUB = 1u << PFF_SUBBITS, PFF_CAP = (uint32_t)CAPI, BPT = PFF_SUB / PFF_TPB;
+    static_assert(CAPI <= 8191 && (E == 8 || E == 16) && PFF_SUBBITS <= 13, "staging slots are 13-bit; ranks are packed 8 per register");
     __shared__ uint32_t pk[PFF_SUB + PFF_SUB / 16];
     __shared__ uint64_t entS[PFF_CAP];
     __shared__ uint32_t scan_tmp[PFF_TPB / 64 + 1];
-    __shared__ uint32_t flags[2];            // [0] a bucket of this round overflows, [1] bail out
-    const uint32_t p = blockIdx.x;
-    const uint64_t s = pstart[p], e = pstart[p + 1];
-    if (e - s > (uint64_t)E * PFF_TPB) {
-        if (threadIdx.x == 0) slow_flag[p] = 1;
-        return;
-    }
-    uint32_t k[E];
-    uint64_t v[E];
-#pragma unroll
-    for (int i = 0; i < E; i++) {
-        const uint64_t x = s + (uint64_t)i * PFF_TPB + threadIdx.x;
-        if (PACKED) {
-            ps_unpack(fmt, x < e ? vals[x] : 0ull, &k[i], &v[i]);
-            if (x >= e) k[i] = 0xFFFFFFFFu;
-        } else {
-            k[i] = x < e ? keys[x] : 0xFFFFFFFFu;
-            v[i] = x < e ? vals[x] : 0ull;
+    __shared__ uint32_t flags[2];            // [0] a bucket overflows, [1] bail out
+    const uint32_t nb = 1u << cb, cbmask = nb - 1u;          // (nb <= PFF_SUB: the launcher sees to it)
+    for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
+        const uint64_t s = pstart[p], e = pstart[p + 1];
+        if (e - s > (uint64_t)E * PFF_TPB) {                  // more records than the registers hold: the general kernel's
+            if (threadIdx.x == 0) slow_flag[p] = 1;
+            continue;
         }
-    }
-    const uint32_t nb = 1u << cb, cbmask = nb - 1u;
-    uint64_t out = s;                                         // where this round's entries start in ent[]
-    for (uint32_t r0 = 0; r0 < nb; r0 += PFF_SUB) {
+        // the partition's records: bucket (all ones: no record) and entry, in registers
+        uint32_t k[E];
+        uint64_t v[E];
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const uint64_t x = s + (uint64_t)i * PFF_TPB + threadIdx.x;
+            if (PACKED) {
+                const uint64_t raw = (fmt.dbg & 16u) ? (((uint64_t)((uint32_t)x * 2654435761u) >> (32 - cb)) << fmt.sh) | (x << PGRC_FP_BITS) : (x < e ? vals[x] : 0ull);
+                ps_unpack(fmt, raw, &k[i], &v[i]);
+            } else {
+                k[i] = x < e ? keys[x] & cbmask : 0u;
+                v[i] = x < e ? vals[x] : 0ull;
+            }
+            if (x >= e) k[i] = 0xFFFFFFFFu;
+        }
         for (uint32_t b = threadIdx.x; b < PFF_SUB + PFF_SUB / 16; b += PFF_TPB) pk[b] = 0;
         if (threadIdx.x < 2) flags[threadIdx.x] = 0;
         __syncthreads();
+        // 1. count; the count a record finds is its rank in its bucket (4 bits per record: only ranks below 13 are used)
+        uint32_t ranks = 0, ranks_lo = 0;
 #pragma unroll
         for (int i = 0; i < E; i++) {
-            const uint32_t b = (k[i] & cbmask) - r0;          // (an invalid record has all key bits set: never in range... unless it is: checked)
-            if (k[i] != 0xFFFFFFFFu && b < PFF_SUB) atomicAdd(&pk[PFF_PAD(b)], 1u);
+            if (k[i] != 0xFFFFFFFFu) ranks |= min(atomicAdd(&pk[PFF_PAD(k[i])], 1u), 15u) << (4 * (i & 7));
+            if (E > 8 && i == 7) { ranks_lo = ranks; ranks = 0; }
         }
         __syncthreads();
-        // 2. scan of the kept counts: 8 consecutive buckets per thread
-        uint32_t total;
+        // 2. scan of the kept counts (low half) and of the entries that go to ent[] (high half): BPT consecutive buckets per thread
+        uint32_t total, xtotal;
         {
-            const uint32_t b0 = threadIdx.x * (PFF_SUB / PFF_TPB);
-            uint32_t c[PFF_SUB / PFF_TPB], sum = 0;
+            const uint32_t b0 = threadIdx.x * BPT;
+            uint32_t c[BPT], sum = 0;
             bool ovf = false;
 #pragma unroll
-            for (uint32_t q = 0; q < PFF_SUB / PFF_TPB; q++) {
+            for (uint32_t q = 0; q < BPT; q++) {
                 c[q] = pk[PFF_PAD(b0 + q)];
                 ovf |= c[q] > PGRC_BUCKET_CAP;
-                sum += min(c[q], PGRC_BUCKET_CAP);
+                const uint32_t kc = min(c[q], PGRC_BUCKET_CAP);
+                sum += kc | ((kc > 2u ? kc - 1u : 0u) << 16);
             }
-            uint32_t off = psc_block_scan(sum, scan_tmp, &total);
+            uint32_t both;
+            uint32_t off = psc_block_scan(sum, scan_tmp, &both);
+            total = both & 0xFFFFu;
+            xtotal = both >> 16;
 #pragma unroll
-            for (uint32_t q = 0; q < PFF_SUB / PFF_TPB; q++) {
-                pk[PFF_PAD(b0 + q)] = off | (min(c[q], 14u) << 17);
+            for (uint32_t q = 0; q < BPT; q++) {
+                const uint32_t kc = min(c[q], PGRC_BUCKET_CAP), o = off & 0xFFFFu;
+                pk[PFF_PAD(b0 + q)] = (o & 0x1FFFu) | (min(c[q], 14u) << 13) | ((off >> 16) << 17);
                 if (c[q] > PGRC_BUCKET_CAP && total <= PFF_CAP)               // an over-full bucket: its slots start as "no entry yet" (step 3)
-                    for (uint32_t j = 0; j < PGRC_BUCKET_CAP; j++) entS[off + j] = ~0ull;
-                off += min(c[q], PGRC_BUCKET_CAP);
+                    for (uint32_t j = 0; j < PGRC_BUCKET_CAP; j++) entS[o + j] = ~0ull;
+                off += kc | ((kc > 2u ? kc - 1u : 0u) << 16);
             }
             if (ovf) flags[0] = 1;
             if (total > PFF_CAP && threadIdx.x == 0) flags[1] = 1;
@@ -432,80 +448,83 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
         __syncthreads();
         if (flags[1]) {                                       // more entries than the staging area holds: the general kernel redoes the partition
             if (threadIdx.x == 0) slow_flag[p] = 1;
-            return;
+            __syncthreads();                                  // (flags[] is rewritten for the next partition)
+            continue;
         }
-        // 3. placement into the staging area
-        if (!flags[0]) {
+        // 3. placement into the staging area: slot = first slot of the bucket + rank.  An over-full bucket keeps its 13
+        //    SMALLEST entries (= positions: the serial build's `cumm[h] <= 12` cap, CopMEMMatcher.cpp:156-159) whatever
+        //    order the records arrive in: 13 rounds of "the smallest entry not taken yet" (LDS atomicMin on slot r), which
+        //    also leaves them in ascending order.
+        uint32_t live = 0;
 #pragma unroll
-            for (int i = 0; i < E; i++) {
-                const uint32_t b = (k[i] & cbmask) - r0;
-                if (k[i] != 0xFFFFFFFFu && b < PFF_SUB) {
-                    const uint32_t w = atomicAdd(&pk[PFF_PAD(b)], 1u << 21);
-                    entS[PFF_OFF(w) + PFF_FILL(w)] = v[i];
-                }
+        for (int i = 0; i < E; i++) {
+            if (k[i] != 0xFFFFFFFFu) {
+                const uint32_t w = pk[PFF_PAD(k[i])];
+                const uint32_t r = ((E > 8 && i < 8 ? ranks_lo : ranks) >> (4 * (i & 7))) & 15u;
+                if (PFF_KEPT(w) <= PGRC_BUCKET_CAP) entS[PFF_OFF(w) + r] = v[i];
+                else live |= 1u << i;
             }
-        } else {
-            // Buckets with at most 13 records take any free slot as above.  An over-full bucket keeps its 13 SMALLEST
-            // entries (= positions: the serial build's `cumm[h] <= 12` cap, CopMEMMatcher.cpp:156-159) whatever order the
-            // records arrive in: 13 rounds of "the smallest entry not taken yet" (LDS atomicMin on slot r), which also
-            // leaves them in ascending order.
-            uint32_t live = 0;
-#pragma unroll
-            for (int i = 0; i < E; i++) {
-                const uint32_t b = (k[i] & cbmask) - r0;
-                if (k[i] != 0xFFFFFFFFu && b < PFF_SUB) {
-                    if (PFF_KEPT(pk[PFF_PAD(b)]) <= PGRC_BUCKET_CAP) {
-                        const uint32_t w = atomicAdd(&pk[PFF_PAD(b)], 1u << 21);
-                        entS[PFF_OFF(w) + PFF_FILL(w)] = v[i];
-                    } else {
-                        live |= 1u << i;
-                    }
-                }
-            }
+        }
+        if (flags[0]) {
             __syncthreads();
+#pragma unroll 1
             for (uint32_t r = 0; r < PGRC_BUCKET_CAP; r++) {
 #pragma unroll
                 for (int i = 0; i < E; i++)
-                    if ((live >> i) & 1u) atomicMin((unsigned long long *)&entS[PFF_OFF(pk[PFF_PAD((k[i] & cbmask) - r0)]) + r], (unsigned long long)v[i]);
+                    if ((live >> i) & 1u) atomicMin((unsigned long long *)&entS[PFF_OFF(pk[PFF_PAD(k[i])]) + r], (unsigned long long)v[i]);
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < E; i++)
-                    if (((live >> i) & 1u) && entS[PFF_OFF(pk[PFF_PAD((k[i] & cbmask) - r0)]) + r] == v[i]) live &= ~(1u << i);
+                    if (((live >> i) & 1u) && entS[PFF_OFF(pk[PFF_PAD(k[i])]) + r] == v[i]) live &= ~(1u << i);
                 __syncthreads();
             }
         }
         __syncthreads();
-        // 4. order inside the buckets, heads (from LDS), then the entries
-        for (uint32_t b = threadIdx.x; b < PFF_SUB; b += PFF_TPB) {
+        // 4. order inside the buckets, record by record (a per-bucket insertion sort made nearly every wave walk its
+        //    slowest lane's loop): a record's place in its bucket = the bucket's entries that are smaller.  All records
+        //    count first, then all move -- within their own bucket's slots, so the staging area is permuted in place.
+        //    Over-full buckets are in order already (step 3); buckets of one have nothing to order.
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            uint32_t less = 15u;                              // 15 = stays where it is
+            if (k[i] != 0xFFFFFFFFu) {
+                const uint32_t w = pk[PFF_PAD(k[i])], c = PFF_KEPT(w);
+                if (c >= 2u && c <= PGRC_BUCKET_CAP) {
+                    less = 0;
+                    for (uint32_t j = 0; j < c; j++) less += entS[PFF_OFF(w) + j] < v[i];
+                }
+            }
+            if (E > 8 && i < 8) ranks_lo = (ranks_lo & ~(15u << (4 * (i & 7)))) | (less << (4 * (i & 7)));
+            else ranks = (ranks & ~(15u << (4 * (i & 7)))) | (less << (4 * (i & 7)));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const uint32_t less = ((E > 8 && i < 8 ? ranks_lo : ranks) >> (4 * (i & 7))) & 15u;
+            if (less != 15u) entS[PFF_OFF(pk[PFF_PAD(k[i])]) + less] = v[i];
+        }
+        __syncthreads();
+        // 5. heads (one contiguous run); entries 1.. of the buckets with three or more go to ent[] (a head holds entry 0,
+        //    and entry 1 of a bucket of two: nothing else is ever read from ent[])
+        for (uint32_t b = threadIdx.x; b < nb; b += PFF_TPB) {
             const uint32_t w = pk[PFF_PAD(b)];
             const uint32_t c = min(PFF_KEPT(w), PGRC_BUCKET_CAP), o = PFF_OFF(w);
             ulonglong2 hd = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
             if (c) {
-                uint64_t v0 = entS[o], v1 = c > 1 ? entS[o + 1] : 0;
-                if (c == 2) {
-                    if (v1 < v0) { const uint64_t t = v0; v0 = v1; v1 = t; entS[o] = v0; entS[o + 1] = v1; }
-                } else if (c > 2) {
-                    for (uint32_t i = 1; i < c; i++) {      // insertion sort of <= 13 values
-                        const uint64_t x = entS[o + i];
-                        uint32_t j = i;
-                        while (j > 0 && entS[o + j - 1] > x) { entS[o + j] = entS[o + j - 1]; j--; }
-                        entS[o + j] = x;
-                    }
-                    v0 = entS[o];
-                }
-                hd.x = v0;
-                if (c == 2) hd.y = v1;
+                hd.x = entS[o];
+                if (c == 2) hd.y = entS[o + 1];
                 else if (c > 2) {
+                    const uint64_t base = s + PFF_XOFF(w);
+                    if (!(fmt.dbg & 8u))
+                        for (uint32_t j = 1; j < c; j++) ent[base + j - 1] = entS[o + j];
                     hd.x |= HEAD_OVF;
-                    hd.y = (out + o + 1) | ((uint64_t)c << 56);   // entries 1.. at ent[base + j - 1]
+                    hd.y = base | ((uint64_t)c << 56);        // entries 1.. at ent[base + j - 1]
                 }
             }
-            head[((uint64_t)p << cb) + r0 + b] = hd;
+            if (!(fmt.dbg & 8u)) head[((uint64_t)p << cb) + b] = hd;
         }
-        __syncthreads();
-        for (uint32_t j = threadIdx.x; j < total; j += PFF_TPB) ent[out + j] = entS[j];
-        out += total;
-        __syncthreads();
+        __syncthreads();                                      // (the next partition reuses counters and staging area)
+        (void)xtotal;
     }
 }
 
@@ -726,29 +745,36 @@ static int ps_launch_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uin
     PsRecFmt fmt;
     fmt.sh = packed_sh;
     fmt.k1 = (uint32_t)c->cp.k1;
+    const char *dbg = getenv("PGRC_OS_DBG");
+    fmt.dbg = dbg ? (uint32_t)atoi(dbg) : 0u;
     const bool packed = packed_sh != 0;
     uint32_t *todo = slow + np, *todo_count = todo + np;
     ulonglong2 *head = (ulonglong2 *)c->d_head.p;
     const uint32_t ggrid = std::min<uint32_t>(np, (uint32_t)c->num_cus * 2u);
     const char *gen = getenv("PGRC_INDEX_FINISH");   // "general": the general finish kernel for every partition (tests)
-    if (gen && !strcmp(gen, "general")) {
+    // (the fast kernel takes a partition's 2^cb buckets in one round of at most 8192: the other front ends' partitions of
+    //  tables beyond 2^29 buckets are larger and all go to the general kernel)
+    if ((gen && !strcmp(gen, "general")) || cb > 13u) {
         if (packed) hipLaunchKernelGGL(k_ps_finish<true>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, (const uint32_t *)nullptr, (const uint32_t *)nullptr, np, fmt);
         else hipLaunchKernelGGL(k_ps_finish<false>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, (const uint32_t *)nullptr, (const uint32_t *)nullptr, np, fmt);
     } else {
         // registers per thread sized for the mean partition (uniform hash values); whatever is larger is flagged
         const uint64_t need = n / np + n / np / 4 + 512;
+        const uint32_t fgrid = std::min<uint32_t>(np, (uint32_t)c->num_cus);     // persistent: one block of 16 waves per CU
         // block shape: 1024 threads x 8 records (16 for larger partitions: tables beyond 2^29 buckets), two 4096-bucket
         // rounds.  Measured at C3 (index build per strand, tools/ab_finish_cfg.sh in the round-2 history): 512 x 16: 15.1 ms,
         // 256 x 32: 16.0, 256 x 32 with 2048-bucket rounds: 16.8, 512 x 16 with 2048-bucket rounds: 16.4, 1024 x 8: 13.5.
 #define PFF_LAUNCH(E, TPB, SB, CAP, PK)                                                                                   \
-        hipLaunchKernelGGL((k_ps_finish_fast<E, TPB, SB, CAP, PK>), dim3(np), dim3(TPB), 0, c->stream, d_keys, d_vals,     \
-                           pst2, cb, d_ent, head, slow, fmt)
+        hipLaunchKernelGGL((k_ps_finish_fast<E, TPB, SB, CAP, PK>), dim3(fgrid), dim3(TPB), 0, c->stream, d_keys, d_vals,  \
+                           pst2, cb, np, d_ent, head, slow, fmt)
+        // (one round of 2^cb <= 8192 buckets; staging area for 6144 entries -- the mean partition holds 0.7 * 8192 -- resp.
+        //  8191 where partitions are larger: tables beyond 2^29 buckets)
         if (packed) {
-            if (need <= 8192) PFF_LAUNCH(8, 1024, 12, 4096, true);
-            else PFF_LAUNCH(16, 1024, 12, 4096, true);
+            if (need <= 8192) PFF_LAUNCH(8, 1024, 13, 6144, true);
+            else PFF_LAUNCH(16, 1024, 13, 8191, true);
         } else {
-            if (need <= 8192) PFF_LAUNCH(8, 1024, 12, 4096, false);
-            else PFF_LAUNCH(16, 1024, 12, 4096, false);
+            if (need <= 8192) PFF_LAUNCH(8, 1024, 13, 6144, false);
+            else PFF_LAUNCH(16, 1024, 13, 8191, false);
         }
 #undef PFF_LAUNCH
         hipLaunchKernelGGL(k_ps_slow_list, dim3((np + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)slow, np, todo, todo_count);

@@ -40,6 +40,7 @@ struct OsPlan {
     uint32_t tbits, rec_sh;               // bits of t; rec_sh = tbits + 22 = where the bucket bits start in a record
     uint32_t k1, K, mask;
     uint64_t n, ntiles1, ntiles2_max;     // sampled positions, tiles of pass 1, upper bound of the tiles of pass 2
+    uint32_t dbg;                         // experiments (PGRC_OS_DBG): 1 = blocks exit at once, 2 = no global stores, 4 = no record loads
 };
 
 __device__ __forceinline__ uint32_t os_block_scan(uint32_t v, uint32_t *smem, uint32_t *total) {
@@ -110,7 +111,7 @@ __device__ __forceinline__ uint64_t os_stage_text(const uint32_t *__restrict__ p
 template <int KQ, int TPB, int E>
 __global__ void __launch_bounds__(TPB)
 k_os_count_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, const OsPlan pl, uint32_t *__restrict__ cnt) {
-    extern __shared__ uint32_t dyn[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];   // (64-bit records are staged in it: 8-byte LDS accesses must be aligned)
     __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
     __shared__ uint32_t h1[OS_MAXD];
     constexpr uint32_t TILE = TPB * E;
@@ -135,48 +136,54 @@ k_os_count_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, const O
 }
 
 // the pass-2 tiles: every pass-1 bin is cut into tiles of its own (so a tile never mixes two values of d_lo)
-struct OsBinTile {
-    uint32_t bin, first;                  // the pass-1 bin (= d_lo), whether this is the bin's first tile
-    uint64_t r0;                          // first record
-    uint32_t nvalid;
+struct __attribute__((aligned(16))) OsBinTile {
+    uint32_t r0, nvalid;                  // first record, records
+    uint32_t bin, first;                  // the pass-1 bin (= d_lo; all ones: no such tile), whether this is the bin's first tile
 };
-__device__ __forceinline__ OsBinTile os_bin_tile(const uint32_t *tstart /* LDS, D1 + 1 */, const uint32_t *__restrict__ off1, const OsPlan &pl,
-                                                 uint32_t tile, uint32_t tile_size) {
+
+// one thread per pass-2 tile: its descriptor (last d with tile_start[d] <= tile)
+__global__ void __launch_bounds__(256)
+k_os_tiles(const OsPlan pl, const uint32_t *__restrict__ off1, const uint32_t *__restrict__ tile_start, uint32_t tile_size, OsBinTile *__restrict__ desc) {
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= pl.ntiles2_max) return;
     const uint32_t D1 = 1u << pl.b1;
-    uint32_t lo = 0, hi = D1;             // last d with tstart[d] <= tile
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (tstart[mid] <= tile) lo = mid;
-        else hi = mid;
+    OsBinTile bt = {0u, 0u, 0xFFFFFFFFu, 0u};
+    if (tile < tile_start[D1]) {
+        uint32_t lo = 0, hi = D1;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (tile_start[mid] <= tile) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t q = tile - tile_start[lo];
+        const uint64_t bin_lo = off1[(uint64_t)lo * pl.ntiles1], bin_hi = lo + 1 < D1 ? off1[(uint64_t)(lo + 1) * pl.ntiles1] : pl.n;
+        const uint64_t r0 = bin_lo + (uint64_t)q * tile_size;
+        bt.r0 = (uint32_t)r0;
+        bt.nvalid = r0 < bin_hi ? (uint32_t)min((uint64_t)tile_size, bin_hi - r0) : 0u;
+        bt.bin = lo;
+        bt.first = q == 0;
     }
-    OsBinTile bt;
-    bt.bin = lo;
-    const uint32_t q = tile - tstart[lo];
-    bt.first = q == 0;
-    const uint64_t bin_lo = off1[(uint64_t)lo * pl.ntiles1], bin_hi = lo + 1 < D1 ? off1[(uint64_t)(lo + 1) * pl.ntiles1] : pl.n;
-    bt.r0 = bin_lo + (uint64_t)q * tile_size;
-    bt.nvalid = bt.r0 < bin_hi ? (uint32_t)min((uint64_t)tile_size, bin_hi - bt.r0) : 0u;
-    return bt;
+    desc[tile] = bt;
 }
 
-// pass 2: counts from the digit bytes alone; cnt[d * ntiles2_max + tile] (tiles past the last one: zeros)
-template <int TPB, int E, typename AUX>
+// pass 2: counts from the digit bytes alone, 16 of them per thread; cnt[d * ntiles2_max + tile] (tiles past the last one: zeros)
+template <int TPB, typename AUX>
 __global__ void __launch_bounds__(TPB)
-k_os_count_bins(const AUX *__restrict__ aux_in, const uint32_t *__restrict__ off1, const OsPlan pl, const uint32_t *__restrict__ tile_start,
-                uint32_t *__restrict__ cnt) {
-    constexpr uint32_t TILE = TPB * E;
+k_os_count_bins(const AUX *__restrict__ aux_in, const OsBinTile *__restrict__ desc, const OsPlan pl, uint32_t *__restrict__ cnt) {
     __shared__ uint32_t h2[OS_MAXD];
-    __shared__ uint32_t tstart[OS_MAXD + 1];
-    const uint32_t D1 = 1u << pl.b1, D2 = 1u << pl.b2, tile = blockIdx.x;
+    const uint32_t D2 = 1u << pl.b2, tile = blockIdx.x;
     for (uint32_t d = threadIdx.x; d < D2; d += TPB) h2[d] = 0;
-    for (uint32_t d = threadIdx.x; d <= D1; d += TPB) tstart[d] = tile_start[d];
+    const OsBinTile bt = desc[tile];
     __syncthreads();
-    if (tile < tstart[D1]) {
-        const OsBinTile bt = os_bin_tile(tstart, off1, pl, tile, TILE);
+    constexpr uint32_t PER = 16 / sizeof(AUX);                  // digits per 16-byte load
+    const uint64_t lo = bt.r0, hi = lo + bt.nvalid, a0 = lo & ~(uint64_t)(PER - 1);
+    for (uint64_t x = a0 + (uint64_t)threadIdx.x * PER; x < hi; x += (uint64_t)TPB * PER) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(aux_in + x);     // (aligned; the buffer has 16 spare entries at its end)
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-        for (int i = 0; i < E; i++) {
-            const uint32_t j = (uint32_t)i * TPB + threadIdx.x;
-            if (j < bt.nvalid) atomicAdd(&h2[aux_in[bt.r0 + j]], 1u);
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t dgt = sizeof(AUX) == 1 ? (ww[k >> 2] >> (8 * (k & 3))) & 0xFFu : (ww[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            if (x + k >= lo && x + k < hi) atomicAdd(&h2[dgt], 1u);
         }
     }
     __syncthreads();
@@ -220,7 +227,7 @@ struct OsTileLds {
 template <int TPB, int E, typename AUX, bool HAS_AUX>
 __device__ __forceinline__ void os_scatter_tile(OsTileLds &s, uint64_t *recS, AUX *auxS, AUX *digS, const uint64_t (&rec)[E], const AUX (&aux)[E],
                                                 const uint32_t (&dig)[E], uint32_t nvalid, uint32_t D, uint64_t *__restrict__ rec_out,
-                                                AUX *__restrict__ aux_out) {
+                                                AUX *__restrict__ aux_out, uint32_t dbg) {
     uint32_t rank[E];
 #pragma unroll
     for (int i = 0; i < E; i++) rank[i] = dig[i] < OS_MAXD ? atomicAdd(&s.cnt[dig[i]], 1u) : 0u;
@@ -248,6 +255,7 @@ __device__ __forceinline__ void os_scatter_tile(OsTileLds &s, uint64_t *recS, AU
         }
     }
     __syncthreads();
+    if (dbg & 2u) return;
     for (uint32_t j = threadIdx.x; j < nvalid; j += TPB) {
         const uint32_t dj = digS[j];
         const uint64_t dest = (uint64_t)s.gbase[dj] + (j - s.dstart[dj]);
@@ -263,7 +271,7 @@ __global__ void __launch_bounds__(TPB, (MINB * TPB) / 256)      // (HIP: threads
 k_os_scatter_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, const OsPlan pl, const uint32_t *__restrict__ off1,
                  uint64_t *__restrict__ rec_out, AUX *__restrict__ aux_out) {
     constexpr uint32_t TILE = TPB * E;
-    extern __shared__ uint32_t dyn[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];   // (64-bit records are staged in it: 8-byte LDS accesses must be aligned)
     __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
     __shared__ OsTileLds s;
     // dynamic LDS: recS[TILE] u64 | auxS[TILE] | digS[TILE]; the text words of the tile alias recS (dead once hashed)
@@ -271,6 +279,7 @@ k_os_scatter_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, const
     AUX *auxS = reinterpret_cast<AUX *>(recS + TILE);
     AUX *digS = auxS + TILE;
     uint32_t *txt = dyn;
+    if (pl.dbg & 1u) return;
     hash_lut_init(lut);
     const uint32_t D1 = 1u << pl.b1, m1 = D1 - 1u, cbmask = (1u << pl.cb) - 1u;
     const uint32_t tile = blockIdx.x;
@@ -288,7 +297,8 @@ k_os_scatter_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, const
     for (int i = 0; i < E; i++) {
         const uint64_t t = t0 + (uint64_t)i * TPB + threadIdx.x;
         uint32_t h = 0, fp = 0;
-        if (t < pl.n) os_hash_at<KQ>(txt, w0, t * pl.k1, pl.K, lut, &h, &fp);
+        if (t < pl.n && !(pl.dbg & 4u)) os_hash_at<KQ>(txt, w0, t * pl.k1, pl.K, lut, &h, &fp);
+        if (pl.dbg & 4u) h = (uint32_t)t * 2654435761u;
         h &= pl.mask;
         rec[i] = ((uint64_t)(h & cbmask) << pl.rec_sh) | (t << PGRC_FP_BITS) | fp;
         aux[i] = (AUX)(h >> (pl.cb + pl.b1));
@@ -296,31 +306,31 @@ k_os_scatter_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, const
     }
     __syncthreads();                                             // the text words are dead: recS may be written
     const uint32_t nvalid = (uint32_t)min((uint64_t)TILE, pl.n - t0);
-    os_scatter_tile<TPB, E, AUX, true>(s, recS, auxS, digS, rec, aux, dig, nvalid, D1, rec_out, aux_out);
+    os_scatter_tile<TPB, E, AUX, true>(s, recS, auxS, digS, rec, aux, dig, nvalid, D1, rec_out, aux_out, pl.dbg);
 }
 
 // ---------------------------------------------------------------- pass 2: bins -> partitions of bucket bits [cb, hbits)
 
 template <int TPB, int E, int MINB, typename AUX>
 __global__ void __launch_bounds__(TPB, (MINB * TPB) / 256)
-k_os_scatter_bins(const uint64_t *__restrict__ rec_in, const AUX *__restrict__ aux_in, const OsPlan pl, const uint32_t *__restrict__ off1,
-                  const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ off2, uint64_t *__restrict__ rec_out,
-                  uint32_t *__restrict__ pstart) {
+k_os_scatter_bins(const uint64_t *__restrict__ rec_in, const AUX *__restrict__ aux_in, const OsPlan pl, const OsBinTile *__restrict__ desc,
+                  const uint32_t *__restrict__ off2, uint64_t *__restrict__ rec_out, uint32_t *__restrict__ pstart) {
     constexpr uint32_t TILE = TPB * E;
-    extern __shared__ uint32_t dyn[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];   // (64-bit records are staged in it: 8-byte LDS accesses must be aligned)
     __shared__ OsTileLds s;
-    __shared__ uint32_t tstart[OS_MAXD + 1];
     uint64_t *recS = reinterpret_cast<uint64_t *>(dyn);
     AUX *digS = reinterpret_cast<AUX *>(recS + TILE);
-    const uint32_t D1 = 1u << pl.b1, D2 = 1u << pl.b2, tile = blockIdx.x;
+    if (pl.dbg & 1u) return;
+    const uint32_t D2 = 1u << pl.b2, tile = blockIdx.x;
+    const OsBinTile bt = desc[tile];
+    if (bt.bin == 0xFFFFFFFFu) return;
     for (uint32_t d = threadIdx.x; d < D2; d += TPB) {
         s.cnt[d] = 0;
-        s.gbase[d] = off2[(uint64_t)d * pl.ntiles2_max + tile];
+        const uint32_t g = off2[(uint64_t)d * pl.ntiles2_max + tile];
+        s.gbase[d] = g;
+        // the first tile of a bin: its offsets are, per d_hi, the records of (d_hi, smaller d_lo) = the start of partition (d_hi, d_lo)
+        if (bt.first) pstart[(d << pl.b1) | bt.bin] = g;
     }
-    for (uint32_t d = threadIdx.x; d <= D1; d += TPB) tstart[d] = tile_start[d];
-    __syncthreads();
-    if (tile >= tstart[D1]) return;
-    const OsBinTile bt = os_bin_tile(tstart, off1, pl, tile, TILE);
     uint64_t rec[E];
     AUX aux[E] = {};
     uint32_t dig[E];
@@ -328,13 +338,79 @@ k_os_scatter_bins(const uint64_t *__restrict__ rec_in, const AUX *__restrict__ a
     for (int i = 0; i < E; i++) {
         const uint32_t j = (uint32_t)i * TPB + threadIdx.x;
         const bool ok = j < bt.nvalid;
-        rec[i] = ok ? rec_in[bt.r0 + j] : 0ull;
-        dig[i] = ok ? (uint32_t)aux_in[bt.r0 + j] : OS_MAXD;
+        rec[i] = (ok && !(pl.dbg & 4u)) ? rec_in[(uint64_t)bt.r0 + j] : 0ull;
+        dig[i] = ok ? ((pl.dbg & 4u) ? (j * 2654435761u >> 7) & (D2 - 1u) : (uint32_t)aux_in[(uint64_t)bt.r0 + j]) : OS_MAXD;
     }
-    // the first tile of a bin: its offsets are, per d_hi, the records of (d_hi, smaller d_lo) = the start of partition (d_hi, d_lo)
-    if (bt.first)
-        for (uint32_t d = threadIdx.x; d < D2; d += TPB) pstart[(d << pl.b1) | bt.bin] = s.gbase[d];
-    os_scatter_tile<TPB, E, AUX, false>(s, recS, (AUX *)nullptr, digS, rec, aux, dig, bt.nvalid, D2, rec_out, (AUX *)nullptr);
+    __syncthreads();
+    os_scatter_tile<TPB, E, AUX, false>(s, recS, (AUX *)nullptr, digS, rec, aux, dig, bt.nvalid, D2, rec_out, (AUX *)nullptr, pl.dbg);
+}
+
+// The same pass as a persistent kernel: one block per CU walks tiles blockIdx.x, + gridDim.x, ... and loads the NEXT
+// tile's records, digits and offsets into registers before it works on the current one (the LDS-staged block leaves room
+// for only one block of 16 waves per CU, so nothing else hides the load burst).
+template <int TPB, int E, typename AUX>
+__global__ void __launch_bounds__(TPB)
+k_os_scatter_bins_p(const uint64_t *__restrict__ rec_in, const AUX *__restrict__ aux_in, const OsPlan pl, const OsBinTile *__restrict__ desc,
+                    const uint32_t *__restrict__ off2, uint64_t *__restrict__ rec_out, uint32_t *__restrict__ pstart) {
+    constexpr uint32_t TILE = TPB * E;
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];   // (64-bit records are staged in it: 8-byte LDS accesses must be aligned)
+    __shared__ OsTileLds s;
+    uint64_t *recS = reinterpret_cast<uint64_t *>(dyn);
+    AUX *digS = reinterpret_cast<AUX *>(recS + TILE);
+    if (pl.dbg & 1u) return;
+    const uint32_t D2 = 1u << pl.b2;
+    const uint32_t ntiles = (uint32_t)pl.ntiles2_max;
+    uint32_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    OsBinTile bt = desc[tile], nbt = bt;
+    uint64_t rec[E], nrec[E];
+    AUX dg[E], ndg[E];
+    uint32_t g = 0, ng = 0;                                      // this thread's digit: where the tile's run starts
+    // unconditional loads, clamped to the tile's last record (the arrays have spare entries behind the last record)
+    auto load = [&](const OsBinTile &t, uint32_t tl, uint64_t *r, AUX *d, uint32_t *gg) {
+        if (threadIdx.x < D2) *gg = off2[(uint64_t)threadIdx.x * pl.ntiles2_max + tl];
+        const uint32_t last = t.nvalid ? t.nvalid - 1u : 0u;
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const uint64_t x = (uint64_t)t.r0 + min((uint32_t)i * TPB + threadIdx.x, last);
+            r[i] = rec_in[x];
+            d[i] = aux_in[x];
+        }
+    };
+    if (bt.bin == 0xFFFFFFFFu) return;
+    load(bt, tile, rec, dg, &g);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): inside the loop only the prefetch is in flight
+    for (;;) {
+        const uint32_t tn = tile + gridDim.x;
+        bool more = tn < ntiles;
+        if (more) {
+            nbt = desc[tn];
+            more = nbt.bin != 0xFFFFFFFFu;
+            if (more) load(nbt, tn, nrec, ndg, &ng);
+        }
+        for (uint32_t d = threadIdx.x; d < OS_MAXD; d += TPB) s.cnt[d] = 0;
+        if (threadIdx.x < D2) {
+            s.gbase[threadIdx.x] = g;
+            // the first tile of a bin: its offsets are, per d_hi, the records of (d_hi, smaller d_lo) = the start of partition (d_hi, d_lo)
+            if (bt.first) pstart[(threadIdx.x << pl.b1) | bt.bin] = g;
+        }
+        uint32_t dig[E];
+        AUX aux[E] = {};
+#pragma unroll
+        for (int i = 0; i < E; i++) dig[i] = (uint32_t)i * TPB + threadIdx.x < bt.nvalid ? (uint32_t)dg[i] : OS_MAXD;
+        __syncthreads();
+        os_scatter_tile<TPB, E, AUX, false>(s, recS, (AUX *)nullptr, digS, rec, aux, dig, bt.nvalid, D2, rec_out, (AUX *)nullptr, pl.dbg);
+        if (!more) break;
+        __syncthreads();                                         // (the staging arrays and counters are reused)
+        tile = tn;
+        bt = nbt;
+        g = ng;
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            rec[i] = nrec[i];
+            dg[i] = ndg[i];
+        }
+    }
 }
 
 // ---------------------------------------------------------------- driver
@@ -360,6 +436,8 @@ static bool os_plan(const pgrc_match_ctx *c, uint32_t hbits, OsPlan *pl) {
     pl->mask = (uint32_t)(c->cp.hash_size - 1);
     pl->n = n;
     pl->ntiles1 = pl->ntiles2_max = 0;
+    const char *dbg = getenv("PGRC_OS_DBG");
+    pl->dbg = dbg ? (uint32_t)atoi(dbg) : 0u;
     return true;
 }
 
@@ -376,12 +454,13 @@ static hipError_t os_allow_lds(F *kernel, size_t bytes) {
 
 struct OsBufs {
     uint32_t *cnt1, *cnt2, *tile_start, *pstart, *slow, *bsum;
+    OsBinTile *desc;
     uint64_t *recA, *recB;
     void *aux;
 };
 
 // everything between the text and the finish, in one block shape: TPB threads x E records, MINB blocks per CU
-template <int TPB, int E, int MINB, typename AUX>
+template <int TPB, int E, int MINB, typename AUX, bool PERSIST2 = false>
 static int os_passes(pgrc_match_ctx *c, int strand, const OsPlan &pl, const OsBufs &b) {
     constexpr uint32_t TILE = TPB * E;
     const uint32_t *pg = (const uint32_t *)c->pg2[strand].p;
@@ -391,7 +470,7 @@ static int os_passes(pgrc_match_ctx *c, int strand, const OsPlan &pl, const OsBu
     const size_t lds1 = std::max<size_t>((size_t)TILE * (8 + 2 * sizeof(AUX)), txt_bytes), lds2 = (size_t)TILE * (8 + sizeof(AUX));
     const bool k7 = pl.K == 28;
     hipError_t he = k7 ? os_allow_lds(k_os_scatter_gen<7, TPB, E, MINB, AUX>, lds1) : os_allow_lds(k_os_scatter_gen<0, TPB, E, MINB, AUX>, lds1);
-    if (he == hipSuccess) he = os_allow_lds(k_os_scatter_bins<TPB, E, MINB, AUX>, lds2);
+    if (he == hipSuccess) he = PERSIST2 ? os_allow_lds(k_os_scatter_bins_p<TPB, E, AUX>, lds2) : os_allow_lds(k_os_scatter_bins<TPB, E, MINB, AUX>, lds2);
     if (he == hipSuccess) he = k7 ? os_allow_lds(k_os_count_gen<7, TPB, E>, txt_bytes) : os_allow_lds(k_os_count_gen<0, TPB, E>, txt_bytes);
     if (he != hipSuccess) { c->err = std::string("index build: ") + hipGetErrorString(he); return pgrc_hip_code(he); }
     const dim3 g1((uint32_t)pl.ntiles1), g2((uint32_t)pl.ntiles2_max), blk(TPB);
@@ -404,10 +483,15 @@ static int os_passes(pgrc_match_ctx *c, int strand, const OsPlan &pl, const OsBu
     if (k7) hipLaunchKernelGGL((k_os_scatter_gen<7, TPB, E, MINB, AUX>), g1, blk, lds1, c->stream, pg, pgw, pl, (const uint32_t *)b.cnt1, b.recA, (AUX *)b.aux);
     else hipLaunchKernelGGL((k_os_scatter_gen<0, TPB, E, MINB, AUX>), g1, blk, lds1, c->stream, pg, pgw, pl, (const uint32_t *)b.cnt1, b.recA, (AUX *)b.aux);
     // pass 2
-    hipLaunchKernelGGL((k_os_count_bins<TPB, E, AUX>), g2, blk, 0, c->stream, (const AUX *)b.aux, (const uint32_t *)b.cnt1, pl, (const uint32_t *)b.tile_start, b.cnt2);
+    hipLaunchKernelGGL(k_os_tiles, dim3((uint32_t)((pl.ntiles2_max + 255) / 256)), dim3(256), 0, c->stream, pl, (const uint32_t *)b.cnt1, (const uint32_t *)b.tile_start, TILE, b.desc);
+    hipLaunchKernelGGL((k_os_count_bins<512, AUX>), g2, dim3(512), 0, c->stream, (const AUX *)b.aux, (const OsBinTile *)b.desc, pl, b.cnt2);
     if ((e = pgrc_ps_scan_u32(c, b.cnt2, (uint64_t)D2 * pl.ntiles2_max, b.bsum))) return e;
-    hipLaunchKernelGGL((k_os_scatter_bins<TPB, E, MINB, AUX>), g2, blk, lds2, c->stream, (const uint64_t *)b.recA, (const AUX *)b.aux, pl,
-                       (const uint32_t *)b.cnt1, (const uint32_t *)b.tile_start, (const uint32_t *)b.cnt2, b.recB, b.pstart);
+    if (PERSIST2)
+        hipLaunchKernelGGL((k_os_scatter_bins_p<TPB, E, AUX>), dim3((uint32_t)std::min<uint64_t>(pl.ntiles2_max, (uint64_t)c->num_cus)), blk, lds2, c->stream,
+                           (const uint64_t *)b.recA, (const AUX *)b.aux, pl, (const OsBinTile *)b.desc, (const uint32_t *)b.cnt2, b.recB, b.pstart);
+    else
+        hipLaunchKernelGGL((k_os_scatter_bins<TPB, E, MINB, AUX>), g2, blk, lds2, c->stream, (const uint64_t *)b.recA, (const AUX *)b.aux, pl,
+                           (const OsBinTile *)b.desc, (const uint32_t *)b.cnt2, b.recB, b.pstart);
     HIP_TRY(c, hipGetLastError());
     return PGRC_OK;
 }
@@ -417,7 +501,7 @@ int pgrc_os_build_index(pgrc_match_ctx *c, int strand, uint32_t hbits) {
     if (!os_plan(c, hbits, &pl)) { c->err = "index build (sweep): not applicable"; return PGRC_E_PARAM; }
     // block shape of the passes (experiments: PGRC_OS_CFG = index into the table below)
     struct Shape { uint32_t tpb, e; };
-    static const Shape shapes[] = {{1024, 8}, {1024, 6}, {512, 8}, {512, 16}};
+    static const Shape shapes[] = {{1024, 8}, {1024, 6}, {512, 8}, {512, 16}, {1024, 8}};
     const char *cfgs = getenv("PGRC_OS_CFG");
     uint32_t cfg = cfgs ? (uint32_t)atoi(cfgs) : 0u;
     if (cfg >= sizeof shapes / sizeof shapes[0]) cfg = 0;
@@ -436,7 +520,7 @@ int pgrc_os_build_index(pgrc_match_ctx *c, int strand, uint32_t hbits) {
     const uint64_t n1 = (uint64_t)D1 * pl.ntiles1, n2 = (uint64_t)D2 * pl.ntiles2_max;
     const uint64_t nbs = pgrc_ps_scan_blocks(std::max(n1, n2)) + 2;
     const uint64_t flag_words = 2ull * np + 2;                 // np flags, the list of flagged partitions, its length (idxsort.hip)
-    const uint64_t words = flag_words + (OS_MAXD + 2) + (np + 2) + nbs + n1 + n2 + 64;
+    const uint64_t words = flag_words + (OS_MAXD + 2) + (np + 2) + nbs + n1 + n2 + 4 * (pl.ntiles2_max + 1) + 64;
     if ((e = pgrc_buf_ensure(c, c->d_sorttmp, words * sizeof(uint32_t)))) return e;
     OsBufs b;
     b.slow = (uint32_t *)c->d_sorttmp.p;
@@ -445,6 +529,7 @@ int pgrc_os_build_index(pgrc_match_ctx *c, int strand, uint32_t hbits) {
     b.bsum = b.pstart + np + 2;
     b.cnt1 = b.bsum + nbs;
     b.cnt2 = b.cnt1 + n1;
+    b.desc = (OsBinTile *)(((uintptr_t)(b.cnt2 + n2) + 15) & ~(uintptr_t)15);
     b.recA = (uint64_t *)c->d_sval[0].p;
     b.recB = (uint64_t *)c->d_sval[1].p;
     b.aux = c->d_skey[0].p;
@@ -453,6 +538,7 @@ int pgrc_os_build_index(pgrc_match_ctx *c, int strand, uint32_t hbits) {
     case 1: e = os_passes<1024, 6, 2, uint8_t>(c, strand, pl, b); break;
     case 2: e = os_passes<512, 8, 3, uint8_t>(c, strand, pl, b); break;
     case 3: e = os_passes<512, 16, 1, uint8_t>(c, strand, pl, b); break;
+    case 4: e = os_passes<1024, 8, 1, uint8_t, true>(c, strand, pl, b); break;
     default:
         if (aux16) e = os_passes<1024, 8, 1, uint16_t>(c, strand, pl, b);
         else e = os_passes<1024, 8, 1, uint8_t>(c, strand, pl, b);

@@ -277,6 +277,12 @@ class MatchContext:
     def set_profiling(self, on: bool = True):
         self._ck(lib.pgrc_match_set_profiling(self._h, 1 if on else 0))
 
+    def redo_flags(self) -> np.ndarray:
+        """per read: did the dual kernel of the last run do it again in the reference's order (pgrc_match_get_redo_flags)"""
+        f = np.zeros(self.n, dtype=np.uint8)
+        self._ck(lib.pgrc_match_get_redo_flags(self._h, f.ctypes.data_as(C.c_void_p)))
+        return f
+
     def counters(self) -> dict:
         c = Counters()
         self._ck(lib.pgrc_match_get_counters(self._h, C.byref(c)))

@@ -87,10 +87,11 @@ def main():
     lib.pgrc_ref_bulk_updates.restype = C.c_uint64
     lib.pgrc_ref_text_match_calls.restype = C.c_uint64
     lib.pgrc_ref_device_exports.restype = C.c_uint64
+    lib.pgrc_ref_dual_runs.restype = C.c_uint64
 
     # default: small enough for the test suite; PGRC_E2E_READS / PGRC_E2E_GENOME scale it up for a one-off check
     n = int(os.environ.get("PGRC_E2E_READS", "60000"))
-    G, L = int(os.environ.get("PGRC_E2E_GENOME", str(5 * n))), 100
+    G, L = int(os.environ.get("PGRC_E2E_GENOME", str(5 * n))), int(os.environ.get("PGRC_E2E_READ_LEN", "100"))
     reads = make_reads(11, G, L, n, paired)
     lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
     out = {"case": case, "reads": n, "read_len": L}
@@ -121,6 +122,7 @@ def main():
         out[leg + "_text_match_calls"] = int(lib.pgrc_ref_text_match_calls())   # matchTexts calls served by HipTextMatcher
         out[leg + "_device_exports"] = int(lib.pgrc_ref_device_exports()) - exports_seen   # exports whose streams came from the device
         exports_seen = int(lib.pgrc_ref_device_exports())
+    out["gpu_dual_runs"] = int(lib.pgrc_ref_dual_runs())     # device runs that took the dual kernel (GPU leg only: the CPU leg has none)
     out["identical"] = digests["cpu"] == digests["gpu"]
     out["sha256"] = digests
 

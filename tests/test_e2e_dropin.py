@@ -78,3 +78,17 @@ def test_archive_identical_with_the_screened_schedule_forced(tmp_path, case):
         pytest.skip("oracle/_ref was built without the encoder harness")
     r = _run(tmp_path, case, cpu_only=False, extra_env={"PGRC_SCREEN": "1"})
     assert r["gpu_gpu_calls"] >= 1 and r["identical"] and r["roundtrip"], r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,read_len,env", [("se", 100, {"PGRC_DUAL": "1"}), ("pe_order", 100, {"PGRC_DUAL": "1"}),
+                                               ("se", 150, {}), ("pe", 150, {}), ("se_order", 150, {})])
+def test_archive_identical_with_the_dual_kernel(tmp_path, case, read_len, env):
+    """The encoder's stage 4 through the dual kernel (one query per read over both strands): forced on 100-bp reads
+    (PGRC_DUAL=1; 37 seeds per read are below the length where the library picks it), and on 150-bp reads, where it is
+    the library's own choice -- at PgRC's shipped -M 3, i.e. k <= 33 / k <= 50.  Same archive, byte for byte."""
+    if not _have_e2e():
+        pytest.skip("oracle/_ref was built without the encoder harness")
+    r = _run(tmp_path, case, cpu_only=False, extra_env=dict(env, PGRC_E2E_READ_LEN=str(read_len)))
+    assert r["gpu_gpu_calls"] >= 1 and r["gpu_dual_runs"] >= 1, r
+    assert r["identical"] and r["roundtrip"], r
