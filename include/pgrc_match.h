@@ -154,6 +154,24 @@ int pgrc_match_get_results_device(pgrc_match_ctx *ctx, void **d_pos, void **d_rc
 int pgrc_match_extract_mismatches(pgrc_match_ctx *ctx, const uint8_t *reversed_flags, uint64_t *cum,
                                   uint8_t *codes, uint16_t *offsets);
 
+/* ---- pipelined hand-over of a whole job (mode c, both strands, first phase; single-device contexts): the steps of
+ *      set_pg / set_reads / run / get_results overlap instead of following each other (pgrc_amd/csrc/stream.hip).
+ *   pgrc_match_set_pg_ascii(ctx, ...);
+ *   pgrc_match_prepare_index(ctx, 1);                 both strands' index builds start now, beneath the upload of the reads
+ *   pgrc_match_begin_reads(ctx, n);
+ *   pgrc_match_stream_begin(ctx, pos, rc, mism);      the caller's result arrays (n entries each)
+ *   pgrc_match_append_reads_*(ctx, rows, count) ...   every block is matched as soon as it is on the device, while the
+ *                                                     caller copies the next; a worker thread brings its results back
+ *   pgrc_match_end_reads(ctx);
+ *   pgrc_match_stream_end(ctx, hist, &matched);       reads with N, histogram, last downloads: the arrays are complete
+ * The results are those of pgrc_match_init_results + pgrc_match_run(ctx, 1) (DefaultReadsMatcher::
+ * matchConstantLengthReads, ReadsMatchers.cpp:162-172).  Afterwards the context is in the state a plain run leaves
+ * (exports, extract_mismatches, get_results work).  PGRC_E_STATE where streaming does not apply (other modes,
+ * min_mismatches > 0, multi-device contexts): take the plain calls. ---- */
+int pgrc_match_prepare_index(pgrc_match_ctx *ctx, int32_t both_strands);
+int pgrc_match_stream_begin(pgrc_match_ctx *ctx, uint64_t *pos, uint8_t *rc, uint8_t *mism);
+int pgrc_match_stream_end(pgrc_match_ctx *ctx, uint64_t hist[256], uint64_t *matched);
+
 /* ---- export of the matches as reads-list streams (DefaultReadsMatcher::exportMatchesInPgOrder /
  *      exportMatchesInOriginalOrder, ReadsMatchers.cpp:563-675; SeparatedPseudoGenomeOutputBuilder::writeReadEntry /
  *      writeReadsFromIterator, pseudogenome/persistence/SeparatedPseudoGenomePersistence.cpp:961-1019) ---- */

@@ -142,6 +142,12 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
     if (!c) return;
     if (c->multi) { pgrc_multi_destroy(c); return; }
     PgrcDeviceScope scope(c->device);
+    pgrc_stream_abort(c);
+    if (c->up_stream) {
+        (void)hipStreamDestroy(c->up_stream);
+        (void)hipEventDestroy(c->up_ev);
+    }
+    pgrc_buf_free(c->up_stage);
     if (c->side_stream) {
         (void)hipStreamDestroy(c->side_stream);
         (void)hipEventDestroy(c->side_ev[0]);
@@ -195,6 +201,10 @@ int pgrc_pg_alloc(pgrc_match_ctx *c, uint64_t G) {
         c->err = "pseudogenome shorter than a read";
         return PGRC_E_PARAM;
     }
+    if (c->idx_prepared) {                       // index builds started ahead of a run may still be reading the old text
+        if (c->build_stream) (void)hipStreamSynchronize(c->build_stream);
+        (void)hipStreamSynchronize(c->stream);
+    }
     if (G != c->G) c->screen_broken = false;     // another text: the second index set may fit now
     c->G = G;
     c->pg_words = (G + 15) / 16;
@@ -207,6 +217,8 @@ int pgrc_pg_alloc(pgrc_match_ctx *c, uint64_t G) {
     c->have_pg = false;
     c->have_rc = false;
     c->index_strand = -1;
+    c->alt_index_strand = -1;
+    c->idx_prepared = false;
     if (c->prm.mode == 'c') {
         int r = pgrc_match_copmem_params(c->prm.seed_len, G, &c->cp);
         if (r) { c->err = "copMEM parameter derivation failed (seed too short?)"; return r; }
@@ -301,6 +313,7 @@ static int alloc_results(pgrc_match_ctx *c, uint64_t n) {
 }
 
 static int begin_reads(pgrc_match_ctx *c, uint64_t n, bool own) {
+    pgrc_stream_abort(c);                        // (a streamed run that was never finished)
     if (n >= (1ull << 32) - 1) { c->err = "reads count must stay below 2^32-1 (uint_reads_cnt_max, pg-config.h:21-22)"; return PGRC_E_PARAM; }
     if (n != c->n) c->screen_broken = false;     // another read set: the screen's per-read arrays may fit now
     c->n = n;
@@ -345,62 +358,75 @@ static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, i
     PGRC_ON_DEVICE(c);
     const uint32_t L = c->prm.read_len;
     const uint32_t rb = symbols == 0 ? L : symbols == 4 ? (L + 3) / 4 : (L + 2) / 3;   // host bytes per row
-    DevBuf stage, flag, lidx;
-    auto cleanup = [&]() { pgrc_buf_free(stage); pgrc_buf_free(flag); pgrc_buf_free(lidx); };
+    DevBuf flag, lidx;
+    auto cleanup = [&]() { pgrc_buf_free(flag); pgrc_buf_free(lidx); };
     int e;
-    const uint64_t CHR = std::max<uint64_t>(1, (256ull << 20) / rb); // rows per staging chunk (~256 MiB)
-    if ((e = pgrc_buf_ensure(c, stage, (size_t)std::min(CHR, std::max<uint64_t>(count, 1)) * rb))) return e;
+    // rows per staging chunk: ~256 MiB, a multiple of 1024 rows (a streamed run matches chunk by chunk: whole lines of the
+    // word-major read array)
+    const uint64_t CHR = std::max<uint64_t>(1024, ((256ull << 20) / rb) & ~1023ull);
+    if ((e = pgrc_buf_ensure(c, c->up_stage, (size_t)std::min(CHR, std::max<uint64_t>(count, 1)) * rb))) return e;
     if ((e = pgrc_buf_ensure(c, flag, sizeof(uint32_t)))) { cleanup(); return e; }
-    (void)hipMemsetAsync(flag.p, 0, sizeof(uint32_t), c->stream);
+    // a streamed run (stream.hip) uploads and unpacks on a stream of its own, beside the matching of the blocks before
+    const bool streamed = c->st_on;
+    hipStream_t main_stream = c->stream, up = streamed ? c->up_stream : c->stream;
+    (void)hipMemsetAsync(flag.p, 0, sizeof(uint32_t), up);
     int rcode = PGRC_OK;
     std::vector<uint8_t> nf, hrows;
     std::vector<uint32_t> local;
     for (uint64_t off = 0; off < count && rcode == PGRC_OK; off += CHR) {
         const uint64_t cnt = std::min(CHR, count - off);
         const uint64_t first = c->up_next + off;
-        if (hipMemcpyAsync(stage.p, rows + off * rb, cnt * rb, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
+        const void *stage = c->up_stage.p;
+        if (hipMemcpyAsync(c->up_stage.p, rows + off * rb, cnt * rb, hipMemcpyHostToDevice, up) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
+        c->stream = up;                                      // (the launchers below queue on c->stream)
         if (symbols == 0)
-            rcode = pgrc_launch_pack_reads_ascii(c, (const uint8_t *)stage.p, first, cnt, L, (uint32_t *)c->reads_own.p, c->stride,
+            rcode = pgrc_launch_pack_reads_ascii(c, (const uint8_t *)stage, first, cnt, L, (uint32_t *)c->reads_own.p, c->stride,
                                                  (uint8_t *)c->nread_flag.p, (uint32_t *)flag.p);
         else if (symbols == 4)
-            rcode = pgrc_launch_repack_reads_ref(c, (const uint8_t *)stage.p, first, cnt, L, (uint32_t *)c->reads_own.p, c->stride);
+            rcode = pgrc_launch_repack_reads_ref(c, (const uint8_t *)stage, first, cnt, L, (uint32_t *)c->reads_own.p, c->stride);
         else
-            rcode = pgrc_launch_unpack_reads_acgnt(c, (const uint8_t *)stage.p, first, cnt, L, (uint32_t *)c->reads_own.p, c->stride,
+            rcode = pgrc_launch_unpack_reads_acgnt(c, (const uint8_t *)stage, first, cnt, L, (uint32_t *)c->reads_own.p, c->stride,
                                                    (uint8_t *)c->nread_flag.p, (uint32_t *)flag.p);
-        if (hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_DEVICE;
-        if (rcode != PGRC_OK || symbols == 4) continue;      // (an ACGT set cannot hold an N)
-        // reads with 'N' -> side list: keep their ASCII rows (they are a small minority)
-        nf.resize(cnt);
-        if (hipMemcpy(nf.data(), (const uint8_t *)c->nread_flag.p + first, cnt, hipMemcpyDeviceToHost) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
-        local.clear();
-        hrows.clear();
-        for (uint64_t k = 0; k < cnt; k++)
-            if (nf[k]) {
-                c->up_nidx.push_back((uint32_t)(first + k));
-                if (symbols == 0) hrows.insert(hrows.end(), rows + (off + k) * rb, rows + (off + k + 1) * rb);
-                else local.push_back((uint32_t)k);
-            }
-        const size_t nn = symbols == 0 ? hrows.size() / L : local.size();
-        if (nn) {      // their ASCII rows stay in HBM: uploaded (ASCII input) or made there (packed input)
-            DevBuf nrows;
-            if ((e = pgrc_buf_ensure(c, nrows, nn * L))) { rcode = e; break; }
-            c->up_nchunks.push_back(nrows);
-            c->up_nchunk_rows.push_back(nn);
-            if (symbols == 0) {
-                if (hipMemcpy(nrows.p, hrows.data(), nn * L, hipMemcpyHostToDevice) != hipSuccess) rcode = PGRC_E_DEVICE;
-            } else {
-                if ((e = pgrc_buf_ensure(c, lidx, nn * sizeof(uint32_t)))) { rcode = e; break; }
-                if (hipMemcpyAsync(lidx.p, local.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
-                rcode = pgrc_launch_nrows_ascii_acgnt(c, (const uint8_t *)stage.p, (const uint32_t *)lidx.p, nn, L, (uint8_t *)nrows.p);
-                if (hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_DEVICE;    // (stage is reused by the next block)
+        c->stream = main_stream;
+        // (the staging area is reused by the next chunk: its copy is queued behind this chunk's kernel on the same stream)
+        if (!(streamed && symbols == 4) && hipStreamSynchronize(up) != hipSuccess) rcode = PGRC_E_DEVICE;
+        if (rcode == PGRC_OK && symbols != 4) {               // (an ACGT set cannot hold an N)
+            // reads with 'N' -> side list: keep their ASCII rows (they are a small minority)
+            nf.resize(cnt);
+            if (hipMemcpy(nf.data(), (const uint8_t *)c->nread_flag.p + first, cnt, hipMemcpyDeviceToHost) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
+            local.clear();
+            hrows.clear();
+            for (uint64_t k = 0; k < cnt; k++)
+                if (nf[k]) {
+                    c->up_nidx.push_back((uint32_t)(first + k));
+                    if (symbols == 0) hrows.insert(hrows.end(), rows + (off + k) * rb, rows + (off + k + 1) * rb);
+                    else local.push_back((uint32_t)k);
+                }
+            const size_t nn = symbols == 0 ? hrows.size() / L : local.size();
+            if (nn) {      // their ASCII rows stay in HBM: uploaded (ASCII input) or made there (packed input)
+                DevBuf nrows;
+                if ((e = pgrc_buf_ensure(c, nrows, nn * L))) { rcode = e; break; }
+                c->up_nchunks.push_back(nrows);
+                c->up_nchunk_rows.push_back(nn);
+                if (symbols == 0) {
+                    if (hipMemcpy(nrows.p, hrows.data(), nn * L, hipMemcpyHostToDevice) != hipSuccess) rcode = PGRC_E_DEVICE;
+                } else {
+                    if ((e = pgrc_buf_ensure(c, lidx, nn * sizeof(uint32_t)))) { rcode = e; break; }
+                    if (hipMemcpyAsync(lidx.p, local.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice, up) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
+                    c->stream = up;
+                    rcode = pgrc_launch_nrows_ascii_acgnt(c, (const uint8_t *)stage, (const uint32_t *)lidx.p, nn, L, (uint8_t *)nrows.p);
+                    c->stream = main_stream;
+                    if (hipStreamSynchronize(up) != hipSuccess) rcode = PGRC_E_DEVICE;    // (stage is reused by the next block)
+                }
             }
         }
+        if (rcode == PGRC_OK && streamed) rcode = pgrc_stream_block_arrived(c, first, cnt, symbols != 4);
     }
     uint32_t bad = 0;
-    if (rcode == PGRC_OK && hipMemcpy(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) rcode = PGRC_E_DEVICE;
+    if (rcode == PGRC_OK && (hipStreamSynchronize(up) != hipSuccess || hipMemcpy(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess)) rcode = PGRC_E_DEVICE;
     cleanup();
-    if (rcode != PGRC_OK) { if (c->err.empty()) c->err = "append_reads: HIP error"; return rcode; }
-    if (bad) { c->err = symbols == 5 ? "packed reads hold a byte outside the ACGNT code range" : "reads contain a symbol outside ACGNT"; return PGRC_E_SYMBOL; }
+    if (rcode != PGRC_OK) { if (c->err.empty()) c->err = "append_reads: HIP error"; pgrc_stream_abort(c); return rcode; }
+    if (bad) { c->err = symbols == 5 ? "packed reads hold a byte outside the ACGNT code range" : "reads contain a symbol outside ACGNT"; pgrc_stream_abort(c); return PGRC_E_SYMBOL; }
     c->up_next += count;
     return PGRC_OK;
 }
@@ -515,6 +541,10 @@ static void swap_index_sets(pgrc_match_ctx *c) {
     std::swap(c->index_strand, c->alt_index_strand);
 }
 
+} // extern "C"
+void pgrc_swap_index_sets(pgrc_match_ctx *c) { swap_index_sets(c); }
+extern "C" {
+
 // Two-pass runs of mode c with min_mismatches == 0 take the screened schedule (copmem.hip, "Exact-match screen") unless
 // PGRC_SCREEN=0 or the second set of index buffers does not fit.
 static bool screen_wanted(const pgrc_match_ctx *c, int first, int last) {
@@ -544,6 +574,78 @@ static bool dual_wanted(const pgrc_match_ctx *c, int first, int last) {
     return k2 && c->prm.read_len >= K && (c->prm.read_len - K) / k2 + 1 >= 48u;
 }
 
+} // extern "C" (a template, and helpers of stream.hip)
+// The RC text and both strands' indexes: strand 0 ends up in the ALTERNATE set of index buffers, strand 1 in the active
+// one (what the dual kernel and the screened schedule expect).  Both builds at once on two streams (they share nothing
+// but the bandwidth; PGRC_BUILD_STREAMS=1: in turn); the main stream is made to wait for the second.  `mark` is called
+// after the RC text and after the builds (profiling events).  PGRC_E_ALLOC: no room for the second set -- the caller frees
+// what it got.
+template <typename F>
+static int pgrc_build_both_indexes(pgrc_match_ctx *c, bool *two_streams, F mark) {
+    int e;
+    if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) return e;
+    c->have_rc = true;
+    mark(); // 1
+    const char *bs = getenv("PGRC_BUILD_STREAMS");
+    bool two = !(bs && bs[0] == '1');
+    if (two && !c->build_stream) {
+        hipError_t he = hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking);
+        for (int k = 0; k < 2 && he == hipSuccess; k++) he = hipEventCreateWithFlags(&c->build_ev[k], hipEventDisableTiming);
+        if (he != hipSuccess) { (void)hipGetLastError(); c->build_stream = nullptr; two = false; }
+    }
+    hipStream_t main_stream = c->stream;
+    if (two) {
+        HIP_TRY(c, hipEventRecord(c->build_ev[0], main_stream));             // the RC text is ready
+        HIP_TRY(c, hipStreamWaitEvent(c->build_stream, c->build_ev[0], 0));
+    }
+    if ((e = pgrc_copmem_build_index(c, 0))) return e;
+    if (!two) mark(); // 2
+    swap_index_sets(c);
+    if (two) c->stream = c->build_stream;
+    // (PGRC_TEST_NO_SECOND_INDEX: tests take the out-of-memory road without exhausting the device)
+    e = getenv("PGRC_TEST_NO_SECOND_INDEX") ? PGRC_E_ALLOC : pgrc_copmem_build_index(c, 1);
+    c->stream = main_stream;
+    if (two) {
+        if (hipEventRecord(c->build_ev[1], c->build_stream) != hipSuccess || hipStreamWaitEvent(main_stream, c->build_ev[1], 0) != hipSuccess) {
+            c->err = "index build streams";
+            return PGRC_E_DEVICE;
+        }
+        mark(); // 2: both indexes (ms_index[0] is then the pair, ms_index[1] ~ 0)
+    }
+    *two_streams = two;
+    return e;
+}
+
+bool pgrc_dual_applies(const pgrc_match_ctx *c) {
+    pgrc_match_ctx probe;                     // (dual_wanted looks at n only to rule out an empty set)
+    probe.prm = c->prm;
+    probe.cp = c->cp;
+    probe.n = 1;
+    probe.screen_broken = c->screen_broken;
+    return dual_wanted(&probe, 0, 1);
+}
+
+// pgrc_match_prepare_index / pgrc_match_stream_begin (stream.hip): both strands' indexes now, on their streams
+int pgrc_prepare_both_indexes(pgrc_match_ctx *c) {
+    bool two = false;
+    const int e = pgrc_build_both_indexes(c, &two, []() {});
+    if (e == PGRC_E_ALLOC) {
+        // no room for the second set: give back what it got; later runs take the two passes with one set
+        (void)hipGetLastError();
+        if (two) (void)hipStreamSynchronize(c->build_stream);
+        DevBuf *part[] = {&c->d_head, &c->d_skey[0], &c->d_skey[1], &c->d_sval[0], &c->d_sval[1], &c->d_sorttmp};
+        for (DevBuf *b : part) pgrc_buf_free(*b);
+        c->ent_ptr = nullptr;
+        c->index_strand = -1;
+        swap_index_sets(c);
+        c->screen_broken = true;
+        c->err = "prepare_index: no room for both strands' indexes";
+    }
+    c->idx_prepared = e == PGRC_OK;
+    return e;
+}
+
+extern "C" {
 static int run_passes(pgrc_match_ctx *c, int first, int last) {
     if (!c) return PGRC_E_PARAM;
     if (c->multi) return pgrc_multi_run(c, first, last);
@@ -567,35 +669,18 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
         screened = false;
     }
     if (screened) {
-        if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) return e;
-        c->have_rc = true;
-        mark(); // 1
-        // both builds at once on two streams (they share nothing but the bandwidth; PGRC_BUILD_STREAMS=1: in turn)
-        const char *bs = getenv("PGRC_BUILD_STREAMS");
-        bool two = !(bs && bs[0] == '1');
-        if (two && !c->build_stream) {
-            hipError_t he = hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking);
-            for (int k = 0; k < 2 && he == hipSuccess; k++) he = hipEventCreateWithFlags(&c->build_ev[k], hipEventDisableTiming);
-            if (he != hipSuccess) { (void)hipGetLastError(); c->build_stream = nullptr; two = false; }
-        }
-        hipStream_t main_stream = c->stream;
-        if (two) {
-            HIP_TRY(c, hipEventRecord(c->build_ev[0], main_stream));             // the RC text is ready
-            HIP_TRY(c, hipStreamWaitEvent(c->build_stream, c->build_ev[0], 0));
-        }
-        if ((e = pgrc_copmem_build_index(c, 0))) return e;
-        if (!two) mark(); // 2
-        swap_index_sets(c);
-        if (two) c->stream = c->build_stream;
-        // (PGRC_TEST_NO_SECOND_INDEX: tests take the out-of-memory road below without exhausting the device)
-        e = getenv("PGRC_TEST_NO_SECOND_INDEX") ? PGRC_E_ALLOC : pgrc_copmem_build_index(c, 1);
-        c->stream = main_stream;
-        if (two) {
-            if (hipEventRecord(c->build_ev[1], c->build_stream) != hipSuccess || hipStreamWaitEvent(main_stream, c->build_ev[1], 0) != hipSuccess) {
-                c->err = "index build streams";
-                return PGRC_E_DEVICE;
-            }
-            mark(); // 2: both indexes (ms_index[0] is then the pair, ms_index[1] ~ 0)
+        bool two = false;
+        if (c->idx_prepared && c->index_strand == 1 && c->alt_index_strand == 0 && c->have_rc) {
+            // both indexes were built ahead of the run (pgrc_match_prepare_index): the builds may still be in flight on
+            // their streams; this run's work is ordered behind them
+            c->idx_prepared = false;
+            mark(); // 1
+            if (c->build_stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->build_ev[1], 0));
+            mark(); // 2
+            e = PGRC_OK;
+            two = true;
+        } else {
+            e = pgrc_build_both_indexes(c, &two, [&]() { mark(); });
         }
         if (e == PGRC_E_ALLOC) {
             // no room for both indexes: free what the second set got, and run the passes in the reference's order

@@ -1294,7 +1294,8 @@ static void launch_dual(pgrc_match_ctx *c, const DualArgs &a) {
 // The dual kernel over all reads without N: the ACTIVE index set must describe the RC strand, the alternate set the
 // forward strand (api.hip builds them in that order).  The reads with N follow in two ordinary passes (phase 4).
 int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
-    if (c->n == 0) return PGRC_OK;
+    const uint64_t lo = std::min<uint64_t>(c->range_lo, c->n), rn = std::min<uint64_t>(c->n - lo, c->range_n);   // (a block of a streamed run, or everything)
+    if (rn == 0) return PGRC_OK;
     if (c->index_strand != 1 || c->alt_index_strand != 0 || !c->ent_ptr || !c->alt_ent_ptr || !c->d_scr_pos.p) {
         c->err = "dual kernel without both indexes";
         return PGRC_E_STATE;
@@ -1303,20 +1304,20 @@ int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     a.pg[0] = (const uint32_t *)c->pg2[0].p;
     a.pg[1] = (const uint32_t *)c->pg2[1].p;
     a.G = c->G;
-    a.reads = c->reads2;
-    a.n = c->n;
+    a.reads = c->reads2 + lo;
+    a.n = rn;
     a.stride = c->stride;
-    a.nflag = c->n_nreads ? (const uint8_t *)c->nread_flag.p : nullptr;
+    a.nflag = (c->n_nreads || c->up_open) ? (const uint8_t *)c->nread_flag.p + lo : nullptr;   // (during an upload the side list is not final yet: the flags are)
     a.head[0] = (const ulonglong2 *)c->alt_head.p;
     a.head[1] = (const ulonglong2 *)c->d_head.p;
     a.ent[0] = c->alt_ent_ptr;
     a.ent[1] = c->ent_ptr;
-    a.pos = (uint64_t *)c->d_pos.p;
-    a.rc = (uint8_t *)c->d_rc.p;
-    a.mism = (uint8_t *)c->d_mism.p;
+    a.pos = (uint64_t *)c->d_pos.p + lo;
+    a.rc = (uint8_t *)c->d_rc.p + lo;
+    a.mism = (uint8_t *)c->d_mism.p + lo;
     a.counters = (unsigned long long *)c->d_counters.p + 24;
     a.work = (unsigned long long *)c->d_counters.p + 18;
-    a.redo_flag = (uint8_t *)c->d_scr_flag.p;     // (zeroed by the caller; the screen's own use of it is another schedule)
+    a.redo_flag = (uint8_t *)c->d_scr_flag.p + lo;     // (zeroed by the caller; the screen's own use of it is another schedule)
     a.L = c->prm.read_len;
     a.K = (uint32_t)c->cp.K;
     a.k1 = (uint32_t)c->cp.k1;
@@ -1369,24 +1370,25 @@ int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) { return pgrc_copmem_m
 // phase: 0 = a plain pass; 1 / 2 = the screen and the flag-honouring forward pass of the screened schedule (kernel comment);
 // 4 = after the dual kernel: only the reads with N (the byte-path kernel), in the strand order of the two passes
 int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase) {
-    if (c->n == 0) return PGRC_OK;
+    const uint64_t lo = std::min<uint64_t>(c->range_lo, c->n), rn = std::min<uint64_t>(c->n - lo, c->range_n);   // (a block of a streamed run, or everything)
+    if (rn == 0) return PGRC_OK;
     MatchArgs a;
     a.pg = (const uint32_t *)c->pg2[strand].p;
     a.G = c->G;
-    a.reads = c->reads2;
-    a.n = c->n;
+    a.reads = c->reads2 + lo;
+    a.n = rn;
     a.stride = c->stride;
-    a.nflag = c->n_nreads ? (const uint8_t *)c->nread_flag.p : nullptr;
+    a.nflag = (c->n_nreads || c->up_open) ? (const uint8_t *)c->nread_flag.p + lo : nullptr;   // (during an upload the side list is not final yet: the flags are)
     a.head = (const ulonglong2 *)c->d_head.p;
     a.ent = c->ent_ptr;
-    a.pos = (uint64_t *)c->d_pos.p;
-    a.rc = (uint8_t *)c->d_rc.p;
-    a.mism = (uint8_t *)c->d_mism.p;
+    a.pos = (uint64_t *)c->d_pos.p + lo;
+    a.rc = (uint8_t *)c->d_rc.p + lo;
+    a.mism = (uint8_t *)c->d_mism.p + lo;
     a.counters = (unsigned long long *)c->d_counters.p + (phase == 1 ? 24 : 8 * strand);   // the screen counts apart
     a.work = (unsigned long long *)c->d_counters.p + (phase == 1 ? 18 : 16 + strand);
     a.phase = (uint32_t)phase;
-    a.scr_pos = (uint64_t *)c->d_scr_pos.p;
-    a.scr_flag = (uint8_t *)c->d_scr_flag.p;
+    a.scr_pos = c->d_scr_pos.p ? (uint64_t *)c->d_scr_pos.p + lo : nullptr;
+    a.scr_flag = c->d_scr_flag.p ? (uint8_t *)c->d_scr_flag.p + lo : nullptr;
     if (phase && (!a.scr_flag || !a.scr_pos)) { c->err = "screened schedule without its buffers"; return PGRC_E_STATE; }
 
     a.L = c->prm.read_len;
@@ -1403,7 +1405,9 @@ int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase) {
     }
     // The reads with N (a percent or two, one lane each, latency-bound) start first on a side stream and run beside the
     // main kernel, whose persistent blocks simply take the remaining slots; the two kernels write disjoint reads.
-    const bool with_n = c->n_nreads && phase != 1;   // (the screen only flags reads; reads with N are never flagged)
+    // (the screen only flags reads; reads with N are never flagged.  The N kernel walks the side list, whose indexes
+    //  count from read 0: it runs on whole-set launches only, never on a block of a streamed run)
+    const bool with_n = c->n_nreads && phase != 1 && !c->range_skip_n && lo == 0 && rn == c->n;
     if (with_n) {
         if (!c->side_stream) {   // stream and both events, or nothing
             hipStream_t st = nullptr;

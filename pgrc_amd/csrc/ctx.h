@@ -15,7 +15,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pgrc_match.h"
@@ -94,6 +98,26 @@ struct pgrc_match_ctx {
     bool screen_broken = false;         // no room for the second set: the passes run as the reference orders them
     hipStream_t build_stream = nullptr; // the RC index is built beside the forward one (screened schedule)
     hipEvent_t build_ev[2]{};
+
+    // pipelined hand-over (stream.hip): both indexes built ahead of the run; blocks of reads matched as they arrive
+    bool idx_prepared = false;          // pgrc_match_prepare_index built (or is building) both strands' indexes of the current text
+    uint64_t range_lo = 0, range_n = ~0ull;   // the match launchers work on reads [range_lo, range_lo + range_n) ...
+    bool range_skip_n = false;          // ... and leave the reads with N to a later pass
+    struct StreamBlock { uint64_t lo, cnt; hipEvent_t done; };
+    bool st_on = false, st_dual = false;
+    uint64_t *st_pos = nullptr;         // the caller's result arrays: a block's results are copied there as soon as they exist
+    uint8_t *st_rc = nullptr, *st_mism = nullptr;
+    DevBuf up_stage;                    // staging area of append_reads_* (grow-only: no allocation per call)
+    hipStream_t up_stream = nullptr;    // uploads and unpacking run beside the matching
+    hipEvent_t up_ev = nullptr;
+    std::thread st_worker;              // downloads finished blocks while the caller uploads the next ones
+    std::mutex st_mu;
+    std::condition_variable st_cv;
+    std::deque<StreamBlock> st_q;
+    bool st_quit = false;
+    int st_err = 0;
+    std::vector<std::pair<uint64_t, uint64_t>> st_nblocks;   // blocks holding reads with N: downloaded again at the end
+    double st_t0 = 0;
 
     // read-side seed index (modes d / i / e)
     DevBuf s_keys, s_vals, s_tab, s_hits, s_tmp;
@@ -203,6 +227,13 @@ int pgrc_ps_scan_u32(pgrc_match_ctx *c, uint32_t *d_io, uint64_t n, uint32_t *d_
 bool pgrc_os_applicable(const pgrc_match_ctx *c, uint32_t hbits);
 int pgrc_os_build_index(pgrc_match_ctx *c, int strand, uint32_t hbits);
 int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand);
+// stream.hip: a block of reads just arrived on the device (append_reads_*): match it now if streaming is on
+int pgrc_stream_block_arrived(pgrc_match_ctx *c, uint64_t lo, uint64_t cnt, bool may_hold_n);
+void pgrc_stream_abort(pgrc_match_ctx *c);
+// api.hip
+void pgrc_swap_index_sets(pgrc_match_ctx *c);
+int pgrc_prepare_both_indexes(pgrc_match_ctx *c);
+bool pgrc_dual_applies(const pgrc_match_ctx *c);
 int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase);
 int pgrc_copmem_match_dual(pgrc_match_ctx *c);
 int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_positions, uint64_t *count);

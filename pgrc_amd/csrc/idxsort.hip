@@ -384,7 +384,12 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
     __shared__ uint64_t entS[PFF_CAP];
     __shared__ uint32_t scan_tmp[PFF_TPB / 64 + 1];
     __shared__ uint32_t flags[2];            // [0] a bucket overflows, [1] bail out
+    __shared__ uint16_t big[PFF_SUB];        // the buckets with three or more entries (any order)
+    __shared__ uint32_t nbig;
     const uint32_t nb = 1u << cb, cbmask = nb - 1u;          // (nb <= PFF_SUB: the launcher sees to it)
+    // (Fetching the NEXT partition's records ahead -- into a second set of registers at the top, or late, while the heads
+    //  are written -- was tried twice and lost both times: 127-128 registers, and the wait for the fetched records also
+    //  waits for the head stores issued after them.  3.37 -> 3.85 ms at C3.)
     for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
         const uint64_t s = pstart[p], e = pstart[p + 1];
         if (e - s > (uint64_t)E * PFF_TPB) {                  // more records than the registers hold: the general kernel's
@@ -408,6 +413,7 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
         }
         for (uint32_t b = threadIdx.x; b < PFF_SUB + PFF_SUB / 16; b += PFF_TPB) pk[b] = 0;
         if (threadIdx.x < 2) flags[threadIdx.x] = 0;
+        if (threadIdx.x == 2) nbig = 0;
         __syncthreads();
         // 1. count; the count a record finds is its rank in its bucket (4 bits per record: only ranks below 13 are used)
         uint32_t ranks = 0, ranks_lo = 0;
@@ -440,6 +446,7 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
                 pk[PFF_PAD(b0 + q)] = (o & 0x1FFFu) | (min(c[q], 14u) << 13) | ((off >> 16) << 17);
                 if (c[q] > PGRC_BUCKET_CAP && total <= PFF_CAP)               // an over-full bucket: its slots start as "no entry yet" (step 3)
                     for (uint32_t j = 0; j < PGRC_BUCKET_CAP; j++) entS[o + j] = ~0ull;
+                if (kc > 2u) big[atomicAdd(&nbig, 1u)] = (uint16_t)(b0 + q);
                 off += kc | ((kc > 2u ? kc - 1u : 0u) << 16);
             }
             if (ovf) flags[0] = 1;
@@ -480,47 +487,35 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
             }
         }
         __syncthreads();
-        // 4. order inside the buckets, record by record (a per-bucket insertion sort made nearly every wave walk its
-        //    slowest lane's loop): a record's place in its bucket = the bucket's entries that are smaller.  All records
-        //    count first, then all move -- within their own bucket's slots, so the staging area is permuted in place.
-        //    Over-full buckets are in order already (step 3); buckets of one have nothing to order.
-#pragma unroll
-        for (int i = 0; i < E; i++) {
-            uint32_t less = 15u;                              // 15 = stays where it is
-            if (k[i] != 0xFFFFFFFFu) {
-                const uint32_t w = pk[PFF_PAD(k[i])], c = PFF_KEPT(w);
-                if (c >= 2u && c <= PGRC_BUCKET_CAP) {
-                    less = 0;
-                    for (uint32_t j = 0; j < c; j++) less += entS[PFF_OFF(w) + j] < v[i];
+        // 4. buckets with three or more entries (3 % of the buckets; one thread each, from the list, so that the lanes of a
+        //    wave all have such a bucket -- done inside the loop over ALL buckets, nearly every wave walked its one slow
+        //    lane's loops): order the entries (over-full buckets are in order already, step 3), entries 1.. go to ent[]
+        //    (a head holds entry 0, and entry 1 of a bucket of two: nothing else is ever read from ent[])
+        for (uint32_t x = threadIdx.x; x < nbig; x += PFF_TPB) {
+            const uint32_t w = pk[PFF_PAD((uint32_t)big[x])];
+            const uint32_t c = min(PFF_KEPT(w), PGRC_BUCKET_CAP), o = PFF_OFF(w);
+            if (PFF_KEPT(w) <= PGRC_BUCKET_CAP) {
+                for (uint32_t i = 1; i < c; i++) {          // insertion sort of <= 13 values
+                    const uint64_t y = entS[o + i];
+                    uint32_t j = i;
+                    while (j > 0 && entS[o + j - 1] > y) { entS[o + j] = entS[o + j - 1]; j--; }
+                    entS[o + j] = y;
                 }
             }
-            if (E > 8 && i < 8) ranks_lo = (ranks_lo & ~(15u << (4 * (i & 7)))) | (less << (4 * (i & 7)));
-            else ranks = (ranks & ~(15u << (4 * (i & 7)))) | (less << (4 * (i & 7)));
+            if (!(fmt.dbg & 8u)) {
+                const uint64_t base = s + PFF_XOFF(w);
+                for (uint32_t j = 1; j < c; j++) ent[base + j - 1] = entS[o + j];
+            }
         }
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < E; i++) {
-            const uint32_t less = ((E > 8 && i < 8 ? ranks_lo : ranks) >> (4 * (i & 7))) & 15u;
-            if (less != 15u) entS[PFF_OFF(pk[PFF_PAD(k[i])]) + less] = v[i];
-        }
-        __syncthreads();
-        // 5. heads (one contiguous run); entries 1.. of the buckets with three or more go to ent[] (a head holds entry 0,
-        //    and entry 1 of a bucket of two: nothing else is ever read from ent[])
+        // 5. heads (one contiguous run)
         for (uint32_t b = threadIdx.x; b < nb; b += PFF_TPB) {
             const uint32_t w = pk[PFF_PAD(b)];
             const uint32_t c = min(PFF_KEPT(w), PGRC_BUCKET_CAP), o = PFF_OFF(w);
-            ulonglong2 hd = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
-            if (c) {
-                hd.x = entS[o];
-                if (c == 2) hd.y = entS[o + 1];
-                else if (c > 2) {
-                    const uint64_t base = s + PFF_XOFF(w);
-                    if (!(fmt.dbg & 8u))
-                        for (uint32_t j = 1; j < c; j++) ent[base + j - 1] = entS[o + j];
-                    hd.x |= HEAD_OVF;
-                    hd.y = base | ((uint64_t)c << 56);        // entries 1.. at ent[base + j - 1]
-                }
-            }
+            const uint64_t e0 = c ? entS[o] : HEAD_EMPTY, e1 = c > 1 ? entS[o + 1] : HEAD_EMPTY;     // (slot o < PFF_CAP also for an empty last bucket)
+            ulonglong2 hd;
+            if (c <= 2) hd = make_ulonglong2(min(e0, e1), c == 2 ? max(e0, e1) : HEAD_EMPTY);      // (c == 0: both HEAD_EMPTY = all ones)
+            else hd = make_ulonglong2(e0 | HEAD_OVF, (s + PFF_XOFF(w)) | ((uint64_t)c << 56));     // entries 1.. at ent[base + j - 1]
             if (!(fmt.dbg & 8u)) head[((uint64_t)p << cb) + b] = hd;
         }
         __syncthreads();                                      // (the next partition reuses counters and staging area)

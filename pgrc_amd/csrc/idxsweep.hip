@@ -93,6 +93,26 @@ __device__ __forceinline__ void os_hash_at(const uint32_t *txt, uint64_t w0, uin
     *fp = f;
 }
 
+// The low 24 bits of the same hash (all the counting pre-pass needs when the pass-1 digit lies below bit 24): xor and
+// multiply are closed modulo 2^24, and v_mul_u32_u24 runs at full rate where the 32-bit multiply takes four issue slots.
+template <int KQ>
+__device__ __forceinline__ uint32_t os_hash24_at(const uint32_t *txt, uint64_t w0, uint64_t p, uint32_t K, const uint32_t *lut) {
+    const uint32_t q = (uint32_t)((p >> 4) - w0);
+    const uint32_t sh = ((uint32_t)p & 15u) * 2u;
+    const uint32_t a0 = txt[q], a1 = txt[q + 1], a2 = txt[q + 2], a3 = txt[q + 3], a4 = txt[q + 4];
+    const uint32_t w[4] = {funnel_r(a0, a1, sh), funnel_r(a1, a2, sh), funnel_r(a2, a3, sh), funnel_r(a3, a4, sh)};
+    uint32_t h = K;
+    const int kq = KQ ? KQ : (int)(K >> 2);
+#pragma unroll
+    for (int j = 0; j < (KQ ? KQ : 14); j++) {
+        if (!KQ && j >= kq) break;
+        const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        const uint32_t x = (j < 3) ? lut[b & 63u] : lut[64u + (b & 15u)];
+        h = __umul24(h ^ (x + (uint32_t)j), 171717u);
+    }
+    return h & 0xFFFFFFu;
+}
+
 // words of text a tile of `tile` sampled positions needs: tile * k1 symbols + the last window + alignment slack
 __host__ __device__ __forceinline__ uint32_t os_txt_words(uint32_t tile, uint32_t k1, uint32_t K) { return (tile * k1 + K + 15u) / 16u + 6u; }
 
@@ -126,9 +146,15 @@ k_os_count_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, const O
     for (int i = 0; i < E; i++) {
         const uint64_t t = t0 + (uint64_t)i * TPB + threadIdx.x;
         if (t < pl.n) {
-            uint32_t h, fp;
-            os_hash_at<KQ>(txt, w0, t * pl.k1, pl.K, lut, &h, &fp);
-            atomicAdd(&h1[((h & pl.mask) >> pl.cb) & m1], 1u);
+            uint32_t h;
+            if (pl.cb + pl.b1 <= 24u && pl.hbits >= 24u) {
+                h = os_hash24_at<KQ>(txt, w0, t * pl.k1, pl.K, lut);
+            } else {
+                uint32_t fp;
+                os_hash_at<KQ>(txt, w0, t * pl.k1, pl.K, lut, &h, &fp);
+                h &= pl.mask;
+            }
+            atomicAdd(&h1[(h >> pl.cb) & m1], 1u);
         }
     }
     __syncthreads();
@@ -240,7 +266,10 @@ __device__ __forceinline__ void os_scatter_tile(OsTileLds &s, uint64_t *recS, AU
         uint32_t tot;
         run = os_block_scan(c[0] + c[1], s.scan_tmp, &tot);
         for (uint32_t q = 0; q < per; q++) {
-            if (d0 + q < D) s.dstart[d0 + q] = run;
+            if (d0 + q < D) {
+                s.dstart[d0 + q] = run;
+                s.gbase[d0 + q] -= run;                          // from here on: output index of staged slot j = gbase[digit] + j
+            }
             run += c[q];
         }
     }
@@ -257,8 +286,7 @@ __device__ __forceinline__ void os_scatter_tile(OsTileLds &s, uint64_t *recS, AU
     __syncthreads();
     if (dbg & 2u) return;
     for (uint32_t j = threadIdx.x; j < nvalid; j += TPB) {
-        const uint32_t dj = digS[j];
-        const uint64_t dest = (uint64_t)s.gbase[dj] + (j - s.dstart[dj]);
+        const uint64_t dest = (uint64_t)(s.gbase[digS[j]] + j);      // (mod 2^32 arithmetic: the sum is the true index < 2^32)
         rec_out[dest] = recS[j];
         if (HAS_AUX) aux_out[dest] = auxS[j];
     }

@@ -127,6 +127,42 @@ class MatchContext:
         self._ck(lib.pgrc_match_end_reads(self._h))
         self.n = total
 
+    # ---- pipelined hand-over (pgrc_amd/csrc/stream.hip)
+    def prepare_index(self, both_strands: bool = True):
+        """start both strands' index builds now (beneath the upload of the reads); the next two-strand run uses them"""
+        self._ck(lib.pgrc_match_prepare_index(self._h, 1 if both_strands else 0))
+
+    def match_streamed(self, sets, blocks: int = 1):
+        """The whole job with its steps overlapped: `sets` as in set_reads_packed_sets, or [(ascii rows, n, 0)]; every
+        appended block is matched while the next one is copied, its results land in the returned arrays as they
+        exist.  blocks > 1 cuts every set into that many append calls.  Returns (pos, rc, mism, hist, matched) -- what
+        init_results() + run(True) + get_results() give."""
+        total = sum(int(n) for _, n, _ in sets)
+        pos = np.empty(total, dtype=np.uint64)
+        rc = np.empty(total, dtype=np.uint8)
+        mism = np.empty(total, dtype=np.uint8)
+        self._ck(lib.pgrc_match_begin_reads(self._h, total))
+        self._ck(lib.pgrc_match_stream_begin(self._h, pos.ctypes.data_as(C.c_void_p), rc.ctypes.data_as(C.c_void_p),
+                                             mism.ctypes.data_as(C.c_void_p)))
+        for rows, n, symbols in sets:
+            a = np.ascontiguousarray(rows, dtype=np.uint8)
+            n = int(n)
+            rb = a.size // n if n else 0
+            a = a.reshape(n, rb) if n else a
+            step = max(1, -(-n // blocks))
+            for lo in range(0, n, step):
+                part = np.ascontiguousarray(a[lo:lo + step])
+                if symbols:
+                    self._ck(lib.pgrc_match_append_reads_packed(self._h, part.ctypes.data_as(C.c_void_p), part.shape[0], int(symbols)))
+                else:
+                    self._ck(lib.pgrc_match_append_reads_ascii(self._h, part.ctypes.data_as(C.c_void_p), part.shape[0]))
+        self._ck(lib.pgrc_match_end_reads(self._h))
+        self.n = total
+        hist = (C.c_uint64 * 256)()
+        matched = C.c_uint64()
+        self._ck(lib.pgrc_match_stream_end(self._h, hist, C.byref(matched)))
+        return pos, rc, mism, np.array(hist, dtype=np.uint64), int(matched.value)
+
     def shards(self):
         """[(device, first_read, n_reads)] -- one entry for a single-device context"""
         out = []
