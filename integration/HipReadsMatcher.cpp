@@ -44,9 +44,9 @@ namespace {
         explicit PhaseLog(const char *w) : what(w) {}
         ~PhaseLog() {
             static const bool on = getenv("PGRC_HIP_TIMING") != nullptr;
-            if (on)
-                fprintf(stderr, "HipReadsMatcher: %s %.3f s\n", what,
-                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            PgTools::HipReadsMatcher::phaseSeconds[what] += s;
+            if (on) fprintf(stderr, "HipReadsMatcher: %s %.3f s\n", what, s);
         }
     };
 }
@@ -57,6 +57,8 @@ namespace PgTools {
     uint64_t HipReadsMatcher::packedHandOvers = 0;
     uint64_t HipReadsMatcher::deviceExports = 0;
     uint64_t HipReadsMatcher::dualRuns = 0;
+    uint64_t HipReadsMatcher::streamedRuns = 0;
+    std::map<std::string, double> HipReadsMatcher::phaseSeconds;
 
     HipReadsMatcher::HipReadsMatcher(char *pgPtr, const uint_pg_len_max pgLength, bool revComplPg,
                                      ConstantLengthReadsSetInterface *readsSet, uint32_t matchPrefixLength,
@@ -115,6 +117,37 @@ namespace PgTools {
         exit(EXIT_FAILURE);
     }
 
+    // The reference's packed sets go over as they are (f3): an "ACGT" set (4 symbols per byte), an "ACGNT" set (3 per
+    // byte), or the LQ + N sum of two such sets; the device unpacks them (pgrc_match_append_reads_packed).
+    bool HipReadsMatcher::packedHalves(PackedConstantLengthReadsSet *half[2], int32_t sym[2]) const {
+        auto packedSymbols = [](PackedConstantLengthReadsSet *p) -> int32_t {
+            if (!p) return 0;
+            const ReadsSetProperties *pr = p->getReadsSetProperties();
+            if (pr->symbolsCount == 4 && strncmp(pr->symbolsList, "ACGT", 4) == 0) return 4;
+            if (pr->symbolsCount == 5 && strncmp(pr->symbolsList, "ACGNT", 5) == 0) return 5;
+            return 0;
+        };
+        half[0] = dynamic_cast<PackedConstantLengthReadsSet *>(readsSet);
+        half[1] = nullptr;
+        if (auto *sum = dynamic_cast<SumOfConstantLengthReadsSets *>(readsSet)) {
+            half[0] = dynamic_cast<PackedConstantLengthReadsSet *>(sum->clrs1);
+            half[1] = dynamic_cast<PackedConstantLengthReadsSet *>(sum->clrs2);
+            if (!half[1]) half[0] = nullptr;
+        }
+        sym[0] = packedSymbols(half[0]);
+        sym[1] = packedSymbols(half[1]);
+        return sym[0] && (!half[1] || sym[1]);
+    }
+
+    void HipReadsMatcher::appendPackedHalves(PackedConstantLengthReadsSet *half[2], const int32_t sym[2], uint_reads_cnt_max count) {
+        uint_reads_cnt_max left = count;
+        for (int h = 0; h < 2 && half[h]; h++) {
+            const uint_reads_cnt_max cnt = std::min<uint64_t>(left, half[h]->readsCount());
+            failOn(pgrc_match_append_reads_packed(ctx, cnt ? half[h]->getPackedRead(0) : nullptr, cnt, sym[h]), "append_reads_packed");
+            left -= cnt;
+        }
+    }
+
     void HipReadsMatcher::upload() {
         if (uploaded) return;
         uploaded = true;
@@ -132,31 +165,11 @@ namespace PgTools {
         PhaseLog log("hand-over of the pseudogenome and the reads");
         const uint_reads_cnt_max readsCount = deviceReads;   // shadows the member for the rest of this function
         failOn(pgrc_match_set_pg_ascii(ctx, pgPtr, pgLength), "set_pg_ascii");
-        // The reference's packed sets go over as they are (f3): an "ACGT" set (4 symbols per byte), an "ACGNT" set (3 per
-        // byte), or the LQ + N sum of two such sets; the device unpacks them (pgrc_match_append_reads_packed).
-        auto packedSymbols = [](PackedConstantLengthReadsSet *p) -> int32_t {
-            if (!p) return 0;
-            const ReadsSetProperties *pr = p->getReadsSetProperties();
-            if (pr->symbolsCount == 4 && strncmp(pr->symbolsList, "ACGT", 4) == 0) return 4;
-            if (pr->symbolsCount == 5 && strncmp(pr->symbolsList, "ACGNT", 5) == 0) return 5;
-            return 0;
-        };
-        PackedConstantLengthReadsSet *half[2] = {dynamic_cast<PackedConstantLengthReadsSet *>(readsSet), nullptr};
-        if (auto *sum = dynamic_cast<SumOfConstantLengthReadsSets *>(readsSet)) {
-            half[0] = dynamic_cast<PackedConstantLengthReadsSet *>(sum->clrs1);
-            half[1] = dynamic_cast<PackedConstantLengthReadsSet *>(sum->clrs2);
-            if (!half[1]) half[0] = nullptr;
-        }
-        const int32_t sym0 = packedSymbols(half[0]), sym1 = packedSymbols(half[1]);
-        if (sym0 && (!half[1] || sym1)) {
+        PackedConstantLengthReadsSet *half[2];
+        int32_t sym[2];
+        if (packedHalves(half, sym)) {
             failOn(pgrc_match_begin_reads(ctx, readsCount), "begin_reads");
-            uint_reads_cnt_max left = readsCount;
-            for (int h = 0; h < 2 && half[h]; h++) {
-                const uint_reads_cnt_max cnt = std::min<uint64_t>(left, half[h]->readsCount());
-                failOn(pgrc_match_append_reads_packed(ctx, cnt ? half[h]->getPackedRead(0) : nullptr, cnt, h ? sym1 : sym0),
-                       "append_reads_packed");
-                left -= cnt;
-            }
+            appendPackedHalves(half, sym, readsCount);
             failOn(pgrc_match_end_reads(ctx), "end_reads");
             packedHandOver = true;
             packedHandOvers++;
@@ -341,16 +354,10 @@ namespace PgTools {
         for (size_t k = 0; k < byPos.size(); k++) order[k] = byPos[k].second;
     }
 
-    void HipReadsMatcher::exportMatchesInPgOrderOnDevice(SeparatedPseudoGenome *sPg, ostream &pgrcOut,
-                                                         uint8_t compressionLevel, const string &outPgPrefix,
-                                                         IndexesMapping *orgIndexesMapping, bool pairFileMode,
-                                                         bool revComplPairFile) {
-        if (!deviceExportPossible(sPg)) {
-            exportMatchesInPgOrder(sPg, pgrcOut, compressionLevel, outPgPrefix, orgIndexesMapping, pairFileMode,
-                                   revComplPairFile);
-            return;
-        }
-        deviceExports++;
+    // everything of the Pg-order export that precedes the builder's own build / compressedBuild: the order of the matched
+    // reads, then the merged streams from the device, appended to `builder`
+    void HipReadsMatcher::makePgOrderStreams(SeparatedPseudoGenome *sPg, IndexesMapping *orgIndexesMapping, bool revComplPairFile,
+                                             SeparatedPseudoGenomeOutputBuilder *builder) {
         std::vector<uint32_t> order;
         {
             PhaseLog log("export: position sort");
@@ -361,25 +368,36 @@ namespace PgTools {
         for (uint_reads_cnt_max i = 0; i < readsCount; i++)
             readOrg[i] = orgIndexesMapping->getReadOriginalIndex(i);
         pgrc_export_streams st;
-        SeparatedPseudoGenomeOutputBuilder *builder = this->createSeparatedPseudoGenomeOutputBuilder(sPg);
-        {
-            PhaseLog log("export: streams from the device");
-            ExtendedReadsListWithConstantAccessOption *rl = sPg->getReadsList();
-            pgrc_export_pg_order_args a;
-            a.order = order.data();
-            a.n_matched = order.size();
-            a.read_org_idx = readOrg.data();
-            a.list_off = rl->off.data();
-            a.list_org_idx = rl->orgIdx.data();
-            a.list_rev_comp = rl->revComp.empty() ? nullptr : rl->revComp.data();
-            a.list_count = rl->readsCount;
-            a.rev_compl_pair_file = revComplPairFile ? 1 : 0;
-            a.byte_per_read_length = PgHelpers::bytePerReadLengthMode ? 1 : 0;
-            failOn(pgrc_match_export_pg_order(ctx, &a, &st), "export_pg_order");
-            pgrc_export_streams_view v{&st};
-            appendStreams(builder, v);
-            pgrc_match_free_export(&st);
+        PhaseLog log("export: streams from the device");
+        ExtendedReadsListWithConstantAccessOption *rl = sPg->getReadsList();
+        pgrc_export_pg_order_args a;
+        a.order = order.data();
+        a.n_matched = order.size();
+        a.read_org_idx = readOrg.data();
+        a.list_off = rl->off.data();
+        a.list_org_idx = rl->orgIdx.data();
+        a.list_rev_comp = rl->revComp.empty() ? nullptr : rl->revComp.data();
+        a.list_count = rl->readsCount;
+        a.rev_compl_pair_file = revComplPairFile ? 1 : 0;
+        a.byte_per_read_length = PgHelpers::bytePerReadLengthMode ? 1 : 0;
+        failOn(pgrc_match_export_pg_order(ctx, &a, &st), "export_pg_order");
+        pgrc_export_streams_view v{&st};
+        appendStreams(builder, v);
+        pgrc_match_free_export(&st);
+    }
+
+    void HipReadsMatcher::exportMatchesInPgOrderOnDevice(SeparatedPseudoGenome *sPg, ostream &pgrcOut,
+                                                         uint8_t compressionLevel, const string &outPgPrefix,
+                                                         IndexesMapping *orgIndexesMapping, bool pairFileMode,
+                                                         bool revComplPairFile) {
+        if (!deviceExportPossible(sPg)) {
+            exportMatchesInPgOrder(sPg, pgrcOut, compressionLevel, outPgPrefix, orgIndexesMapping, pairFileMode,
+                                   revComplPairFile);
+            return;
         }
+        deviceExports++;
+        SeparatedPseudoGenomeOutputBuilder *builder = this->createSeparatedPseudoGenomeOutputBuilder(sPg);
+        makePgOrderStreams(sPg, orgIndexesMapping, revComplPairFile, builder);
         PhaseLog log("export: the reference's stream compression");
         builder->build(outPgPrefix);
         builder->compressedBuild(pgrcOut, compressionLevel);
@@ -452,7 +470,56 @@ namespace PgTools {
         fetchResults();
     }
 
+    // matchConstantLengthReads (ReadsMatchers.cpp:162-172) with its steps overlapped instead of in turn -- the library's
+    // pipelined hand-over (include/pgrc_match.h): both index builds start as soon as the text is on the device, every
+    // block of packed rows is matched while the next one is copied, results come back block by block.  Taken where it
+    // applies (mode c, both strands, first phase, one device, packed sets); PGRC_NO_STREAM=1 keeps the steps in turn.
+    bool HipReadsMatcher::matchStreamed() {
+        PackedConstantLengthReadsSet *half[2];
+        int32_t sym[2];
+        if (hipMode != 'c' || !revComplPg || minMismatches != 0 || uploaded || readsCount == 0 || getenv("PGRC_DEVICES") ||
+            getenv("PGRC_NO_STREAM") || !packedHalves(half, sym))
+            return false;
+        PhaseLog log("streamed hand-over + matching + results");
+        DefaultReadsMatcher::initMatching();
+        readMismatchesCount.assign(readsCount, NOT_MATCHED_COUNT);
+        uploaded = true;
+        deviceReads = readsCount;
+        failOn(pgrc_match_set_pg_ascii(ctx, pgPtr, pgLength), "set_pg_ascii");
+        const bool ahead = pgrc_match_prepare_index(ctx, 1) == PGRC_OK;   // (no room for both indexes: the plain steps below)
+        failOn(pgrc_match_begin_reads(ctx, readsCount), "begin_reads");
+        std::vector<uint8_t> rc(readsCount);
+        const bool streamed = ahead && pgrc_match_stream_begin(ctx, readMatchPos.data(), rc.data(), readMismatchesCount.data()) == PGRC_OK;
+        appendPackedHalves(half, sym, readsCount);
+        failOn(pgrc_match_end_reads(ctx), "end_reads");
+        packedHandOver = true;
+        packedHandOvers++;
+        if (!streamed) {
+            failOn(pgrc_match_init_results(ctx), "init_results");
+            failOn(pgrc_match_run(ctx, 1), "run");
+            fetchResults();
+            return true;
+        }
+        uint64_t hist[NOT_MATCHED_COUNT + 1] = {0}, matched = 0;
+        failOn(pgrc_match_stream_end(ctx, hist, &matched), "stream_end");
+        streamedRuns++;
+        pgrc_match_counters ctr;
+        if (pgrc_match_get_counters(ctx, &ctr) == PGRC_OK && ctr.screened == 2) dualRuns++;
+        const uint64_t chunk = 64u * 4096u, total = readsCount;     // (vector<bool>: threads share it along word boundaries only)
+        #pragma omp parallel for schedule(static)
+        for (uint64_t c0 = 0; c0 < total; c0 += chunk) {
+            const uint64_t c1 = std::min<uint64_t>(c0 + chunk, total);
+            for (uint64_t i = c0; i < c1; i++)
+                readMatchRC[i] = rc[i] != 0;
+        }
+        matchedReadsCount = matched;
+        for (int k = 0; k <= NOT_MATCHED_COUNT; k++)
+            matchedCountPerMismatches[k] = hist[k];
+        return true;
+    }
+
     void HipReadsMatcher::matchConstantLengthReadsOnDevice() {
+        if (matchStreamed()) return;
         initMatching();
         {
             PhaseLog log("device run (both strands)");

@@ -9,6 +9,9 @@
 #ifndef PGTOOLS_HIPREADSMATCHER_H
 #define PGTOOLS_HIPREADSMATCHER_H
 
+#include <map>
+#include <string>
+
 #include "matching/ReadsMatchers.h"
 
 struct pgrc_match_ctx;
@@ -33,6 +36,9 @@ namespace PgTools {
 
         void failOn(int code, const char *what);
         void upload();
+        bool packedHalves(PgReadsSet::PackedConstantLengthReadsSet *half[2], int32_t sym[2]) const;
+        void appendPackedHalves(PgReadsSet::PackedConstantLengthReadsSet *half[2], const int32_t sym[2], uint_reads_cnt_max count);
+        bool matchStreamed();
         void fetchResults();
         bool deviceExportPossible(SeparatedPseudoGenome *sPg) const;
         void appendStreams(SeparatedPseudoGenomeOutputBuilder *builder, const struct pgrc_export_streams_view &s);
@@ -87,8 +93,12 @@ namespace PgTools {
         void exportMatchesInOriginalOrderOnDevice(SeparatedPseudoGenome *sPg, ostream &pgrcOut, uint8_t compressionLevel,
                                                   const string &outPgPrefix, IndexesMapping *orgIndexesMapping,
                                                   bool pairFileMode, bool revComplPairFile);
+        void makePgOrderStreams(SeparatedPseudoGenome *sPg, IndexesMapping *orgIndexesMapping, bool revComplPairFile,
+                                SeparatedPseudoGenomeOutputBuilder *builder);
         // exports that took the device path (diagnostics / tests)
         static uint64_t deviceExports;
+        // seconds spent per phase of the adapter, summed over calls (diagnostics; PGRC_HIP_TIMING=1 also logs them)
+        static std::map<std::string, double> phaseSeconds;
         // the matched reads in the order exportMatchesInPgOrder walks them (ReadsMatchers.cpp:567-574): the reference's
         // sort algorithm with the reference's comparator outcome, run on (position, index) pairs
         static void positionOrder(const vector<uint64_t> &readMatchPos, uint_reads_cnt_max matchedReadsCount,
@@ -100,6 +110,8 @@ namespace PgTools {
         static uint64_t packedHandOvers;
         // device runs that took the dual kernel (one query per read over both strands; diagnostics / tests)
         static uint64_t dualRuns;
+        // ... that overlapped hand-over, matching and result fetch (matchStreamed)
+        static uint64_t streamedRuns;
     };
 }
 

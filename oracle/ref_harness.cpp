@@ -347,6 +347,107 @@ extern "C" uint64_t pgrc_ref_bulk_updates() { return HipReadsMatcher::bulkUpdate
 extern "C" uint64_t pgrc_ref_packed_handovers() { return HipReadsMatcher::packedHandOvers; }
 extern "C" uint64_t pgrc_ref_device_exports() { return HipReadsMatcher::deviceExports; }
 extern "C" uint64_t pgrc_ref_dual_runs() { return HipReadsMatcher::dualRuns; }
+extern "C" uint64_t pgrc_ref_streamed_runs() { return HipReadsMatcher::streamedRuns; }
+extern "C" double pgrc_ref_phase_seconds(const char *name) {
+    auto it = HipReadsMatcher::phaseSeconds.find(name);
+    return it == HipReadsMatcher::phaseSeconds.end() ? 0.0 : it->second;
+}
+
+// Stage 4 of the encoder at full size (tools/stage4_c3.py): PgTools::mapReadsIntoPg's matcher on the encoder's LQ + N sum set,
+// given as the reference's own packed rows (no FASTQ, no division: the sets are filled with copyPackedRead), either the
+// reference's CopMEMReadsApproxMatcher (`index_threads` = PgHelpers::numberOfThreads, `omp_threads`) or HipReadsMatcher;
+// with_export: the adapter's Pg-order export up to the builder's own compression (position sort + streams from the
+// device) against a synthetic reads list of `list_count` entries already on the pseudogenome.
+// secs[0] = read sets built, [1] = matcher constructed + matchConstantLengthReads, [2] = export part; fnv = checksum of
+// the result vectors.
+namespace {
+struct Stage4Probe : HipReadsMatcher {
+    using HipReadsMatcher::HipReadsMatcher;
+    using HipReadsMatcher::createSeparatedPseudoGenomeOutputBuilder;
+    using HipReadsMatcher::readMatchPos;
+    using HipReadsMatcher::readMismatchesCount;
+    using HipReadsMatcher::readMatchRC;
+    using HipReadsMatcher::matchedReadsCount;
+};
+struct Stage4Cpu : CopMEMReadsApproxMatcher {
+    using CopMEMReadsApproxMatcher::CopMEMReadsApproxMatcher;
+    using CopMEMReadsApproxMatcher::readMatchPos;
+    using CopMEMReadsApproxMatcher::readMismatchesCount;
+    using CopMEMReadsApproxMatcher::readMatchRC;
+    using CopMEMReadsApproxMatcher::matchedReadsCount;
+};
+template <class M>
+uint64_t stage4_fnv(M &m, uint64_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (uint64_t i = 0; i < n; i++) {
+        h = (h ^ m.readMatchPos[i]) * 1099511628211ull;
+        h = (h ^ (uint64_t)(m.readMismatchesCount[i] | (m.readMatchRC[i] ? 256u : 0u))) * 1099511628211ull;
+    }
+    return h;
+}
+}
+extern "C" int pgrc_ref_stage4(int use_adapter, char *pg, uint64_t G, const uint8_t *lq_rows, uint64_t n_lq, const uint8_t *n_rows,
+                               uint64_t n_n, uint32_t L, uint32_t seed, uint8_t kmax, int index_threads, int omp_threads, int with_export,
+                               uint64_t list_count, double *secs, uint64_t *matched, uint64_t *fnv) {
+    Silence quiet;
+    PgHelpers::numberOfThreads = index_threads;
+    omp_set_num_threads(omp_threads);
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t = now();
+    PackedConstantLengthReadsSet lq(L, "ACGT", 4), nset(L, "ACGNT", 5);
+    lq.resize(n_lq);
+    if (n_lq) lq.copyPackedRead(lq_rows, 0, n_lq);
+    nset.resize(n_n);
+    if (n_n) nset.copyPackedRead(n_rows, 0, n_n);
+    SumOfConstantLengthReadsSets sum(&lq, &nset);                 // pgrc-encoder.cpp:349-352
+    secs[0] = now() - t;
+    const uint64_t n = n_lq + n_n;
+    const uint32_t pm = DefaultReadsMatcher::DISABLED_PREFIX_MODE;
+    secs[2] = 0;
+    if (!use_adapter) {
+        t = now();
+        Stage4Cpu m(pg, G, true, &sum, pm, seed, kmax, 0);
+        m.matchConstantLengthReads();
+        secs[1] = now() - t;
+        *matched = m.matchedReadsCount;
+        *fnv = stage4_fnv(m, n);
+        return 0;
+    }
+    t = now();
+    Stage4Probe m(pg, G, true, &sum, pm, seed, kmax, 0, 'c');
+    m.matchConstantLengthReadsOnDevice();
+    secs[1] = now() - t;
+    *matched = m.matchedReadsCount;
+    *fnv = stage4_fnv(m, n);
+    if (with_export) {
+        ReadsSetProperties props;
+        props.readsCount = list_count;
+        props.allReadsLength = list_count * L;
+        props.constantReadLength = true;
+        props.minReadLength = props.maxReadLength = L;
+        props.symbolsCount = 4;
+        strcpy(props.symbolsList, "ACGT");
+        props.generateSymbolOrder();
+        auto *rl = new ExtendedReadsListWithConstantAccessOption(L);
+        rl->off.resize(list_count);
+        rl->orgIdx.resize(list_count);
+        rl->revComp.resize(list_count);
+        const uint64_t step = list_count ? std::max<uint64_t>(1, std::min<uint64_t>(255, (G - L) / list_count)) : 1;
+        for (uint64_t k = 0; k < list_count; k++) {
+            rl->off[k] = (uint8_t) step;
+            rl->orgIdx[k] = (uint32_t) (n + k);
+            rl->revComp[k] = (uint8_t) ((k * 2654435761u >> 13) & 1u);
+        }
+        SeparatedPseudoGenome sPg(std::string(), rl, &props);
+        DirectMapping mapping((uint_reads_cnt_max) n);
+        t = now();
+        SeparatedPseudoGenomeOutputBuilder *builder = m.createSeparatedPseudoGenomeOutputBuilder(&sPg);
+        m.makePgOrderStreams(&sPg, &mapping, false, builder);
+        secs[2] = now() - t;
+        delete builder;
+    }
+    return 0;
+}
 // the adapter's position order (the reference's sort on (position, index) pairs) of a given result state
 extern "C" uint64_t pgrc_ref_position_order(const uint64_t *pos, uint64_t n, int omp_threads, uint32_t *order) {
     omp_set_num_threads(omp_threads);

@@ -143,11 +143,13 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
     if (c->multi) { pgrc_multi_destroy(c); return; }
     PgrcDeviceScope scope(c->device);
     pgrc_stream_abort(c);
-    if (c->up_stream) {
-        (void)hipStreamDestroy(c->up_stream);
-        (void)hipEventDestroy(c->up_ev);
+    for (int k = 0; k < 2; k++) {
+        if (c->up_stream[k]) {
+            (void)hipStreamDestroy(c->up_stream[k]);
+            (void)hipEventDestroy(c->up_ev[k]);
+        }
+        pgrc_buf_free(c->up_stage[k]);
     }
-    pgrc_buf_free(c->up_stage);
     if (c->side_stream) {
         (void)hipStreamDestroy(c->side_stream);
         (void)hipEventDestroy(c->side_ev[0]);
@@ -339,7 +341,15 @@ int pgrc_match_begin_reads(pgrc_match_ctx *c, uint64_t n) {
     int e = begin_reads(c, n, true);
     if (e) return e;
     if ((e = pgrc_buf_ensure(c, c->nread_flag, n))) return e;
-    HIP_TRY(c, hipMemsetAsync(c->nread_flag.p, 0, n ? n : 1, c->stream));
+    // (cleared on a stream of its own and waited for: the main stream may hold index builds started ahead of the run --
+    //  pgrc_match_prepare_index --, which neither this nor the uploads that follow should queue behind)
+    if (!c->up_stream[0]) {
+        hipError_t he = hipStreamCreateWithFlags(&c->up_stream[0], hipStreamNonBlocking);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&c->up_ev[0], hipEventDisableTiming);
+        if (he != hipSuccess) { c->up_stream[0] = nullptr; c->err = std::string("begin_reads: ") + hipGetErrorString(he); return pgrc_hip_code(he); }
+    }
+    HIP_TRY(c, hipMemsetAsync(c->nread_flag.p, 0, n ? n : 1, c->up_stream[0]));
+    HIP_TRY(c, hipStreamSynchronize(c->up_stream[0]));
     c->up_next = 0;
     c->up_nidx.clear();
     for (DevBuf &b : c->up_nchunks) pgrc_buf_free(b);
@@ -363,21 +373,28 @@ static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, i
     int e;
     // rows per staging chunk: ~256 MiB, a multiple of 1024 rows (a streamed run matches chunk by chunk: whole lines of the
     // word-major read array)
-    const uint64_t CHR = std::max<uint64_t>(1024, ((256ull << 20) / rb) & ~1023ull);
-    if ((e = pgrc_buf_ensure(c, c->up_stage, (size_t)std::min(CHR, std::max<uint64_t>(count, 1)) * rb))) return e;
+    // (a streamed run matches chunk by chunk, and every launch of the persistent match kernel pays ~4 ms of ramp and drain:
+    //  C3 through the boundary 0.29 / 0.23 / 0.22 / 0.20 s with chunks of 128 / 256 / 512 / 1024 MiB, profiles/r03_boundary_c3.json)
+    uint64_t chunk_mib = c->st_on ? 1024 : 256;
+    if (const char *v = getenv("PGRC_UPLOAD_CHUNK_MB")) chunk_mib = std::max<uint64_t>(1, std::min<uint64_t>(4096, (uint64_t)atoll(v)));   // (experiments)
+    const uint64_t CHR = std::max<uint64_t>(1024, ((chunk_mib << 20) / rb) & ~1023ull);
+    for (int k = 0; k < 2; k++)
+        if ((e = pgrc_buf_ensure(c, c->up_stage[k], (size_t)std::min(CHR, std::max<uint64_t>(count, 1)) * rb))) return e;
     if ((e = pgrc_buf_ensure(c, flag, sizeof(uint32_t)))) { cleanup(); return e; }
-    // a streamed run (stream.hip) uploads and unpacks on a stream of its own, beside the matching of the blocks before
+    // a streamed run (stream.hip) uploads and unpacks on streams of its own, beside the matching of the blocks before
     const bool streamed = c->st_on;
-    hipStream_t main_stream = c->stream, up = streamed ? c->up_stream : c->stream;
-    (void)hipMemsetAsync(flag.p, 0, sizeof(uint32_t), up);
+    hipStream_t main_stream = c->stream;
+    if (hipMemset(flag.p, 0, sizeof(uint32_t)) != hipSuccess) { cleanup(); c->err = "append_reads: HIP error"; return PGRC_E_DEVICE; }
     int rcode = PGRC_OK;
     std::vector<uint8_t> nf, hrows;
     std::vector<uint32_t> local;
     for (uint64_t off = 0; off < count && rcode == PGRC_OK; off += CHR) {
         const uint64_t cnt = std::min(CHR, count - off);
         const uint64_t first = c->up_next + off;
-        const void *stage = c->up_stage.p;
-        if (hipMemcpyAsync(c->up_stage.p, rows + off * rb, cnt * rb, hipMemcpyHostToDevice, up) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
+        const int turn = (int)(c->up_chunk++ & 1u);
+        hipStream_t up = streamed ? c->up_stream[turn] : c->stream;
+        void *stage = c->up_stage[turn].p;
+        if (hipMemcpyAsync(stage, rows + off * rb, cnt * rb, hipMemcpyHostToDevice, up) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
         c->stream = up;                                      // (the launchers below queue on c->stream)
         if (symbols == 0)
             rcode = pgrc_launch_pack_reads_ascii(c, (const uint8_t *)stage, first, cnt, L, (uint32_t *)c->reads_own.p, c->stride,
@@ -420,10 +437,12 @@ static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, i
                 }
             }
         }
-        if (rcode == PGRC_OK && streamed) rcode = pgrc_stream_block_arrived(c, first, cnt, symbols != 4);
+        if (rcode == PGRC_OK && streamed) rcode = pgrc_stream_block_arrived(c, first, cnt, symbols != 4, turn);
     }
     uint32_t bad = 0;
-    if (rcode == PGRC_OK && (hipStreamSynchronize(up) != hipSuccess || hipMemcpy(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess)) rcode = PGRC_E_DEVICE;
+    if (rcode == PGRC_OK && streamed && (hipStreamSynchronize(c->up_stream[0]) != hipSuccess || hipStreamSynchronize(c->up_stream[1]) != hipSuccess)) rcode = PGRC_E_DEVICE;
+    if (rcode == PGRC_OK && !streamed && hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_DEVICE;
+    if (rcode == PGRC_OK && hipMemcpy(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) rcode = PGRC_E_DEVICE;
     cleanup();
     if (rcode != PGRC_OK) { if (c->err.empty()) c->err = "append_reads: HIP error"; pgrc_stream_abort(c); return rcode; }
     if (bad) { c->err = symbols == 5 ? "packed reads hold a byte outside the ACGNT code range" : "reads contain a symbol outside ACGNT"; pgrc_stream_abort(c); return PGRC_E_SYMBOL; }

@@ -285,6 +285,7 @@ struct MatchArgs {
     unsigned long long *work;     // global read cursor of the persistent match kernel
     uint32_t L, K, k2, mask, kmax, kmin, strand;
     uint32_t k1, early;           // sampling step of the index; early = 1: stop a read once nothing can be accepted any more
+    uint32_t chunk;               // reads a wave reserves per visit to the work counter (pgrc_match_chunk)
     // the screened schedule of a two-pass run (see "Exact-match screen" at the kernel): phase 0 = a plain pass,
     // 1 = screen (RC text, exact alignments only, flags and positions to scr_*), 2 = forward pass that honours the flags
     uint32_t phase;
@@ -359,6 +360,16 @@ __device__ __forceinline__ uint32_t hash_fp_window(const uint32_t w0, const uint
 #ifndef MATCH_CHUNK
 #define MATCH_CHUNK 1024u // reads a wave reserves per visit to the global work counter (256 / 512 / 1024: step +0 / -0.2 / -0.4 %)
 #endif
+
+// reads a wave reserves per visit to the global work counter: 1024 for a whole read set (256 / 512 / 1024: step +0 / -0.2 /
+// -0.4 % at C3), less for a short launch -- a block of a streamed run: 7 M reads over ~5000 resident waves are 1.35 chunks of
+// 1024 per wave, i.e. half the waves do two chunks while the others wait (10 ms per block instead of 6)
+static uint32_t pgrc_match_chunk(const pgrc_match_ctx *c, uint64_t n) {
+    const uint64_t waves = (uint64_t)c->num_cus * 20u;           // (about what is resident)
+    uint32_t chunk = MATCH_CHUNK;
+    while (chunk > 64u && n / chunk < waves * 8u) chunk >>= 1;
+    return chunk;
+}
 
 // Persistent, self-refilling lanes.  With one read per lane for the lifetime of a wave, ~35 % of the
 // lane-iterations are idle: reads that match exactly leave after a few seeds (30 % of the reads in the forward
@@ -475,10 +486,10 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
         if (need) {
             if (cnext == cend) { // reserve another chunk (one atomic per wave and MATCH_CHUNK reads)
                 unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(a.work, (unsigned long long)MATCH_CHUNK);
+                if (lane == 0) base = atomicAdd(a.work, (unsigned long long)a.chunk);
                 base = __shfl(base, 0, 64);
                 cnext = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base, a.n));
-                cend = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base + MATCH_CHUNK, a.n));
+                cend = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base + a.chunk, a.n));
             }
             if (STAGE > 0 && wnext == wend && cnext != cend) {    // the window is used up: stage the chunk's next reads
                 const uint32_t nst = min((uint32_t)SW, cend - cnext);
@@ -940,6 +951,7 @@ struct DualArgs {
     unsigned long long *work;
     uint8_t *redo_flag;           // per read: 2 = done again in the reference's order (F_SEQ); introspection only
     uint32_t L, K, k1, k2, mask, kmax;
+    uint32_t chunk;               // reads a wave reserves per visit to the work counter (pgrc_match_chunk)
 };
 
 template <int NW, int KQ, bool POS64>
@@ -1011,10 +1023,10 @@ k_copmem_match_dual(const DualArgs a) {
         if (need) {
             if (cnext == cend) {
                 unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(a.work, (unsigned long long)MATCH_CHUNK);
+                if (lane == 0) base = atomicAdd(a.work, (unsigned long long)a.chunk);
                 base = __shfl(base, 0, 64);
                 cnext = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base, a.n));
-                cend = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base + MATCH_CHUNK, a.n));
+                cend = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base + a.chunk, a.n));
             }
             if (wnext == wend && cnext != cend) {
                 const uint32_t nst = min((uint32_t)SW, cend - cnext);
@@ -1318,6 +1330,7 @@ int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     a.counters = (unsigned long long *)c->d_counters.p + 24;
     a.work = (unsigned long long *)c->d_counters.p + 18;
     a.redo_flag = (uint8_t *)c->d_scr_flag.p + lo;     // (zeroed by the caller; the screen's own use of it is another schedule)
+    a.chunk = pgrc_match_chunk(c, rn);
     a.L = c->prm.read_len;
     a.K = (uint32_t)c->cp.K;
     a.k1 = (uint32_t)c->cp.k1;
@@ -1399,6 +1412,7 @@ int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase) {
     a.kmin = c->prm.min_mismatches;
     a.strand = (uint32_t)strand;
     a.k1 = (uint32_t)c->cp.k1;
+    a.chunk = pgrc_match_chunk(c, rn);
     {
         const char *es = getenv("PGRC_EARLY_STOP");       // 0: every read probes all its seeds (A/B runs, tests)
         a.early = (es && es[0] == '0') ? 0u : 1u;

@@ -107,9 +107,10 @@ struct pgrc_match_ctx {
     bool st_on = false, st_dual = false;
     uint64_t *st_pos = nullptr;         // the caller's result arrays: a block's results are copied there as soon as they exist
     uint8_t *st_rc = nullptr, *st_mism = nullptr;
-    DevBuf up_stage;                    // staging area of append_reads_* (grow-only: no allocation per call)
-    hipStream_t up_stream = nullptr;    // uploads and unpacking run beside the matching
-    hipEvent_t up_ev = nullptr;
+    DevBuf up_stage[2];                 // staging areas of append_reads_* (grow-only: no allocation per call), used in turn
+    hipStream_t up_stream[2] = {nullptr, nullptr};   // a streamed run uploads and unpacks beside the matching, on two streams in
+    hipEvent_t up_ev[2] = {nullptr, nullptr};        // turn: the copy of chunk k+1 must not queue behind the unpacking of chunk k,
+    uint64_t up_chunk = 0;                           // which waits for a free CU while the persistent match kernel of chunk k-1 runs
     std::thread st_worker;              // downloads finished blocks while the caller uploads the next ones
     std::mutex st_mu;
     std::condition_variable st_cv;
@@ -228,7 +229,7 @@ bool pgrc_os_applicable(const pgrc_match_ctx *c, uint32_t hbits);
 int pgrc_os_build_index(pgrc_match_ctx *c, int strand, uint32_t hbits);
 int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand);
 // stream.hip: a block of reads just arrived on the device (append_reads_*): match it now if streaming is on
-int pgrc_stream_block_arrived(pgrc_match_ctx *c, uint64_t lo, uint64_t cnt, bool may_hold_n);
+int pgrc_stream_block_arrived(pgrc_match_ctx *c, uint64_t lo, uint64_t cnt, bool may_hold_n, int turn);
 void pgrc_stream_abort(pgrc_match_ctx *c);
 // api.hip
 void pgrc_swap_index_sets(pgrc_match_ctx *c);

@@ -15,13 +15,18 @@
 //   * pgrc_match_stream_end runs what needs the whole set (the reads with N: their side list is complete only after
 //     pgrc_match_end_reads; the histogram) and waits for the last download.
 // Results are those of pgrc_match_init_results + pgrc_match_run(ctx, 1): tests/test_gpu_stream.py compares them bit for bit.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
 
 #include "ctx.h"
 
+// PGRC_STREAM_TIMING=1: host-clock milestones of a streamed run on stderr
+static bool timing_on() { static const bool on = getenv("PGRC_STREAM_TIMING") != nullptr; return on; }
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define ST_MARK(c, what) do { if (timing_on()) fprintf(stderr, "pgrc stream: %8.2f ms  %s\n", (now_s() - (c)->st_t0) * 1e3, what); } while (0)
 
 extern "C" int pgrc_match_prepare_index(pgrc_match_ctx *c, int32_t both_strands) {
     if (!c) return PGRC_E_PARAM;
@@ -56,6 +61,7 @@ static void stream_worker(pgrc_match_ctx *c) {
             if (he == hipSuccess) he = hipMemcpyAsync(c->st_mism + b.lo, (const uint8_t *)c->d_mism.p + b.lo, b.cnt, hipMemcpyDeviceToHost, down);
             if (he == hipSuccess) he = hipStreamSynchronize(down);
         }
+        if (timing_on()) fprintf(stderr, "pgrc stream: %8.2f ms  results of block [%llu, +%llu) on the host\n", (now_s() - c->st_t0) * 1e3, (unsigned long long)b.lo, (unsigned long long)b.cnt);
         if (b.done) (void)hipEventDestroy(b.done);
         if (he != hipSuccess) {
             std::lock_guard<std::mutex> g(c->st_mu);
@@ -103,14 +109,14 @@ extern "C" int pgrc_match_stream_begin(pgrc_match_ctx *c, uint64_t *pos, uint8_t
     HIP_TRY(c, hipMemsetAsync(c->d_scr_flag.p, 0, c->n ? c->n : 1, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, 32 * sizeof(uint64_t), c->stream));
     memset(&c->ctr, 0, sizeof c->ctr);
-    if (!c->up_stream) {
-        hipError_t he = hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking);
-        if (he == hipSuccess) he = hipEventCreateWithFlags(&c->up_ev, hipEventDisableTiming);
-        if (he != hipSuccess) { c->up_stream = nullptr; c->err = std::string("stream_begin: ") + hipGetErrorString(he); return pgrc_hip_code(he); }
+    for (int k = 0; k < 2; k++) {
+        if (c->up_stream[k]) continue;
+        hipError_t he = hipStreamCreateWithFlags(&c->up_stream[k], hipStreamNonBlocking);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&c->up_ev[k], hipEventDisableTiming);
+        if (he != hipSuccess) { c->up_stream[k] = nullptr; c->err = std::string("stream_begin: ") + hipGetErrorString(he); return pgrc_hip_code(he); }
     }
-    // the upload stream must not overtake what begin_reads queued on the main stream (the N flags' memset)
-    HIP_TRY(c, hipEventRecord(c->up_ev, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->up_stream, c->up_ev, 0));
+    // (begin_reads cleared the N flags with a blocking call when index builds were in flight: the upload streams need not
+    //  -- and must not -- wait for the main stream, where those builds are queued)
     c->st_pos = pos;
     c->st_rc = rc;
     c->st_mism = mism;
@@ -122,14 +128,16 @@ extern "C" int pgrc_match_stream_begin(pgrc_match_ctx *c, uint64_t *pos, uint8_t
     c->st_on = true;
     c->have_results = false;
     c->st_t0 = now_s();
+    ST_MARK(c, "stream_begin done");
     return PGRC_OK;
 }
 
 // rows [lo, lo + cnt) are unpacked (queued on the upload stream): match them on the main stream, hand them to the worker
-int pgrc_stream_block_arrived(pgrc_match_ctx *c, uint64_t lo, uint64_t cnt, bool may_hold_n) {
+int pgrc_stream_block_arrived(pgrc_match_ctx *c, uint64_t lo, uint64_t cnt, bool may_hold_n, int turn) {
     if (!c->st_on || !cnt) return PGRC_OK;
-    HIP_TRY(c, hipEventRecord(c->up_ev, c->up_stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->up_ev, 0));
+    if (timing_on()) fprintf(stderr, "pgrc stream: %8.2f ms  block [%llu, +%llu) copied and queued for unpacking\n", (now_s() - c->st_t0) * 1e3, (unsigned long long)lo, (unsigned long long)cnt);
+    HIP_TRY(c, hipEventRecord(c->up_ev[turn], c->up_stream[turn]));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->up_ev[turn], 0));
     // the kernels' read cursors start at zero for every launch
     HIP_TRY(c, hipMemsetAsync((uint64_t *)c->d_counters.p + 16, 0, 3 * sizeof(uint64_t), c->stream));
     c->range_lo = lo;
@@ -166,6 +174,8 @@ extern "C" int pgrc_match_stream_end(pgrc_match_ctx *c, uint64_t hist[256], uint
     if (c->up_open || !c->have_reads) { pgrc_stream_abort(c); c->err = "stream_end: call pgrc_match_end_reads first"; return PGRC_E_STATE; }
     PGRC_ON_DEVICE(c);
     int e = PGRC_OK;
+    ST_MARK(c, "stream_end called");
+    if (timing_on()) { (void)hipStreamSynchronize(c->stream); ST_MARK(c, "all blocks matched"); }
     // the reads with N: the byte-path kernel over their side list, forward strand then RC strand (ReadsMatchers.cpp:162-172)
     if (c->n_nreads) {
         pgrc_swap_index_sets(c);
@@ -173,12 +183,15 @@ extern "C" int pgrc_match_stream_end(pgrc_match_ctx *c, uint64_t hist[256], uint
         pgrc_swap_index_sets(c);
         if (!e) e = pgrc_copmem_match_phase(c, 1, 4);
     }
+    if (timing_on()) { (void)hipStreamSynchronize(c->stream); ST_MARK(c, "reads with N done"); }
     if (!e) e = pgrc_launch_hist(c);                                 // synchronises the main stream: every block is done
+    ST_MARK(c, "histogram done");
     if (!e && c->n_nreads) {
         std::lock_guard<std::mutex> g(c->st_mu);
         for (const auto &b : c->st_nblocks) c->st_q.push_back({b.first, b.second, nullptr});
     }
     stop_worker(c);                                                  // (drains the queue first)
+    ST_MARK(c, "last download done");
     c->st_on = false;
     if (!e && c->st_err) { e = c->st_err; c->err = "stream_end: a result download failed"; }
     if (e) return e;

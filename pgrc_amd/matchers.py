@@ -132,15 +132,14 @@ class MatchContext:
         """start both strands' index builds now (beneath the upload of the reads); the next two-strand run uses them"""
         self._ck(lib.pgrc_match_prepare_index(self._h, 1 if both_strands else 0))
 
-    def match_streamed(self, sets, blocks: int = 1):
+    def match_streamed(self, sets, blocks: int = 1, out=None):
         """The whole job with its steps overlapped: `sets` as in set_reads_packed_sets, or [(ascii rows, n, 0)]; every
         appended block is matched while the next one is copied, its results land in the returned arrays as they
         exist.  blocks > 1 cuts every set into that many append calls.  Returns (pos, rc, mism, hist, matched) -- what
         init_results() + run(True) + get_results() give."""
         total = sum(int(n) for _, n, _ in sets)
-        pos = np.empty(total, dtype=np.uint64)
-        rc = np.empty(total, dtype=np.uint8)
-        mism = np.empty(total, dtype=np.uint8)
+        pos, rc, mism = out if out is not None else (np.empty(total, dtype=np.uint64), np.empty(total, dtype=np.uint8), np.empty(total, dtype=np.uint8))
+        assert pos.size == total and rc.size == total and mism.size == total and pos.dtype == np.uint64 and rc.dtype == np.uint8 and mism.dtype == np.uint8
         self._ck(lib.pgrc_match_begin_reads(self._h, total))
         self._ck(lib.pgrc_match_stream_begin(self._h, pos.ctypes.data_as(C.c_void_p), rc.ctypes.data_as(C.c_void_p),
                                              mism.ctypes.data_as(C.c_void_p)))
@@ -196,14 +195,14 @@ class MatchContext:
         """one executeMatching(revCompMode) (ReadsMatchers.h:46)"""
         self._ck(lib.pgrc_match_run_pass(self._h, int(strand)))
 
-    def get_results(self, arrays: bool = True):
+    def get_results(self, arrays: bool = True, out=None):
+        """out = (pos, rc, mism): existing arrays to fill (the reference's matcher holds its result vectors before the run)"""
         n = self.n
         hist = np.zeros(256, dtype=np.uint64)
         matched = C.c_uint64(0)
         if arrays:
-            pos = np.empty(n, dtype=np.uint64)
-            rc = np.empty(n, dtype=np.uint8)
-            mism = np.empty(n, dtype=np.uint8)
+            pos, rc, mism = out if out is not None else (np.empty(n, dtype=np.uint64), np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.uint8))
+            assert pos.size == n and rc.size == n and mism.size == n and pos.dtype == np.uint64 and rc.dtype == np.uint8 and mism.dtype == np.uint8
             self._ck(lib.pgrc_match_get_results(self._h, pos.ctypes.data_as(C.c_void_p), rc.ctypes.data_as(C.c_void_p),
                                                 mism.ctypes.data_as(C.c_void_p), hist.ctypes.data_as(C.c_void_p),
                                                 C.byref(matched)))

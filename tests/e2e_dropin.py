@@ -88,6 +88,7 @@ def main():
     lib.pgrc_ref_text_match_calls.restype = C.c_uint64
     lib.pgrc_ref_device_exports.restype = C.c_uint64
     lib.pgrc_ref_dual_runs.restype = C.c_uint64
+    lib.pgrc_ref_streamed_runs.restype = C.c_uint64
 
     # default: small enough for the test suite; PGRC_E2E_READS / PGRC_E2E_GENOME scale it up for a one-off check
     n = int(os.environ.get("PGRC_E2E_READS", "60000"))
@@ -123,6 +124,7 @@ def main():
         out[leg + "_device_exports"] = int(lib.pgrc_ref_device_exports()) - exports_seen   # exports whose streams came from the device
         exports_seen = int(lib.pgrc_ref_device_exports())
     out["gpu_dual_runs"] = int(lib.pgrc_ref_dual_runs())     # device runs that took the dual kernel (GPU leg only: the CPU leg has none)
+    out["gpu_streamed_runs"] = int(lib.pgrc_ref_streamed_runs())   # ... that overlapped hand-over, matching and result fetch
     out["identical"] = digests["cpu"] == digests["gpu"]
     out["sha256"] = digests
 

@@ -54,6 +54,18 @@ def test_archive_identical_with_gpu_matcher(tmp_path, case):
     assert r["roundtrip"], r
     if case not in ("se_modeD", "se_modeI", "se_exact"):     # (those match nothing: the sum-set quirk)
         assert r["gpu_device_exports"] >= 1 and r["cpu_device_exports"] == 0, r   # the export streams came from the device
+    if case in ("se", "se_order", "pe", "pe_order"):
+        assert r["gpu_streamed_runs"] >= 1, r               # stage 4 took the pipelined hand-over (first phase of mode c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["se", "pe_order"])
+def test_archive_identical_with_the_steps_in_turn(tmp_path, case):
+    """PGRC_NO_STREAM=1: hand-over, run and result fetch one after the other (the path every other configuration takes)."""
+    if not _have_e2e():
+        pytest.skip("oracle/_ref was built without the encoder harness")
+    r = _run(tmp_path, case, cpu_only=False, extra_env={"PGRC_NO_STREAM": "1"})
+    assert r["gpu_gpu_calls"] >= 1 and r["gpu_streamed_runs"] == 0 and r["identical"] and r["roundtrip"], r
 
 
 @pytest.mark.gpu

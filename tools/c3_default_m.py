@@ -19,6 +19,8 @@ for kmax in (3, 10, 50):
         ctx.init_results(); torch.cuda.synchronize(); t = time.perf_counter(); ctx.run(True); ts.append(time.perf_counter() - t)
     _, _, _, hist, matched = ctx.get_results(arrays=False)
     c = ctx.counters()
-    print(json.dumps({"kmax": kmax, "best_s": min(ts), "reads_per_s": n / min(ts), "matched": matched, "probes": c["probes"], "verifies": c["verifies"],
-                      "entry_fetches": c["entry_fetches"], "ms_match": c["ms_match"]}), flush=True)
+    print(json.dumps({"kmax": kmax, "best_s": min(ts), "reads_per_s": n / min(ts), "matched": matched,
+                      "schedule": {0: "two passes", 1: "screened", 2: "dual"}[c["screened"]], "redo_reads": c["redo_reads"], "dual": c["dual"],
+                      "ms_index_pair": c["ms_index"][0], "ms_dual_kernel": c["ms_screen"], "ms_match_after": c["ms_match"],
+                      "probes": c["probes"], "verifies": c["verifies"], "entry_fetches": c["entry_fetches"]}), flush=True)
     del ctx
