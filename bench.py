@@ -215,7 +215,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": (f"{args.workload}: {n_per} x {L} bp {'PE' if paired else 'SE'} reads per GPU" if n_total == n_per * world else
+            "config": {"workload": (f"{args.workload}: {n_per} x {L} bp {'PE' if paired else 'SE'} reads per GPU" if not (args.scaling == "strong" and world > 1) else
                                     f"{args.workload} (strong scaling): {n_total} x {L} bp {'PE' if paired else 'SE'} reads in total, split over {world} GPUs,")
                                    + f" vs Pg of {G} bp, mode {mode}, seed {seed_len}, -M {M} (k<={kmax}), both strands",
                        "symbols": "2-bit packed, 16 per u32 word (integer xor/popcount work, no floating point)",

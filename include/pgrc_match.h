@@ -154,6 +154,11 @@ int pgrc_match_get_results_device(pgrc_match_ctx *ctx, void **d_pos, void **d_rc
 int pgrc_match_extract_mismatches(pgrc_match_ctx *ctx, const uint8_t *reversed_flags, uint64_t *cum,
                                   uint8_t *codes, uint16_t *offsets);
 
+/* Large device buffers of destroyed contexts are kept for the next context of the process (re-allocating tens of GB right
+ * after freeing them can stall for seconds; at most PGRC_DEVICE_POOL_GB, default 96, 0 = keep nothing).  This returns them
+ * to the driver; the result is the number of bytes freed. */
+uint64_t pgrc_match_trim_device_memory(void);
+
 /* ---- pipelined hand-over of a whole job (mode c, both strands, first phase; single-device contexts): the steps of
  *      set_pg / set_reads / run / get_results overlap instead of following each other (pgrc_amd/csrc/stream.hip).
  *   pgrc_match_set_pg_ascii(ctx, ...);

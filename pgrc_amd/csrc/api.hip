@@ -12,15 +12,50 @@
 #include "ctx.h"
 #include "devutil.h"
 
+// Large device buffers that a context gives back are kept for the next context of the process instead of going back to
+// the driver: re-allocating tens of GB right after freeing them can stall for seconds (the driver scrubs freed memory
+// before it hands it out again: tools/ubench/realloc.hip, and 1.3-2.2 s seen for the second matcher of a process in
+// tools/boundary_c3.py) -- and PgRC creates one matcher per phase.  At most PGRC_DEVICE_POOL_GB (default 96, 0 = off) are held
+// per process; pgrc_match_trim_device_memory() returns them.
+namespace {
+struct PooledBuf { void *p; size_t bytes; int device; };
+std::mutex g_pool_mu;
+std::vector<PooledBuf> g_pool;
+size_t g_pool_bytes = 0;
+size_t pool_cap() {
+    static const size_t cap = []() {
+        const char *v = getenv("PGRC_DEVICE_POOL_GB");
+        return (size_t)(v ? std::max(0ll, atoll(v)) : 96ll) << 30;
+    }();
+    return cap;
+}
+const size_t POOL_MIN = 64ull << 20;
+}
+
 int pgrc_buf_ensure(pgrc_match_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b.p && b.bytes >= bytes) return PGRC_OK;
-    if (b.p) {
-        (void)hipFree(b.p);
-        b.p = nullptr;
-        b.bytes = 0;
+    pgrc_buf_free(b);
+    int dev = -1;
+    if (bytes >= POOL_MIN && hipGetDevice(&dev) == hipSuccess) {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        size_t best = g_pool.size();
+        for (size_t k = 0; k < g_pool.size(); k++)        // smallest fitting buffer of this device, not more than twice the size
+            if (g_pool[k].device == dev && g_pool[k].bytes >= bytes && g_pool[k].bytes <= 2 * bytes && (best == g_pool.size() || g_pool[k].bytes < g_pool[best].bytes))
+                best = k;
+        if (best != g_pool.size()) {
+            b.p = g_pool[best].p;
+            b.bytes = g_pool[best].bytes;
+            g_pool_bytes -= b.bytes;
+            g_pool.erase(g_pool.begin() + (long)best);
+            return PGRC_OK;
+        }
     }
     hipError_t e = hipMalloc(&b.p, bytes);
+    if (e == hipErrorOutOfMemory && pgrc_match_trim_device_memory() > 0) {   // what the pool holds may be what is missing
+        (void)hipGetLastError();
+        e = hipMalloc(&b.p, bytes);
+    }
     if (e != hipSuccess) {
         b.p = nullptr;
         c->err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
@@ -32,9 +67,40 @@ int pgrc_buf_ensure(pgrc_match_ctx *c, DevBuf &b, size_t bytes) {
 }
 
 void pgrc_buf_free(DevBuf &b) {
-    if (b.p) (void)hipFree(b.p);
+    if (b.p) {
+        int dev = -1;
+        bool kept = false;
+        if (b.bytes >= POOL_MIN && hipGetDevice(&dev) == hipSuccess) {
+            std::lock_guard<std::mutex> g(g_pool_mu);
+            if (g_pool_bytes + b.bytes <= pool_cap()) {
+                g_pool.push_back({b.p, b.bytes, dev});
+                g_pool_bytes += b.bytes;
+                kept = true;
+            }
+        }
+        if (!kept) (void)hipFree(b.p);
+    }
     b.p = nullptr;
     b.bytes = 0;
+}
+
+extern "C" uint64_t pgrc_match_trim_device_memory(void) {
+    std::vector<PooledBuf> take;
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        take.swap(g_pool);
+        g_pool_bytes = 0;
+    }
+    uint64_t freed = 0;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    for (const PooledBuf &pb : take) {
+        if (pb.device != cur) (void)hipSetDevice(pb.device);
+        (void)hipFree(pb.p);
+        freed += pb.bytes;
+        if (pb.device != cur && cur >= 0) (void)hipSetDevice(cur);
+    }
+    return freed;
 }
 
 static thread_local std::string g_create_err; // reported by pgrc_match_last_error(NULL)
