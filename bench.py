@@ -187,9 +187,10 @@ def main():
         # this process, so the value comes from the committed separate `rocprofv3 --pmc` passes of this very command
         # (tools/pmc_groups.sh + tools/pmc_traffic.py -> profiles/); null for workloads that were not profiled.
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", f"r02_{args.workload.lower()}_traffic.json")
-        if not os.path.exists(tp):
-            tp = os.path.join(ROOT, "profiles", f"r01_final_{args.workload.lower()}_traffic.json")
+        tp = os.path.join(ROOT, "profiles", f"r03_{args.workload.lower()}_traffic.json")
+        for older in (f"r02_{args.workload.lower()}_traffic.json", f"r01_final_{args.workload.lower()}_traffic.json"):
+            if not os.path.exists(tp):
+                tp = os.path.join(ROOT, "profiles", older)
         if world == 1 and os.path.exists(tp):
             try:
                 tj = json.load(open(tp))

@@ -527,14 +527,17 @@ static int os_passes(pgrc_match_ctx *c, int strand, const OsPlan &pl, const OsBu
 int pgrc_os_build_index(pgrc_match_ctx *c, int strand, uint32_t hbits) {
     OsPlan pl;
     if (!os_plan(c, hbits, &pl)) { c->err = "index build (sweep): not applicable"; return PGRC_E_PARAM; }
-    // block shape of the passes (experiments: PGRC_OS_CFG = index into the table below)
+    // Block shape of the passes (PGRC_OS_CFG = index into the table below: A/B runs).  Default 1: 1024 threads x 6 records,
+    // 61 KB of LDS and 64 registers: two blocks per CU, one hashing while the other stores.  C3, per strand (profiles/
+    // r03_os_cfgs.txt): pass 1 / pass 2 = 3.0 / 1.8 ms (shape 0: 1024 x 8, one block per CU), 1.8 / 1.75 (1), 2.2 / 2.1 (2: 512 x 8,
+    // three per CU), 3.3 / 2.75 (3: 512 x 16), 3.0 / 2.4 (4: shape 0 with a persistent, prefetching pass 2).
     struct Shape { uint32_t tpb, e; };
     static const Shape shapes[] = {{1024, 8}, {1024, 6}, {512, 8}, {512, 16}, {1024, 8}};
     const char *cfgs = getenv("PGRC_OS_CFG");
-    uint32_t cfg = cfgs ? (uint32_t)atoi(cfgs) : 0u;
-    if (cfg >= sizeof shapes / sizeof shapes[0]) cfg = 0;
+    uint32_t cfg = cfgs ? (uint32_t)atoi(cfgs) : 1u;
+    if (cfg >= sizeof shapes / sizeof shapes[0]) cfg = 1;
     const bool aux16 = pl.b2 > 8;
-    if (aux16) cfg = 0;                                        // (9-bit digits: one digit per thread needs 512+ threads and u16 digits)
+    if (aux16) cfg = 0;                                        // (9-bit digits: 16-bit digit arrays: the 8-record shape, one block per CU)
     const uint64_t n = pl.n, tile = (uint64_t)shapes[cfg].tpb * shapes[cfg].e;
     const uint32_t D1 = 1u << pl.b1, D2 = 1u << pl.b2, np = 1u << (pl.hbits - pl.cb);
     pl.ntiles1 = (n + tile - 1) / tile;
