@@ -38,6 +38,27 @@ def _check(mode, pg, reads, seed_len, kmax, threads=16):
     return orc.oracle_match(mode, pg, reads, seed_len, kmax, 0, True, threads)
 
 
+def _sample_over_all_reads(ctx, n, n_stride, n_redo, first=0):
+    """read indexes for a parity sample that is not just the head of the set: the first `first` reads, a stride over ALL
+    reads, and a stride over the reads the dual kernel of the last run did again in the reference's order (the ones in
+    repeat families, where the falses budget matters: pgrc_match_get_redo_flags)"""
+    redo = np.flatnonzero(ctx.redo_flags())
+    parts = [np.arange(min(first, n), dtype=np.int64), np.linspace(0, n - 1, n_stride).astype(np.int64)]
+    if redo.size:
+        parts.append(redo[np.linspace(0, redo.size - 1, min(n_redo, redo.size)).astype(np.int64)].astype(np.int64))
+    idx = np.unique(np.concatenate(parts))
+    return idx, int(np.isin(idx, redo).sum())
+
+
+def _rows_from_hbm(d_rd, idx, L, stride):
+    """ASCII rows of reads `idx` from the word-major 2-bit read set in HBM: exactly what the GPU matched"""
+    nw = (L + 15) // 16
+    ix = torch.as_tensor(idx, device=d_rd.device)
+    rows = torch.stack([d_rd[w * stride + ix] for w in range(nw)], dim=1).cpu().numpy().view(np.uint32)
+    sym = (rows[:, :, None] >> (2 * np.arange(16, dtype=np.uint32))[None, None, :]) & 3
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[sym.reshape(idx.size, nw * 16)[:, :L]]
+
+
 def _bookkeeping(n, G, L, kmax, pos, rc, mism, hist, matched):
     assert int(hist.sum()) == n and matched == n - int(hist[255])
     assert np.array_equal(np.bincount(mism, minlength=256).astype(np.uint64), hist)
@@ -104,6 +125,8 @@ def test_c3_full_size_properties_and_sample(c3world):
     ctx.init_results()
     ctx.run(True)
     pos, rc, mism, hist, matched = ctx.get_results()
+    idx, n_redo = _sample_over_all_reads(ctx, n, 30_000, 30_000)          # (the redo flags are those of THIS run)
+    assert ctx.counters()["screened"] == 2 and n_redo >= 10_000
     # 1. bookkeeping: histogram = histogram of the per-read counts; matched = reads with a position
     _bookkeeping(n, G, L, kmax, pos, rc, mism, hist, matched)
     # 2. idempotence: a second run over the finished state changes nothing (every pass must strictly improve)
@@ -119,6 +142,11 @@ def test_c3_full_size_properties_and_sample(c3world):
     m = w.ns
     r = w.ref_se
     assert np.array_equal(pos[:m], r["pos"]) and np.array_equal(rc[:m], r["rc"]) and np.array_equal(mism[:m], r["mism"])
+    # ... and on a stride over ALL reads plus the reads the dual kernel redid in the reference's order (rows read back from HBM)
+    rows = _rows_from_hbm(d_rd, idx, L, stride)
+    assert np.array_equal(rows[:50], reads[idx[:50]]) if idx[49] < reads.shape[0] else True
+    r2 = _check("c", pg, rows, seed_len, kmax)
+    assert np.array_equal(pos[idx], r2["pos"]) and np.array_equal(rc[idx], r2["rc"]) and np.array_equal(mism[idx], r2["mism"])
     # the generator plants 60 % exact reads (3 % of all reads are random): at least that many must match exactly
     assert hist[0] >= 0.55 * n and matched >= 0.85 * n
     # 5. the read-side seed-index modes on the same inputs: reported alignments are real, the exact matches agree with mode c
@@ -214,9 +242,15 @@ def _full_size_run(n, L, G, seed_len, kmax, sample, also_mode=None):
     pg = _unpack(d_pg.cpu().numpy().view(np.uint32)[:pgw], G)
     reads = synth.reads_host(g, pg, rs, 0, sample)
     _alignments_are_real(pg, reads, pos[:sample], rc[:sample], mism[:sample])
-    r = _check("c", pg, reads, seed_len, kmax)
+    # the parity sample: the first reads, a stride over all of them, and a stride over the reads the dual kernel redid in
+    # the reference's order -- one checker run over the whole text for the lot (rows read back from HBM)
+    idx, n_redo = _sample_over_all_reads(ctx, n, sample // 4, sample // 4, first=sample // 2)
+    assert n_redo >= min(1000, int(ctx.counters()["redo_reads"]))
+    rows = _rows_from_hbm(d_rd, idx, L, stride)
+    assert np.array_equal(rows[: sample // 2], reads[: sample // 2])
+    r = _check("c", pg, rows, seed_len, kmax)
     for k, v in (("pos", pos), ("rc", rc), ("mism", mism)):
-        assert np.array_equal(v[:sample], r[k]), k
+        assert np.array_equal(v[idx], r[k]), k
     if also_mode:
         # a read-side seed-index mode on the same inputs: reported alignments are real, every read mode c matched exactly
         # is matched exactly (every part of such a read hits at its occurrence)
