@@ -61,7 +61,11 @@ typedef struct {
     uint64_t probes;       /* destination windows hashed */
     uint64_t events;       /* (window, index entry) pairs with equal K-mers */
     uint64_t stale_lookups;/* events that needed the stale-register emulation on the host */
-    float ms_index, ms_probe, ms_sort, ms_extend, ms_host;
+    float ms_index, ms_probe, ms_sort, ms_extend;
+    float ms_host;         /* compaction + download of the matches */
+    float ms_replay;       /* the sequential rules on the device, all rounds (host clock) */
+    uint32_t replay_rounds;/* passes over the event blocks until every block had seen the last match before it */
+    uint32_t event_blocks; /* blocks of 256 windows that hold events */
 } pgrc_mem_counters;
 int pgrc_mem_get_counters(pgrc_mem_ctx *ctx, pgrc_mem_counters *out);
 

@@ -76,7 +76,8 @@ class TextMatch(C.Structure):     # pgrc_text_match (include/pgrc_mem.h) = TextM
 
 class MemCounters(C.Structure):
     _fields_ = [("probes", C.c_uint64), ("events", C.c_uint64), ("stale_lookups", C.c_uint64), ("ms_index", C.c_float),
-                ("ms_probe", C.c_float), ("ms_sort", C.c_float), ("ms_extend", C.c_float), ("ms_host", C.c_float)]
+                ("ms_probe", C.c_float), ("ms_sort", C.c_float), ("ms_extend", C.c_float), ("ms_host", C.c_float),
+                ("ms_replay", C.c_float), ("replay_rounds", C.c_uint32), ("event_blocks", C.c_uint32)]
 
 
 # every symbol include/pgrc_match.h and include/pgrc_mem.h declare: (name, restype, argtypes)

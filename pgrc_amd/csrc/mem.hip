@@ -15,11 +15,14 @@
 //   2. rocPRIM sort  : events by (window, bucket order) = the order the reference meets them;
 //   3. k_mem_flags .. k_mem_apply : the side-context test (c) per event; the maximal extension (d) once per RUN of
 //                      events that one match produces on its diagonal (linear in the text, however long the match);
-//   4. host          : one pass over the events replays (b), the jumps (which never leave a block of 256 windows in
-//                      the main loop, :365-424, but carry through in the tail loop, :428-476) and the acceptance.
+//   4. k_mem_replay  : (b), the jumps (which never leave a block of 256 windows in the main loop, :365-424, but carry
+//                      through in the tail loop, :428-476) and the acceptance, one thread per block of windows that
+//                      holds events, in rounds until every block has seen the last match recorded before it;
+//   5. k_mem_emit    : the accepted events, compacted in discovery order -- the only thing the host receives.
 // The side-context registers l1/r1/l2/r2 are refreshed only when their 4 bytes lie inside the text (:381-382,
 // :401-402): for the handful of events at the text ends the host re-creates the stale value the reference would
-// hold by walking back through the windows actually examined (bucket lookups from the device on demand).
+// hold by walking back through the windows actually examined (one block's outcomes and bucket lookups from the device
+// on demand), tells the device the verdict and lets the replay continue.
 //
 // All integer work, bound by the random head gathers (one per window): no MFMA.
 #include <algorithm>
@@ -33,6 +36,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "ctx.h"
 #include "devutil.h"
@@ -48,9 +52,8 @@ struct pgrc_mem_ctx {
     bool have_src = false;
     DevBuf d_dest, d_nmap, d_stage, d_flag, d_cursor, d_evk[2], d_evv[2], d_tmp, d_orun, d_oflag;
     DevBuf d_skey[2], d_sidx[2], d_first, d_runid, d_rstart, d_rend;   // events by (diagonal, window): sort ping-pong, runs
-    // pinned, grow-only host mirrors of the event arrays (a std::vector would zero-fill gigabytes per call)
-    struct HostBuf { void *p = nullptr; size_t bytes = 0; bool pinned = false; } h_key, h_pos, h_run, h_rstart, h_rend, h_flag;
-    hipEvent_t ev[4]{};               // phase timing (created on first use)
+    DevBuf d_rdend, d_outc, d_ebstart, d_ebin, d_ebout, d_ebinc, d_small, d_match;   // the replay: per run, per event, per event block
+    hipEvent_t ev[5]{};               // phase timing (created on first use)
     bool have_ev = false;
     pgrc_mem_counters ctr{};
     std::string err;
@@ -66,33 +69,6 @@ struct pgrc_mem_ctx {
     } while (0)
 
 static thread_local std::string g_mem_create_err; // reported by pgrc_mem_last_error(NULL)
-
-static void host_release(pgrc_mem_ctx::HostBuf &b) {
-    if (b.p) {
-        if (b.pinned) (void)hipHostFree(b.p);
-        else free(b.p);
-    }
-    b.p = nullptr;
-    b.bytes = 0;
-}
-
-static int host_ensure(pgrc_mem_ctx *m, pgrc_mem_ctx::HostBuf &b, size_t bytes) {
-    if (b.p && b.bytes >= bytes) return PGRC_OK;
-    host_release(b);
-    if (hipHostMalloc(&b.p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess) {
-        b.pinned = true;
-    } else {                              // no pinned memory left: pageable memory works too, the copies are just slower
-        (void)hipGetLastError();
-        b.p = malloc(bytes ? bytes : 16);
-        b.pinned = false;
-        if (!b.p) {
-            m->err = "host allocation of " + std::to_string(bytes) + " bytes failed";
-            return PGRC_E_ALLOC;
-        }
-    }
-    b.bytes = bytes;
-    return PGRC_OK;
-}
 
 // ------------------------------------------------------------------------------------------------ device side
 
@@ -233,6 +209,7 @@ k_mem_probe(const MemArgs a, unsigned long long *cursor, uint64_t *__restrict__ 
 #define MF_R2_OK 8u
 #define MF_L_EQ 16u    // both left contexts fresh and equal
 #define MF_R_EQ 32u
+#define MF_LONG 64u    // the match of the event's run is long enough to be recorded (:413)
 
 // 3. side contexts and extensions.  Every event of one maximal match (same diagonal, connected by equal symbols) has the
 // same extents, and a long match carries one event per lcm(k1, k2) symbols: extending each of them separately would be
@@ -242,7 +219,7 @@ k_mem_probe(const MemArgs a, unsigned long long *cursor, uint64_t *__restrict__ 
 // the left, the last one to the right, and everybody takes its run's extents: linear in the text.
 __global__ void __launch_bounds__(256)
 k_mem_flags(const MemArgs a, const uint64_t *__restrict__ evk, const uint64_t *__restrict__ evv, uint64_t nev,
-            uint8_t *__restrict__ oflag, uint64_t *__restrict__ qkey, uint64_t *__restrict__ idx) {
+            uint8_t *__restrict__ oflag, uint64_t *__restrict__ qkey, uint64_t *__restrict__ idx, uint32_t *nstale) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nev) return;
     const uint64_t q = (evk[i] >> 4) * a.k2, p = evv[i];
@@ -256,6 +233,7 @@ k_mem_flags(const MemArgs a, const uint64_t *__restrict__ evk, const uint64_t *_
     oflag[i] = (uint8_t)fl;
     qkey[i] = q;
     idx[i] = i;
+    if ((fl & 15u) != 15u) atomicAdd(nstale, 1u);                    // (a handful: only at the ends of the texts)
 }
 
 // diagonal of event idx[k] (offset by N so that it is not negative), as the key of the second, stable sort
@@ -295,7 +273,7 @@ k_mem_connect(const MemArgs a, const uint64_t *__restrict__ evk, const uint64_t 
 __global__ void __launch_bounds__(256)
 k_mem_run_ends(const MemArgs a, const uint64_t *__restrict__ evk, const uint64_t *__restrict__ evv, const uint64_t *__restrict__ idx,
                const uint32_t *__restrict__ first, const uint32_t *__restrict__ runid, uint64_t nev,
-               uint64_t *__restrict__ run_start, uint64_t *__restrict__ run_end) {
+               uint64_t *__restrict__ run_start, uint64_t *__restrict__ run_end, uint64_t *__restrict__ run_dend) {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nev) return;
     const bool leader = first[k] != 0, tail = (k + 1 == nev) || first[k + 1] != 0;
@@ -313,6 +291,7 @@ k_mem_run_ends(const MemArgs a, const uint64_t *__restrict__ evk, const uint64_t
             x += 16;
         }
         run_end[r] = p + a.K + min(x, rlim);                         // source position after the match
+        run_dend[r] = q + a.K + min(x, rlim);                        // ... and the destination position after it
     }
     if (leader) {
         // left: symbols before the K-mer (:409-411); the loop of the reference stops ON symbol 0 without consuming it
@@ -334,12 +313,176 @@ k_mem_run_ends(const MemArgs a, const uint64_t *__restrict__ evk, const uint64_t
     }
 }
 
-// every event learns its run (the host reads the extents per run: 4 bytes per event instead of 16)
+// every event learns its run and whether that run's match is long enough to be recorded: right - p1 > minMatchLength
+// with right - p1 = length + 1 (:413)
 __global__ void __launch_bounds__(256)
-k_mem_apply(const uint64_t *__restrict__ idx, const uint32_t *__restrict__ runid, uint64_t nev, uint32_t *__restrict__ orun) {
+k_mem_apply(const uint64_t *__restrict__ idx, const uint32_t *__restrict__ runid, uint64_t nev, const uint64_t *__restrict__ run_start,
+            const uint64_t *__restrict__ run_end, uint32_t min_len, uint32_t *__restrict__ orun, uint8_t *__restrict__ oflag) {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nev) return;
-    orun[idx[k]] = runid[k] - 1u;
+    const uint32_t r = runid[k] - 1u;
+    const uint64_t i = idx[k];
+    orun[i] = r;
+    if (run_end[r] - run_start[r] + 1 > (uint64_t)min_len) oflag[i] |= MF_LONG;
+}
+
+// 4. the sequential rules, over the events only.  The reference's scan is sequential for two reasons: a jump skips the
+// next K/k1 - 1 windows -- but never beyond its block of 256 windows (main loop; the tail loop is one block of its own),
+// so blocks are independent there -- and rule (b) looks at the LAST match recorded, which carries from block to block.
+// One wave replays one block's events ("event block": only blocks that hold events exist here).  Round 0 assumes
+// "no match recorded before"; then every block takes the last match recorded by the nearest block before it that
+// recorded one (an exclusive scan with "rightmost valid"), and is replayed again if that match reaches into it (rule
+// (b) could fire) and is not what it assumed: round after round until nothing changes.  After round r the first r
+// blocks are final, so the rounds end; usually after two or three (a match that straddles a block boundary costs its
+// successor one more replay, ONE 20 Mbp match over 26 000 blocks: two rounds).
+// A match is named by its run: every event of a run records the same (source, length, destination) triple, and an event
+// on the diagonal of the last match lies inside it (q + K < its end) only if it belongs to its run -- two runs on one
+// diagonal are separated by a difference.
+#define MO_NONE 0u
+#define MO_JUMP 1u             // rule (b): inside the previous match, the scan jumped (:393-399)
+#define MO_ACCEPT 2u           // recorded a match and jumped (:413-419)
+#define MO_STALE 3u            // reached, could record a match, but a side-context register is stale: the host decides
+#define MR_NONE 0xFFFFFFFFu    // "no match recorded so far"
+#define MR_DIRTY 0xFFFFFFFEu   // assumed incoming match of a block that has to be replayed whatever comes in
+
+__host__ __device__ __forceinline__ uint64_t mem_block_of(uint64_t t, uint64_t nmain) { return t < nmain ? t >> 8 : (nmain >> 8) + 1; }
+
+__global__ void __launch_bounds__(256)
+k_mem_lead(const uint64_t *__restrict__ ek, uint64_t nev, uint64_t nmain, uint32_t *__restrict__ lead) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nev) return;
+    lead[i] = (i == 0 || mem_block_of(ek[i] >> 4, nmain) != mem_block_of(ek[i - 1] >> 4, nmain)) ? 1u : 0u;
+}
+// lid = inclusive sum of lead[]: event block of event i = lid[i] - 1
+__global__ void __launch_bounds__(256)
+k_mem_eb_start(const uint32_t *__restrict__ lead, const uint32_t *__restrict__ lid, uint64_t nev, uint32_t *__restrict__ eb_start) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nev) return;
+    if (lead[i]) eb_start[lid[i] - 1u] = (uint32_t)i;
+    if (i + 1 == nev) eb_start[lid[i]] = (uint32_t)nev;
+}
+
+struct MemReplayArgs {
+    const uint64_t *ek;          // events in the reference's order: (window << 4) | bucket order
+    const uint32_t *orun;        // run of an event
+    const uint8_t *oflag;
+    uint8_t *outc;               // MO_* per event
+    const uint64_t *run_dend;    // destination position after a run's match
+    const uint32_t *eb_start;    // [neb + 1]
+    uint32_t *eb_in, *eb_out;    // incoming match a block assumed in its last replay / last match it recorded (MR_NONE: none)
+    const uint32_t *eb_inc;      // last match recorded before the block, from the blocks' current eb_out
+    uint32_t neb, K, k2, skip;
+    uint32_t *changed;
+    int first;
+};
+
+// One WAVE per event block: 64 events are loaded at once (coalesced) and classified in parallel -- "would record a
+// match" and "stale" do not depend on the scan's state, "inside the last match" (b) only on the last match -- and the
+// wave then steps through the events that the scan REACHES and that do something (a jump, an acceptance, a stale mark),
+// in order: every one of them removes the rest of its window and the next `skip` windows from the candidates with one
+// ballot.  The state (last match, its end, window of the last jump) is wave-uniform.
+#define MEM_RP_WAVES 4
+__global__ void __launch_bounds__(64 * MEM_RP_WAVES)
+k_mem_replay(const MemReplayArgs r) {
+    const uint32_t eb = blockIdx.x * MEM_RP_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (eb >= r.neb) return;
+    const uint32_t i0 = r.eb_start[eb], i1 = r.eb_start[eb + 1];
+    uint32_t in = MR_NONE;
+    if (!r.first) {
+        const uint32_t inc = r.eb_inc[eb];
+        if (inc != MR_NONE && (r.ek[i0] >> 4) * r.k2 + r.K < r.run_dend[inc]) in = inc;   // else rule (b) cannot fire in here
+        if (in == r.eb_in[eb]) return;
+        if (lane == 0) *r.changed = 1u;
+    }
+    if (lane == 0) r.eb_in[eb] = in;
+    uint32_t last = in, out = MR_NONE;
+    uint64_t last_dend = in != MR_NONE ? r.run_dend[in] : 0;
+    uint64_t jump_end = 0;       // windows below it are finished: the last jump skipped them (or one of their entries jumped)
+    for (uint32_t base = i0; base < i1; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < i1;
+        const uint64_t t = valid ? r.ek[i] >> 4 : 0;
+        const uint32_t run = valid ? r.orun[i] : MR_NONE, fl = valid ? r.oflag[i] : 0u;
+        const uint64_t qk = t * r.k2 + r.K;
+        const bool is_long = (fl & MF_LONG) != 0, fresh = (fl & 15u) == 15u;
+        const bool c_stale = is_long && !fresh, c_acc = is_long && fresh && (fl & (MF_L_EQ | MF_R_EQ)) != 0;
+        uint64_t live = __ballot(valid && t >= jump_end);                                 // events of windows the scan still visits
+        uint64_t mb = last != MR_NONE ? __ballot(run == last && qk < last_dend) : 0ull;    // (b)
+        const uint64_t msa = __ballot(c_stale || c_acc), mstale = __ballot(c_stale);
+        uint32_t oc = MO_NONE;
+        for (;;) {
+            const uint64_t todo = live & (mb | msa);
+            if (!todo) break;
+            const uint32_t l = (uint32_t)__builtin_ctzll(todo);                            // the next event that does something
+            const uint64_t bit = 1ull << l;
+            const uint64_t tl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(t >> 32), l) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t, l);
+            if (mb & bit) {                                                               // (b): jump
+                if (lane == l) oc = MO_JUMP;
+                jump_end = tl + r.skip + 1;
+                live &= __ballot(t >= jump_end);
+            } else if (mstale & bit) {                                                    // until resolved: as if it failed (c)
+                if (lane == l) oc = MO_STALE;
+                live &= ~bit;
+            } else {                                                                      // (c), (d): record, jump
+                if (lane == l) oc = MO_ACCEPT;
+                last = out = (uint32_t)__builtin_amdgcn_readlane((int)run, l);
+                last_dend = r.run_dend[last];
+                jump_end = tl + r.skip + 1;
+                live &= __ballot(t >= jump_end);
+                mb = __ballot(run == last && qk < last_dend);
+            }
+        }
+        if (valid) r.outc[i] = (uint8_t)oc;
+    }
+    if (lane == 0) r.eb_out[eb] = out;
+}
+
+struct MemLastValid {          // scan operator: the rightmost recorded match
+    __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return b != MR_NONE ? b : a; }
+};
+struct MemIsAccept {
+    __host__ __device__ uint32_t operator()(uint8_t oc) const { return oc == MO_ACCEPT ? 1u : 0u; }
+};
+
+// smallest event index with outcome MO_STALE (everything before it is final)
+__global__ void __launch_bounds__(256)
+k_mem_first_stale(const uint8_t *__restrict__ outc, uint64_t nev, uint32_t *first) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nev; i += (uint64_t)gridDim.x * blockDim.x)
+        if (outc[i] == MO_STALE) atomicMin(first, (uint32_t)i);
+}
+// the host's verdict on event x: its flags now read "all four contexts fresh, left ones equal / different"
+__global__ void k_mem_resolve(uint32_t x, int pass, uint8_t *oflag, const uint32_t *lid, uint32_t *eb_in) {
+    oflag[x] = (uint8_t)(15u | (pass ? MF_L_EQ : 0u) | (oflag[x] & MF_LONG));
+    eb_in[lid[x] - 1u] = MR_DIRTY;
+}
+// [lo, hi) = the events of the windows [tlo, thi)
+__global__ void k_mem_find_range(const uint64_t *__restrict__ ek, uint64_t nev, uint64_t tlo, uint64_t thi, uint64_t *out) {
+    for (int k = 0; k < 2; k++) {
+        const uint64_t key = (k ? thi : tlo) << 4;
+        uint64_t lo = 0, hi = nev;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (ek[mid] < key) lo = mid + 1;
+            else hi = mid;
+        }
+        out[k] = lo;
+    }
+}
+// 5. the accepted events in discovery order (slot = inclusive count of accepted events - 1)
+__global__ void __launch_bounds__(256)
+k_mem_emit(const uint64_t *__restrict__ ek, const uint64_t *__restrict__ ep, const uint32_t *__restrict__ orun,
+           const uint8_t *__restrict__ outc, const uint32_t *__restrict__ slot, uint64_t nev, uint32_t k2,
+           const uint64_t *__restrict__ run_start, const uint64_t *__restrict__ run_end, pgrc_text_match *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nev || outc[i] != MO_ACCEPT) return;
+    const uint32_t r = orun[i];
+    const uint64_t ms = run_start[r], q = (ek[i] >> 4) * k2;
+    pgrc_text_match tm;
+    tm.pos_src = ms;
+    tm.length = run_end[r] - ms;
+    tm.pos_dest = q - (ep[i] - ms);
+    out[slot[i] - 1u] = tm;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -362,48 +505,62 @@ static uint32_t le32(const char *p) {
     return v;
 }
 
-struct Replay {
+// The stale registers.  Near the ends of the texts the reference does not refresh l1 / r1 / l2 / r2 and compares against
+// what an earlier bucket entry or window left there (:381-382, :401-402).  The device marks the first such event that the
+// scan reaches and that could record a match (MO_STALE); everything before it is final, so the host walks back through
+// the windows actually examined -- one block's jumps (the events with outcome MO_JUMP / MO_ACCEPT) and single bucket
+// lookups, fetched from the device on demand -- to the entry that wrote the register last.
+struct StaleWalk {
     pgrc_mem_ctx *m;
     const char *dest;
     uint64_t N2;
     bool dest_is_src, rev_compl;
     uint64_t skip, nmain;                        // probes jumped over after a hit; probes of the main loop (whole blocks of 256)
-    // history of the probes that ended with a jump: (probe, order of the entry that caused it, 1 = recorded a match)
+    const uint64_t *d_ek;                        // device: the events in the reference's order, their outcomes
+    const uint8_t *d_outc;
+    uint64_t nev;
+    uint64_t *d_range;                           // device scratch, 2 words
+    // the probes of one block that ended with a jump: (probe, order of the entry that caused it, 1 = recorded a match)
     struct Jump { uint64_t t; uint32_t order; uint32_t accepted; };
-    // the jumps recorded so far, in probe order: the finished chunks' lists (none empty, ascending) and the list of the
-    // chunk being replayed
-    std::vector<const std::vector<Jump> *> hist;
-    const std::vector<Jump> *cur = nullptr;
+    uint64_t cached = ~0ull;
+    std::vector<Jump> jumps;
+    std::vector<uint64_t> hk;
+    std::vector<uint8_t> ho;
     int lookup_err = 0;
 
-    uint64_t block_of(uint64_t t) const { return t < nmain ? t / 256 : nmain / 256 + 1; }   // the tail loop is one block
     static bool jump_lt(const Jump &j, uint64_t v) { return j.t < v; }
-    // the list that holds the latest jump at a probe < t (or <= t), if any
-    const std::vector<Jump> *list_for(uint64_t t, bool inclusive) const {
-        if (cur && !cur->empty() && (inclusive ? cur->front().t <= t : cur->front().t < t)) return cur;
-        size_t lo = 0, hi = hist.size();                 // first list whose first jump lies beyond t
-        while (lo < hi) {
-            const size_t mid = (lo + hi) / 2;
-            const uint64_t f = hist[mid]->front().t;
-            if (inclusive ? f <= t : f < t) lo = mid + 1;
-            else hi = mid;
-        }
-        return lo ? hist[lo - 1] : nullptr;
+    // the jumps of the block that probe t belongs to (a jump never leaves its block)
+    void load_block(uint64_t t) {
+        const uint64_t b = mem_block_of(t, nmain);
+        if (b == cached) return;
+        cached = b;
+        jumps.clear();
+        const uint64_t tlo = t < nmain ? t & ~255ull : nmain, thi = t < nmain ? tlo + 256 : (1ull << 59);
+        pgrc_match_ctx *c = m->base;
+        hipLaunchKernelGGL(k_mem_find_range, dim3(1), dim3(1), 0, c->stream, d_ek, nev, tlo, thi, d_range);
+        uint64_t rg[2] = {0, 0};
+        if (hipMemcpyAsync(rg, d_range, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { lookup_err = 1; return; }
+        const uint64_t cnt = rg[1] - rg[0];
+        if (!cnt) return;
+        hk.resize(cnt);
+        ho.resize(cnt);
+        if (hipMemcpy(hk.data(), d_ek + rg[0], cnt * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(ho.data(), d_outc + rg[0], cnt, hipMemcpyDeviceToHost) != hipSuccess) { lookup_err = 1; return; }
+        for (uint64_t i = 0; i < cnt; i++)
+            if (ho[i] == MO_JUMP || ho[i] == MO_ACCEPT) jumps.push_back({hk[i] >> 4, (uint32_t)(hk[i] & 15u), ho[i] == MO_ACCEPT ? 1u : 0u});
     }
-    // was probe t visited, given the jumps recorded so far?
-    bool examined(uint64_t t) const {
-        // only the latest jump before t can still cover it (jumps are skip probes long, and recorded in order)
-        const std::vector<Jump> *v = list_for(t, false);
-        if (!v) return true;
-        auto it = std::lower_bound(v->begin(), v->end(), t, jump_lt);     // > begin: the list's first jump is before t
-        --it;
-        return !(block_of(it->t) == block_of(t) && t <= it->t + skip);
+    // was probe t visited?  (only asked for probes before the event being resolved: their outcomes are final)
+    bool examined(uint64_t t) {
+        load_block(t);
+        auto it = std::lower_bound(jumps.begin(), jumps.end(), t, jump_lt);     // first jump at a probe >= t
+        if (it == jumps.begin()) return true;
+        --it;                                        // only the latest jump before t can still cover it
+        return !(t <= it->t + skip);
     }
-    const Jump *jump_at(uint64_t t) const {
-        const std::vector<Jump> *v = list_for(t, true);
-        if (!v) return nullptr;
-        auto it = std::lower_bound(v->begin(), v->end(), t, jump_lt);
-        return (it != v->end() && it->t == t) ? &*it : nullptr;
+    const Jump *jump_at(uint64_t t) {
+        load_block(t);
+        auto it = std::lower_bound(jumps.begin(), jumps.end(), t, jump_lt);
+        return (it != jumps.end() && it->t == t) ? &*it : nullptr;
     }
     // the bucket of a destination window, from the device (rare path)
     int bucket(uint64_t q, uint64_t *pos) {
@@ -443,7 +600,7 @@ struct Replay {
             }
             // previous examined probe
             for (;;) {
-                if (tt == 0) return 0u;              // nothing before: the register still holds its initial 0
+                if (tt == 0 || lookup_err) return 0u; // nothing before: the register still holds its initial 0
                 tt--;
                 if (examined(tt)) break;
             }
@@ -458,7 +615,7 @@ struct Replay {
     uint32_t stale_r2(uint64_t t) {
         uint64_t pos[PGRC_BUCKET_CAP];
         uint64_t tt = t;
-        while (tt > 0) {
+        while (tt > 0 && !lookup_err) {
             tt--;
             if (!examined(tt)) continue;
             const uint64_t q = tt * (uint64_t)m->k2;
@@ -500,11 +657,11 @@ void pgrc_mem_destroy(pgrc_mem_ctx *m) {
     if (!m) return;
     DevBuf *bufs[] = {&m->d_dest, &m->d_nmap, &m->d_stage, &m->d_flag, &m->d_cursor, &m->d_evk[0], &m->d_evk[1], &m->d_evv[0],
                       &m->d_evv[1], &m->d_tmp, &m->d_orun, &m->d_oflag, &m->d_skey[0], &m->d_skey[1], &m->d_sidx[0],
-                      &m->d_sidx[1], &m->d_first, &m->d_runid, &m->d_rstart, &m->d_rend};
+                      &m->d_sidx[1], &m->d_first, &m->d_runid, &m->d_rstart, &m->d_rend, &m->d_rdend, &m->d_outc, &m->d_ebstart,
+                      &m->d_ebin, &m->d_ebout, &m->d_ebinc, &m->d_small, &m->d_match};
     for (DevBuf *b : bufs) pgrc_buf_free(*b);
     if (m->have_ev)
         for (auto &x : m->ev) (void)hipEventDestroy(x);
-    for (pgrc_mem_ctx::HostBuf *h : {&m->h_key, &m->h_pos, &m->h_run, &m->h_rstart, &m->h_rend, &m->h_flag}) host_release(*h);
     pgrc_match_destroy(m->base);
     delete m;
 }
@@ -641,303 +798,181 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     }
     (void)hipEventRecord(ev[1], c->stream);
     m->ctr.events = nev;
-    if ((e = host_ensure(m, m->h_key, nev * 8)) || (e = host_ensure(m, m->h_pos, nev * 8)) || (e = host_ensure(m, m->h_run, nev * 4)) ||
-        (e = host_ensure(m, m->h_flag, nev))) { return e; }
-    const uint64_t *hk = (const uint64_t *)m->h_key.p, *hp = (const uint64_t *)m->h_pos.p;
-    const uint32_t *hr = (const uint32_t *)m->h_run.p;          // run of an event; the extents are per run
-    const uint64_t *hrs = nullptr, *hre = nullptr;
-    const uint8_t *hf = (const uint8_t *)m->h_flag.p;
-    if (nev) {
-        // ---- 2. the order in which the reference meets them: by window, then by bucket order
-        int tb = 1;
-        while ((1ull << tb) < nprobes) tb++;
-        rocprim::double_buffer<uint64_t> keys((uint64_t *)m->d_evk[0].p, (uint64_t *)m->d_evk[1].p);
-        rocprim::double_buffer<uint64_t> vals((uint64_t *)m->d_evv[0].p, (uint64_t *)m->d_evv[1].p);
-        size_t tbytes = 0;
-        hipError_t he = rocprim::radix_sort_pairs(nullptr, tbytes, keys, vals, (size_t)nev, 0, 4 + tb, c->stream);
-        if (he == hipSuccess && (e = pgrc_buf_ensure(c, m->d_tmp, tbytes + 16))) { m->err = c->err; return e; }
-        if (he == hipSuccess) he = rocprim::radix_sort_pairs(m->d_tmp.p, tbytes, keys, vals, (size_t)nev, 0, 4 + tb, c->stream);
-        (void)hipEventRecord(ev[2], c->stream);
-        // ---- 3. side contexts; extents per run of connected events on a diagonal
-        if (nev >= (1ull << 32)) { m->err = "more than 2^32 events"; return PGRC_E_PARAM; }
-        if (he == hipSuccess && ((e = pgrc_buf_ensure(c, m->d_orun, cap * 4)) ||
-                                 (e = pgrc_buf_ensure(c, m->d_oflag, cap)) || (e = pgrc_buf_ensure(c, m->d_first, cap * 4)) ||
-                                 (e = pgrc_buf_ensure(c, m->d_runid, cap * 4)) || (e = pgrc_buf_ensure(c, m->d_rstart, cap * 8)) ||
-                                 (e = pgrc_buf_ensure(c, m->d_rend, cap * 8)))) { m->err = c->err; return e; }
-        for (int k = 0; k < 2 && he == hipSuccess; k++)
-            if ((e = pgrc_buf_ensure(c, m->d_skey[k], cap * 8)) || (e = pgrc_buf_ensure(c, m->d_sidx[k], cap * 8))) { m->err = c->err; return e; }
-        if (he == hipSuccess) {
-            const uint32_t g = (uint32_t)((nev + 255) / 256);
-            const uint64_t *ek = (const uint64_t *)keys.current(), *ep = (const uint64_t *)vals.current();
-            rocprim::double_buffer<uint64_t> sk((uint64_t *)m->d_skey[0].p, (uint64_t *)m->d_skey[1].p);
-            rocprim::double_buffer<uint64_t> si((uint64_t *)m->d_sidx[0].p, (uint64_t *)m->d_sidx[1].p);
-            hipLaunchKernelGGL(k_mem_flags, dim3(g), dim3(256), 0, c->stream, a, ek, ep, (uint64_t)nev, (uint8_t *)m->d_oflag.p, sk.current(), si.current());
-            int qb = 1, db = 1;
-            while ((1ull << qb) < N2) qb++;
-            while ((1ull << db) < N2 + m->N) db++;
-            size_t t1 = 0, t2 = 0, t3 = 0;
-            he = rocprim::radix_sort_pairs(nullptr, t1, sk, si, (size_t)nev, 0, qb, c->stream);
-            if (he == hipSuccess) he = rocprim::radix_sort_pairs(nullptr, t2, sk, si, (size_t)nev, 0, db, c->stream);
-            if (he == hipSuccess) he = rocprim::inclusive_scan(nullptr, t3, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)nev, rocprim::plus<uint32_t>(), c->stream);
-            if (he == hipSuccess && (e = pgrc_buf_ensure(c, m->d_tmp, std::max(std::max(t1, t2), std::max(t3, tbytes)) + 16))) { m->err = c->err; return e; }
-            // stable sorts: by window first, then by diagonal => (diagonal, window)
-            if (he == hipSuccess) he = rocprim::radix_sort_pairs(m->d_tmp.p, t1, sk, si, (size_t)nev, 0, qb, c->stream);
-            if (he == hipSuccess) {
-                hipLaunchKernelGGL(k_mem_diag, dim3(g), dim3(256), 0, c->stream, a, ek, ep, (const uint64_t *)si.current(), (uint64_t)nev, sk.current());
-                he = rocprim::radix_sort_pairs(m->d_tmp.p, t2, sk, si, (size_t)nev, 0, db, c->stream);
-            }
-            if (he == hipSuccess) {
-                const uint64_t *sidx = si.current(), *skey = sk.current();
-                hipLaunchKernelGGL(k_mem_connect, dim3(g), dim3(256), 0, c->stream, a, ek, ep, sidx, skey, (uint64_t)nev, (uint32_t *)m->d_first.p);
-                he = rocprim::inclusive_scan(m->d_tmp.p, t3, (uint32_t *)m->d_first.p, (uint32_t *)m->d_runid.p, (size_t)nev, rocprim::plus<uint32_t>(), c->stream);
-                if (he == hipSuccess) {
-                    hipLaunchKernelGGL(k_mem_run_ends, dim3(g), dim3(256), 0, c->stream, a, ek, ep, sidx, (const uint32_t *)m->d_first.p,
-                                       (const uint32_t *)m->d_runid.p, (uint64_t)nev, (uint64_t *)m->d_rstart.p, (uint64_t *)m->d_rend.p);
-                    hipLaunchKernelGGL(k_mem_apply, dim3(g), dim3(256), 0, c->stream, sidx, (const uint32_t *)m->d_runid.p, (uint64_t)nev,
-                                       (uint32_t *)m->d_orun.p);
-                    he = hipGetLastError();
-                }
-            }
-        }
-        (void)hipEventRecord(ev[3], c->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(m->h_key.p, keys.current(), nev * 8, hipMemcpyDeviceToHost, c->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(m->h_pos.p, vals.current(), nev * 8, hipMemcpyDeviceToHost, c->stream);
-        uint32_t nruns = 0;
-        if (he == hipSuccess) he = hipMemcpyAsync(&nruns, (const uint32_t *)m->d_runid.p + (nev - 1), 4, hipMemcpyDeviceToHost, c->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(m->h_run.p, m->d_orun.p, nev * 4, hipMemcpyDeviceToHost, c->stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-        if (he == hipSuccess && ((e = host_ensure(m, m->h_rstart, (size_t)nruns * 8)) || (e = host_ensure(m, m->h_rend, (size_t)nruns * 8)))) return e;
-        if (he == hipSuccess) he = hipMemcpyAsync(m->h_rstart.p, m->d_rstart.p, (size_t)nruns * 8, hipMemcpyDeviceToHost, c->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(m->h_rend.p, m->d_rend.p, (size_t)nruns * 8, hipMemcpyDeviceToHost, c->stream);
-        hrs = (const uint64_t *)m->h_rstart.p;
-        hre = (const uint64_t *)m->h_rend.p;
-        if (he == hipSuccess) he = hipMemcpyAsync(m->h_flag.p, m->d_oflag.p, nev, hipMemcpyDeviceToHost, c->stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-        if (he != hipSuccess) { m->err = std::string("event passes: ") + hipGetErrorString(he); return PGRC_E_DEVICE; }
-        (void)hipEventElapsedTime(&m->ctr.ms_sort, ev[1], ev[2]);
-        (void)hipEventElapsedTime(&m->ctr.ms_extend, ev[2], ev[3]);
-    } else {
-        (void)hipEventSynchronize(ev[1]);
-    }
+    m->ctr.replay_rounds = m->ctr.event_blocks = 0;
+    m->ctr.ms_sort = m->ctr.ms_extend = m->ctr.ms_replay = m->ctr.ms_host = 0.f;
+    (void)hipEventSynchronize(ev[1]);
     (void)hipEventElapsedTime(&m->ctr.ms_probe, ev[0], ev[1]);
+    if (!nev) return PGRC_OK;
+    if (nev >= 0xFFFFFFF0ull) { m->err = "more than 2^32 events"; return PGRC_E_PARAM; }
 
-    // ---- 4. the sequential rules, over the events only.
-    // The scan is sequential for two reasons: a jump skips the next windows -- but never beyond its block of 256 windows
-    // (main loop), so blocks are independent there -- and rule (b) looks at the LAST match recorded, which carries from
-    // block to block.  The events are therefore cut into chunks at block boundaries and replayed by several host
-    // threads speculatively (incoming last match: none); then the chunks are resolved in order: a chunk whose true
-    // incoming match cannot reach into it (it ends before the chunk's first window) keeps its speculative result, the
-    // others are replayed again with the right incoming state, round after round until nothing changes (one round when
-    // no match straddles a chunk boundary; the chain is at worst sequential).  Chunks holding an event whose side
-    // context lies outside a text (the stale-register walk needs the whole jump history) run in order on one thread.
-    const auto th0 = std::chrono::steady_clock::now();
-    Replay rp;
-    rp.m = m; rp.dest = dest; rp.N2 = N2; rp.dest_is_src = dest_is_src != 0; rp.rev_compl = rev_compl != 0;
-    rp.skip = (uint64_t)(m->K / m->k1 - 1);                                        // :352
+    // ---- 2. the order in which the reference meets them: by window, then by bucket order
+    int tb = 1;
+    while ((1ull << tb) < nprobes) tb++;
+    rocprim::double_buffer<uint64_t> keys((uint64_t *)m->d_evk[0].p, (uint64_t *)m->d_evk[1].p);
+    rocprim::double_buffer<uint64_t> vals((uint64_t *)m->d_evv[0].p, (uint64_t *)m->d_evv[1].p);
+    size_t tbytes = 0;
+    MEM_TRY(m, rocprim::radix_sort_pairs(nullptr, tbytes, keys, vals, (size_t)nev, 0, 4 + tb, c->stream));
+    if ((e = pgrc_buf_ensure(c, m->d_tmp, tbytes + 16))) { m->err = c->err; return e; }
+    MEM_TRY(m, rocprim::radix_sort_pairs(m->d_tmp.p, tbytes, keys, vals, (size_t)nev, 0, 4 + tb, c->stream));
+    (void)hipEventRecord(ev[2], c->stream);
+    const uint64_t *ek = (const uint64_t *)keys.current(), *ep = (const uint64_t *)vals.current();
+
+    // ---- 3. side contexts; extents per run of connected events on a diagonal
+    if ((e = pgrc_buf_ensure(c, m->d_orun, cap * 4)) || (e = pgrc_buf_ensure(c, m->d_oflag, cap)) || (e = pgrc_buf_ensure(c, m->d_first, cap * 4)) ||
+        (e = pgrc_buf_ensure(c, m->d_runid, cap * 4)) || (e = pgrc_buf_ensure(c, m->d_rstart, cap * 8)) || (e = pgrc_buf_ensure(c, m->d_rend, cap * 8)) ||
+        (e = pgrc_buf_ensure(c, m->d_rdend, cap * 8)) || (e = pgrc_buf_ensure(c, m->d_outc, cap)) || (e = pgrc_buf_ensure(c, m->d_small, 64))) { m->err = c->err; return e; }
+    for (int k = 0; k < 2; k++)
+        if ((e = pgrc_buf_ensure(c, m->d_skey[k], cap * 8)) || (e = pgrc_buf_ensure(c, m->d_sidx[k], cap * 8))) { m->err = c->err; return e; }
+    // d_small: [0] "a block was replayed" flag, [1] first stale event, [2] events with a context outside a text, [4..7] two u64 of a range
+    uint32_t *d_changed = (uint32_t *)m->d_small.p, *d_first_stale = d_changed + 1, *d_nstale = d_changed + 2;
+    uint64_t *d_range = (uint64_t *)m->d_small.p + 2;
+    MEM_TRY(m, hipMemsetAsync(m->d_small.p, 0, 64, c->stream));
+    const uint32_t g = (uint32_t)((nev + 255) / 256);
+    size_t t3 = 0;
+    {
+        rocprim::double_buffer<uint64_t> sk((uint64_t *)m->d_skey[0].p, (uint64_t *)m->d_skey[1].p);
+        rocprim::double_buffer<uint64_t> si((uint64_t *)m->d_sidx[0].p, (uint64_t *)m->d_sidx[1].p);
+        hipLaunchKernelGGL(k_mem_flags, dim3(g), dim3(256), 0, c->stream, a, ek, ep, (uint64_t)nev, (uint8_t *)m->d_oflag.p, sk.current(), si.current(), d_nstale);
+        int qb = 1, db = 1;
+        while ((1ull << qb) < N2) qb++;
+        while ((1ull << db) < N2 + m->N) db++;
+        size_t t1 = 0, t2 = 0;
+        MEM_TRY(m, rocprim::radix_sort_pairs(nullptr, t1, sk, si, (size_t)nev, 0, qb, c->stream));
+        MEM_TRY(m, rocprim::radix_sort_pairs(nullptr, t2, sk, si, (size_t)nev, 0, db, c->stream));
+        MEM_TRY(m, rocprim::inclusive_scan(nullptr, t3, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)nev, rocprim::plus<uint32_t>(), c->stream));
+        if ((e = pgrc_buf_ensure(c, m->d_tmp, std::max(std::max(t1, t2), std::max(t3, tbytes)) + 16))) { m->err = c->err; return e; }
+        // stable sorts: by window first, then by diagonal => (diagonal, window)
+        MEM_TRY(m, rocprim::radix_sort_pairs(m->d_tmp.p, t1, sk, si, (size_t)nev, 0, qb, c->stream));
+        hipLaunchKernelGGL(k_mem_diag, dim3(g), dim3(256), 0, c->stream, a, ek, ep, (const uint64_t *)si.current(), (uint64_t)nev, sk.current());
+        MEM_TRY(m, rocprim::radix_sort_pairs(m->d_tmp.p, t2, sk, si, (size_t)nev, 0, db, c->stream));
+        const uint64_t *sidx = si.current(), *skey = sk.current();
+        hipLaunchKernelGGL(k_mem_connect, dim3(g), dim3(256), 0, c->stream, a, ek, ep, sidx, skey, (uint64_t)nev, (uint32_t *)m->d_first.p);
+        MEM_TRY(m, rocprim::inclusive_scan(m->d_tmp.p, t3, (uint32_t *)m->d_first.p, (uint32_t *)m->d_runid.p, (size_t)nev, rocprim::plus<uint32_t>(), c->stream));
+        hipLaunchKernelGGL(k_mem_run_ends, dim3(g), dim3(256), 0, c->stream, a, ek, ep, sidx, (const uint32_t *)m->d_first.p,
+                           (const uint32_t *)m->d_runid.p, (uint64_t)nev, (uint64_t *)m->d_rstart.p, (uint64_t *)m->d_rend.p, (uint64_t *)m->d_rdend.p);
+        hipLaunchKernelGGL(k_mem_apply, dim3(g), dim3(256), 0, c->stream, sidx, (const uint32_t *)m->d_runid.p, (uint64_t)nev,
+                           (const uint64_t *)m->d_rstart.p, (const uint64_t *)m->d_rend.p, min_len, (uint32_t *)m->d_orun.p, (uint8_t *)m->d_oflag.p);
+        MEM_TRY(m, hipGetLastError());
+    }
+    (void)hipEventRecord(ev[3], c->stream);
+
+    // ---- 4. the sequential rules on the device (k_mem_replay)
+    uint64_t nmain;
     {   // main loop: blocks of 256 windows while i1 + K + 256 * k2 < N2 + 1 (:365)
         const uint64_t block = 256 * k2;
         const uint64_t lim = N2 + 1;                                               // i1 + K + block < lim
         uint64_t nb = 0;
         if (lim > K + block) nb = (lim - K - block + block - 1) / block;
-        rp.nmain = nb * 256;
+        nmain = nb * 256;
     }
-    struct ChunkRun {
-        uint64_t i0 = 0, i1 = 0;
-        bool barrier = false;                    // holds an event that may need the stale-register walk: sequential only
-        std::vector<pgrc_text_match> res;
-        std::vector<Replay::Jump> jumps;
-        bool in_have = false, out_have = false;  // incoming match this run assumed / last match recorded inside the chunk
-        pgrc_text_match in_last{0, 0, 0}, out_last{0, 0, 0};
+    uint32_t *d_lead = (uint32_t *)m->d_first.p, *d_lid = (uint32_t *)m->d_runid.p;      // (free again: the runs are numbered)
+    hipLaunchKernelGGL(k_mem_lead, dim3(g), dim3(256), 0, c->stream, ek, (uint64_t)nev, nmain, d_lead);
+    MEM_TRY(m, rocprim::inclusive_scan(m->d_tmp.p, t3, d_lead, d_lid, (size_t)nev, rocprim::plus<uint32_t>(), c->stream));
+    uint32_t neb = 0, nstale = 0;
+    MEM_TRY(m, hipMemcpyAsync(&neb, d_lid + (nev - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    MEM_TRY(m, hipMemcpyAsync(&nstale, d_nstale, 4, hipMemcpyDeviceToHost, c->stream));
+    MEM_TRY(m, hipStreamSynchronize(c->stream));
+    m->ctr.event_blocks = neb;
+    if ((e = pgrc_buf_ensure(c, m->d_ebstart, ((size_t)neb + 1) * 4)) || (e = pgrc_buf_ensure(c, m->d_ebin, (size_t)neb * 4)) ||
+        (e = pgrc_buf_ensure(c, m->d_ebout, (size_t)neb * 4)) || (e = pgrc_buf_ensure(c, m->d_ebinc, (size_t)neb * 4))) { m->err = c->err; return e; }
+    hipLaunchKernelGGL(k_mem_eb_start, dim3(g), dim3(256), 0, c->stream, (const uint32_t *)d_lead, (const uint32_t *)d_lid, (uint64_t)nev, (uint32_t *)m->d_ebstart.p);
+    size_t t4 = 0;
+    MEM_TRY(m, rocprim::exclusive_scan(nullptr, t4, (uint32_t *)nullptr, (uint32_t *)nullptr, MR_NONE, (size_t)neb, MemLastValid(), c->stream));
+    if (t4 + 16 > m->d_tmp.bytes && (e = pgrc_buf_ensure(c, m->d_tmp, t4 + 16))) { m->err = c->err; return e; }
+    MemReplayArgs ra;
+    ra.ek = ek;
+    ra.orun = (const uint32_t *)m->d_orun.p;
+    ra.oflag = (const uint8_t *)m->d_oflag.p;
+    ra.outc = (uint8_t *)m->d_outc.p;
+    ra.run_dend = (const uint64_t *)m->d_rdend.p;
+    ra.eb_start = (const uint32_t *)m->d_ebstart.p;
+    ra.eb_in = (uint32_t *)m->d_ebin.p;
+    ra.eb_out = (uint32_t *)m->d_ebout.p;
+    ra.eb_inc = (const uint32_t *)m->d_ebinc.p;
+    ra.neb = neb;
+    ra.K = (uint32_t)K;
+    ra.k2 = (uint32_t)k2;
+    ra.skip = (uint32_t)(m->K / m->k1 - 1);                                            // :352
+    ra.changed = d_changed;
+    ra.first = 1;
+    const uint32_t gb = (neb + MEM_RP_WAVES - 1) / MEM_RP_WAVES;
+    hipLaunchKernelGGL(k_mem_replay, dim3(gb), dim3(64 * MEM_RP_WAVES), 0, c->stream, ra);
+    m->ctr.replay_rounds = 1;
+    ra.first = 0;
+    // rounds until no block's incoming match differs from what it assumed
+    auto settle = [&]() -> int {
+        for (;;) {
+            uint32_t changed = 0;
+            MEM_TRY(m, rocprim::exclusive_scan(m->d_tmp.p, t4, (uint32_t *)m->d_ebout.p, (uint32_t *)m->d_ebinc.p, MR_NONE, (size_t)neb, MemLastValid(), c->stream));
+            MEM_TRY(m, hipMemsetAsync(d_changed, 0, 4, c->stream));
+            hipLaunchKernelGGL(k_mem_replay, dim3(gb), dim3(64 * MEM_RP_WAVES), 0, c->stream, ra);
+            MEM_TRY(m, hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
+            MEM_TRY(m, hipStreamSynchronize(c->stream));
+            if (!changed) return PGRC_OK;
+            m->ctr.replay_rounds++;
+        }
     };
-    // events [i0, i1) with the incoming last match `in`; seq: the run may meet stale events and then walks the jump
-    // history of everything before the chunk (rp.hist) and its own jumps so far (rp.cur)
-    auto replay_chunk = [&](ChunkRun &ck, bool in_have, const pgrc_text_match &in, bool seq) -> int {
-        ck.res.clear();
-        ck.jumps.clear();
-        ck.in_have = in_have;
-        ck.in_last = in;
-        ck.out_have = false;
-        std::vector<Replay::Jump> &jumps = ck.jumps;
-        if (seq) rp.cur = &ck.jumps;
-        bool have_last = in_have;
-        pgrc_text_match last = in;
-        uint64_t i = ck.i0;
-        while (i < ck.i1) {
-            const uint64_t t = hk[i] >> 4;
-            uint64_t jend = i;
-            while (jend < ck.i1 && (hk[jend] >> 4) == t) jend++;
-            // probes come in ascending order and a chunk starts with a new block: only the chunk's own latest jump can
-            // still cover this one (Replay::examined, the general form, is for the walk-back of the stale registers)
-            const bool visited = jumps.empty() || !(rp.block_of(jumps.back().t) == rp.block_of(t) && t <= jumps.back().t + rp.skip);
-            if (visited) {
-                const uint64_t q = t * k2;
-                for (uint64_t x = i; x < jend; x++) {
-                    const uint64_t p = hp[x];
-                    const uint32_t order = (uint32_t)(hk[x] & 15u);
-                    // (b) the window lies inside the previous match, on its diagonal (:393-399)
-                    if (have_last && q - p == last.pos_dest - last.pos_src && q + K < last.pos_dest + last.length) {
-                        jumps.push_back({t, order, 0u});
-                        break;
-                    }
-                    // (c) side contexts (:401-404); registers whose 4 bytes lie outside a text keep their previous value
-                    const uint32_t fl = hf[x];
-                    bool pass;
-                    if ((fl & 15u) == 15u) {
-                        pass = (fl & (MF_L_EQ | MF_R_EQ)) != 0;
-                    } else {
-                        if (!seq) return -1;             // (cannot happen: such chunks are barriers)
-                        m->ctr.stale_lookups++;
-                        const uint32_t l1 = (fl & MF_L1_OK) ? le32(m->src + p - m->LK2) : rp.stale_src_reg(true, t, order);
-                        const uint32_t r1 = (fl & MF_R1_OK) ? le32(m->src + p + m->KLK24) : rp.stale_src_reg(false, t, order);
-                        const uint32_t l2 = (fl & MF_L2_OK) ? le32(dest + q - m->LK2) : 0u;   // windows below LK2 come first: still the initial 0
-                        const uint32_t r2 = (fl & MF_R2_OK) ? le32(dest + q + m->KLK24) : rp.stale_r2(t);
-                        pass = r1 == r2 || l1 == l2;
-                        if (rp.lookup_err) return -2;
-                    }
-                    if (!pass) continue;
-                    // (d) long enough?  right - p1 > minMatchLength with right - p1 = length + 1 (:413)
-                    const uint64_t mstart = hrs[hr[x]], mlen = hre[hr[x]] - mstart;
-                    if (mlen + 1 > (uint64_t)min_len) {
-                        last.pos_src = mstart;
-                        last.length = mlen;
-                        last.pos_dest = q - (p - mstart);
-                        have_last = true;
-                        ck.out_have = true;
-                        ck.out_last = last;
-                        ck.res.push_back(last);
-                        jumps.push_back({t, order, 1u});
-                        break;
-                    }
-                }
-            }
-            i = jend;
-        }
-        return 0;
-    };
-    // chunks: cut where the block of 256 windows changes
-    std::vector<ChunkRun> chunks;
-    {
-        unsigned hw = std::thread::hardware_concurrency();
-        const char *knob = getenv("PGRC_MEM_REPLAY_THREADS");                         // test / A-B knob (1 = one sequential chunk)
-        const uint64_t nthreads = knob ? (uint64_t)std::max(1, atoi(knob)) : std::min<uint64_t>(16, hw ? hw : 1);
-        const char *cknob = getenv("PGRC_MEM_REPLAY_CHUNK");                          // test knob: events per chunk
-        const uint64_t target = cknob ? (uint64_t)std::max(1, atoi(cknob))
-                                      : (nthreads <= 1 || nev < 200000 ? nev + 1 : std::max<uint64_t>(50000, nev / (4 * nthreads)));
-        uint64_t i0 = 0;
-        while (i0 < nev) {
-            uint64_t i1 = std::min<uint64_t>(nev, i0 + target);
-            while (i1 < nev && rp.block_of(hk[i1] >> 4) == rp.block_of(hk[i1 - 1] >> 4)) i1++;
-            ChunkRun ck;
-            ck.i0 = i0;
-            ck.i1 = i1;
-            chunks.push_back(std::move(ck));
-            i0 = i1;
-        }
-        const bool single = chunks.size() <= 1;
-        // run `ids` on the thread pool; a chunk is first scanned for stale-capable events (those make it a barrier)
-        auto run_parallel = [&](const std::vector<size_t> &ids, const std::vector<std::pair<bool, pgrc_text_match>> &inc) {
-            std::atomic<size_t> next{0};
-            auto worker = [&]() {
-                for (;;) {
-                    const size_t w = next.fetch_add(1);
-                    if (w >= ids.size()) break;
-                    ChunkRun &ck = chunks[ids[w]];
-                    (void)replay_chunk(ck, inc[w].first, inc[w].second, false);
-                }
-            };
-            const size_t nt = std::min<size_t>(nthreads, ids.size());
-            std::vector<std::thread> th;
-            for (size_t k = 1; k < nt; k++) th.emplace_back(worker);
-            worker();
-            for (auto &t : th) t.join();
-        };
-        if (single) {
-            for (ChunkRun &ck : chunks) ck.barrier = true;
-        } else {
-            // barriers: any event whose four side contexts are not all inside the texts
-            std::atomic<size_t> next{0};
-            auto scan = [&]() {
-                for (;;) {
-                    const size_t w = next.fetch_add(1);
-                    if (w >= chunks.size()) break;
-                    ChunkRun &ck = chunks[w];
-                    for (uint64_t x = ck.i0; x < ck.i1; x++)
-                        if ((hf[x] & 15u) != 15u) { ck.barrier = true; break; }
-                }
-            };
-            {
-                std::vector<std::thread> th;
-                for (size_t k = 1; k < std::min<size_t>(nthreads, chunks.size()); k++) th.emplace_back(scan);
-                scan();
-                for (auto &t : th) t.join();
-            }
-            std::vector<size_t> ids;
-            for (size_t k = 0; k < chunks.size(); k++)
-                if (!chunks[k].barrier) ids.push_back(k);
-            run_parallel(ids, std::vector<std::pair<bool, pgrc_text_match>>(ids.size(), {false, pgrc_text_match{0, 0, 0}}));
-        }
-        // resolve in order
-        auto reaches = [&](bool have, const pgrc_text_match &l, const ChunkRun &ck) {
-            return have && (hk[ck.i0] >> 4) * k2 + K < l.pos_dest + l.length;   // rule (b) could fire inside the chunk
-        };
-        auto same = [](bool ha, const pgrc_text_match &a, bool hb, const pgrc_text_match &b) {
-            return ha == hb && (!ha || (a.pos_src == b.pos_src && a.length == b.length && a.pos_dest == b.pos_dest));
-        };
-        bool cur_have = false;
-        pgrc_text_match cur{0, 0, 0};
-        size_t k = 0;
-        while (k < chunks.size()) {
-            if (chunks[k].barrier) {
-                const int rcx = replay_chunk(chunks[k], cur_have, cur, true);
-                rp.cur = nullptr;
-                if (rcx) { m->err = "bucket lookup failed"; return PGRC_E_DEVICE; }
-                if (!chunks[k].jumps.empty()) rp.hist.push_back(&chunks[k].jumps);
-                if (chunks[k].out_have) { cur_have = true; cur = chunks[k].out_last; }
-                k++;
-                continue;
-            }
-            size_t k2e = k;
-            while (k2e < chunks.size() && !chunks[k2e].barrier) k2e++;
-            for (;;) {      // rounds over [k, k2e)
-                std::vector<size_t> ids;
-                std::vector<std::pair<bool, pgrc_text_match>> inc;
-                bool h = cur_have;
-                pgrc_text_match l = cur;
-                for (size_t x = k; x < k2e; x++) {
-                    const bool eh = reaches(h, l, chunks[x]);
-                    if (!same(eh, l, chunks[x].in_have, chunks[x].in_last)) {
-                        ids.push_back(x);
-                        inc.push_back({eh, eh ? l : pgrc_text_match{0, 0, 0}});
-                    }
-                    if (chunks[x].out_have) { h = true; l = chunks[x].out_last; }
-                }
-                if (ids.empty()) {
-                    cur_have = h;
-                    cur = l;
-                    break;
-                }
-                run_parallel(ids, inc);
-            }
-            for (size_t x = k; x < k2e; x++)
-                if (!chunks[x].jumps.empty()) rp.hist.push_back(&chunks[x].jumps);
-            k = k2e;
-        }
+    if ((e = settle())) return e;
+    // events whose registers are stale, in order: the first one reached is decided on the host, then the replay goes on
+    while (nstale) {
+        uint32_t x = MR_NONE;
+        MEM_TRY(m, hipMemsetAsync(d_first_stale, 0xFF, 4, c->stream));
+        hipLaunchKernelGGL(k_mem_first_stale, dim3((uint32_t)std::min<uint64_t>((nev + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                           (const uint8_t *)m->d_outc.p, (uint64_t)nev, d_first_stale);
+        MEM_TRY(m, hipMemcpyAsync(&x, d_first_stale, 4, hipMemcpyDeviceToHost, c->stream));
+        MEM_TRY(m, hipStreamSynchronize(c->stream));
+        if (x == MR_NONE) break;
+        uint64_t key = 0, p = 0;
+        uint8_t fl8 = 0;
+        MEM_TRY(m, hipMemcpy(&key, ek + x, 8, hipMemcpyDeviceToHost));
+        MEM_TRY(m, hipMemcpy(&p, ep + x, 8, hipMemcpyDeviceToHost));
+        MEM_TRY(m, hipMemcpy(&fl8, (const uint8_t *)m->d_oflag.p + x, 1, hipMemcpyDeviceToHost));
+        StaleWalk sw;
+        sw.m = m; sw.dest = dest; sw.N2 = N2; sw.dest_is_src = dest_is_src != 0; sw.rev_compl = rev_compl != 0;
+        sw.skip = ra.skip; sw.nmain = nmain; sw.d_ek = ek; sw.d_outc = (const uint8_t *)m->d_outc.p; sw.nev = nev; sw.d_range = d_range;
+        const uint64_t t = key >> 4, q = t * k2;
+        const uint32_t order = (uint32_t)(key & 15u), fl = fl8;
+        m->ctr.stale_lookups++;
+        // (c) with the registers as the reference holds them (:401-404)
+        const uint32_t l1 = (fl & MF_L1_OK) ? le32(m->src + p - m->LK2) : sw.stale_src_reg(true, t, order);
+        const uint32_t r1 = (fl & MF_R1_OK) ? le32(m->src + p + m->KLK24) : sw.stale_src_reg(false, t, order);
+        const uint32_t l2 = (fl & MF_L2_OK) ? le32(dest + q - m->LK2) : 0u;   // windows below LK2 come first: still the initial 0
+        const uint32_t r2 = (fl & MF_R2_OK) ? le32(dest + q + m->KLK24) : sw.stale_r2(t);
+        if (sw.lookup_err) { m->err = "bucket lookup failed"; return PGRC_E_DEVICE; }
+        hipLaunchKernelGGL(k_mem_resolve, dim3(1), dim3(1), 0, c->stream, x, (r1 == r2 || l1 == l2) ? 1 : 0, (uint8_t *)m->d_oflag.p,
+                           (const uint32_t *)d_lid, (uint32_t *)m->d_ebin.p);
+        if ((e = settle())) return e;
     }
-    std::vector<pgrc_text_match> res;
-    {
-        size_t total = 0;
-        for (const ChunkRun &ck : chunks) total += ck.res.size();
-        res.reserve(total);
-        for (const ChunkRun &ck : chunks) res.insert(res.end(), ck.res.begin(), ck.res.end());
-    }
-    m->ctr.ms_host = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - th0).count();
-    if (!res.empty()) {
-        pgrc_text_match *outp = (pgrc_text_match *)malloc(res.size() * sizeof(pgrc_text_match));
+    (void)hipEventRecord(ev[4], c->stream);
+
+    // ---- 5. the matches, in discovery order
+    const auto th0 = std::chrono::steady_clock::now();
+    uint32_t *d_slot = (uint32_t *)m->d_first.p;                                       // (the block leaders are not needed any more)
+    auto acc_in = rocprim::make_transform_iterator((const uint8_t *)m->d_outc.p, MemIsAccept());
+    size_t t5 = 0;
+    MEM_TRY(m, rocprim::inclusive_scan(nullptr, t5, acc_in, d_slot, (size_t)nev, rocprim::plus<uint32_t>(), c->stream));
+    if (t5 + 16 > m->d_tmp.bytes && (e = pgrc_buf_ensure(c, m->d_tmp, t5 + 16))) { m->err = c->err; return e; }
+    MEM_TRY(m, rocprim::inclusive_scan(m->d_tmp.p, t5, acc_in, d_slot, (size_t)nev, rocprim::plus<uint32_t>(), c->stream));
+    uint32_t nmatch = 0;
+    MEM_TRY(m, hipMemcpyAsync(&nmatch, d_slot + (nev - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    MEM_TRY(m, hipStreamSynchronize(c->stream));
+    if (nmatch) {
+        if ((e = pgrc_buf_ensure(c, m->d_match, (size_t)nmatch * sizeof(pgrc_text_match)))) { m->err = c->err; return e; }
+        hipLaunchKernelGGL(k_mem_emit, dim3(g), dim3(256), 0, c->stream, ek, ep, (const uint32_t *)m->d_orun.p, (const uint8_t *)m->d_outc.p,
+                           (const uint32_t *)d_slot, (uint64_t)nev, (uint32_t)k2, (const uint64_t *)m->d_rstart.p, (const uint64_t *)m->d_rend.p,
+                           (pgrc_text_match *)m->d_match.p);
+        pgrc_text_match *outp = (pgrc_text_match *)malloc((size_t)nmatch * sizeof(pgrc_text_match));
         if (!outp) { m->err = "out of host memory"; return PGRC_E_ALLOC; }
-        memcpy(outp, res.data(), res.size() * sizeof(pgrc_text_match));
+        hipError_t he = hipMemcpyAsync(outp, m->d_match.p, (size_t)nmatch * sizeof(pgrc_text_match), hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) { free(outp); m->err = std::string("match download: ") + hipGetErrorString(he); return PGRC_E_DEVICE; }
         *matches = outp;
     }
-    *count = res.size();
+    *count = nmatch;
+    (void)hipEventElapsedTime(&m->ctr.ms_sort, ev[1], ev[2]);
+    (void)hipEventElapsedTime(&m->ctr.ms_extend, ev[2], ev[3]);
+    (void)hipEventElapsedTime(&m->ctr.ms_replay, ev[3], ev[4]);                       // (with the host's part between the rounds)
+    m->ctr.ms_host = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - th0).count();
     return PGRC_OK;
 }
 

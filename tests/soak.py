@@ -100,12 +100,6 @@ def main():
         min_len = target + int(rng.integers(0, 2)) * int(rng.integers(0, 40))
         mseed = int(rng.integers(0, 1 << 30))
         src, other = mem_sweep_texts(mseed, target)
-        if rng.random() < 0.6:      # the parallel replay with small chunks (the default only cuts above 200 k events)
-            os.environ["PGRC_MEM_REPLAY_CHUNK"] = str(int(rng.choice([1, 10, 100, 1000])))
-            os.environ["PGRC_MEM_REPLAY_THREADS"] = str(int(rng.integers(1, 9)))
-        else:
-            os.environ.pop("PGRC_MEM_REPLAY_CHUNK", None)
-            os.environ.pop("PGRC_MEM_REPLAY_THREADS", None)
         m = CopMEMMatcher(src, target)
         for dis, rc in ((0, 1), (1, 1), (0, 0), (1, 0)):
             d = orc.mem_dest(src, other, dis, rc)

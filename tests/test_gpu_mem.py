@@ -74,7 +74,7 @@ def test_mem_matches_touching_the_text_ends_and_stale_registers():
         assert np.array_equal(g, orc.oracle_mem_match(src, d, dest_is_src, rev_compl)), (dest_is_src, rev_compl)
         if HAVE_REF:
             assert np.array_equal(g, orc.ref_mem_match(src, d, dest_is_src, rev_compl)), (dest_is_src, rev_compl)
-    assert stale > 0        # the host-side register emulation was exercised
+    assert stale > 0        # the host-side register emulation was exercised (between rounds of the device replay)
 
 
 @pytest.mark.skipif(not HAVE_REF, reason="needs oracle/_ref")
@@ -114,18 +114,31 @@ def test_mem_long_matches():
             assert np.array_equal(g, orc.ref_mem_match(src, d, dest_is_src, rev_compl))
 
 
-@pytest.mark.parametrize("chunk,threads", [(1, 4), (37, 3), (500, 8), (5000, 2)])
-def test_mem_parallel_replay_of_the_sequential_rules(monkeypatch, chunk, threads):
-    """The host replay cuts the events into chunks at block boundaries, replays them speculatively on several threads and
-    resolves the last-match dependency in rounds (mem.hip, step 4).  Tiny chunks force every path on small inputs: long
-    matches that straddle many chunks (rounds), texts with stale-register events (barrier chunks), low complexity."""
-    monkeypatch.setenv("PGRC_MEM_REPLAY_CHUNK", str(chunk))
-    monkeypatch.setenv("PGRC_MEM_REPLAY_THREADS", str(threads))
+def test_mem_replay_rounds_on_the_device():
+    """The sequential rules run on the device, one thread per block of 256 windows, in rounds until every block has seen the
+    last match recorded before it (mem.hip, step 4).  One long copy makes every block after the first record the match
+    again in round 0 and take rule (b) in round 1; matches that straddle a block boundary cost their successor a replay."""
+    from pgrc_amd import CopMEMMatcher
+    rng = np.random.default_rng(91)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    src = rng.choice(acgt, size=400000)
+    other = rng.choice(acgt, size=300000)
+    other[1000:201000] = src[100000:300000]                    # a 200 kbp copy: 260 blocks of 768 symbols
+    for k in range(300):                                        # and 300 short ones, many across a block boundary
+        d = 201500 + k * 320
+        other[d:d + 300] = src[k * 300: k * 300 + 300]
+    m = CopMEMMatcher(src, 45)
+    g = m.matchTexts(other, False, False)
+    c = m.counters()
+    assert np.array_equal(g, orc.oracle_mem_match(src, other, 0, 0))
+    if HAVE_REF:
+        assert np.array_equal(g, orc.ref_mem_match(src, other, 0, 0))
+    assert c["event_blocks"] > 300 and c["replay_rounds"] >= 2, c
+    assert len(g) >= 300 and int(g[:, 1].max()) >= 199000
+    m.close()
     for seed, with_n, lowc in ((0, False, False), (1, True, True), (2, False, True)):
         src, other = make_pair(seed, with_n=with_n, low_complexity=lowc)
-        assert check(src, other, what=f"chunk {chunk} seed {seed}") > 100
-    test_mem_long_matches()
-    test_mem_matches_touching_the_text_ends_and_stale_registers()
+        assert check(src, other, what=f"seed {seed}") > 100
 
 
 def test_mem_event_buffer_regrows(monkeypatch):
