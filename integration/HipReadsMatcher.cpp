@@ -30,10 +30,17 @@
 #include "readsset/PackedConstantLengthReadsSet.h"
 
 #include <chrono>
+#include <omp.h>
+#include <thread>
 #include <parallel/algorithm>
 
+// what an export call of the library returned, freed with the object
 struct pgrc_export_streams_view {
-    const pgrc_export_streams *s;
+    pgrc_export_streams s;
+    pgrc_export_streams_view() { memset(&s, 0, sizeof s); }
+    ~pgrc_export_streams_view() { pgrc_match_free_export(&s); }
+    pgrc_export_streams_view(const pgrc_export_streams_view &) = delete;
+    pgrc_export_streams_view &operator=(const pgrc_export_streams_view &) = delete;
 };
 
 namespace {
@@ -318,17 +325,34 @@ namespace PgTools {
         return true;
     }
 
-    // what writeReadEntry (SeparatedPseudoGenomePersistence.cpp:961-989) appends entry by entry, as whole streams
+    // Makes [src, src + bytes) the CONTENTS of a string stream of the builder without copying it: libstdc++'s
+    // basic_stringbuf::setbuf(s, n) adopts the external array as the buffer, n characters long (its str() returns them and
+    // a later write grows into a string of its own).  GCC's documented extension -- PgRC builds with GCC only, it sorts
+    // with __gnu_parallel.  The array must outlive the stream.  A stream that already holds something, or is not a string
+    // stream, gets an ordinary write.  (Written entry by entry, or as one block, a stream of a C3-size export grows by
+    // doubling and copies itself as it goes: 0.5 s for the 1.4 GB of the six streams.)
+    static void adoptAsContents(std::ostream *dest, const void *src, uint64_t bytes) {
+        auto *oss = dynamic_cast<std::ostringstream *>(dest);
+        if (!oss || bytes == 0 || oss->tellp() != std::streampos(0)) {
+            dest->write((const char *) src, (std::streamsize) bytes);
+            return;
+        }
+        oss->rdbuf()->pubsetbuf(const_cast<char *>((const char *) src), (std::streamsize) bytes);
+        oss->seekp(0, std::ios_base::end);
+    }
+
+    // what writeReadEntry (SeparatedPseudoGenomePersistence.cpp:961-989) appends entry by entry, as whole streams; the
+    // builder's streams READ FROM `v` until the builder is deleted
     void HipReadsMatcher::appendStreams(SeparatedPseudoGenomeOutputBuilder *builder, const pgrc_export_streams_view &v) {
-        const pgrc_export_streams &s = *v.s;
-        builder->rlOffDest->write((const char *) s.off, (std::streamsize) (s.n_entries * s.off_width));
-        builder->rlOrgIdxDest->write((const char *) s.org_idx, (std::streamsize) (s.n_entries * sizeof(uint_reads_cnt_std)));
+        const pgrc_export_streams &s = v.s;
+        adoptAsContents(builder->rlOffDest, s.off, s.n_entries * s.off_width);
+        adoptAsContents(builder->rlOrgIdxDest, s.org_idx, s.n_entries * sizeof(uint_reads_cnt_std));
         if (!builder->disableRevComp)
-            builder->rlRevCompDest->write((const char *) s.rev_comp, (std::streamsize) s.n_entries);
+            adoptAsContents(builder->rlRevCompDest, s.rev_comp, s.n_entries);
         if (!builder->disableMismatches) {
-            builder->rlMisCntDest->write((const char *) s.mis_cnt, (std::streamsize) s.n_entries);
-            builder->rlMisSymDest->write((const char *) s.mis_sym, (std::streamsize) s.n_mismatches);
-            builder->rlMisRevOffDest->write((const char *) s.mis_rev_off, (std::streamsize) (s.n_mismatches * s.off_width));
+            adoptAsContents(builder->rlMisCntDest, s.mis_cnt, s.n_entries);
+            adoptAsContents(builder->rlMisSymDest, s.mis_sym, s.n_mismatches);
+            adoptAsContents(builder->rlMisRevOffDest, s.mis_rev_off, s.n_mismatches * s.off_width);
         }
         builder->readsCounter += s.n_entries;
         builder->lastWrittenPos = s.last_pos;
@@ -339,36 +363,89 @@ namespace PgTools {
     // (parallel_algorithm::sort = __gnu_parallel::sort, sequential std::sort below its size / thread thresholds) on
     // (position, index) pairs, compared by position alone, sees the same outcome for every comparison it makes and so
     // moves its elements the same way: the same permutation, ties included, without the comparator's random accesses.
+    // (The size of an element does not enter the algorithm either -- introsort's and the multiway merge's thresholds count
+    // elements --, so positions below 2^32 are sorted as 8-byte (position, index) records: less memory to move.)
+    namespace {
+        template<typename P>
+        void sortedByPosition(const vector<uint64_t> &readMatchPos, const std::vector<uint64_t> &first, uint64_t m,
+                              std::vector<uint32_t> &order) {
+            struct PosIdx { P pos; uint32_t idx; };                  // (no constructor: the array is not filled twice)
+            const uint64_t n = readMatchPos.size();
+            const int T = (int) first.size() - 1;
+            std::unique_ptr<PosIdx[]> byPos(new PosIdx[m ? m : 1]);
+            {
+                PhaseLog log("  sort: (position, read) pairs");
+                #pragma omp parallel num_threads(T)
+                {
+                    const int t = omp_get_thread_num();
+                    const uint64_t lo = n * t / T, hi = n * (t + 1) / T;
+                    uint64_t at = first[t];
+                    for (uint64_t i = lo; i < hi; i++)
+                        if (readMatchPos[i] != DefaultReadsMatcher::NOT_MATCHED_POSITION) {
+                            byPos[at].pos = (P) readMatchPos[i];
+                            byPos[at].idx = (uint32_t) i;
+                            at++;
+                        }
+                }
+            }
+            {
+                PhaseLog log("  sort: the reference's sort");
+                __gnu_parallel::sort(byPos.get(), byPos.get() + m,
+                                     [](const PosIdx &a, const PosIdx &b) -> bool { return a.pos < b.pos; });
+            }
+            PhaseLog log("  sort: order array");
+            order.resize(m);
+            #pragma omp parallel for schedule(static)
+            for (uint64_t k = 0; k < m; k++) order[k] = byPos[k].idx;
+        }
+    }
+
     void HipReadsMatcher::positionOrder(const vector<uint64_t> &readMatchPos, uint_reads_cnt_max matchedReadsCount,
                                         std::vector<uint32_t> &order) {
-        typedef std::pair<uint64_t, uint_reads_cnt_max> PosIdx;
-        std::vector<PosIdx> byPos;
-        byPos.reserve(matchedReadsCount);
-        const uint_reads_cnt_max n = readMatchPos.size();
-        for (uint_reads_cnt_max i = 0; i < n; i++)
-            if (readMatchPos[i] != NOT_MATCHED_POSITION)
-                byPos.emplace_back(readMatchPos[i], i);
-        __gnu_parallel::sort(byPos.begin(), byPos.end(),
-                             [](const PosIdx &a, const PosIdx &b) -> bool { return a.first < b.first; });
-        order.resize(byPos.size());
-        for (size_t k = 0; k < byPos.size(); k++) order[k] = byPos[k].second;
+        // the matched reads in index order -- what the reference's serial loop collects (:567-571) -- made by all threads:
+        // matched reads per slice (and the largest position), slice offsets, every slice written at its offset
+        const uint64_t n = readMatchPos.size();
+        const int T = std::max(1, omp_get_max_threads());
+        std::vector<uint64_t> first((size_t) T + 1, 0), top((size_t) T, 0);
+        #pragma omp parallel num_threads(T)
+        {
+            const int t = omp_get_thread_num();
+            const uint64_t lo = n * t / T, hi = n * (t + 1) / T;
+            uint64_t cnt = 0, mx = 0;
+            for (uint64_t i = lo; i < hi; i++)
+                if (readMatchPos[i] != NOT_MATCHED_POSITION) {
+                    cnt++;
+                    mx = std::max<uint64_t>(mx, readMatchPos[i]);
+                }
+            first[t + 1] = cnt;
+            top[t] = mx;
+        }
+        for (int k = 0; k < T; k++) first[k + 1] += first[k];
+        (void) matchedReadsCount;
+        if (*std::max_element(top.begin(), top.end()) <= UINT32_MAX)
+            sortedByPosition<uint32_t>(readMatchPos, first, first[T], order);
+        else
+            sortedByPosition<uint64_t>(readMatchPos, first, first[T], order);
     }
 
     // everything of the Pg-order export that precedes the builder's own build / compressedBuild: the order of the matched
     // reads, then the merged streams from the device, appended to `builder`
-    void HipReadsMatcher::makePgOrderStreams(SeparatedPseudoGenome *sPg, IndexesMapping *orgIndexesMapping, bool revComplPairFile,
-                                             SeparatedPseudoGenomeOutputBuilder *builder) {
+    std::shared_ptr<void> HipReadsMatcher::makePgOrderStreams(SeparatedPseudoGenome *sPg, IndexesMapping *orgIndexesMapping,
+                                                              bool revComplPairFile, SeparatedPseudoGenomeOutputBuilder *builder) {
         std::vector<uint32_t> order;
         {
             PhaseLog log("export: position sort");
             positionOrder(readMatchPos, matchedReadsCount, order);
         }
-        std::vector<uint32_t> readOrg(readsCount);
-        #pragma omp parallel for
-        for (uint_reads_cnt_max i = 0; i < readsCount; i++)
-            readOrg[i] = orgIndexesMapping->getReadOriginalIndex(i);
-        pgrc_export_streams st;
+        auto st = std::make_shared<pgrc_export_streams_view>();
         PhaseLog log("export: streams from the device");
+        std::vector<uint32_t> readOrg(readsCount);
+        {
+            PhaseLog log2("  streams: original indexes");
+            #pragma omp parallel for
+            for (uint_reads_cnt_max i = 0; i < readsCount; i++)
+                readOrg[i] = orgIndexesMapping->getReadOriginalIndex(i);
+        }
         ExtendedReadsListWithConstantAccessOption *rl = sPg->getReadsList();
         pgrc_export_pg_order_args a;
         a.order = order.data();
@@ -380,10 +457,15 @@ namespace PgTools {
         a.list_count = rl->readsCount;
         a.rev_compl_pair_file = revComplPairFile ? 1 : 0;
         a.byte_per_read_length = PgHelpers::bytePerReadLengthMode ? 1 : 0;
-        failOn(pgrc_match_export_pg_order(ctx, &a, &st), "export_pg_order");
-        pgrc_export_streams_view v{&st};
-        appendStreams(builder, v);
-        pgrc_match_free_export(&st);
+        {
+            PhaseLog log2("  streams: library call");
+            failOn(pgrc_match_export_pg_order(ctx, &a, &st->s), "export_pg_order");
+        }
+        {
+            PhaseLog log2("  streams: append to the builder");
+            appendStreams(builder, *st);
+        }
+        return st;
     }
 
     void HipReadsMatcher::exportMatchesInPgOrderOnDevice(SeparatedPseudoGenome *sPg, ostream &pgrcOut,
@@ -397,7 +479,7 @@ namespace PgTools {
         }
         deviceExports++;
         SeparatedPseudoGenomeOutputBuilder *builder = this->createSeparatedPseudoGenomeOutputBuilder(sPg);
-        makePgOrderStreams(sPg, orgIndexesMapping, revComplPairFile, builder);
+        const std::shared_ptr<void> streams = makePgOrderStreams(sPg, orgIndexesMapping, revComplPairFile, builder);   // (outlives the builder)
         PhaseLog log("export: the reference's stream compression");
         builder->build(outPgPrefix);
         builder->compressedBuild(pgrcOut, compressionLevel);
@@ -444,6 +526,7 @@ namespace PgTools {
         list->orgIdx.clear();
         list->off.clear();
         SeparatedPseudoGenomeOutputBuilder *builder = this->createSeparatedPseudoGenomeOutputBuilder(sPg);
+        pgrc_export_streams_view st;                                     // (outlives the builder, whose streams read from it)
         {
             PhaseLog log("export: entry list and streams from the device");
             pgrc_export_original_order_args a;
@@ -452,11 +535,8 @@ namespace PgTools {
             a.pair_file_mode = pairFileMode ? 1 : 0;
             a.rev_compl_pair_file = revComplPairFile ? 1 : 0;
             a.byte_per_read_length = PgHelpers::bytePerReadLengthMode ? 1 : 0;
-            pgrc_export_streams st;
-            failOn(pgrc_match_export_original_order(ctx, &a, &st), "export_original_order");
-            pgrc_export_streams_view v{&st};
-            appendStreams(builder, v);
-            pgrc_match_free_export(&st);
+            failOn(pgrc_match_export_original_order(ctx, &a, &st.s), "export_original_order");
+            appendStreams(builder, st);
         }
         PhaseLog log("export: the reference's stream compression");
         builder->build(outPgPrefix);
@@ -481,14 +561,45 @@ namespace PgTools {
             getenv("PGRC_NO_STREAM") || !packedHalves(half, sym))
             return false;
         PhaseLog log("streamed hand-over + matching + results");
-        DefaultReadsMatcher::initMatching();
-        readMismatchesCount.assign(readsCount, NOT_MATCHED_COUNT);
+        std::vector<uint8_t> rc;
+        // the result vectors of the reference (initMatching: 0.9 GB filled by one thread at C3 size) are made on two helper
+        // threads while this one hands the pseudogenome over and starts the index builds
+        // (their pages are touched by all threads first -- the fills below then run at memory speed, not at one thread's
+        //  page-fault rate; clear() + insert() of initMatching keep the reserved storage)
+        readMatchPos.clear();
+        readMatchPos.reserve(readsCount);
+        readMismatchesCount.clear();
+        readMismatchesCount.reserve(readsCount);
+        rc.reserve(readsCount);
+        {
+            struct Area { volatile char *p; size_t bytes; } areas[3] = {{(volatile char *) readMatchPos.data(), (size_t) readsCount * sizeof(uint64_t)},
+                                                                       {(volatile char *) readMismatchesCount.data(), (size_t) readsCount},
+                                                                       {(volatile char *) rc.data(), (size_t) readsCount}};
+            for (const Area &ar : areas) {
+                const int64_t pages = (int64_t) ((ar.bytes + 4095) / 4096);
+                #pragma omp parallel for schedule(static)
+                for (int64_t pg = 0; pg < pages; pg++) ar.p[(size_t) pg * 4096] = 0;
+            }
+        }
+        std::thread fillA([&]() { DefaultReadsMatcher::initMatching(); });
+        std::thread fillB([&]() { readMismatchesCount.assign(readsCount, NOT_MATCHED_COUNT); rc.resize(readsCount); });
         uploaded = true;
         deviceReads = readsCount;
-        failOn(pgrc_match_set_pg_ascii(ctx, pgPtr, pgLength), "set_pg_ascii");
-        const bool ahead = pgrc_match_prepare_index(ctx, 1) == PGRC_OK;   // (no room for both indexes: the plain steps below)
+        bool ahead = false;
+        int pgErr;
+        {
+            PhaseLog log2("  library: pseudogenome up, index builds started");
+            pgErr = pgrc_match_set_pg_ascii(ctx, pgPtr, pgLength);
+            if (!pgErr) ahead = pgrc_match_prepare_index(ctx, 1) == PGRC_OK;   // (no room for both indexes: the plain steps below)
+        }
+        {
+            PhaseLog log2("  host: result vectors (the wait for them)");
+            fillA.join();
+            fillB.join();
+        }
+        failOn(pgErr, "set_pg_ascii");
+        PhaseLog log3("  library: reads up, matching, results down (+ strand flags)");
         failOn(pgrc_match_begin_reads(ctx, readsCount), "begin_reads");
-        std::vector<uint8_t> rc(readsCount);
         const bool streamed = ahead && pgrc_match_stream_begin(ctx, readMatchPos.data(), rc.data(), readMismatchesCount.data()) == PGRC_OK;
         appendPackedHalves(half, sym, readsCount);
         failOn(pgrc_match_end_reads(ctx), "end_reads");

@@ -10,6 +10,7 @@
 #define PGTOOLS_HIPREADSMATCHER_H
 
 #include <map>
+#include <memory>
 #include <string>
 
 #include "matching/ReadsMatchers.h"
@@ -93,8 +94,10 @@ namespace PgTools {
         void exportMatchesInOriginalOrderOnDevice(SeparatedPseudoGenome *sPg, ostream &pgrcOut, uint8_t compressionLevel,
                                                   const string &outPgPrefix, IndexesMapping *orgIndexesMapping,
                                                   bool pairFileMode, bool revComplPairFile);
-        void makePgOrderStreams(SeparatedPseudoGenome *sPg, IndexesMapping *orgIndexesMapping, bool revComplPairFile,
-                                SeparatedPseudoGenomeOutputBuilder *builder);
+        // (returns the keeper of the library's stream buffers: the builder's streams read from them, keep it until the
+        //  builder is deleted)
+        std::shared_ptr<void> makePgOrderStreams(SeparatedPseudoGenome *sPg, IndexesMapping *orgIndexesMapping,
+                                                 bool revComplPairFile, SeparatedPseudoGenomeOutputBuilder *builder);
         // exports that took the device path (diagnostics / tests)
         static uint64_t deviceExports;
         // seconds spent per phase of the adapter, summed over calls (diagnostics; PGRC_HIP_TIMING=1 also logs them)

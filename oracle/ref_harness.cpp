@@ -442,7 +442,7 @@ extern "C" int pgrc_ref_stage4(int use_adapter, char *pg, uint64_t G, const uint
         DirectMapping mapping((uint_reads_cnt_max) n);
         t = now();
         SeparatedPseudoGenomeOutputBuilder *builder = m.createSeparatedPseudoGenomeOutputBuilder(&sPg);
-        m.makePgOrderStreams(&sPg, &mapping, false, builder);
+        const std::shared_ptr<void> streams = m.makePgOrderStreams(&sPg, &mapping, false, builder);   // (outlives the builder)
         secs[2] = now() - t;
         delete builder;
     }

@@ -4,6 +4,7 @@
 // entry point needs a HIP device.
 #include <stdio.h>
 #include <stdlib.h>
+#include <chrono>
 #include <string.h>
 
 #include <algorithm>
@@ -216,6 +217,9 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
         }
         pgrc_buf_free(c->up_stage[k]);
     }
+    pgrc_buf_free(c->up_flag);
+    pgrc_buf_free(c->up_lidx);
+    if (c->st_ready) (void)hipEventDestroy(c->st_ready);
     if (c->side_stream) {
         (void)hipStreamDestroy(c->side_stream);
         (void)hipEventDestroy(c->side_ev[0]);
@@ -429,13 +433,15 @@ int pgrc_match_begin_reads(pgrc_match_ctx *c, uint64_t n) {
 // ACGT packing (4 symbols per byte), 5 = its ACGNT packing (3 symbols per byte).  Staged through a bounded device
 // buffer and converted to the word-major 2-bit layout there; reads holding an N are flagged, and their ASCII rows
 // (made on the device for the packed formats) are kept for the side list of end_reads.
+static bool up_timing_on() { static const bool on = getenv("PGRC_STREAM_TIMING") != nullptr; return on; }
+#define UP_MARK(c, what) do { if (up_timing_on() && (c)->st_on) fprintf(stderr, "pgrc stream: %8.2f ms    append: %s\n", (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - (c)->st_t0) * 1e3, what); } while (0)
 static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, int32_t symbols) {
     if (!c->up_open || c->up_next + count > c->n) { c->err = "append_reads: outside begin/end or too many rows"; return PGRC_E_STATE; }
     PGRC_ON_DEVICE(c);
     const uint32_t L = c->prm.read_len;
     const uint32_t rb = symbols == 0 ? L : symbols == 4 ? (L + 3) / 4 : (L + 2) / 3;   // host bytes per row
-    DevBuf flag, lidx;
-    auto cleanup = [&]() { pgrc_buf_free(flag); pgrc_buf_free(lidx); };
+    DevBuf &flag = c->up_flag, &lidx = c->up_lidx;
+    auto cleanup = [&]() {};
     int e;
     // rows per staging chunk: ~256 MiB, a multiple of 1024 rows (a streamed run matches chunk by chunk: whole lines of the
     // word-major read array)
@@ -448,9 +454,11 @@ static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, i
         if ((e = pgrc_buf_ensure(c, c->up_stage[k], (size_t)std::min(CHR, std::max<uint64_t>(count, 1)) * rb))) return e;
     if ((e = pgrc_buf_ensure(c, flag, sizeof(uint32_t)))) { cleanup(); return e; }
     // a streamed run (stream.hip) uploads and unpacks on streams of its own, beside the matching of the blocks before
+    // (no call on the null stream and no hipFree in here: both wait for the main stream, where a streamed run's matching is queued)
     const bool streamed = c->st_on;
     hipStream_t main_stream = c->stream;
-    if (hipMemset(flag.p, 0, sizeof(uint32_t)) != hipSuccess) { cleanup(); c->err = "append_reads: HIP error"; return PGRC_E_DEVICE; }
+    hipStream_t ctl = streamed ? c->up_stream[0] : c->stream;
+    if (hipMemsetAsync(flag.p, 0, sizeof(uint32_t), ctl) != hipSuccess || hipStreamSynchronize(ctl) != hipSuccess) { cleanup(); c->err = "append_reads: HIP error"; return PGRC_E_DEVICE; }
     int rcode = PGRC_OK;
     std::vector<uint8_t> nf, hrows;
     std::vector<uint32_t> local;
@@ -472,11 +480,14 @@ static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, i
                                                    (uint8_t *)c->nread_flag.p, (uint32_t *)flag.p);
         c->stream = main_stream;
         // (the staging area is reused by the next chunk: its copy is queued behind this chunk's kernel on the same stream)
+        if (symbols != 4) UP_MARK(c, "rows copied, unpack queued");
         if (!(streamed && symbols == 4) && hipStreamSynchronize(up) != hipSuccess) rcode = PGRC_E_DEVICE;
+        if (symbols != 4) UP_MARK(c, "unpacked");
         if (rcode == PGRC_OK && symbols != 4) {               // (an ACGT set cannot hold an N)
             // reads with 'N' -> side list: keep their ASCII rows (they are a small minority)
             nf.resize(cnt);
-            if (hipMemcpy(nf.data(), (const uint8_t *)c->nread_flag.p + first, cnt, hipMemcpyDeviceToHost) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
+            if (hipMemcpyAsync(nf.data(), (const uint8_t *)c->nread_flag.p + first, cnt, hipMemcpyDeviceToHost, up) != hipSuccess ||
+                hipStreamSynchronize(up) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
             local.clear();
             hrows.clear();
             for (uint64_t k = 0; k < cnt; k++)
@@ -486,13 +497,15 @@ static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, i
                     else local.push_back((uint32_t)k);
                 }
             const size_t nn = symbols == 0 ? hrows.size() / L : local.size();
+            UP_MARK(c, "N flags on the host, list made");
             if (nn) {      // their ASCII rows stay in HBM: uploaded (ASCII input) or made there (packed input)
                 DevBuf nrows;
                 if ((e = pgrc_buf_ensure(c, nrows, nn * L))) { rcode = e; break; }
+                UP_MARK(c, "room for the N rows");
                 c->up_nchunks.push_back(nrows);
                 c->up_nchunk_rows.push_back(nn);
                 if (symbols == 0) {
-                    if (hipMemcpy(nrows.p, hrows.data(), nn * L, hipMemcpyHostToDevice) != hipSuccess) rcode = PGRC_E_DEVICE;
+                    if (hipMemcpyAsync(nrows.p, hrows.data(), nn * L, hipMemcpyHostToDevice, up) != hipSuccess || hipStreamSynchronize(up) != hipSuccess) rcode = PGRC_E_DEVICE;
                 } else {
                     if ((e = pgrc_buf_ensure(c, lidx, nn * sizeof(uint32_t)))) { rcode = e; break; }
                     if (hipMemcpyAsync(lidx.p, local.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice, up) != hipSuccess) { rcode = PGRC_E_DEVICE; break; }
@@ -500,6 +513,7 @@ static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, i
                     rcode = pgrc_launch_nrows_ascii_acgnt(c, (const uint8_t *)stage, (const uint32_t *)lidx.p, nn, L, (uint8_t *)nrows.p);
                     c->stream = main_stream;
                     if (hipStreamSynchronize(up) != hipSuccess) rcode = PGRC_E_DEVICE;    // (stage is reused by the next block)
+                    UP_MARK(c, "N rows as ASCII on the device");
                 }
             }
         }
@@ -508,7 +522,7 @@ static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, i
     uint32_t bad = 0;
     if (rcode == PGRC_OK && streamed && (hipStreamSynchronize(c->up_stream[0]) != hipSuccess || hipStreamSynchronize(c->up_stream[1]) != hipSuccess)) rcode = PGRC_E_DEVICE;
     if (rcode == PGRC_OK && !streamed && hipStreamSynchronize(c->stream) != hipSuccess) rcode = PGRC_E_DEVICE;
-    if (rcode == PGRC_OK && hipMemcpy(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) rcode = PGRC_E_DEVICE;
+    if (rcode == PGRC_OK && (hipMemcpyAsync(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost, ctl) != hipSuccess || hipStreamSynchronize(ctl) != hipSuccess)) rcode = PGRC_E_DEVICE;
     cleanup();
     if (rcode != PGRC_OK) { if (c->err.empty()) c->err = "append_reads: HIP error"; pgrc_stream_abort(c); return rcode; }
     if (bad) { c->err = symbols == 5 ? "packed reads hold a byte outside the ACGNT code range" : "reads contain a symbol outside ACGNT"; pgrc_stream_abort(c); return PGRC_E_SYMBOL; }
@@ -540,14 +554,20 @@ int pgrc_match_end_reads(pgrc_match_ctx *c) {
         const uint32_t L = c->prm.read_len;
         if ((e = pgrc_buf_ensure(c, c->nread_idx, c->up_nidx.size() * sizeof(uint32_t)))) return e;
         if ((e = pgrc_buf_ensure(c, c->nread_ascii, c->n_nreads * L))) return e;
-        HIP_TRY(c, hipMemcpy(c->nread_idx.p, c->up_nidx.data(), c->up_nidx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        // (a streamed run has its matching queued on the main stream: the side list is put together beside it)
+        hipStream_t s = (c->st_on && c->up_stream[0]) ? c->up_stream[0] : c->stream;
+        HIP_TRY(c, hipMemcpyAsync(c->nread_idx.p, c->up_nidx.data(), c->up_nidx.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         uint64_t at = 0;
         for (size_t k = 0; k < c->up_nchunks.size(); k++) {
-            HIP_TRY(c, hipMemcpyAsync((uint8_t *)c->nread_ascii.p + at * L, c->up_nchunks[k].p, c->up_nchunk_rows[k] * L, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync((uint8_t *)c->nread_ascii.p + at * L, c->up_nchunks[k].p, c->up_nchunk_rows[k] * L, hipMemcpyDeviceToDevice, s));
             at += c->up_nchunk_rows[k];
         }
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(s));
     }
+    // (chunks below the pool's size go back through hipFree, which waits for the device: a streamed run keeps them until its end)
+    if (c->st_on) {
+        for (DevBuf &b : c->up_nchunks) c->st_keep.push_back(b);
+    } else
     for (DevBuf &b : c->up_nchunks) pgrc_buf_free(b);
     c->up_nchunks.clear();
     c->up_nchunk_rows.clear();

@@ -1439,8 +1439,12 @@ int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase) {
             c->side_ev[0] = e0;
             c->side_ev[1] = e1;
         }
-        HIP_TRY(c, hipEventRecord(c->side_ev[0], c->stream));               // the index (and the previous pass) are complete
-        HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->side_ev[0], 0));
+        if (c->n_after) {                                                   // (a streamed run: not behind the blocks still queued)
+            HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->n_after, 0));
+        } else {
+            HIP_TRY(c, hipEventRecord(c->side_ev[0], c->stream));           // the index (and the previous pass) are complete
+            HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->side_ev[0], 0));
+        }
         const uint32_t grid = (uint32_t)((c->n_nreads + NREAD_TPB - 1) / NREAD_TPB);
         const uint32_t lds = 2u * ((uint32_t)c->nw + 1u) * NREAD_TPB * (uint32_t)sizeof(uint32_t);
         hipLaunchKernelGGL(k_copmem_match_n, dim3(grid), dim3(NREAD_TPB), lds, c->side_stream, a,

@@ -107,6 +107,11 @@ struct pgrc_match_ctx {
     bool st_on = false, st_dual = false;
     uint64_t *st_pos = nullptr;         // the caller's result arrays: a block's results are copied there as soon as they exist
     uint8_t *st_rc = nullptr, *st_mism = nullptr;
+    DevBuf up_flag, up_lidx;            // append_reads_*: bad-symbol flag, positions of a block's N rows (kept: freeing a small buffer
+                                        // goes to hipFree, which waits for the whole device -- i.e. for the matching of a streamed run)
+    std::vector<DevBuf> st_keep;        // streamed run: small device buffers to give back at its end (see end_reads)
+    hipEvent_t st_ready = nullptr;      // streamed run: indexes built and per-read state initialised (what the N passes wait for)
+    hipEvent_t n_after = nullptr;       // when set: the N kernel's side stream waits for this event instead of the main stream's tail
     DevBuf up_stage[2];                 // staging areas of append_reads_* (grow-only: no allocation per call), used in turn
     hipStream_t up_stream[2] = {nullptr, nullptr};   // a streamed run uploads and unpacks beside the matching, on two streams in
     hipEvent_t up_ev[2] = {nullptr, nullptr};        // turn: the copy of chunk k+1 must not queue behind the unpacking of chunk k,

@@ -23,6 +23,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <initializer_list>
+#include <thread>
+#include <utility>
+#include <vector>
+
 #include "ctx.h"
 #include "devutil.h"
 
@@ -365,6 +371,27 @@ struct Bufs {
 }
 
 // emc / eread / eorg (device) are filled: scan the counts, extract the mismatch streams, bring everything to the host
+// First touch of fresh host allocations by several threads: a device-to-host copy into untouched pages runs at the
+// page-fault rate of ONE thread (13 GB/s against the link's 56, profiles/r03_ubench_pcie.txt).
+static void touch_pages(std::initializer_list<std::pair<void *, size_t>> bufs) {
+    size_t total = 0;
+    for (const auto &b : bufs) total += b.second;
+    if (total < (64u << 20)) return;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned T = std::max(1u, std::min(8u, hw ? hw : 1u));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++)
+        th.emplace_back([&, t]() {
+            for (const auto &b : bufs) {
+                volatile uint8_t *p = (volatile uint8_t *)b.first;
+                const size_t lo = b.second * t / T, hi = b.second * (t + 1) / T;
+                for (size_t x = (lo + 4095) & ~(size_t)4095; x < hi; x += 4096) p[x] = 0;
+                if (t == 0 && b.second) p[0] = 0;
+            }
+        });
+    for (auto &x : th) x.join();
+}
+
 static int finish_export(pgrc_match_ctx *c, Bufs &b, uint64_t ne, int pair_file, uint32_t width, pgrc_export_streams *out) {
     int e;
     if ((e = pgrc_buf_ensure(c, b.mbase, (ne + 1) * sizeof(uint64_t)))) return e;
@@ -411,6 +438,8 @@ static int finish_export(pgrc_match_ctx *c, Bufs &b, uint64_t ne, int pair_file,
         c->err = "export: host allocation failed";
         return PGRC_E_ALLOC;
     }
+    touch_pages({{out->off, ne * width}, {out->org_idx, ne * sizeof(uint32_t)}, {out->rev_comp, ne}, {out->mis_cnt, ne}, {out->mis_sym, total},
+                 {out->mis_rev_off, total * width}});            // (while the mismatch kernel runs)
     if (ne) {
         HIP_TRY(c, hipMemcpyAsync(out->off, b.off.p, ne * width, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(out->org_idx, b.eorg.p, ne * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

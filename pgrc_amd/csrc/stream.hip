@@ -19,7 +19,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
+#include <vector>
 
 #include "ctx.h"
 
@@ -84,7 +86,13 @@ static void stop_worker(pgrc_match_ctx *c) {
     c->st_q.clear();
 }
 
+static void release_kept(pgrc_match_ctx *c) {
+    for (DevBuf &b : c->st_keep) pgrc_buf_free(b);
+    c->st_keep.clear();
+}
+
 void pgrc_stream_abort(pgrc_match_ctx *c) {
+    release_kept(c);
     if (!c->st_on && !c->st_worker.joinable()) return;
     stop_worker(c);
     c->st_on = false;
@@ -109,6 +117,10 @@ extern "C" int pgrc_match_stream_begin(pgrc_match_ctx *c, uint64_t *pos, uint8_t
     HIP_TRY(c, hipMemsetAsync(c->d_scr_flag.p, 0, c->n ? c->n : 1, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, 32 * sizeof(uint64_t), c->stream));
     memset(&c->ctr, 0, sizeof c->ctr);
+    if (!c->st_ready) HIP_TRY(c, hipEventCreateWithFlags(&c->st_ready, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->st_ready, c->stream));              // both indexes built, per-read state initialised
+    // (Tried and dropped: the blocks' match kernels on a CU-masked stream that leaves two CUs per XCD to the small kernels of
+    //  the upload side, which otherwise wait for a persistent launch to end -- the whole job was 2 % slower, A/B in one process.)
     for (int k = 0; k < 2; k++) {
         if (c->up_stream[k]) continue;
         hipError_t he = hipStreamCreateWithFlags(&c->up_stream[k], hipStreamNonBlocking);
@@ -175,15 +187,18 @@ extern "C" int pgrc_match_stream_end(pgrc_match_ctx *c, uint64_t hist[256], uint
     PGRC_ON_DEVICE(c);
     int e = PGRC_OK;
     ST_MARK(c, "stream_end called");
-    if (timing_on()) { (void)hipStreamSynchronize(c->stream); ST_MARK(c, "all blocks matched"); }
-    // the reads with N: the byte-path kernel over their side list, forward strand then RC strand (ReadsMatchers.cpp:162-172)
+    // the reads with N: their kernel over the side list, forward strand then RC strand (ReadsMatchers.cpp:162-172), on the
+    // side stream and BESIDE the blocks that are still being matched (one lane per read, latency-bound: it fits in; the
+    // blocks' kernels skip the reads with N, so the two write disjoint reads); the main stream joins it at its tail
     if (c->n_nreads) {
+        c->n_after = c->st_ready;
         pgrc_swap_index_sets(c);
         e = pgrc_copmem_match_phase(c, 0, 4);
         pgrc_swap_index_sets(c);
         if (!e) e = pgrc_copmem_match_phase(c, 1, 4);
+        c->n_after = nullptr;
     }
-    if (timing_on()) { (void)hipStreamSynchronize(c->stream); ST_MARK(c, "reads with N done"); }
+    if (timing_on()) { (void)hipStreamSynchronize(c->stream); ST_MARK(c, "all blocks matched, reads with N done"); }
     if (!e) e = pgrc_launch_hist(c);                                 // synchronises the main stream: every block is done
     ST_MARK(c, "histogram done");
     if (!e && c->n_nreads) {
@@ -193,6 +208,7 @@ extern "C" int pgrc_match_stream_end(pgrc_match_ctx *c, uint64_t hist[256], uint
     stop_worker(c);                                                  // (drains the queue first)
     ST_MARK(c, "last download done");
     c->st_on = false;
+    release_kept(c);
     if (!e && c->st_err) { e = c->st_err; c->err = "stream_end: a result download failed"; }
     if (e) return e;
     uint64_t scr[8];

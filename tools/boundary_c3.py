@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--nfrac", type=float, default=0.02)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--legs", default="plain,pipelined")
+    ap.add_argument("--ab-env", default="", help="NAME=v1,v2: the pipelined leg alternates the variable between the values, rep by rep (one process)")
     a = ap.parse_args()
     import numpy as np
     from pgrc_amd import MatchContext
@@ -89,6 +90,9 @@ def main():
     for leg in a.legs.split(","):
         runs = []
         for rep in range(a.reps):
+            if a.ab_env and leg == "pipelined":
+                name, vals = a.ab_env.split("=")
+                os.environ[name] = vals.split(",")[rep % len(vals.split(","))]
             t = [time.perf_counter()]
             ctx = MatchContext(L, 38, L // 50, 0, "c"); ctx.set_pg_ascii(pg); t.append(time.perf_counter())
             if leg == "plain":
@@ -101,6 +105,8 @@ def main():
                 pos, rc, mism, hist, matched = ctx.match_streamed(sets, out=res); t.append(time.perf_counter())
                 ph = {"set_pg_s": t[1] - t[0], "prepare_index_call_s": t[2] - t[1], "streamed_upload_match_download_s": t[3] - t[2]}
             total = t[-1] - t[0]
+            if a.ab_env and leg == "pipelined":
+                ph["env"] = a.ab_env.split("=")[0] + "=" + os.environ[a.ab_env.split("=")[0]]
             ph.update({"total_s": total, "reads_per_s_incl_pcie": n / total, "matched": int(matched), "redo_reads": int(ctx.counters()["redo_reads"])})
             runs.append(ph)
             if ref is None:

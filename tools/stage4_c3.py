@@ -34,7 +34,10 @@ def main():
     pg, lq_rows, n_rows, n_lq, n_n = boundary_c3.make_host_inputs(n, L, G, a.nfrac)
     out = {"reads": n, "L": L, "pg": G, "n_set_reads": n_n, "prep_s": time.perf_counter() - t0, "threads": a.threads}
     phases = ["streamed hand-over + matching + results", "hand-over of the pseudogenome and the reads", "device run (both strands)", "result fetch",
-              "export: position sort", "export: streams from the device"]
+              "export: position sort", "export: streams from the device",
+              "  host: result vectors (the wait for them)", "  library: pseudogenome up, index builds started", "  library: reads up, matching, results down (+ strand flags)",
+              "  sort: (position, read) pairs", "  sort: the reference's sort", "  sort: order array",
+              "  streams: original indexes", "  streams: library call", "  streams: append to the builder"]
 
     def run(use_adapter, lq, nl, nr, nn, with_export, list_count):
         secs = (C.c_double * 4)()
