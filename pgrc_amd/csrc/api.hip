@@ -210,6 +210,9 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
     if (c->multi) { pgrc_multi_destroy(c); return; }
     PgrcDeviceScope scope(c->device);
     pgrc_stream_abort(c);
+    // nothing of this context may still be running when its buffers go to the pool, from where the next context takes them
+    // (index builds started ahead and never used, an abandoned streamed run)
+    (void)hipDeviceSynchronize();
     for (int k = 0; k < 2; k++) {
         if (c->up_stream[k]) {
             (void)hipStreamDestroy(c->up_stream[k]);

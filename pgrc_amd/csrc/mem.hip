@@ -688,6 +688,10 @@ int pgrc_mem_create(uint32_t target_len, uint32_t ctor_min_len, int32_t device, 
 
 void pgrc_mem_destroy(pgrc_mem_ctx *m) {
     if (!m) return;
+    {
+        PgrcDeviceScope scope(m->base->device);
+        (void)hipDeviceSynchronize();          // (its buffers go to the pool of device buffers: nothing may still be running)
+    }
     DevBuf *bufs[] = {&m->d_dest, &m->d_nmap, &m->d_stage, &m->d_flag, &m->d_cursor, &m->d_evk[0], &m->d_evk[1], &m->d_evv[0],
                       &m->d_evv[1], &m->d_tmp, &m->d_orun, &m->d_oflag, &m->d_skey[0], &m->d_skey[1], &m->d_sidx[0],
                       &m->d_sidx[1], &m->d_first, &m->d_runid, &m->d_rstart, &m->d_rend, &m->d_rdend, &m->d_outc, &m->d_ebstart,
