@@ -1,0 +1,109 @@
+// DividedPCLReadsSets keeps its LQ / N mappings private and has no setter: only its own static factories fill them
+// (readsset/DividedPCLReadsSets.cpp:94-96).  In a PgRC tree the maintainer adds
+// `friend class PgTools::HipDividedReadsSets;` to that class.  Built against an UNPATCHED tree
+// (-DPGRC_UNPATCHED_TREE; oracle/Makefile compiles the reference's sources where they lie and must not edit them) this
+// one translation unit opens the class up instead; layout and ABI are unaffected.
+#ifdef PGRC_UNPATCHED_TREE
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+#define private public
+#include "readsset/DividedPCLReadsSets.h"
+#undef private
+#endif
+
+#include "HipDividedReadsSets.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "pgrc_reads.h"
+
+namespace PgTools {
+
+    uint64_t HipDividedReadsSets::batchesServed = 0;
+
+    namespace {
+        void failOn(int code, const pgrc_divider *d, const char *what) {
+            if (code == PGRC_OK) return;
+            fprintf(stderr, "HipDividedReadsSets: %s failed (%d): %s\n", what, code, pgrc_divider_last_error(d));
+            exit(EXIT_FAILURE);
+        }
+
+        // the packed rows of one set's part of a batch, behind the reads the set already holds
+        void appendRows(PackedConstantLengthReadsSet *set, const uint8_t *rows, uint64_t count) {
+            if (!count) return;
+            const uint_reads_cnt_max had = set->readsCount();
+            set->resize(had + (uint_reads_cnt_max) count);
+            set->copyPackedRead(rows, had, (uint_reads_cnt_max) count);
+        }
+    }
+
+    DividedPCLReadsSets *HipDividedReadsSets::getQualityDivisionBasedReadsSets(
+            ReadsSourceIteratorTemplate<uint_read_len_max> *readsIt, uint_read_len_max readLength, double error_limit,
+            bool simplified_suffix_mode, bool separateNReadsSet, bool nReadsLQ) {
+        DividedPCLReadsSets *readsSets = new DividedPCLReadsSets(readLength, separateNReadsSet, nReadsLQ);
+        pgrc_divide_params prm;
+        prm.read_len = readLength;
+        prm.error_limit = error_limit;
+        prm.simplified_suffix_mode = simplified_suffix_mode ? 1 : 0;
+        prm.separate_n_reads_set = separateNReadsSet ? 1 : 0;
+        prm.n_reads_lq = nReadsLQ ? 1 : 0;
+        prm.device = -1;
+        pgrc_divider *divider = nullptr;
+        failOn(pgrc_divider_create(&prm, &divider), nullptr, "divider_create");
+        const bool byQuality = error_limit < 1;
+        // records per batch: two row arrays of this many rows on the host and in HBM (PGRC_DIVIDE_BATCH: tests use tiny ones)
+        uint64_t batch = 4u << 20;
+        if (const char *v = getenv("PGRC_DIVIDE_BATCH")) batch = std::max<uint64_t>(1, strtoull(v, nullptr, 10));
+        std::vector<char> rows(batch * readLength), quals(byQuality ? batch * readLength : 0);
+        vector<uint_reads_cnt_max> lqMapping, nMapping;
+        uint_reads_cnt_max seen = 0;
+        bool more = true;
+        while (more) {
+            uint64_t cnt = 0;
+            while (cnt < batch && (more = readsIt->moveNext())) {
+                if (readsIt->getReadLength() != readLength) {               // addRead, PackedConstantLengthReadsSet.cpp:37-40
+                    fprintf(stderr, "Unsupported variable length reads.\n");
+                    exit(EXIT_FAILURE);
+                }
+                memcpy(rows.data() + cnt * readLength, readsIt->getRead().data(), readLength);
+                if (byQuality) memcpy(quals.data() + cnt * readLength, readsIt->getQualityInfo().data(), readLength);
+                cnt++;
+            }
+            if (!cnt) break;
+            pgrc_divided_reads part;                        // (the divider's arrays: valid until its next run)
+            failOn(pgrc_divider_run(divider, rows.data(), byQuality ? quals.data() : nullptr, cnt, &part), divider, "divider_run");
+            batchesServed++;
+            appendRows(readsSets->getHqReadsSet(), part.hq_rows, part.n_hq);
+            appendRows(readsSets->getLqReadsSet(), part.lq_rows, part.n_lq);
+            if (separateNReadsSet) appendRows(readsSets->getNReadsSet(), part.n_rows, part.n_n);
+            for (uint64_t k = 0; k < part.n_lq; k++) lqMapping.push_back(seen + part.lq_index[k]);
+            for (uint64_t k = 0; k < part.n_n; k++) nMapping.push_back(seen + part.n_index[k]);
+            seen += (uint_reads_cnt_max) cnt;
+        }
+        pgrc_divider_destroy(divider);
+        cout << "Filtered " << (lqMapping.size() + nMapping.size());
+        if (separateNReadsSet)
+            cout << " (including " << nMapping.size() << " containing N)";
+        cout << " reads (out of " << seen << ") on the device." << endl;
+        readsSets->lqMapping = new VectorMapping(std::move(lqMapping), seen);
+        if (separateNReadsSet)
+            readsSets->nMapping = new VectorMapping(std::move(nMapping), seen);
+        return readsSets;
+    }
+
+    DividedPCLReadsSets *HipDividedReadsSets::getSimpleDividedPCLReadsSets(
+            ReadsSourceIteratorTemplate<uint_read_len_max> *readsIt, uint_read_len_max readLength, bool separateNReadsSet,
+            bool nReadsLQ) {
+        // (the reference's own shortcut for "no N division" only skips the N test: error_limit = 1 does the same here)
+        return getQualityDivisionBasedReadsSets(readsIt, readLength, 1, false, separateNReadsSet, nReadsLQ);
+    }
+}

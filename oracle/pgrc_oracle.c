@@ -1082,3 +1082,75 @@ int pgrc_or_mem_match(const char *src, uint64_t N, const char *dest, uint64_t N2
 }
 
 void pgrc_or_mem_free(pgrc_or_text_match *m) { free(m); }
+
+/* ------------------------------------------------------------------ row f3: the read sets */
+
+#include <math.h>
+
+/* qualityLut (utils/helper.cpp:284-327): 0 below '!', the probability 1 - 10^(-q/10) that a call of Phred quality q is
+ * right for '!' + 0 .. '!' + 40, as a float; 1 for the next 59 characters.  (The reference writes the 41 values as
+ * decimal literals; tests/test_divide_oracle.py compares this formula with the table of the compiled reference.) */
+float pgrc_or_quality_lut(int c) {
+    if (c < 33 || c > 132) return 0.f;
+    if (c - 33 > 40) return 1.f;
+    return (float)(1.0 - pow(10.0, -(double)(c - 33) / 10.0));
+}
+
+/* qualityScore2correctProbArithAvg(quality, 1, true) (utils/helper.cpp:452-475): fractionLength = rightLength = length, so
+ * the left part is skipped and i starts at 0; val1 takes the even positions, val2 the odd ones, an odd last one val1 */
+static double quality_arith_avg(const char *q, uint32_t len) {
+    double val1 = 0, val2 = 0;
+    uint32_t i = 0;
+    for (; i < (len / 2) * 2; i += 2) {
+        val1 += pgrc_or_quality_lut((unsigned char)q[i]);
+        val2 += pgrc_or_quality_lut((unsigned char)q[i + 1]);
+    }
+    for (; i < len; i++) val1 += pgrc_or_quality_lut((unsigned char)q[i]);
+    return (val1 + val2) / (int)len;
+}
+
+int pgrc_or_divide_reads(const char *reads, const char *quals, uint64_t n, uint32_t L, double error_limit, int simplified,
+                         int separate_n, int n_reads_lq, uint8_t *hq_rows, uint8_t *lq_rows, uint8_t *n_rows,
+                         uint32_t *lq_index, uint32_t *n_index, uint64_t counts[3], uint32_t symbols[3]) {
+    /* the constructor, DividedPCLReadsSets.cpp:10-21 */
+    const char *alpha_hq = (separate_n || n_reads_lq) ? "ACGT" : "ACGNT";
+    const char *alpha_lq = separate_n ? "ACGT" : "ACGNT";
+    const uint32_t rb_hq = (L + (strlen(alpha_hq) == 4 ? 4 : 3) - 1) / (strlen(alpha_hq) == 4 ? 4 : 3);
+    const uint32_t rb_lq = (L + (strlen(alpha_lq) == 4 ? 4 : 3) - 1) / (strlen(alpha_lq) == 4 ? 4 : 3);
+    const uint32_t rb_n = (L + 2) / 3;
+    symbols[0] = (uint32_t)strlen(alpha_hq);
+    symbols[1] = (uint32_t)strlen(alpha_lq);
+    symbols[2] = separate_n ? 5u : 0u;
+    counts[0] = counts[1] = counts[2] = 0;
+    /* QualityDividingReadsSetIterator's constructor, DivisionReadsSetDecorators.cpp:14 */
+    const int suffix_pos = (int)((double)L * (1 - error_limit));
+    for (uint64_t i = 0; i < n; i++) {                       /* :68-87 */
+        const char *r = reads + i * L;
+        if (separate_n || n_reads_lq) {
+            if (memchr(r, 'N', L)) {                         /* containsN, DivisionReadsSetDecorators.cpp:66-69 */
+                if (separate_n) {
+                    pgrc_or_pack_read(r, L, "ACGNT", n_rows + counts[2] * rb_n);
+                    n_index[counts[2]++] = (uint32_t)i;
+                } else {
+                    pgrc_or_pack_read(r, L, alpha_lq, lq_rows + counts[1] * rb_lq);
+                    lq_index[counts[1]++] = (uint32_t)i;
+                }
+                continue;
+            }
+        }
+        int high = 1;
+        if (error_limit < 1) {                               /* isQualityHigh, DivisionReadsSetDecorators.cpp:30-38 */
+            const char *q = quals + i * L;
+            if (simplified) high = q[suffix_pos] > '#';
+            else high = (1 - quality_arith_avg(q, L) <= error_limit);
+        }
+        if (error_limit < 1 && !high) {
+            pgrc_or_pack_read(r, L, alpha_lq, lq_rows + counts[1] * rb_lq);
+            lq_index[counts[1]++] = (uint32_t)i;
+        } else {
+            pgrc_or_pack_read(r, L, alpha_hq, hq_rows + counts[0] * rb_hq);
+            counts[0]++;
+        }
+    }
+    return 0;
+}

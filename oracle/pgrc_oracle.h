@@ -180,6 +180,17 @@ uint8_t pgrc_or_sym2val(char c);                             /* helper.cpp:277-2
 void pgrc_or_pack_read(const char *read, uint32_t read_len, const char *alphabet, uint8_t *dst);
 void pgrc_or_unpack_read(const uint8_t *src, uint32_t read_len, const char *alphabet, char *dst);
 
+
+/* Row f3: DividedPCLReadsSets::getQualityDivisionBasedReadsSets (readsset/DividedPCLReadsSets.cpp:59-100) over n records
+ * given as symbol rows and quality rows (read_len bytes each; quals may be NULL when error_limit >= 1).  The packed rows
+ * of the three sets (caller's buffers, n * ceil(read_len / 3) bytes are enough for each), the batch indexes of the LQ / N
+ * reads (n entries each), counts[3] = reads per set (HQ, LQ, N), symbols[3] = alphabet size of each set (0: no such set). */
+int pgrc_or_divide_reads(const char *reads, const char *quals, uint64_t n, uint32_t read_len, double error_limit,
+                         int simplified_suffix_mode, int separate_n, int n_reads_lq, uint8_t *hq_rows, uint8_t *lq_rows,
+                         uint8_t *n_rows, uint32_t *lq_index, uint32_t *n_index, uint64_t counts[3], uint32_t symbols[3]);
+/* qualityLut[c] (utils/helper.cpp:284-327) as this file restates it */
+float pgrc_or_quality_lut(int c);
+
 #ifdef __cplusplus
 }
 #endif

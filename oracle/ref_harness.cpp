@@ -19,7 +19,9 @@
 #include "matching/ReadsMatchers.h"
 #include "readsset/PackedConstantLengthReadsSet.h"
 #include "utils/helper.h"
+#include "readsset/DividedPCLReadsSets.h"
 #ifdef PGRC_WITH_HIP_ADAPTER
+#include "HipDividedReadsSets.h"
 #include "HipReadsMatcher.h"
 #include "HipTextMatcher.h"
 #include "matching/SimplePgMatcher.h"
@@ -311,6 +313,35 @@ namespace PgTools {
     }
 }
 
+// The two factories of DividedPCLReadsSets the encoder calls (pgrc-encoder.cpp:258, :279).  oracle/Makefile keeps the
+// reference's own under the names below; these definitions forward to them, or -- g_gpu_division -- to
+// integration/HipDividedReadsSets (the call-site change of INTEGRATION.md).
+static bool g_gpu_division = false;
+static int g_division_calls = 0;
+extern "C" DividedPCLReadsSets *pgrc_ref_divide_quality_original(ReadsSourceIteratorTemplate<uint_read_len_max> *readsIt,
+                                                                  uint_read_len_max readLength, double error_limit,
+                                                                  bool simplified_suffix_mode, bool separateNReadsSet, bool nReadsLQ);
+extern "C" DividedPCLReadsSets *pgrc_ref_divide_simple_original(ReadsSourceIteratorTemplate<uint_read_len_max> *readsIt,
+                                                                 uint_read_len_max readLength, bool separateNReadsSet, bool nReadsLQ);
+namespace PgTools {
+    DividedPCLReadsSets *DividedPCLReadsSets::getQualityDivisionBasedReadsSets(
+            ReadsSourceIteratorTemplate<uint_read_len_max> *readsIt, uint_read_len_max readLength, double error_limit,
+            bool simplified_suffix_mode, bool separateNReadsSet, bool nReadsLQ) {
+        if (!g_gpu_division)
+            return pgrc_ref_divide_quality_original(readsIt, readLength, error_limit, simplified_suffix_mode, separateNReadsSet, nReadsLQ);
+        g_division_calls++;
+        return HipDividedReadsSets::getQualityDivisionBasedReadsSets(readsIt, readLength, error_limit, simplified_suffix_mode,
+                                                                     separateNReadsSet, nReadsLQ);
+    }
+    DividedPCLReadsSets *DividedPCLReadsSets::getSimpleDividedPCLReadsSets(
+            ReadsSourceIteratorTemplate<uint_read_len_max> *readsIt, uint_read_len_max readLength, bool separateNReadsSet, bool nReadsLQ) {
+        if (!g_gpu_division) return pgrc_ref_divide_simple_original(readsIt, readLength, separateNReadsSet, nReadsLQ);
+        g_division_calls++;
+        return HipDividedReadsSets::getSimpleDividedPCLReadsSets(readsIt, readLength, separateNReadsSet, nReadsLQ);
+    }
+}
+extern "C" int pgrc_ref_division_calls() { return g_division_calls; }
+
 // Runs the reference's whole encoder (PgRC.cpp:244-262) on a FASTQ file with the CPU or the GPU matcher.
 // Returns the number of times the GPU mapReadsIntoPg ran (>= 0), or a negative error.
 extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const char *archive, int threads, int use_gpu,
@@ -321,6 +352,7 @@ extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const 
     omp_set_num_threads(threads);
     g_gpu_matching = (use_gpu & 1) != 0;          // bit 0: reads -> Pg matching (stage 4) on the GPU
     g_gpu_text_matching = (use_gpu & 2) != 0;     // bit 1: Pg -> Pg matching (stage 7) on the GPU
+    g_gpu_division = (use_gpu & 4) != 0;          // bit 2: read-set division + packing (stage 1) on the GPU
     g_gpu_calls = 0;
     g_map_reads_s = g_text_match_s = 0;
     PgRCParams *params = new PgRCParams();
@@ -333,6 +365,11 @@ extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const 
     if (pre_mode) params->setPreMatchingMode(pre_mode);
     if (pre_seed_len > 0) params->setPreReadsExactMatchingChars((uint16_t) pre_seed_len);
     params->setPgRCFileName(archive);
+    // quality-based division (PgRC's -q): PGRC_REF_Q_PROMILS = error limit in promils, PGRC_REF_Q_FULL=1 = the arithmetic-mean
+    // test instead of the one-position one (PgRC.cpp's -q options; kept out of the signature: test knobs)
+    if (const char *v = getenv("PGRC_REF_Q_PROMILS")) params->setQualityBasedDivisionErrorLimitInPromils((uint16_t) atoi(v));
+    if (getenv("PGRC_REF_Q_FULL")) params->disableSimplifiedSuffixMode4QualityBasedDivision();
+    if (getenv("PGRC_REF_N_READS_LQ")) params->setNReadsLQ();
     {
         PgRCEncoder encoder(params);
         encoder.executePgRCChain();
@@ -340,6 +377,7 @@ extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const 
     delete params;
     g_gpu_matching = false;
     g_gpu_text_matching = false;
+    g_gpu_division = false;
     return g_gpu_calls;
 }
 
@@ -664,3 +702,78 @@ void pgrc_ref_free(void *p) { free(p); }
 int pgrc_ref_max_threads(void) { return omp_get_num_procs(); }
 
 } // extern "C"
+
+// ---- row f3: the reference's read-set division over in-memory FASTQ records -------------------------------------------
+
+namespace {
+// n records as two row arrays behind the reference's iterator interface (readsset/iterator/ReadsSetIterator.h:80-96)
+struct RowsIterator : ReadsSourceIteratorTemplate<uint_read_len_max> {
+    const char *rows, *quals;
+    uint64_t n;
+    uint32_t L;
+    int64_t at = -1;
+    std::string read, qual;
+    RowsIterator(const char *r, const char *q, uint64_t n_, uint32_t L_) : rows(r), quals(q), n(n_), L(L_) {}
+    bool moveNext() override {
+        if (at + 1 >= (int64_t) n) return false;
+        at++;
+        read.assign(rows + (size_t) at * L, L);
+        if (quals) qual.assign(quals + (size_t) at * L, L);
+        return true;
+    }
+    std::string &getRead() override { return read; }
+    std::string &getQualityInfo() override { return qual; }
+    uint_read_len_max getReadLength() override { return (uint_read_len_max) L; }
+    void rewind() override { at = -1; }
+    IndexesMapping *retainVisitedIndexesMapping() override { return new DirectMapping((uint_reads_cnt_max) n); }
+};
+}
+
+// DividedPCLReadsSets::getQualityDivisionBasedReadsSets (use_adapter = 0) or integration/HipDividedReadsSets (1) over the
+// records; the sets' packed rows and the mappings go to the caller's buffers (n * ceil(L / 3) bytes / n entries each)
+extern "C" int pgrc_ref_divide(int use_adapter, const char *reads, const char *quals, uint64_t n, uint32_t L, double error_limit,
+                               int simplified, int separate_n, int n_reads_lq, uint8_t *hq_rows, uint8_t *lq_rows, uint8_t *n_rows,
+                               uint32_t *lq_index, uint32_t *n_index, uint64_t counts[3], uint32_t symbols[3]) {
+    Silence quiet;
+    RowsIterator it(reads, quals, n, L);
+    DividedPCLReadsSets *sets = nullptr;
+    if (use_adapter) {
+#ifdef PGRC_WITH_HIP_ADAPTER
+        sets = HipDividedReadsSets::getQualityDivisionBasedReadsSets(&it, (uint_read_len_max) L, error_limit, simplified != 0,
+                                                                      separate_n != 0, n_reads_lq != 0);
+#else
+        return -1;
+#endif
+    } else {
+#ifdef PGRC_WITH_HIP_ADAPTER
+        sets = pgrc_ref_divide_quality_original(&it, (uint_read_len_max) L, error_limit, simplified != 0, separate_n != 0, n_reads_lq != 0);
+#else
+        sets = DividedPCLReadsSets::getQualityDivisionBasedReadsSets(&it, (uint_read_len_max) L, error_limit, simplified != 0,
+                                                                     separate_n != 0, n_reads_lq != 0);
+#endif
+    }
+    PackedConstantLengthReadsSet *set[3] = {sets->getHqReadsSet(), sets->getLqReadsSet(), sets->getNReadsSet()};
+    uint8_t *dst[3] = {hq_rows, lq_rows, n_rows};
+    for (int k = 0; k < 3; k++) {
+        counts[k] = set[k] ? set[k]->readsCount() : 0;
+        symbols[k] = set[k] ? set[k]->getReadsSetProperties()->symbolsCount : 0;
+        if (!set[k] || !counts[k]) continue;
+        const uint32_t per = symbols[k] == 4 ? 4 : 3, rb = (L + per - 1) / per;
+        memcpy(dst[k], set[k]->getPackedRead(0), (size_t) counts[k] * rb);
+    }
+    IndexesMapping *lm = sets->getLqReadsIndexesMapping(), *nm = sets->getNReadsIndexesMapping();
+    if (lm && lm->getMappedReadsCount() != counts[1]) return 2;
+    for (uint64_t i = 0; lm && i < counts[1]; i++) lq_index[i] = (uint32_t) lm->getReadOriginalIndex((uint_reads_cnt_max) i);
+    if (nm && nm->getMappedReadsCount() != counts[2]) return 3;
+    for (uint64_t i = 0; nm && i < counts[2]; i++) n_index[i] = (uint32_t) nm->getReadOriginalIndex((uint_reads_cnt_max) i);
+    if (lm && lm->getReadsTotalCount() != n) return 4;
+    delete sets;
+    return 0;
+}
+
+// the reference's table of per-quality probabilities (utils/helper.cpp:284-327, a global of that file)
+extern float *qualityLut;
+extern "C" float pgrc_ref_quality_lut(int c) { return qualityLut[c]; }
+#ifdef PGRC_WITH_HIP_ADAPTER
+extern "C" uint64_t pgrc_ref_divide_batches() { return HipDividedReadsSets::batchesServed; }
+#endif

@@ -17,4 +17,5 @@ from .matchers import (  # noqa: F401
     mapReadsIntoPg,
 )
 from .textmatch import CopMEMMatcher  # noqa: F401
+from .readsets import DividedPCLReadsSets  # noqa: F401
 from . import synth  # noqa: F401

@@ -74,6 +74,19 @@ class TextMatch(C.Structure):     # pgrc_text_match (include/pgrc_mem.h) = TextM
     _fields_ = [("pos_src", C.c_uint64), ("length", C.c_uint64), ("pos_dest", C.c_uint64)]
 
 
+class DivideParams(C.Structure):
+    _fields_ = [("read_len", C.c_uint32), ("error_limit", C.c_double), ("simplified_suffix_mode", C.c_int32),
+                ("separate_n_reads_set", C.c_int32), ("n_reads_lq", C.c_int32), ("device", C.c_int32)]
+
+
+class DividedReads(C.Structure):
+    _fields_ = [("n_hq", C.c_uint64), ("n_lq", C.c_uint64), ("n_n", C.c_uint64),
+                ("hq_symbols", C.c_uint32), ("lq_symbols", C.c_uint32), ("n_symbols", C.c_uint32),
+                ("hq_row_bytes", C.c_uint32), ("lq_row_bytes", C.c_uint32), ("n_row_bytes", C.c_uint32),
+                ("hq_rows", C.c_void_p), ("lq_rows", C.c_void_p), ("n_rows", C.c_void_p),
+                ("lq_index", C.c_void_p), ("n_index", C.c_void_p)]
+
+
 class MemCounters(C.Structure):
     _fields_ = [("probes", C.c_uint64), ("events", C.c_uint64), ("stale_lookups", C.c_uint64), ("ms_index", C.c_float),
                 ("ms_probe", C.c_float), ("ms_sort", C.c_float), ("ms_extend", C.c_float), ("ms_host", C.c_float),
@@ -139,6 +152,12 @@ _PROTOS = [
                                        C.POINTER(C.c_uint64)]),
     ("pgrc_mem_free_matches", None, [C.POINTER(TextMatch)]),
     ("pgrc_mem_get_counters", C.c_int, [_P, C.POINTER(MemCounters)]),
+    # include/pgrc_reads.h
+    ("pgrc_divider_create", C.c_int, [C.POINTER(DivideParams), C.POINTER(_P)]),
+    ("pgrc_divider_destroy", None, [_P]),
+    ("pgrc_divider_last_error", C.c_char_p, [_P]),
+    ("pgrc_divider_run", C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(DividedReads)]),
+    ("pgrc_divider_last_ms", C.c_int, [_P, C.POINTER(C.c_float * 3)]),
 ]
 
 EXPORTED_SYMBOLS = [p[0] for p in _PROTOS]

@@ -35,12 +35,24 @@ CASES = {
 }
 
 
-def write_fastq(path, reads):
+def write_fastq(path, reads, quality_seed=None):
+    """quality_seed None: every base 'I' (Phred 40); else varied quality rows -- good reads, reads with a bad tail, reads
+    noisy all over -- so that PgRC's quality-based division (-q) has something to cut"""
     lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
     L = reads.shape[1]
     qual = b"I" * L
+    rng = np.random.default_rng(quality_seed) if quality_seed is not None else None
     with open(path, "wb") as f:
         for i, r in enumerate(reads):
+            if rng is not None:
+                q = rng.integers(30, 42, size=L)
+                u = rng.random()
+                if u < 0.15:
+                    k = int(rng.integers(1, L))
+                    q[k:] = rng.integers(2, 12, size=L - k)
+                elif u < 0.3:
+                    q = rng.integers(2, 42, size=L)
+                qual = (q + 33).astype(np.uint8).tobytes()
             f.write(b"@r%d\n" % i + lut[r].tobytes() + b"\n+\n" + qual + b"\n")
 
 
@@ -89,6 +101,7 @@ def main():
     lib.pgrc_ref_device_exports.restype = C.c_uint64
     lib.pgrc_ref_dual_runs.restype = C.c_uint64
     lib.pgrc_ref_streamed_runs.restype = C.c_uint64
+    lib.pgrc_ref_division_calls.restype = C.c_int
 
     # default: small enough for the test suite; PGRC_E2E_READS / PGRC_E2E_GENOME scale it up for a one-off check
     n = int(os.environ.get("PGRC_E2E_READS", "60000"))
@@ -99,19 +112,21 @@ def main():
     digests = {}
     # PGRC_E2E_CPU_ONLY=1: both legs on the CPU (no GPU needed) -- checks the harness itself: the reference encoder is
     # deterministic at -t 1 and its archive decodes to the input
-    # GPU leg: bit 0 = stage 4 (reads -> Pg, HipReadsMatcher), bit 1 = stage 7 (Pg -> Pg, HipTextMatcher)
+    # GPU leg: bit 0 = stage 4 (reads -> Pg, HipReadsMatcher), bit 1 = stage 7 (Pg -> Pg, HipTextMatcher), bit 2 = stage 1 (the read
+    # sets: division + packing, HipDividedReadsSets)
     gpu_leg = 0 if os.environ.get("PGRC_E2E_CPU_ONLY") == "1" else int(os.environ.get("PGRC_E2E_GPU_STAGES", "3"))
     exports_seen = 0
     for leg, use_gpu in (("cpu", 0), ("gpu", gpu_leg)):
         d = os.path.join(work, case, leg)
         os.makedirs(d, exist_ok=True)
         os.chdir(d)       # same relative archive name in both legs: the archive embeds a name derived from it
+        qseed = 5 if os.environ.get("PGRC_REF_Q_PROMILS") else None    # (quality division asked for: varied quality rows)
         if paired:
-            write_fastq("in_1.fastq", reads[0::2])
-            write_fastq("in_2.fastq", reads[1::2])
+            write_fastq("in_1.fastq", reads[0::2], qseed)
+            write_fastq("in_2.fastq", reads[1::2], None if qseed is None else qseed + 1)
             src, pair = b"in_1.fastq", b"in_2.fastq"
         else:
-            write_fastq("in.fastq", reads)
+            write_fastq("in.fastq", reads, qseed)
             src, pair = b"in.fastq", b""
         calls = lib.pgrc_ref_encode(src, pair, b"out.pgrc", 1, use_gpu, 1 if order else 0,
                                     (mode or "\0").encode(), seed, mcpm, (pre_mode or "\0").encode(), pre_seed)
@@ -123,6 +138,7 @@ def main():
         out[leg + "_text_match_calls"] = int(lib.pgrc_ref_text_match_calls())   # matchTexts calls served by HipTextMatcher
         out[leg + "_device_exports"] = int(lib.pgrc_ref_device_exports()) - exports_seen   # exports whose streams came from the device
         exports_seen = int(lib.pgrc_ref_device_exports())
+    out["gpu_division_calls"] = int(lib.pgrc_ref_division_calls())   # read-set divisions that ran on the device (bit 2 of the GPU stages)
     out["gpu_dual_runs"] = int(lib.pgrc_ref_dual_runs())     # device runs that took the dual kernel (GPU leg only: the CPU leg has none)
     out["gpu_streamed_runs"] = int(lib.pgrc_ref_streamed_runs())   # ... that overlapped hand-over, matching and result fetch
     out["identical"] = digests["cpu"] == digests["gpu"]

@@ -10,9 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "pgrc_match.h")).read() + open(os.path.join(ROOT, "include", "pgrc_mem.h")).read()
+    txt = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("pgrc_match.h", "pgrc_mem.h", "pgrc_reads.h"))
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(pgrc_(?:match|synth|mem)_\w+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(pgrc_(?:match|synth|mem|divider)_\w+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():
