@@ -127,6 +127,7 @@ struct pgrc_match_ctx {
 
     // read-side seed index (modes d / i / e)
     DevBuf s_keys, s_vals, s_tab, s_hits, s_tmp;
+    DevBuf s_filter;        // modes d/i/e: one bit per slice of the key space (seedidx.hip)
     DevBuf s_nmask;                             // N masks of the reads with N (modes d/i/e)
     DevBuf s_heavy;                             // reads handed to the wave-per-read replay
     DevBuf s_sorted, s_sorttmp, s_mm, s_rstart; // sorted hits, rocPRIM scratch, Hamming count per hit, first hit per read

@@ -69,6 +69,8 @@ struct SeedArgs {
     uint64_t *tkeys;
     uint32_t *theads;
     uint64_t tmask;
+    uint32_t *filter;          // one bit per 2^-fbits of the key space: set iff some indexed key falls there
+    uint32_t fshift;           // 64 - fbits: the filter takes the TOP bits of the mixed key, the table its low bits
     uint32_t *next;
     uint64_t *pos;
     uint8_t *rc, *mism;
@@ -82,7 +84,12 @@ __device__ __forceinline__ uint32_t part_offset(const SeedArgs &a, uint32_t j) {
 
 // ---- 1. insert every (read, part) key
 __device__ __forceinline__ void table_insert(const SeedArgs &a, uint64_t key, uint32_t e) {
-    uint64_t slot = mix64d(key) & a.tmask;
+    const uint64_t mixed = mix64d(key);
+    if (a.filter) {
+        const uint64_t fb = mixed >> a.fshift;
+        atomicOr(&a.filter[fb >> 5], 1u << (fb & 31u));
+    }
+    uint64_t slot = mixed & a.tmask;
     for (;;) {
         const unsigned long long prev = atomicCAS((unsigned long long *)&a.tkeys[slot], (unsigned long long)SX_EMPTY, (unsigned long long)key);
         if (prev == SX_EMPTY || prev == key) {
@@ -174,11 +181,14 @@ k_seed_scan(const SeedArgs a, uint64_t nwin, uint64_t pg_words_alloc, unsigned l
     // loads, then the heads of the keys found -- a dependent round trip per batch instead of one per start
     for (uint32_t r0 = 0; r0 < SCAN_R; r0 += SCAN_B) {
         uint64_t keyv[SCAN_B], slotv[SCAN_B], kv[SCAN_B];
-        uint32_t ev[SCAN_B];
+        uint32_t ev[SCAN_B], fw[SCAN_B], fbit[SCAN_B];
 #pragma unroll
         for (int b = 0; b < SCAN_B; b++) {
             keyv[b] = key_fix(h0, h1);
-            slotv[b] = mix64d(keyv[b]) & a.tmask;
+            const uint64_t mixed = mix64d(keyv[b]);
+            slotv[b] = mixed & a.tmask;
+            fbit[b] = (uint32_t)((mixed >> a.fshift) & 31u);
+            fw[b] = (uint32_t)(mixed >> a.fshift >> 5);
             if (worker) {                                     // roll to the next start (cyclichash.h:110-118)
                 const uint32_t xo = x0 + (r0 + b) * cs;
                 const uint32_t co = sym(xo), cn = sym(xo + m * cs);
@@ -187,11 +197,16 @@ k_seed_scan(const SeedArgs a, uint64_t nwin, uint64_t pg_words_alloc, unsigned l
                 h1 = rotl1(h1) ^ ((o1 << mr) | (mr ? o1 >> (32u - mr) : 0u)) ^ cyc_t1(cn);
             }
         }
+        // the filter first: a window whose bit is clear equals no indexed key -- one 4-byte gather in a bitmap of a thirty-second
+        // of the table's bytes; only the windows that pass (the hits and ~3 % more) go on to the table, whose probes each
+        // cost a random line of their own, collision steps included (the line of the previous slot is long gone from L1 / L2)
 #pragma unroll
         for (int b = 0; b < SCAN_B; b++) {
             const uint64_t t = s0 + (uint64_t)(r0 + b) * cs;
-            kv[b] = (worker && t < nwin) ? a.tkeys[slotv[b]] : SX_EMPTY;
+            fw[b] = (worker && t < nwin) ? (a.filter ? a.filter[fw[b]] : 0xFFFFFFFFu) : 0u;
         }
+#pragma unroll
+        for (int b = 0; b < SCAN_B; b++) kv[b] = ((fw[b] >> fbit[b]) & 1u) ? a.tkeys[slotv[b]] : SX_EMPTY;
         // collisions (the slot holds another key) of the whole batch are resolved together: every round issues the
         // next-slot loads of all starts still searching before any of them is looked at
         uint32_t srch = 0, fnd = 0;
@@ -477,12 +492,28 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
     // read-part table
     const uint64_t nent = a.n * a.P;
     uint64_t tsize = 1024;
-    while (tsize < 2 * nent) tsize <<= 1;   // (4 * nent was tried: -1 % time for twice the memory)
+    while (tsize < 2 * nent) tsize <<= 1;   // (4 / 8 * nent: the exact matcher at C3 12 / 16 % faster, modes d / i unchanged; the filter below does better)
     int e;
     if ((e = pgrc_buf_ensure(c, c->s_keys, tsize * sizeof(uint64_t)))) return e;
     if ((e = pgrc_buf_ensure(c, c->s_vals, tsize * sizeof(uint32_t)))) return e;
     if ((e = pgrc_buf_ensure(c, c->s_tab, nent * sizeof(uint32_t)))) return e;
     if ((e = pgrc_buf_ensure(c, c->s_tmp, 64))) return e;
+    // the filter: 32 bits per indexed key (3 % of the windows of a random text pass it by chance), at most 2^36 bits.  It
+    // pays when most windows of the text equal no key -- the exact matcher at C3: 100 M keys against 1.9 G windows, 0.20 ->
+    // 0.16 s -- and costs a dependent round trip where many do (modes d / i with four parts per read: 0.42 -> 0.43 s): used
+    // when there is at most one key per eight text positions (PGRC_SEED_FILTER=0 / 1: never / always, tests and A/B runs)
+    bool use_filter = nent * 8 <= c->G;
+    if (const char *v = getenv("PGRC_SEED_FILTER")) use_filter = v[0] != '0';
+    a.filter = nullptr;
+    a.fshift = 0;
+    if (use_filter) {
+        int fbits = 10;
+        while (fbits < 36 && (1ull << fbits) < 32 * nent) fbits++;
+        if ((e = pgrc_buf_ensure(c, c->s_filter, (size_t)(1ull << fbits) / 8))) return e;
+        HIP_TRY(c, hipMemsetAsync(c->s_filter.p, 0, (size_t)(1ull << fbits) / 8, c->stream));
+        a.filter = (uint32_t *)c->s_filter.p;
+        a.fshift = 64u - (uint32_t)fbits;
+    }
     a.tkeys = (uint64_t *)c->s_keys.p;
     a.theads = (uint32_t *)c->s_vals.p;
     a.tmask = tsize - 1;

@@ -120,6 +120,18 @@ def test_seedindex_text_segments_and_read_batches(monkeypatch, mode):
         assert_same_results(gpu_match(mode, pg, reads, seed_len, kmax, 0, devices=[0, 0]), o, f"mode {mode}, 2 shards, segment {seg} batch {batch}")
 
 
+@pytest.mark.parametrize("mode", ["d", "i", "e"])
+@pytest.mark.parametrize("filt", ["0", "1"])
+def test_seedindex_scan_filter_on_and_off(monkeypatch, mode, filt):
+    """The scan asks a one-bit-per-key-slice filter before it probes the table when keys are sparse against the text
+    (seedidx.hip); PGRC_SEED_FILTER forces it on / off: same results, also with reads that hold an N and with tandem repeats."""
+    monkeypatch.setenv("PGRC_SEED_FILTER", filt)
+    L = 100
+    pg, reads = make_inputs(200_000, 6000, L, seed=78, n_with_n=200, pool_div=64, tandem_every=3)
+    seed_len, kmax = (L, 0) if mode == "e" else (38, 2)
+    assert_same_results(gpu_match(mode, pg, reads, seed_len, kmax, 0), orc.oracle_match(mode, pg, reads, seed_len, kmax, 0), f"mode {mode} filter {filt}")
+
+
 CASES = [
     # L, seed, M, mode, G, n
     (100, 38, 50, "c", 400000, 20000),
