@@ -318,6 +318,7 @@ namespace PgTools {
 // integration/HipDividedReadsSets (the call-site change of INTEGRATION.md).
 static bool g_gpu_division = false;
 static int g_division_calls = 0;
+static double g_division_s = 0;                  // wall time inside the two factories, whichever implementation ran
 extern "C" DividedPCLReadsSets *pgrc_ref_divide_quality_original(ReadsSourceIteratorTemplate<uint_read_len_max> *readsIt,
                                                                   uint_read_len_max readLength, double error_limit,
                                                                   bool simplified_suffix_mode, bool separateNReadsSet, bool nReadsLQ);
@@ -327,6 +328,7 @@ namespace PgTools {
     DividedPCLReadsSets *DividedPCLReadsSets::getQualityDivisionBasedReadsSets(
             ReadsSourceIteratorTemplate<uint_read_len_max> *readsIt, uint_read_len_max readLength, double error_limit,
             bool simplified_suffix_mode, bool separateNReadsSet, bool nReadsLQ) {
+        StageTimer timer(g_division_s);
         if (!g_gpu_division)
             return pgrc_ref_divide_quality_original(readsIt, readLength, error_limit, simplified_suffix_mode, separateNReadsSet, nReadsLQ);
         g_division_calls++;
@@ -335,12 +337,14 @@ namespace PgTools {
     }
     DividedPCLReadsSets *DividedPCLReadsSets::getSimpleDividedPCLReadsSets(
             ReadsSourceIteratorTemplate<uint_read_len_max> *readsIt, uint_read_len_max readLength, bool separateNReadsSet, bool nReadsLQ) {
+        StageTimer timer(g_division_s);
         if (!g_gpu_division) return pgrc_ref_divide_simple_original(readsIt, readLength, separateNReadsSet, nReadsLQ);
         g_division_calls++;
         return HipDividedReadsSets::getSimpleDividedPCLReadsSets(readsIt, readLength, separateNReadsSet, nReadsLQ);
     }
 }
 extern "C" int pgrc_ref_division_calls() { return g_division_calls; }
+extern "C" double pgrc_ref_division_seconds() { return g_division_s; }
 
 // Runs the reference's whole encoder (PgRC.cpp:244-262) on a FASTQ file with the CPU or the GPU matcher.
 // Returns the number of times the GPU mapReadsIntoPg ran (>= 0), or a negative error.
@@ -354,7 +358,7 @@ extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const 
     g_gpu_text_matching = (use_gpu & 2) != 0;     // bit 1: Pg -> Pg matching (stage 7) on the GPU
     g_gpu_division = (use_gpu & 4) != 0;          // bit 2: read-set division + packing (stage 1) on the GPU
     g_gpu_calls = 0;
-    g_map_reads_s = g_text_match_s = 0;
+    g_map_reads_s = g_text_match_s = g_division_s = 0;
     PgRCParams *params = new PgRCParams();
     params->setSrcFastqFile(fastq);
     if (pair_fastq && pair_fastq[0]) params->setPairFastqFile(pair_fastq);

@@ -62,7 +62,10 @@ def main():
     write_fastq(fq, genome, a.reads, a.read_len, 7)
     print(json.dumps({"fastq_s": round(time.time() - t, 1), "reads": a.reads, "genome": a.genome}), flush=True)
     out = {"reads": a.reads, "read_len": a.read_len, "genome": a.genome, "threads": a.threads, "legs": {}}
-    for leg, use_gpu in (("cpu", 0), ("gpu", 3)):
+    has_div = hasattr(lib, "pgrc_ref_division_seconds")
+    if has_div:
+        lib.pgrc_ref_division_seconds.restype = C.c_double
+    for leg, use_gpu in (("cpu", 0), ("gpu", 7 if has_div else 3)):       # GPU leg: stages 1 (read sets), 4 and 7
         d = os.path.join(os.path.abspath(a.workdir), leg)
         os.makedirs(d, exist_ok=True)
         os.chdir(d)
@@ -74,6 +77,8 @@ def main():
         out["legs"][leg] = {"encode_wall_s": round(wall, 2), "archive_bytes": os.path.getsize("out.pgrc"),
                             "mapReadsIntoPg_s (stage 4, incl. export)": round(s4.value, 3),
                             "text_matcher_s (stage 7: index + matchTexts)": round(s7.value, 3)}
+        if has_div:
+            out["legs"][leg]["read_sets_s (stage 1: FASTQ iterator + division + packing)"] = round(lib.pgrc_ref_division_seconds(), 3)
         print(json.dumps({leg: out["legs"][leg]}), flush=True)
     print(json.dumps(out))
 
