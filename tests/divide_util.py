@@ -24,7 +24,7 @@ def make_records(seed, n, L, n_frac=0.04, low_quality_frac=0.3):
     q = rng.integers(30, 42, size=(n, L))
     bad = rng.random(n) < low_quality_frac
     for i in np.flatnonzero(bad):
-        if rng.random() < 0.5:
+        if rng.random() < 0.5 and L > 1:
             k = int(rng.integers(1, L))
             q[i, k:] = rng.integers(2, 12, size=L - k)           # a bad tail
         else:

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-off randomized soak (not part of the suite): HIP path vs oracle on many random small configurations of both the
 read matcher (modes c/d/i/e; reads handed over as ASCII rows or as the reference's packed LQ + N sets; one device or a
-matcher over 2-5 shards; every index-build variant) with the export streams of every case, and of the text matcher.
+matcher over 2-5 shards; every index-build variant) with the export streams of every case, of the text matcher, and of
+the read-set division (row f3).
 usage: python tests/soak.py [seconds] [seed]"""
 import os
 import sys
@@ -108,6 +109,23 @@ def main():
                 sys.exit(1)
         m.close()
         n_mem_cases += 1
+        # --- read-set division (row f3)
+        from divide_util import make_records, oracle_divide, same
+        from pgrc_amd import DividedPCLReadsSets
+        dL = int(rng.integers(1, 256))
+        dn = int(rng.choice([1, 63, 64, 65, 1000, 5000, 40000]))
+        lim = float(rng.choice([1.0, 1.0, 0.001, 0.01, 0.05, 0.2, 0.5, 0.9, 0.999]))
+        simp, sepn, nlq = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        if lim < 1 and simp and not (0 <= int(dL * (1 - lim)) < dL):
+            simp = False
+        dseed = int(rng.integers(0, 1 << 30))
+        dr, dq = make_records(dseed, dn, dL, n_frac=float(rng.choice([0.0, 0.02, 0.5])), low_quality_frac=float(rng.choice([0.0, 0.3, 1.0])))
+        dv = DividedPCLReadsSets(dL, lim, simp, sepn, nlq)
+        bad = same(dv.divide(dr, dq), oracle_divide(dr, dq, lim, simp, sepn, nlq))
+        dv.close()
+        if bad is not None:
+            print("DIVIDE MISMATCH", dict(L=dL, n=dn, error_limit=lim, simplified=simp, separate_n=sepn, n_reads_lq=nlq, seed=dseed, field=bad), flush=True)
+            sys.exit(1)
         if (n_reads_cases % 50) == 0:
             print(f"{n_reads_cases} read-matcher cases, {n_mem_cases} text-matcher cases ok ({time.time() - t0:.0f} s)", flush=True)
     print(f"soak ok: {n_reads_cases} read-matcher cases, {n_mem_cases} text-matcher cases, {time.time() - t0:.0f} s")
