@@ -40,6 +40,7 @@ struct pgrc_match_ctx {
     // several devices behind this object (pgrc_match_create_multi): it is then only the front, the work happens in
     // one child context per device
     pgrc_multi *multi = nullptr;
+    void *export_view = nullptr;        // multi-device front: the shards' reads and results gathered on the first device (export.hip)
 
     pgrc_match_params prm{};
     int device = 0;
@@ -204,6 +205,7 @@ int pgrc_multi_get_counters(pgrc_match_ctx *f, pgrc_match_counters *out);
 void pgrc_multi_destroy(pgrc_match_ctx *f);
 struct PgrcShardView { pgrc_match_ctx *ctx; uint64_t lo, hi; };     // one shard of a multi-device context: reads [lo, hi)
 std::vector<PgrcShardView> pgrc_multi_shards(pgrc_match_ctx *f);
+void pgrc_export_drop_view(pgrc_match_ctx *front);   // export.hip: forget the gathered view (text, reads or results change)
 
 // pack.hip
 int pgrc_launch_pack_ascii(pgrc_match_ctx *c, const uint8_t *d_ascii, uint64_t count, uint32_t *d_words,

@@ -594,6 +594,32 @@ struct GatheredView {
 };
 }
 
+// The gathered view of a multi-device context is kept for the next export call (the adapter asks for the mismatch lists and
+// for one or two exports of the same results: gathering 3.5 + 0.9 GB at C3 size each time would be the larger part of them);
+// whatever changes the text, the reads or the results drops it (pgrc_export_drop_view, called from multi.hip).
+static int view_for(pgrc_match_ctx *c, pgrc_match_ctx **w) {
+    *w = c;
+    if (!c->multi) return PGRC_OK;
+    GatheredView *gv = (GatheredView *)c->export_view;
+    if (!gv) {
+        gv = new GatheredView();
+        const int e = gv->build(c);
+        if (e) { delete gv; return e; }
+        c->export_view = gv;
+    }
+    *w = &gv->view;
+    return PGRC_OK;
+}
+
+void pgrc_export_drop_view(pgrc_match_ctx *c) {
+    if (!c || !c->export_view) return;
+    GatheredView *gv = (GatheredView *)c->export_view;
+    c->export_view = nullptr;
+    if (!c->multi) { delete gv; return; }
+    PgrcDeviceScope scope(gv->view.device);
+    delete gv;
+}
+
 extern "C" int pgrc_match_export_pg_order(pgrc_match_ctx *c, const pgrc_export_pg_order_args *x, pgrc_export_streams *out) {
     if (!c || !x || !out || (x->n_matched && !x->order) || (x->list_count && (!x->list_off || !x->list_org_idx))) return PGRC_E_PARAM;
     memset(out, 0, sizeof *out);
@@ -601,13 +627,9 @@ extern "C" int pgrc_match_export_pg_order(pgrc_match_ctx *c, const pgrc_export_p
     if (x->n_matched > c->n) { c->err = "export: more matched reads than reads"; return PGRC_E_PARAM; }
     for (uint64_t j = 0; j < x->n_matched; j++)
         if (x->order[j] >= c->n) { c->err = "export_pg_order: read index out of range"; return PGRC_E_PARAM; }
-    GatheredView gv;
     pgrc_match_ctx *w = c;
-    if (c->multi) {
-        int ge = gv.build(c);
-        if (ge) return ge;
-        w = &gv.view;
-    }
+    int ge = view_for(c, &w);
+    if (ge) return ge;
     PgrcDeviceScope scope(w->device);
     Bufs b;
     int e = export_pg_order(w, x, b, out);
@@ -688,13 +710,9 @@ extern "C" int pgrc_match_export_entries(pgrc_match_ctx *c, const uint32_t *entr
     if (!c->have_results || !c->have_pg || !c->have_reads) { c->err = "export: run first"; return PGRC_E_STATE; }
     for (uint64_t k = 0; k < n_entries; k++)
         if (entry_read[k] != EX_NONE && entry_read[k] >= c->n) { c->err = "export_entries: read index out of range"; return PGRC_E_PARAM; }
-    GatheredView gv;
     pgrc_match_ctx *w = c;
-    if (c->multi) {
-        int ge = gv.build(c);
-        if (ge) return ge;
-        w = &gv.view;
-    }
+    int ge = view_for(c, &w);
+    if (ge) return ge;
     PgrcDeviceScope scope(w->device);
     Bufs b;
     int e = export_entries(w, entry_read, entry_org_idx, n_entries, rev_compl_pair_file, byte_per_read_length ? 1u : 2u, b, out);
@@ -709,13 +727,9 @@ extern "C" int pgrc_match_export_original_order(pgrc_match_ctx *c, const pgrc_ex
     memset(out, 0, sizeof *out);
     if (!c->have_results || !c->have_pg || !c->have_reads) { c->err = "export: run first"; return PGRC_E_STATE; }
     if (x->reads_total_count >= EX_SKIP) { c->err = "export_original_order: too many original indexes"; return PGRC_E_PARAM; }
-    GatheredView gv;
     pgrc_match_ctx *w = c;
-    if (c->multi) {
-        int ge = gv.build(c);
-        if (ge) return ge;
-        w = &gv.view;
-    }
+    int ge = view_for(c, &w);
+    if (ge) return ge;
     PgrcDeviceScope scope(w->device);
     Bufs b;
     int e = export_original_order(w, x, b, out);

@@ -175,6 +175,7 @@ std::vector<PgrcShardView> pgrc_multi_shards(pgrc_match_ctx *f) {
 }
 
 void pgrc_multi_destroy(pgrc_match_ctx *f) {
+    pgrc_export_drop_view(f);
     pgrc_multi *m = f->multi;
     if (m) {
         for (size_t r = 0; r < m->comm.size(); r++)
@@ -248,6 +249,7 @@ static int allgather_text(pgrc_match_ctx *f, uint64_t sw) {
 }
 
 int pgrc_multi_set_pg_ascii(pgrc_match_ctx *f, const char *pg, uint64_t G) {
+    pgrc_export_drop_view(f);
     pgrc_multi *m = f->multi;
     const size_t k = m->child.size();
     const uint64_t words = (G + 15) / 16, sw = (words + k - 1) / k;     // k * sw <= words + k - 1 < words + PGRC_PG_PAD_WORDS
@@ -273,6 +275,7 @@ int pgrc_multi_set_pg_ascii(pgrc_match_ctx *f, const char *pg, uint64_t G) {
 }
 
 int pgrc_multi_set_pg_packed_device(pgrc_match_ctx *f, const void *d_words, uint64_t G) {
+    pgrc_export_drop_view(f);
     pgrc_multi *m = f->multi;
     int e = on_children(f, [&](size_t r) { return pgrc_match_set_pg_packed_device(m->child[r], d_words, G); });
     if (e) return e;
@@ -314,6 +317,7 @@ int pgrc_multi_export_index(pgrc_match_ctx *f, int strand, uint32_t *cumm, uint3
 // ------------------------------------------------------------------ reads
 
 int pgrc_multi_begin_reads(pgrc_match_ctx *f, uint64_t n) {
+    pgrc_export_drop_view(f);
     pgrc_multi *m = f->multi;
     const size_t k = m->child.size();
     if (n >= (1ull << 32) - 1) { f->err = "reads count must stay below 2^32-1 (uint_reads_cnt_max, pg-config.h:21-22)"; return PGRC_E_PARAM; }
@@ -361,6 +365,7 @@ int pgrc_multi_end_reads(pgrc_match_ctx *f) {
 }
 
 int pgrc_multi_set_reads_device(pgrc_match_ctx *f, const void *d_words, uint64_t n, uint64_t stride) {
+    pgrc_export_drop_view(f);
     pgrc_multi *m = f->multi;
     if (m->child.size() != 1) { f->err = "set_reads_device: reads resident on one device cannot feed several"; return PGRC_E_PARAM; }
     int e = pgrc_match_set_reads_device(m->child[0], d_words, n, stride);
@@ -376,6 +381,7 @@ int pgrc_multi_set_reads_device(pgrc_match_ctx *f, const void *d_words, uint64_t
 // ------------------------------------------------------------------ matching
 
 int pgrc_multi_init_results(pgrc_match_ctx *f) {
+    pgrc_export_drop_view(f);
     pgrc_multi *m = f->multi;
     if (!f->have_reads) { f->err = "init_results: no reads set"; return PGRC_E_STATE; }
     int e = on_children(f, [&](size_t r) { return pgrc_match_init_results(m->child[r]); });
@@ -384,6 +390,7 @@ int pgrc_multi_init_results(pgrc_match_ctx *f) {
 }
 
 int pgrc_multi_set_results(pgrc_match_ctx *f, const uint64_t *pos, const uint8_t *rc, const uint8_t *mism) {
+    pgrc_export_drop_view(f);
     pgrc_multi *m = f->multi;
     if (!f->have_reads) { f->err = "set_results: no reads set"; return PGRC_E_STATE; }
     int e = on_children(f, [&](size_t r) { return pgrc_match_set_results(m->child[r], pos + m->lo[r], rc + m->lo[r], mism + m->lo[r]); });
@@ -392,6 +399,7 @@ int pgrc_multi_set_results(pgrc_match_ctx *f, const uint64_t *pos, const uint8_t
 }
 
 int pgrc_multi_run(pgrc_match_ctx *f, int first, int last) {
+    pgrc_export_drop_view(f);
     pgrc_multi *m = f->multi;
     if (!f->have_pg || !f->have_reads) { f->err = "run: set the pseudogenome and the reads first"; return PGRC_E_STATE; }
     int e = on_children(f, [&](size_t r) -> int {
