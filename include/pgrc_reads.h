@@ -64,7 +64,24 @@ const char *pgrc_divider_last_error(const pgrc_divider *d);   /* NULL: why the l
  * -- the caller appends them to its sets right away (PackedConstantLengthReadsSet::copyPackedRead). */
 int pgrc_divider_run(pgrc_divider *d, const char *reads, const char *quals, uint64_t n, pgrc_divided_reads *out);
 
-/* timing of the last run in milliseconds (upload, kernels, download) */
+/* The same straight from FASTQ text (FASTQReadsSourceIterator, readsset/iterator/ReadsSetIterator.cpp:189-224: four lines per
+ * record read with std::getline -- identifier, symbols, '+' line, qualities; the read is the leading run of letters of the
+ * symbol line and must be read_len long, the quality string is cut or zero-padded to that length).  `text` is a piece of
+ * the file, in file order; the call takes every COMPLETE record of it, divides them as pgrc_divider_run does and reports in
+ * *consumed where the next piece has to start (the caller keeps the rest and appends what it reads next).  final_piece != 0:
+ * nothing follows -- a last line without a newline counts; text that ends inside a record is PGRC_E_PARAM (what the
+ * reference makes of a cut-off last record depends on strings left over from the record before: not reproduced).
+ * pair_text != NULL: the second file of a pair (ManagedReadsSetIterator, readsset/persistance/ReadsSetPersistence.cpp:20-56):
+ * records are taken from the two texts in turn, the first file first, as many whole pairs as both pieces hold (at the final
+ * piece: until one file has no more, like the reference); rev_compl_pair != 0 reverse-complements the second file's reads
+ * (RevComplPairReadsSetIterator, ReadsSetIterator.cpp:256-274; qualities are not reversed).  *n_records = records taken,
+ * the batch indexes in *out count them in that order.  Pieces must be shorter than 2 GiB.  A record whose read is not
+ * read_len letters long is PGRC_E_PARAM (the reference exits with "Unsupported variable length reads"). */
+int pgrc_divider_run_fastq(pgrc_divider *d, const char *text, uint64_t bytes, const char *pair_text, uint64_t pair_bytes,
+                           int32_t rev_compl_pair, int32_t final_piece, uint64_t *consumed, uint64_t *pair_consumed,
+                           uint64_t *n_records, pgrc_divided_reads *out);
+
+/* timing of the last run in milliseconds (upload [+ parsing], kernels, download) */
 int pgrc_divider_last_ms(const pgrc_divider *d, float ms[3]);
 
 #ifdef __cplusplus

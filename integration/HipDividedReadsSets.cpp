@@ -24,6 +24,11 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "pgrc_reads.h"
 
 namespace PgTools {
@@ -94,6 +99,93 @@ namespace PgTools {
         if (separateNReadsSet)
             cout << " (including " << nMapping.size() << " containing N)";
         cout << " reads (out of " << seen << ") on the device." << endl;
+        readsSets->lqMapping = new VectorMapping(std::move(lqMapping), seen);
+        if (separateNReadsSet)
+            readsSets->nMapping = new VectorMapping(std::move(nMapping), seen);
+        return readsSets;
+    }
+
+    DividedPCLReadsSets *HipDividedReadsSets::getQualityDivisionBasedReadsSetsFromFastq(
+            const string &srcFastqFile, const string &pairFastqFile, bool revComplPairFile, uint_read_len_max readLength,
+            double error_limit, bool simplified_suffix_mode, bool separateNReadsSet, bool nReadsLQ) {
+        DividedPCLReadsSets *readsSets = new DividedPCLReadsSets(readLength, separateNReadsSet, nReadsLQ);
+        pgrc_divide_params prm;
+        prm.read_len = readLength;
+        prm.error_limit = error_limit;
+        prm.simplified_suffix_mode = simplified_suffix_mode ? 1 : 0;
+        prm.separate_n_reads_set = separateNReadsSet ? 1 : 0;
+        prm.n_reads_lq = nReadsLQ ? 1 : 0;
+        prm.device = -1;
+        pgrc_divider *divider = nullptr;
+        failOn(pgrc_divider_create(&prm, &divider), nullptr, "divider_create");
+        const bool paired = !pairFastqFile.empty();
+        // the files are mapped and handed over window by window: no read() into a buffer of ours, the copy to the device is
+        // the only pass over the text (PGRC_FASTQ_PIECE bytes of each file per call; tests use tiny ones).  A window starts
+        // where the records taken so far end: what a piece ends with -- a record cut in two, records whose mates have not
+        // come yet -- is simply seen again.
+        struct Mapped { const char *p = nullptr; size_t bytes = 0, at = 0; } in[2];
+        const string *names[2] = {&srcFastqFile, &pairFastqFile};
+        for (int f = 0; f < (paired ? 2 : 1); f++) {
+            const int fd = open(names[f]->c_str(), O_RDONLY);
+            struct stat st;
+            if (fd < 0 || fstat(fd, &st) != 0) {
+                fprintf(stderr, "cannot open reads file %s\n", names[f]->c_str());
+                exit(EXIT_FAILURE);
+            }
+            in[f].bytes = (size_t) st.st_size;
+            if (in[f].bytes) {
+                void *m = mmap(nullptr, in[f].bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m == MAP_FAILED) {
+                    fprintf(stderr, "cannot map reads file %s\n", names[f]->c_str());
+                    exit(EXIT_FAILURE);
+                }
+                (void) madvise(m, in[f].bytes, MADV_SEQUENTIAL);
+                in[f].p = (const char *) m;
+            }
+            close(fd);
+        }
+        size_t piece = 256u << 20;
+        if (const char *v = getenv("PGRC_FASTQ_PIECE")) piece = std::max<size_t>(64, strtoull(v, nullptr, 10));
+        vector<uint_reads_cnt_max> lqMapping, nMapping;
+        uint_reads_cnt_max seen = 0;
+        size_t window[2] = {piece, piece};                  // grows when a window holds no whole record (or no mate for one)
+        for (;;) {
+            size_t len[2];
+            bool final = true;
+            for (int f = 0; f < (paired ? 2 : 1); f++) {
+                len[f] = std::min(window[f], in[f].bytes - in[f].at);
+                final = final && in[f].at + len[f] == in[f].bytes;
+                if (len[f] >= (1ull << 31)) {
+                    fprintf(stderr, "HipDividedReadsSets: a FASTQ record or the lag between the two files exceeds 2 GiB\n");
+                    exit(EXIT_FAILURE);
+                }
+            }
+            pgrc_divided_reads part;                        // (the divider's arrays: valid until its next run)
+            uint64_t used[2] = {0, 0}, cnt = 0;
+            failOn(pgrc_divider_run_fastq(divider, in[0].p + in[0].at, len[0], paired ? (in[1].p ? in[1].p + in[1].at : "") : nullptr,
+                                          paired ? len[1] : 0, revComplPairFile ? 1 : 0, final ? 1 : 0, &used[0], paired ? &used[1] : nullptr, &cnt,
+                                          &part), divider, "divider_run_fastq");
+            batchesServed++;
+            appendRows(readsSets->getHqReadsSet(), part.hq_rows, part.n_hq);
+            appendRows(readsSets->getLqReadsSet(), part.lq_rows, part.n_lq);
+            if (separateNReadsSet) appendRows(readsSets->getNReadsSet(), part.n_rows, part.n_n);
+            for (uint64_t k = 0; k < part.n_lq; k++) lqMapping.push_back(seen + part.lq_index[k]);
+            for (uint64_t k = 0; k < part.n_n; k++) nMapping.push_back(seen + part.n_index[k]);
+            seen += (uint_reads_cnt_max) cnt;
+            if (final) break;
+            for (int f = 0; f < (paired ? 2 : 1); f++) {
+                in[f].at += used[f];
+                // nothing taken from a window that did not reach the end of its file: it has to show more next time
+                window[f] = (used[f] == 0 && in[f].at + len[f] < in[f].bytes) ? window[f] * 2 : piece;
+            }
+        }
+        for (int f = 0; f < (paired ? 2 : 1); f++)
+            if (in[f].p) munmap((void *) in[f].p, in[f].bytes);
+        pgrc_divider_destroy(divider);
+        cout << "Filtered " << (lqMapping.size() + nMapping.size());
+        if (separateNReadsSet)
+            cout << " (including " << nMapping.size() << " containing N)";
+        cout << " reads (out of " << seen << ") on the device, from the FASTQ text." << endl;
         readsSets->lqMapping = new VectorMapping(std::move(lqMapping), seen);
         if (separateNReadsSet)
             readsSets->nMapping = new VectorMapping(std::move(nMapping), seen);

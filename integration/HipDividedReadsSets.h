@@ -26,6 +26,14 @@ namespace PgTools {
                 ReadsSourceIteratorTemplate<uint_read_len_max> *readsIt, uint_read_len_max readLength,
                 bool separateNReadsSet, bool nReadsLQ);
 
+        // The same sets straight from the FASTQ file(s): what the two factories above make of
+        // ReadsSetPersistence::createManagedReadsIterator(srcFastqFile, pairFastqFile, revComplPairFile)
+        // (pgrc-encoder.cpp:255-256, ReadsSetPersistence.cpp:20-56), with the lines of the text found on the device too: the
+        // files are read in pieces and go up as they are.  error_limit = 1 gives getSimpleDividedPCLReadsSets' result.
+        static DividedPCLReadsSets *getQualityDivisionBasedReadsSetsFromFastq(
+                const string &srcFastqFile, const string &pairFastqFile, bool revComplPairFile, uint_read_len_max readLength,
+                double error_limit, bool simplified_suffix_mode, bool separateNReadsSet = false, bool nReadsLQ = false);
+
         static uint64_t batchesServed;     // diagnostics / tests
     };
 }

@@ -1154,3 +1154,42 @@ int pgrc_or_divide_reads(const char *reads, const char *quals, uint64_t n, uint3
     }
     return 0;
 }
+
+/* std::getline over a text in memory: the next line (without its newline) or 0 at the end; *len may be 0 for an empty line */
+static int next_line(const char *t, uint64_t n, uint64_t *at, const char **line, uint64_t *len) {
+    if (*at >= n) return 0;                                  /* nothing extracted at the end: the stream fails */
+    const char *s = t + *at, *e = memchr(s, '\n', n - *at);
+    *line = s;
+    *len = e ? (uint64_t)(e - s) : n - *at;
+    *at += *len + (e ? 1 : 0);
+    return 1;
+}
+
+int64_t pgrc_or_fastq_records(const char *text, uint64_t bytes, const char *pair_text, uint64_t pair_bytes, int rev_compl_pair,
+                              uint32_t L, char *reads, char *quals, uint64_t max_records) {
+    uint64_t at[2] = {0, 0}, k = 0;
+    const char *t[2] = {text, pair_text};
+    const uint64_t n[2] = {bytes, pair_bytes};
+    int pair = 0;                                            /* FASTQReadsSourceIterator::moveNext, ReadsSetIterator.cpp:206-224 */
+    for (;; k++) {
+        const int f = (pair && pair_text) ? 1 : 0;
+        pair = !pair;
+        const char *id, *line = "", *opt, *qual = "";
+        uint64_t idl, linel = 0, optl, quall = 0;
+        if (!next_line(t[f], n[f], &at[f], &id, &idl)) break;
+        /* a cut-off last record: the reference goes on with whatever its strings held before (a getline on a stream at its
+         * end leaves them alone) -- not restated, reported */
+        if (!next_line(t[f], n[f], &at[f], &line, &linel) || !next_line(t[f], n[f], &at[f], &opt, &optl) ||
+            !next_line(t[f], n[f], &at[f], &qual, &quall))
+            return -3;
+        uint64_t length = 0;
+        while (length < linel && ((line[length] >= 'A' && line[length] <= 'Z') || (line[length] >= 'a' && line[length] <= 'z'))) length++;
+        if (length != L) return -1;                          /* addRead: "Unsupported variable length reads" */
+        if (k >= max_records) return -2;
+        char *r = reads + k * L, *q = quals + k * L;
+        memcpy(r, line, L);                                  /* getRead: line.resize(length) */
+        for (uint32_t x = 0; x < L; x++) q[x] = x < quall ? qual[x] : 0;   /* getQualityInfo: quality.resize(length) */
+        if (pair_text && rev_compl_pair && (k & 1)) pgrc_or_revcomp(r, L);  /* RevComplPairReadsSetIterator::getRead, :267-274 */
+    }
+    return (int64_t)k;
+}

@@ -188,6 +188,12 @@ void pgrc_or_unpack_read(const uint8_t *src, uint32_t read_len, const char *alph
 int pgrc_or_divide_reads(const char *reads, const char *quals, uint64_t n, uint32_t read_len, double error_limit,
                          int simplified_suffix_mode, int separate_n, int n_reads_lq, uint8_t *hq_rows, uint8_t *lq_rows,
                          uint8_t *n_rows, uint32_t *lq_index, uint32_t *n_index, uint64_t counts[3], uint32_t symbols[3]);
+/* FASTQReadsSourceIterator + RevComplPairReadsSetIterator over whole files held in memory (readsset/iterator/ReadsSetIterator.cpp:
+ * 189-224, :256-284): the records' symbol rows and quality rows (read_len bytes each; the caller's buffers), records taken
+ * from the two texts in turn when pair_text != NULL.  Returns the number of records, -1 when a read is not read_len long,
+ * -3 when the text ends inside a record. */
+int64_t pgrc_or_fastq_records(const char *text, uint64_t bytes, const char *pair_text, uint64_t pair_bytes, int rev_compl_pair,
+                              uint32_t read_len, char *reads, char *quals, uint64_t max_records);
 /* qualityLut[c] (utils/helper.cpp:284-327) as this file restates it */
 float pgrc_or_quality_lut(int c);
 

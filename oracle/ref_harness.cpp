@@ -20,6 +20,7 @@
 #include "readsset/PackedConstantLengthReadsSet.h"
 #include "utils/helper.h"
 #include "readsset/DividedPCLReadsSets.h"
+#include "readsset/persistance/ReadsSetPersistence.h"
 #ifdef PGRC_WITH_HIP_ADAPTER
 #include "HipDividedReadsSets.h"
 #include "HipReadsMatcher.h"
@@ -319,6 +320,10 @@ namespace PgTools {
 static bool g_gpu_division = false;
 static int g_division_calls = 0;
 static double g_division_s = 0;                  // wall time inside the two factories, whichever implementation ran
+// the FASTQ files of the running encode (pgrc_ref_encode): the GPU division reads them itself unless PGRC_DIVIDE_FROM_ROWS is
+// set, in which case it takes the records from the reference's iterator
+static std::string g_src_fastq, g_pair_fastq;
+static const PgRCParams *g_params = nullptr;     // (revComplPairFile is decided inside the encoder, pgrc-encoder.cpp:49-52: read when needed)
 extern "C" DividedPCLReadsSets *pgrc_ref_divide_quality_original(ReadsSourceIteratorTemplate<uint_read_len_max> *readsIt,
                                                                   uint_read_len_max readLength, double error_limit,
                                                                   bool simplified_suffix_mode, bool separateNReadsSet, bool nReadsLQ);
@@ -332,6 +337,9 @@ namespace PgTools {
         if (!g_gpu_division)
             return pgrc_ref_divide_quality_original(readsIt, readLength, error_limit, simplified_suffix_mode, separateNReadsSet, nReadsLQ);
         g_division_calls++;
+        if (!getenv("PGRC_DIVIDE_FROM_ROWS") && !g_src_fastq.empty())
+            return HipDividedReadsSets::getQualityDivisionBasedReadsSetsFromFastq(g_src_fastq, g_pair_fastq, g_params && g_params->revComplPairFile, readLength,
+                                                                                  error_limit, simplified_suffix_mode, separateNReadsSet, nReadsLQ);
         return HipDividedReadsSets::getQualityDivisionBasedReadsSets(readsIt, readLength, error_limit, simplified_suffix_mode,
                                                                      separateNReadsSet, nReadsLQ);
     }
@@ -340,6 +348,9 @@ namespace PgTools {
         StageTimer timer(g_division_s);
         if (!g_gpu_division) return pgrc_ref_divide_simple_original(readsIt, readLength, separateNReadsSet, nReadsLQ);
         g_division_calls++;
+        if (!getenv("PGRC_DIVIDE_FROM_ROWS") && !g_src_fastq.empty())
+            return HipDividedReadsSets::getQualityDivisionBasedReadsSetsFromFastq(g_src_fastq, g_pair_fastq, g_params && g_params->revComplPairFile, readLength, 1,
+                                                                                  false, separateNReadsSet, nReadsLQ);
         return HipDividedReadsSets::getSimpleDividedPCLReadsSets(readsIt, readLength, separateNReadsSet, nReadsLQ);
     }
 }
@@ -374,11 +385,16 @@ extern "C" int pgrc_ref_encode(const char *fastq, const char *pair_fastq, const 
     if (const char *v = getenv("PGRC_REF_Q_PROMILS")) params->setQualityBasedDivisionErrorLimitInPromils((uint16_t) atoi(v));
     if (getenv("PGRC_REF_Q_FULL")) params->disableSimplifiedSuffixMode4QualityBasedDivision();
     if (getenv("PGRC_REF_N_READS_LQ")) params->setNReadsLQ();
+    g_src_fastq = fastq;
+    g_pair_fastq = (pair_fastq && pair_fastq[0]) ? pair_fastq : "";
+    g_params = params;
     {
         PgRCEncoder encoder(params);
         encoder.executePgRCChain();
     }
     delete params;
+    g_src_fastq.clear();
+    g_params = nullptr;
     g_gpu_matching = false;
     g_gpu_text_matching = false;
     g_gpu_division = false;
@@ -733,6 +749,27 @@ struct RowsIterator : ReadsSourceIteratorTemplate<uint_read_len_max> {
 };
 }
 
+static int divide_out(DividedPCLReadsSets *sets, uint64_t n, uint32_t L, uint8_t *hq_rows, uint8_t *lq_rows, uint8_t *n_rows,
+                      uint32_t *lq_index, uint32_t *n_index, uint64_t counts[3], uint32_t symbols[3]) {
+    PackedConstantLengthReadsSet *set[3] = {sets->getHqReadsSet(), sets->getLqReadsSet(), sets->getNReadsSet()};
+    uint8_t *dst[3] = {hq_rows, lq_rows, n_rows};
+    for (int k = 0; k < 3; k++) {
+        counts[k] = set[k] ? set[k]->readsCount() : 0;
+        symbols[k] = set[k] ? set[k]->getReadsSetProperties()->symbolsCount : 0;
+        if (!set[k] || !counts[k]) continue;
+        const uint32_t per = symbols[k] == 4 ? 4 : 3, rb = (L + per - 1) / per;
+        memcpy(dst[k], set[k]->getPackedRead(0), (size_t) counts[k] * rb);
+    }
+    IndexesMapping *lm = sets->getLqReadsIndexesMapping(), *nm = sets->getNReadsIndexesMapping();
+    if (lm && lm->getMappedReadsCount() != counts[1]) return 2;
+    for (uint64_t i = 0; lm && i < counts[1]; i++) lq_index[i] = (uint32_t) lm->getReadOriginalIndex((uint_reads_cnt_max) i);
+    if (nm && nm->getMappedReadsCount() != counts[2]) return 3;
+    for (uint64_t i = 0; nm && i < counts[2]; i++) n_index[i] = (uint32_t) nm->getReadOriginalIndex((uint_reads_cnt_max) i);
+    if (n != ~0ull && lm && lm->getReadsTotalCount() != n) return 4;
+    delete sets;
+    return 0;
+}
+
 // DividedPCLReadsSets::getQualityDivisionBasedReadsSets (use_adapter = 0) or integration/HipDividedReadsSets (1) over the
 // records; the sets' packed rows and the mappings go to the caller's buffers (n * ceil(L / 3) bytes / n entries each)
 extern "C" int pgrc_ref_divide(int use_adapter, const char *reads, const char *quals, uint64_t n, uint32_t L, double error_limit,
@@ -756,23 +793,35 @@ extern "C" int pgrc_ref_divide(int use_adapter, const char *reads, const char *q
                                                                      separate_n != 0, n_reads_lq != 0);
 #endif
     }
-    PackedConstantLengthReadsSet *set[3] = {sets->getHqReadsSet(), sets->getLqReadsSet(), sets->getNReadsSet()};
-    uint8_t *dst[3] = {hq_rows, lq_rows, n_rows};
-    for (int k = 0; k < 3; k++) {
-        counts[k] = set[k] ? set[k]->readsCount() : 0;
-        symbols[k] = set[k] ? set[k]->getReadsSetProperties()->symbolsCount : 0;
-        if (!set[k] || !counts[k]) continue;
-        const uint32_t per = symbols[k] == 4 ? 4 : 3, rb = (L + per - 1) / per;
-        memcpy(dst[k], set[k]->getPackedRead(0), (size_t) counts[k] * rb);
+    return divide_out(sets, n, L, hq_rows, lq_rows, n_rows, lq_index, n_index, counts, symbols);
+}
+
+// ... the same over FASTQ FILES: the reference's managed iterator (ReadsSetPersistence.cpp:20-56) feeding its factory, or
+// HipDividedReadsSets::getQualityDivisionBasedReadsSetsFromFastq, which parses the text on the device (buffers for max_reads)
+extern "C" int pgrc_ref_divide_files(int use_adapter, const char *src, const char *pair, int rev_compl_pair, uint32_t L, double error_limit,
+                                     int simplified, int separate_n, int n_reads_lq, uint8_t *hq_rows, uint8_t *lq_rows, uint8_t *n_rows,
+                                     uint32_t *lq_index, uint32_t *n_index, uint64_t counts[3], uint32_t symbols[3]) {
+    Silence quiet;
+    DividedPCLReadsSets *sets = nullptr;
+    const std::string pairFile = (pair && pair[0]) ? pair : "";
+    if (use_adapter) {
+#ifdef PGRC_WITH_HIP_ADAPTER
+        sets = HipDividedReadsSets::getQualityDivisionBasedReadsSetsFromFastq(src, pairFile, rev_compl_pair != 0, (uint_read_len_max) L, error_limit,
+                                                                               simplified != 0, separate_n != 0, n_reads_lq != 0);
+#else
+        return -1;
+#endif
+    } else {
+        ReadsSourceIteratorTemplate<uint_read_len_max> *it = ReadsSetPersistence::createManagedReadsIterator(src, pairFile, rev_compl_pair != 0);
+#ifdef PGRC_WITH_HIP_ADAPTER
+        sets = pgrc_ref_divide_quality_original(it, (uint_read_len_max) L, error_limit, simplified != 0, separate_n != 0, n_reads_lq != 0);
+#else
+        sets = DividedPCLReadsSets::getQualityDivisionBasedReadsSets(it, (uint_read_len_max) L, error_limit, simplified != 0, separate_n != 0,
+                                                                     n_reads_lq != 0);
+#endif
+        delete it;
     }
-    IndexesMapping *lm = sets->getLqReadsIndexesMapping(), *nm = sets->getNReadsIndexesMapping();
-    if (lm && lm->getMappedReadsCount() != counts[1]) return 2;
-    for (uint64_t i = 0; lm && i < counts[1]; i++) lq_index[i] = (uint32_t) lm->getReadOriginalIndex((uint_reads_cnt_max) i);
-    if (nm && nm->getMappedReadsCount() != counts[2]) return 3;
-    for (uint64_t i = 0; nm && i < counts[2]; i++) n_index[i] = (uint32_t) nm->getReadOriginalIndex((uint_reads_cnt_max) i);
-    if (lm && lm->getReadsTotalCount() != n) return 4;
-    delete sets;
-    return 0;
+    return divide_out(sets, ~0ull, L, hq_rows, lq_rows, n_rows, lq_index, n_index, counts, symbols);
 }
 
 // the reference's table of per-quality probabilities (utils/helper.cpp:284-327, a global of that file)

@@ -157,6 +157,8 @@ _PROTOS = [
     ("pgrc_divider_destroy", None, [_P]),
     ("pgrc_divider_last_error", C.c_char_p, [_P]),
     ("pgrc_divider_run", C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(DividedReads)]),
+    ("pgrc_divider_run_fastq", C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(DividedReads)]),
     ("pgrc_divider_last_ms", C.c_int, [_P, C.POINTER(C.c_float * 3)]),
 ]
 

@@ -40,6 +40,7 @@ struct pgrc_divider {
     pgrc_divide_params prm{};
     int suffix_pos = 0;
     DevBuf d_reads, d_quals, d_flags, d_high, d_cls, d_cnt[3], d_bsum, d_rows[3], d_idx[2], d_lut, d_err;
+    DevBuf d_text[2], d_nl[2], d_ls[2];   // FASTQ text of one or two files, newlines per 16 bytes, line starts
     // the results of a run on the host: pinned, grow-only, the divider's (fresh pageable pages would be touched for the first
     // time by the copy, at one thread's page-fault rate: 11 GB/s against the link's 56)
     struct HostBuf { void *p = nullptr; size_t bytes = 0; } h_rows[3], h_idx[2];
@@ -213,6 +214,83 @@ k_dv_pack(const DvPackArgs a) {
     if (b == 0 && c != DV_HQ) a.idx[c - 1][slot] = (uint32_t)r;
 }
 
+// ---- FASTQ text: lines and rows
+// newlines per 16 bytes (entry n16: 0, the end of the scan)
+__global__ void __launch_bounds__(256)
+k_fq_count(const uint8_t *__restrict__ text, uint64_t bytes, uint64_t n16, uint32_t *__restrict__ cnt) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n16) return;
+    uint32_t c = 0;
+    if (i < n16) {
+        const uint4 v = *(const uint4 *)(text + 16 * i);                 // (32 zero bytes follow the text)
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (uint32_t k = 0; k < 16 && 16 * i + k < bytes; k++) c += ((w[k >> 2] >> (8 * (k & 3))) & 255u) == '\n';
+    }
+    cnt[i] = c;
+}
+// ls[k] = first byte of line k: ls[0] = 0, ls[j + 1] = position after the j-th newline; ls[nl + 1 ..] = bytes (the end of a last
+// line that has no newline)
+__global__ void __launch_bounds__(256)
+k_fq_starts(const uint8_t *__restrict__ text, uint64_t bytes, uint64_t n16, const uint32_t *__restrict__ before, uint32_t nl,
+            uint32_t *__restrict__ ls) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        ls[0] = 0;
+        for (uint32_t k = 1; k <= 6; k++) ls[nl + k] = (uint32_t)bytes;
+    }
+    if (i >= n16) return;
+    uint32_t j = before[i];
+    const uint4 v = *(const uint4 *)(text + 16 * i);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    for (uint32_t k = 0; k < 16 && 16 * i + k < bytes; k++)
+        if (((w[k >> 2] >> (8 * (k & 3))) & 255u) == '\n') ls[++j] = (uint32_t)(16 * i + k + 1);
+}
+
+struct FqRowsArgs {
+    const uint8_t *text[2];
+    const uint32_t *ls[2];
+    uint32_t len[2], nl[2];     // bytes and newlines of each text
+    uint32_t paired, rc_second, L;
+    uint64_t n;
+    uint8_t *reads, *quals;     // quals: null when the division does not ask them
+    uint32_t *err;
+};
+__device__ __forceinline__ bool fq_alpha(uint32_t ch) { return (ch - 'A') < 26u || (ch - 'a') < 26u; }
+// complementsLut for the letters a read may hold (utils/helper.cpp:263-276); anything else is reported by k_dv_symbols
+__device__ __forceinline__ uint32_t fq_complement(uint32_t ch) { return ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch; }
+
+// record k of the batch = record k (or k / 2 of file k % 2) of the text: column x < L copies symbol and quality character,
+// column L checks that the run of letters ends there (FASTQReadsSourceIterator::moveNext, :218-220)
+__global__ void __launch_bounds__(256)
+k_fq_rows(const FqRowsArgs a) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t k = g / (a.L + 1);
+    const uint32_t x = (uint32_t)(g % (a.L + 1));
+    if (k >= a.n) return;
+    const uint32_t f = a.paired ? (uint32_t)(k & 1) : 0u;
+    const uint64_t r = a.paired ? k >> 1 : k;
+    const uint8_t *t = a.text[f];
+    const uint32_t *ls = a.ls[f];
+    // line j spans [ls[j], ls[j + 1] - 1) -- up to its newline --, a last line without one [ls[j], ls[j + 1]) = up to the end
+    const uint32_t nl = a.nl[f];
+    const uint32_t j1 = (uint32_t)(4 * r + 1), j3 = j1 + 2;
+    const uint32_t s = ls[j1];
+    const uint32_t e = ls[j1 + 1] - (j1 < nl ? 1u : 0u);
+    const uint32_t ch = (s + x < e) ? t[s + x] : 0u;
+    if (x == a.L) {
+        if (fq_alpha(ch)) atomicOr(a.err, 1u);                         // the read is longer than read_len
+        return;
+    }
+    if (!fq_alpha(ch)) atomicOr(a.err, 1u);                            // ... or shorter
+    const bool rc = a.rc_second && f == 1;
+    a.reads[k * a.L + (rc ? a.L - 1 - x : x)] = (uint8_t)(rc ? fq_complement(ch) : ch);
+    if (a.quals) {
+        const uint32_t qs = ls[j3];
+        const uint32_t qe = ls[j3 + 1] - (j3 < nl ? 1u : 0u);
+        a.quals[k * a.L + x] = (qs + x < qe) ? t[qs + x] : (uint8_t)0;  // quality.resize(length): cut or zero-padded, never reversed
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 
 #define DIV_TRY(d, expr)                                                                     \
@@ -280,7 +358,8 @@ void pgrc_divider_destroy(pgrc_divider *d) {
     PgrcDeviceScope scope(d->base.device);
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&d->d_reads, &d->d_quals, &d->d_flags, &d->d_high, &d->d_cls, &d->d_cnt[0], &d->d_cnt[1], &d->d_cnt[2], &d->d_bsum,
-                      &d->d_rows[0], &d->d_rows[1], &d->d_rows[2], &d->d_idx[0], &d->d_idx[1], &d->d_lut, &d->d_err};
+                      &d->d_rows[0], &d->d_rows[1], &d->d_rows[2], &d->d_idx[0], &d->d_idx[1], &d->d_lut, &d->d_err,
+                      &d->d_text[0], &d->d_text[1], &d->d_nl[0], &d->d_nl[1], &d->d_ls[0], &d->d_ls[1]};
     for (DevBuf *b : bufs) pgrc_buf_free(*b);
     for (auto *h : {&d->h_rows[0], &d->h_rows[1], &d->h_rows[2], &d->h_idx[0], &d->h_idx[1]})
         if (h->p) (void)hipHostFree(h->p);
@@ -296,16 +375,12 @@ int pgrc_divider_last_ms(const pgrc_divider *d, float ms[3]) {
     return PGRC_OK;
 }
 
-int pgrc_divider_run(pgrc_divider *d, const char *reads, const char *quals, uint64_t n, pgrc_divided_reads *out) {
-    if (!d || !out || (n && !reads)) return PGRC_E_PARAM;
-    memset(out, 0, sizeof *out);
+// the sets of n records whose symbol rows (and quality rows, when the division asks them) lie in d_reads / d_quals;
+// ev[1] has been recorded by the caller where its own part (upload or parsing) ended
+static int divide_resident(pgrc_divider *d, uint64_t n, pgrc_divided_reads *out) {
     const pgrc_divide_params &p = d->prm;
     const bool by_quality = p.error_limit < 1;
-    if (by_quality && n && !quals) { d->base.err = "divider: quality rows are needed when error_limit < 1"; return PGRC_E_PARAM; }
-    if (n >= (1ull << 32) - 1) { d->base.err = "divider: batches of less than 2^32 - 1 reads"; return PGRC_E_PARAM; }
     pgrc_match_ctx *c = &d->base;
-    PgrcDeviceScope scope(c->device);
-    if (!scope.ok) { c->err = "hipSetDevice failed"; return PGRC_E_NO_DEVICE; }
     const uint32_t L = p.read_len;
     const bool n_apart = p.separate_n_reads_set || p.n_reads_lq;
     // alphabets (DividedPCLReadsSets.cpp:10-21)
@@ -318,23 +393,14 @@ int pgrc_divider_run(pgrc_divider *d, const char *reads, const char *quals, uint
     out->hq_symbols = sym[0]; out->lq_symbols = sym[1]; out->n_symbols = sym[2];
     out->hq_row_bytes = rb[0]; out->lq_row_bytes = rb[1]; out->n_row_bytes = rb[2];
     if (n == 0) return PGRC_OK;
-    if (!d->have_ev) {
-        for (auto &x : d->ev) DIV_TRY(d, hipEventCreate(&x));
-        d->have_ev = true;
-    }
     int e;
     const size_t bytes = (size_t)n * L;
-    if ((e = pgrc_buf_ensure(c, d->d_reads, bytes + 16)) || (by_quality && (e = pgrc_buf_ensure(c, d->d_quals, bytes + 16))) ||
-        (e = pgrc_buf_ensure(c, d->d_flags, n * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, d->d_high, n)) || (e = pgrc_buf_ensure(c, d->d_cls, n)) ||
+    if ((e = pgrc_buf_ensure(c, d->d_flags, n * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, d->d_high, n)) || (e = pgrc_buf_ensure(c, d->d_cls, n)) ||
         (e = pgrc_buf_ensure(c, d->d_bsum, (pgrc_ps_scan_blocks(n + 1) + 1) * sizeof(uint32_t))))
         return e;
     for (int k = 0; k < 3; k++)
         if ((e = pgrc_buf_ensure(c, d->d_cnt[k], (n + 1) * sizeof(uint32_t)))) return e;
     hipStream_t s = c->stream;
-    (void)hipEventRecord(d->ev[0], s);
-    DIV_TRY(d, hipMemcpyAsync(d->d_reads.p, reads, bytes, hipMemcpyHostToDevice, s));
-    if (by_quality) DIV_TRY(d, hipMemcpyAsync(d->d_quals.p, quals, bytes, hipMemcpyHostToDevice, s));
-    (void)hipEventRecord(d->ev[1], s);
     DIV_TRY(d, hipMemsetAsync(d->d_flags.p, 0, n * sizeof(uint32_t), s));
     DIV_TRY(d, hipMemsetAsync(d->d_err.p, 0, sizeof(uint32_t), s));
     const uint32_t g = (uint32_t)((n + 1 + 255) / 256);
@@ -398,6 +464,143 @@ int pgrc_divider_run(pgrc_divider *d, const char *reads, const char *quals, uint
     out->n_index = (const uint32_t *)d->h_idx[1].p;
     for (int k = 0; k < 3; k++) (void)hipEventElapsedTime(&d->ms[k], d->ev[k], d->ev[k + 1]);
     return PGRC_OK;
+}
+
+static int dv_events(pgrc_divider *d) {
+    if (d->have_ev) return PGRC_OK;
+    for (auto &x : d->ev) DIV_TRY(d, hipEventCreate(&x));
+    d->have_ev = true;
+    return PGRC_OK;
+}
+
+int pgrc_divider_run(pgrc_divider *d, const char *reads, const char *quals, uint64_t n, pgrc_divided_reads *out) {
+    if (!d || !out || (n && !reads)) return PGRC_E_PARAM;
+    memset(out, 0, sizeof *out);
+    const bool by_quality = d->prm.error_limit < 1;
+    if (by_quality && n && !quals) { d->base.err = "divider: quality rows are needed when error_limit < 1"; return PGRC_E_PARAM; }
+    if (n >= (1ull << 32) - 1) { d->base.err = "divider: batches of less than 2^32 - 1 reads"; return PGRC_E_PARAM; }
+    pgrc_match_ctx *c = &d->base;
+    PgrcDeviceScope scope(c->device);
+    if (!scope.ok) { c->err = "hipSetDevice failed"; return PGRC_E_NO_DEVICE; }
+    int e;
+    if ((e = dv_events(d))) return e;
+    const size_t bytes = (size_t)n * d->prm.read_len;
+    if (n) {
+        if ((e = pgrc_buf_ensure(c, d->d_reads, bytes + 16)) || (by_quality && (e = pgrc_buf_ensure(c, d->d_quals, bytes + 16)))) return e;
+        (void)hipEventRecord(d->ev[0], c->stream);
+        DIV_TRY(d, hipMemcpyAsync(d->d_reads.p, reads, bytes, hipMemcpyHostToDevice, c->stream));
+        if (by_quality) DIV_TRY(d, hipMemcpyAsync(d->d_quals.p, quals, bytes, hipMemcpyHostToDevice, c->stream));
+        (void)hipEventRecord(d->ev[1], c->stream);
+    }
+    return divide_resident(d, n, out);
+}
+
+// ---- FASTQ text in, sets out (FASTQReadsSourceIterator, readsset/iterator/ReadsSetIterator.cpp:189-224; the pairing and the
+// reverse complement of the second file's reads, RevComplPairReadsSetIterator, :256-284; ManagedReadsSetIterator,
+// readsset/persistance/ReadsSetPersistence.cpp:20-56).  The reference reads four lines per record with std::getline --
+// identifier, symbols, '+' line, qualities --, alternately from the two files of a pair; the read is the leading run of
+// letters of the symbol line, the quality string is cut or zero-padded to that length.  Here the caller hands over a piece
+// of each file's text; the lines are found by all threads (newlines counted per 16 bytes, an exclusive scan, line starts
+// written in place), the records' rows are copied out byte-parallel -- every second record of a pair reverse-complemented
+// when asked -- and the division above runs on them where they are: the text goes up once, nothing else.
+int pgrc_divider_run_fastq(pgrc_divider *d, const char *text, uint64_t bytes, const char *pair_text, uint64_t pair_bytes,
+                           int32_t rev_compl_pair, int32_t final_piece, uint64_t *consumed, uint64_t *pair_consumed,
+                           uint64_t *n_records, pgrc_divided_reads *out) {
+    if (!d || !out || !consumed || !n_records || (bytes && !text) || (pair_bytes && !pair_text) || (pair_text && !pair_consumed)) return PGRC_E_PARAM;
+    memset(out, 0, sizeof *out);
+    *consumed = 0;
+    *n_records = 0;
+    if (pair_consumed) *pair_consumed = 0;
+    pgrc_match_ctx *c = &d->base;
+    if (bytes >= (1ull << 31) || pair_bytes >= (1ull << 31)) { c->err = "divider: pieces of FASTQ text below 2 GiB"; return PGRC_E_PARAM; }
+    PgrcDeviceScope scope(c->device);
+    if (!scope.ok) { c->err = "hipSetDevice failed"; return PGRC_E_NO_DEVICE; }
+    int e;
+    if ((e = dv_events(d))) return e;
+    const uint32_t L = d->prm.read_len;
+    const bool paired = pair_text != nullptr;
+    const bool by_quality = d->prm.error_limit < 1;
+    hipStream_t s = c->stream;
+    const char *src[2] = {text, pair_text};
+    const uint64_t len[2] = {bytes, pair_bytes};
+    uint64_t lines[2] = {0, 0};
+    uint32_t nls[2] = {0, 0};
+    (void)hipEventRecord(d->ev[0], s);
+    for (int f = 0; f < (paired ? 2 : 1); f++) {
+        const uint64_t n16 = (len[f] + 15) / 16;
+        if ((e = pgrc_buf_ensure(c, d->d_text[f], len[f] + 32)) || (e = pgrc_buf_ensure(c, d->d_nl[f], (n16 + 1) * sizeof(uint32_t))) ||
+            (e = pgrc_buf_ensure(c, d->d_bsum, (pgrc_ps_scan_blocks(n16 + 1) + 1) * sizeof(uint32_t))))
+            return e;
+        if (len[f]) DIV_TRY(d, hipMemcpyAsync(d->d_text[f].p, src[f], len[f], hipMemcpyHostToDevice, s));
+        DIV_TRY(d, hipMemsetAsync((uint8_t *)d->d_text[f].p + len[f], 0, 32, s));
+        hipLaunchKernelGGL(k_fq_count, dim3((uint32_t)((n16 + 1 + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d->d_text[f].p, len[f], n16,
+                           (uint32_t *)d->d_nl[f].p);
+        if ((e = pgrc_ps_scan_u32(c, (uint32_t *)d->d_nl[f].p, n16 + 1, (uint32_t *)d->d_bsum.p))) return e;
+        uint32_t nl = 0;
+        uint8_t last = '\n';
+        DIV_TRY(d, hipMemcpyAsync(&nl, (const uint32_t *)d->d_nl[f].p + n16, sizeof nl, hipMemcpyDeviceToHost, s));
+        DIV_TRY(d, hipStreamSynchronize(s));
+        if (len[f]) last = (uint8_t)src[f][len[f] - 1];
+        // std::getline: a last piece without its newline is a line too, once nothing more will come
+        lines[f] = nl + ((final_piece && len[f] && last != '\n') ? 1u : 0u);
+        nls[f] = nl;
+        if ((e = pgrc_buf_ensure(c, d->d_ls[f], ((size_t)nl + 8) * sizeof(uint32_t)))) return e;
+        hipLaunchKernelGGL(k_fq_starts, dim3((uint32_t)((n16 + 255) / 256 + 1)), dim3(256), 0, s, (const uint8_t *)d->d_text[f].p, len[f], n16,
+                           (const uint32_t *)d->d_nl[f].p, nl, (uint32_t *)d->d_ls[f].p);
+        DIV_TRY(d, hipGetLastError());
+    }
+    // whole records in what we have: four lines each
+    const uint64_t rec[2] = {lines[0] / 4, lines[1] / 4};
+    uint64_t n;                       // records taken: the two files in turn, first file first, until one of them has no more
+    uint64_t take[2];
+    if (!paired) { n = rec[0]; take[0] = rec[0]; take[1] = 0; }
+    else if (final_piece) { n = rec[0] <= rec[1] ? 2 * rec[0] : 2 * rec[1] + 1; take[0] = (n + 1) / 2; take[1] = n / 2; }
+    else { const uint64_t m = std::min(rec[0], rec[1]); n = 2 * m; take[0] = take[1] = m; }
+    if (final_piece) {
+        // The record the reference would read next: none (its source is through: it stops) -- or the beginning of one.  What it
+        // makes of a cut-off last record depends on state left over in its iterator (a std::getline on a stream already at
+        // its end leaves the string of the record BEFORE in place): not reproduced, reported instead.
+        const int f = paired ? (int)(n & 1) : 0;
+        if (lines[f] % 4 && rec[f] == (paired ? n >> 1 : n)) {
+            c->err = "FASTQ text ends inside a record";
+            return PGRC_E_PARAM;
+        }
+    }
+    if (n >= (1ull << 32) - 1) { c->err = "divider: batches of less than 2^32 - 1 reads"; return PGRC_E_PARAM; }
+    const size_t rows = (size_t)n * L;
+    if ((e = pgrc_buf_ensure(c, d->d_reads, rows + 16)) || (by_quality && (e = pgrc_buf_ensure(c, d->d_quals, rows + 16)))) return e;
+    DIV_TRY(d, hipMemsetAsync(d->d_err.p, 0, sizeof(uint32_t), s));
+    uint32_t ends[2] = {0, 0};        // first byte after the last record taken from each piece
+    if (n) {
+        FqRowsArgs a;
+        for (int f = 0; f < 2; f++) {
+            a.text[f] = (const uint8_t *)d->d_text[f].p;
+            a.ls[f] = (const uint32_t *)d->d_ls[f].p;
+            a.len[f] = (uint32_t)len[f];
+            a.nl[f] = nls[f];
+        }
+        a.paired = paired ? 1u : 0u;
+        a.rc_second = (paired && rev_compl_pair) ? 1u : 0u;
+        a.L = L;
+        a.n = n;
+        a.reads = (uint8_t *)d->d_reads.p;
+        a.quals = by_quality ? (uint8_t *)d->d_quals.p : nullptr;
+        a.err = (uint32_t *)d->d_err.p;
+        const uint64_t work = n * (L + 1);
+        hipLaunchKernelGGL(k_fq_rows, dim3((uint32_t)((work + 255) / 256)), dim3(256), 0, s, a);
+        DIV_TRY(d, hipGetLastError());
+        uint32_t bad = 0;
+        DIV_TRY(d, hipMemcpyAsync(&bad, d->d_err.p, sizeof bad, hipMemcpyDeviceToHost, s));
+        for (int f = 0; f < (paired ? 2 : 1); f++)         // line 4 * take starts where the records taken end (ls[nl + 1] = the end of the text)
+            if (take[f]) DIV_TRY(d, hipMemcpyAsync(&ends[f], (const uint32_t *)d->d_ls[f].p + 4 * take[f], sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        DIV_TRY(d, hipStreamSynchronize(s));
+        if (bad) { c->err = "Unsupported variable length reads (a FASTQ record whose read is not read_len letters long)"; return PGRC_E_PARAM; }
+    }
+    *consumed = ends[0];
+    if (paired) *pair_consumed = ends[1];
+    (void)hipEventRecord(d->ev[1], s);
+    *n_records = n;
+    return divide_resident(d, n, out);
 }
 
 } // extern "C"

@@ -58,6 +58,35 @@ class DividedPCLReadsSets:
                "lq_index": arr(out.lq_index, out.n_lq, np.uint32), "n_index": arr(out.n_index, out.n_n, np.uint32)}
         return res
 
+    def _result(self, out) -> dict:
+        def arr(ptr, count, dtype):
+            if not count:
+                return np.zeros(0, dtype=dtype)
+            a = np.empty(count, dtype=dtype)
+            C.memmove(a.ctypes.data, ptr, a.nbytes)
+            return a
+        return {"n_hq": int(out.n_hq), "n_lq": int(out.n_lq), "n_n": int(out.n_n),
+                "symbols": (int(out.hq_symbols), int(out.lq_symbols), int(out.n_symbols)),
+                "row_bytes": (int(out.hq_row_bytes), int(out.lq_row_bytes), int(out.n_row_bytes)),
+                "hq_rows": arr(out.hq_rows, out.n_hq * out.hq_row_bytes, np.uint8),
+                "lq_rows": arr(out.lq_rows, out.n_lq * out.lq_row_bytes, np.uint8),
+                "n_rows": arr(out.n_rows, out.n_n * out.n_row_bytes, np.uint8),
+                "lq_index": arr(out.lq_index, out.n_lq, np.uint32), "n_index": arr(out.n_index, out.n_n, np.uint32)}
+
+    def divide_fastq(self, text: bytes, pair_text: Optional[bytes] = None, rev_compl_pair: bool = False, final: bool = True):
+        """One piece of FASTQ text (and of the pair file's): (result dict, records taken, bytes consumed, pair bytes consumed)."""
+        out = _lib.DividedReads()
+        used, pused, nrec = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        t = np.frombuffer(text, dtype=np.uint8) if len(text) else np.zeros(1, np.uint8)
+        pt = None
+        if pair_text is not None:
+            pt = np.frombuffer(pair_text, dtype=np.uint8) if len(pair_text) else np.zeros(1, np.uint8)
+        self._ck(lib.pgrc_divider_run_fastq(self._h, t.ctypes.data_as(C.c_void_p), len(text),
+                                            pt.ctypes.data_as(C.c_void_p) if pt is not None else None,
+                                            len(pair_text) if pair_text is not None else 0, int(bool(rev_compl_pair)), int(bool(final)),
+                                            C.byref(used), C.byref(pused), C.byref(nrec), C.byref(out)))
+        return self._result(out), int(nrec.value), int(used.value), int(pused.value)
+
     def last_ms(self):
         ms = (C.c_float * 3)()
         self._ck(lib.pgrc_divider_last_ms(self._h, C.byref(ms)))

@@ -87,3 +87,49 @@ def same(a, b):
         if not np.array_equal(a[k], b[k]):
             return k
     return None
+
+
+# ---- FASTQ text (the reference's FASTQReadsSourceIterator reads it line by line)
+
+def make_fastq(reads, quals, seed=0, crlf=False, trailing_newline=True):
+    """records with identifier lines of varying length (so that nothing lines up), optionally CR LF line ends"""
+    rng = np.random.default_rng(seed)
+    nl = b"\r\n" if crlf else b"\n"
+    parts = []
+    for i in range(reads.shape[0]):
+        name = b"@r%d" % i + b"x" * int(rng.integers(0, 40)) + (b" len=%d" % reads.shape[1] if i % 3 == 0 else b"")
+        parts += [name, nl, reads[i].tobytes(), nl, b"+" + (name[1:] if i % 5 == 0 else b""), nl, quals[i].tobytes(), nl]
+    text = b"".join(parts)
+    return text if trailing_newline else text[: -len(nl)]
+
+
+def oracle_fastq_rows(text, pair_text, rev_compl_pair, L):
+    f = orc.oracle().pgrc_or_fastq_records
+    f.restype = C.c_int64
+    f.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_int, C.c_uint32, _P, _P, C.c_uint64]
+    cap = (len(text) + (len(pair_text) if pair_text else 0)) // (2 * L + 4) + 4
+    reads, quals = np.zeros((cap, L), np.uint8), np.zeros((cap, L), np.uint8)
+    n = f(text, len(text), pair_text, len(pair_text) if pair_text is not None else 0, int(rev_compl_pair), L, reads.ctypes.data, quals.ctypes.data, cap)
+    if n < 0:
+        return None, None
+    return reads[:n].copy(), quals[:n].copy()
+
+
+def oracle_divide_fastq(text, pair_text, rev_compl_pair, L, combo):
+    reads, quals = oracle_fastq_rows(text, pair_text, rev_compl_pair, L)
+    if reads is None:
+        return None
+    return oracle_divide(reads, quals, *combo)
+
+
+def ref_divide_files(src, pair, rev_compl_pair, L, n_max, combo, use_adapter=False):
+    f = orc.ref().pgrc_ref_divide_files
+    f.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_uint32, C.c_double, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P,
+                  C.POINTER(C.c_uint64 * 3), C.POINTER(C.c_uint32 * 3)]
+    bufs = _alloc(n_max, L)
+    counts, symbols = (C.c_uint64 * 3)(), (C.c_uint32 * 3)()
+    error_limit, simplified, separate_n, n_reads_lq = combo
+    e = f(int(use_adapter), str(src).encode(), str(pair).encode() if pair else b"", int(rev_compl_pair), L, error_limit, int(simplified),
+          int(separate_n), int(n_reads_lq), *[b.ctypes.data for b in bufs], C.byref(counts), C.byref(symbols))
+    assert e == 0, e
+    return _result(bufs, list(counts), list(symbols), L)

@@ -107,19 +107,20 @@ def test_archive_identical_with_the_dual_kernel(tmp_path, case, read_len, env):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,env", [("se", {}), ("pe_order", {}),
+@pytest.mark.parametrize("case,env", [("se", {}), ("pe_order", {}), ("pe", {"PGRC_DIVIDE_FROM_ROWS": "1"}),
                                       ("se", {"PGRC_REF_Q_PROMILS": "50"}),                              # one-position quality test
                                       ("se", {"PGRC_REF_Q_PROMILS": "120", "PGRC_REF_Q_FULL": "1"}),     # arithmetic-mean test
                                       ("pe", {"PGRC_REF_Q_PROMILS": "200", "PGRC_REF_Q_FULL": "1"})])
 # (N reads in the LQ set -- PgRC's -N -- together with a division ends in the reference's "Unimplemented transferring reads between
 #  reads sets packed with different alphabet": that combination is covered at the factory level, tests/test_gpu_divide.py)
 def test_archive_identical_with_the_read_sets_made_on_the_device(tmp_path, case, env):
-    """Row f3 inside the whole encoder: DividedPCLReadsSets' factories replaced by integration/HipDividedReadsSets (the FASTQ
-    records go to the device in batches of 7 000; classification, packing and the LQ / N mappings come back) on top of the
-    GPU matcher and text matcher.  Same archive as the untouched reference, byte for byte, also with PgRC's quality-based
-    division in both of its forms."""
+    """Row f3 inside the whole encoder: DividedPCLReadsSets' factories replaced by integration/HipDividedReadsSets -- the FASTQ
+    files go to the device as text, in pieces of 100 000 bytes, are parsed there (lines, records, the pair file's reads reverse-
+    complemented), and classification, packing and the LQ / N mappings come back; PGRC_DIVIDE_FROM_ROWS: the records are taken
+    from the reference's iterator instead, 7 000 per batch -- on top of the GPU matcher and text matcher.  Same archive as the
+    untouched reference, byte for byte, also with PgRC's quality-based division in both of its forms."""
     if not _have_e2e() or not hasattr(orc.ref(), "pgrc_ref_division_calls"):
         pytest.skip("oracle/_ref was built without the division harness")
-    r = _run(tmp_path, case, cpu_only=False, extra_env=dict(env, PGRC_E2E_GPU_STAGES="7", PGRC_DIVIDE_BATCH="7000"))
+    r = _run(tmp_path, case, cpu_only=False, extra_env=dict(env, PGRC_E2E_GPU_STAGES="7", PGRC_DIVIDE_BATCH="7000", PGRC_FASTQ_PIECE="100000"))
     assert r["gpu_division_calls"] >= 1 and r["gpu_gpu_calls"] >= 1, r
     assert r["identical"] and r["roundtrip"], r

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle as orc
-from divide_util import COMBOS, make_records, oracle_divide, ref_divide, same
+from divide_util import (COMBOS, make_fastq, make_records, oracle_divide, oracle_divide_fastq, ref_divide, ref_divide_files, same)
 
 pytestmark = pytest.mark.gpu
 
@@ -111,3 +111,113 @@ def test_divide_larger_batch_and_rate():
     o = oracle_divide(reads, quals, 0.05, False, True, False)
     assert same(g, o) is None
     assert ms["upload"] > 0 and ms["kernels"] > 0
+
+
+def _concat(parts):
+    """division results of consecutive pieces -> one result (indexes shifted by the records before)"""
+    out = {k: parts[0][0][k] for k in ("symbols", "row_bytes")}
+    base = 0
+    acc = {k: [] for k in ("hq_rows", "lq_rows", "n_rows", "lq_index", "n_index")}
+    tot = {"n_hq": 0, "n_lq": 0, "n_n": 0}
+    for res, nrec in parts:
+        for k in ("hq_rows", "lq_rows", "n_rows"):
+            acc[k].append(res[k])
+        acc["lq_index"].append(res["lq_index"] + np.uint32(base))
+        acc["n_index"].append(res["n_index"] + np.uint32(base))
+        for k in tot:
+            tot[k] += res[k]
+        base += nrec
+    out.update(tot)
+    out.update({k: np.concatenate(v) for k, v in acc.items()})
+    return out, base
+
+
+def gpu_divide_fastq(text, pair_text, rev, L, combo, piece=None):
+    """the whole text in one call, or fed in pieces of `piece` bytes the way a file reader would (what a call leaves
+    unconsumed is kept and the next piece appended)"""
+    from pgrc_amd import DividedPCLReadsSets
+    d = DividedPCLReadsSets(L, *combo)
+    if piece is None:
+        res, nrec, used, pused = d.divide_fastq(text, pair_text, rev, final=True)
+        d.close()
+        return res, nrec
+    parts, buf, at = [], [b"", b""], [0, 0]
+    src = [text, pair_text if pair_text is not None else b""]
+    while True:
+        for f in range(2 if pair_text is not None else 1):
+            buf[f] += src[f][at[f]: at[f] + piece]
+            at[f] += piece
+        final = at[0] >= len(src[0]) and at[1] >= len(src[1])
+        res, nrec, used, pused = d.divide_fastq(buf[0], buf[1] if pair_text is not None else None, rev, final=final)
+        parts.append((res, nrec))
+        buf[0], buf[1] = buf[0][used:], buf[1][pused:]
+        if final:
+            break
+    d.close()
+    return _concat(parts)
+
+
+@pytest.mark.parametrize("paired,rev", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("crlf,trailing", [(False, True), (True, True), (False, False)])
+def test_divide_fastq_text_parity(paired, rev, crlf, trailing):
+    """FASTQ text parsed on the device: lines found by all threads, records' rows copied out, every second record of a pair
+    reverse-complemented -- against the oracle's line reader; whole text at once and in pieces of odd sizes"""
+    L, n = 100, 6000
+    reads, quals = make_records(seed=13, n=n, L=L)
+    a = make_fastq(reads[0::2] if paired else reads, quals[0::2] if paired else quals, seed=1, crlf=crlf, trailing_newline=trailing)
+    b = make_fastq(reads[1::2], quals[1::2], seed=2, crlf=crlf, trailing_newline=trailing) if paired else None
+    for combo in (COMBOS[1], COMBOS[5], COMBOS[8]):
+        o = oracle_divide_fastq(a, b, rev, L, combo)
+        g, nrec = gpu_divide_fastq(a, b, rev, L, combo)
+        assert nrec == n and same(g, o) is None, (combo, same(g, o))
+    for piece in (997, 65536, 300_001):
+        g, nrec = gpu_divide_fastq(a, b, rev, L, COMBOS[5], piece=piece)
+        assert nrec == n and same(g, oracle_divide_fastq(a, b, rev, L, COMBOS[5])) is None, piece
+
+
+def test_divide_fastq_edges():
+    from pgrc_amd import DividedPCLReadsSets, PgrcMatchError
+    L = 64
+    reads, quals = make_records(seed=9, n=41, L=L)
+    combo = (0.2, False, True, False)
+    # the second file one record short: the reference stops after the first file's extra read
+    a, b = make_fastq(reads[0::2], quals[0::2], seed=1), make_fastq(reads[1::2], quals[1::2], seed=2)
+    g, nrec = gpu_divide_fastq(a, b, True, L, combo)
+    assert nrec == 41 and same(g, oracle_divide_fastq(a, b, True, L, combo)) is None
+    d = DividedPCLReadsSets(L, *combo)
+    res, nrec, used, _ = d.divide_fastq(b"", None, False, final=True)                 # nothing at all
+    assert nrec == 0 and used == 0
+    res, nrec, used, _ = d.divide_fastq(a[:50], None, False, final=False)            # less than a record: wait for more
+    assert nrec == 0 and used == 0
+    cut = a[: a.rstrip(b"\n").rfind(b"\n+")]
+    with pytest.raises(PgrcMatchError):
+        d.divide_fastq(cut, None, False, final=True)                                  # ends inside a record
+    longer = a.replace(reads[0].tobytes(), reads[0].tobytes() + b"A", 1)
+    with pytest.raises(PgrcMatchError):
+        d.divide_fastq(longer, None, False, final=True)                               # a read of another length
+    shorter = a.replace(reads[2].tobytes(), reads[2].tobytes()[:-1], 1)
+    with pytest.raises(PgrcMatchError):
+        d.divide_fastq(shorter, None, False, final=True)
+    res, nrec, _, _ = d.divide_fastq(a, None, False, final=True)                      # the context survives the errors
+    assert nrec == 21 and same(res, oracle_divide_fastq(a, None, False, L, combo)) is None
+    d.close()
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="needs oracle/_ref")
+@pytest.mark.parametrize("piece", [64, 5000, 1 << 20])
+def test_divide_fastq_files_through_the_adapter(tmp_path, monkeypatch, piece):
+    """HipDividedReadsSets::getQualityDivisionBasedReadsSetsFromFastq (files read in pieces, text parsed on the device) against
+    the reference's managed iterator + factory on the same files: single file and pair, second file reverse-complemented"""
+    if not hasattr(orc.ref(), "pgrc_ref_divide_files"):
+        pytest.skip("oracle/_ref was built without the file harness")
+    monkeypatch.setenv("PGRC_FASTQ_PIECE", str(piece))
+    L, n = 100, 1200 if piece >= 5000 else 200
+    reads, quals = make_records(seed=21, n=n, L=L)
+    (tmp_path / "se.fq").write_bytes(make_fastq(reads, quals, seed=5))
+    (tmp_path / "a.fq").write_bytes(make_fastq(reads[0::2], quals[0::2], seed=1, crlf=True))
+    (tmp_path / "b.fq").write_bytes(make_fastq(reads[1::2], quals[1::2], seed=2, crlf=True, trailing_newline=False))
+    for combo in (COMBOS[1], COMBOS[5], COMBOS[8]):
+        for src, pair, rev in ((tmp_path / "se.fq", None, False), (tmp_path / "a.fq", tmp_path / "b.fq", True), (tmp_path / "a.fq", tmp_path / "b.fq", False)):
+            a = ref_divide_files(src, pair, rev, L, n, combo, use_adapter=True)
+            r = ref_divide_files(src, pair, rev, L, n, combo)
+            assert same(a, r) is None, (combo, pair is not None, rev, same(a, r))
