@@ -30,6 +30,7 @@
 #include <unistd.h>
 
 #include "pgrc_reads.h"
+#include "readsset/persistance/ReadsSetPersistence.h"
 
 namespace PgTools {
 
@@ -108,6 +109,20 @@ namespace PgTools {
     DividedPCLReadsSets *HipDividedReadsSets::getQualityDivisionBasedReadsSetsFromFastq(
             const string &srcFastqFile, const string &pairFastqFile, bool revComplPairFile, uint_read_len_max readLength,
             double error_limit, bool simplified_suffix_mode, bool separateNReadsSet, bool nReadsLQ) {
+        {   // FASTQ only (ManagedReadsSetIterator picks the format by the first byte, ReadsSetPersistence.cpp:36-46): FASTA and
+            // plain concatenated reads take the reference's iterator and the record-by-record form above
+            FILE *probe = fopen(srcFastqFile.c_str(), "rb");
+            const int first = probe ? fgetc(probe) : EOF;
+            if (probe) fclose(probe);
+            if (first != '@') {
+                ReadsSourceIteratorTemplate<uint_read_len_max> *it =
+                        ReadsSetPersistence::createManagedReadsIterator(srcFastqFile, pairFastqFile, revComplPairFile);
+                DividedPCLReadsSets *sets = getQualityDivisionBasedReadsSets(it, readLength, error_limit, simplified_suffix_mode,
+                                                                            separateNReadsSet, nReadsLQ);
+                delete it;
+                return sets;
+            }
+        }
         DividedPCLReadsSets *readsSets = new DividedPCLReadsSets(readLength, separateNReadsSet, nReadsLQ);
         pgrc_divide_params prm;
         prm.read_len = readLength;

@@ -221,3 +221,18 @@ def test_divide_fastq_files_through_the_adapter(tmp_path, monkeypatch, piece):
             a = ref_divide_files(src, pair, rev, L, n, combo, use_adapter=True)
             r = ref_divide_files(src, pair, rev, L, n, combo)
             assert same(a, r) is None, (combo, pair is not None, rev, same(a, r))
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="needs oracle/_ref")
+def test_divide_fasta_file_takes_the_reference_iterator(tmp_path):
+    """a FASTA file through the adapter's file entry: not FASTQ (first byte), so the records come from the reference's own
+    iterator and only classification + packing run on the device -- same sets as the reference"""
+    if not hasattr(orc.ref(), "pgrc_ref_divide_files"):
+        pytest.skip("oracle/_ref was built without the file harness")
+    L, n = 100, 900
+    reads, _ = make_records(seed=31, n=n, L=L)
+    (tmp_path / "r.fa").write_bytes(b"".join(b">r%d\n" % i + reads[i].tobytes() + b"\n" for i in range(n)))
+    for combo in COMBOS[:4]:
+        a = ref_divide_files(tmp_path / "r.fa", None, False, L, n, combo, use_adapter=True)
+        assert same(a, ref_divide_files(tmp_path / "r.fa", None, False, L, n, combo)) is None, combo
+        assert a["n_hq"] + a["n_lq"] + a["n_n"] == n
