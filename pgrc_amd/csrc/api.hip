@@ -234,7 +234,7 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
         (void)hipEventDestroy(c->build_ev[1]);
     }
     DevBuf *bufs[] = {&c->pg2[0], &c->pg2[1], &c->reads_own, &c->nread_idx, &c->nread_ascii, &c->nread_flag, &c->d_pos,
-                      &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_head, &c->d_skey[0], &c->d_skey[1], &c->d_sval[0], &c->d_sval[1], &c->d_sorttmp,
+                      &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_head, &c->d_headpair, &c->d_skey[0], &c->d_skey[1], &c->d_sval[0], &c->d_sval[1], &c->d_sorttmp,
                       &c->alt_head, &c->alt_skey[0], &c->alt_skey[1], &c->alt_sval[0], &c->alt_sval[1], &c->alt_sorttmp, &c->d_scr_pos, &c->d_scr_flag,
                       &c->s_keys, &c->s_filter, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp, &c->s_sorted, &c->s_sorttmp, &c->s_mm, &c->s_rstart, &c->s_heavy, &c->s_nmask};
     for (DevBuf *b : bufs) pgrc_buf_free(*b);
@@ -640,6 +640,8 @@ int pgrc_match_set_results(pgrc_match_ctx *c, const uint64_t *pos, const uint8_t
 // the two sets of index buffers of the screened schedule swap roles
 static void swap_index_sets(pgrc_match_ctx *c) {
     std::swap(c->d_head, c->alt_head);
+    std::swap(c->head_ptr, c->alt_head_ptr);
+    std::swap(c->head_sh, c->alt_head_sh);
     for (int k = 0; k < 2; k++) {
         std::swap(c->d_skey[k], c->alt_skey[k]);
         std::swap(c->d_sval[k], c->alt_sval[k]);
@@ -706,12 +708,26 @@ static int pgrc_build_both_indexes(pgrc_match_ctx *c, bool *two_streams, F mark)
         HIP_TRY(c, hipEventRecord(c->build_ev[0], main_stream));             // the RC text is ready
         HIP_TRY(c, hipStreamWaitEvent(c->build_stream, c->build_ev[0], 0));
     }
-    if ((e = pgrc_copmem_build_index(c, 0))) return e;
+    // Both strands' heads go into ONE table of 32-byte slots {forward head, RC head} per bucket number (round 4): the dual
+    // kernel's two gathers of a seed then hit one 64-byte line and one translation.  PGRC_HEAD_PAIR=0: a table per strand
+    // (A/B runs); no room for the pair table: the same.
+    {
+        const char *hp = getenv("PGRC_HEAD_PAIR");
+        bool pair = !(hp && hp[0] == '0');
+        if (pair) {
+            const int pe = pgrc_buf_ensure(c, c->d_headpair, (size_t)c->cp.hash_size * 4 * sizeof(uint64_t));
+            if (pe == PGRC_E_ALLOC) { (void)hipGetLastError(); pair = false; }
+            else if (pe) return pe;
+        }
+        c->pair_build = pair;
+    }
+    if ((e = pgrc_copmem_build_index(c, 0))) { c->pair_build = false; return e; }
     if (!two) mark(); // 2
     swap_index_sets(c);
     if (two) c->stream = c->build_stream;
     // (PGRC_TEST_NO_SECOND_INDEX: tests take the out-of-memory road without exhausting the device)
     e = getenv("PGRC_TEST_NO_SECOND_INDEX") ? PGRC_E_ALLOC : pgrc_copmem_build_index(c, 1);
+    c->pair_build = false;
     c->stream = main_stream;
     if (two) {
         if (hipEventRecord(c->build_ev[1], c->build_stream) != hipSuccess || hipStreamWaitEvent(main_stream, c->build_ev[1], 0) != hipSuccess) {
@@ -746,6 +762,14 @@ int pgrc_prepare_both_indexes(pgrc_match_ctx *c) {
         c->ent_ptr = nullptr;
         c->index_strand = -1;
         swap_index_sets(c);
+        if (c->head_sh) {                   // (the forward index that was built sits in the pair table: nothing keeps it)
+            (void)hipStreamSynchronize(c->stream);
+            pgrc_buf_free(c->d_headpair);
+            c->head_ptr = c->alt_head_ptr = nullptr;
+            c->head_sh = c->alt_head_sh = 0;
+            c->ent_ptr = nullptr;
+            c->index_strand = -1;
+        }
         c->screen_broken = true;
         c->err = "prepare_index: no room for both strands' indexes";
     }
@@ -804,7 +828,10 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
             mark(); // 3
             if ((e = pgrc_copmem_match_pass(c, 0))) return e;
             mark(); // 4
-            if ((e = pgrc_copmem_build_index(c, 1))) return e;
+            c->pair_build = c->head_sh == 1;      // (the forward index sits in the pair table: the RC heads take its other half)
+            e = pgrc_copmem_build_index(c, 1);
+            c->pair_build = false;
+            if (e) return e;
             mark(); // 5
             if ((e = pgrc_copmem_match_pass(c, 1))) return e;
             mark(); // 6

@@ -93,7 +93,7 @@ k_copmem_index_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, uin
 #define HEADS_CAP 2048u
 __global__ void __launch_bounds__(HEADS_TPB)
 k_copmem_index_heads(const uint32_t *__restrict__ sk, const uint64_t *__restrict__ se, uint64_t n, uint64_t hs,
-                     ulonglong2 *__restrict__ head) {
+                     ulonglong2 *__restrict__ head, uint32_t hsh) {
     __shared__ ulonglong2 tile[HEADS_CAP];
     __shared__ uint32_t skey[HEADS_REC + 16];        // keys i0-1 .. i1+12 (0xFFFFFFFF beyond the end: never a bucket)
     const uint64_t i0 = (uint64_t)blockIdx.x * HEADS_REC;
@@ -138,12 +138,18 @@ k_copmem_index_heads(const uint32_t *__restrict__ sk, const uint64_t *__restrict
         for (int k = 0; k < HEADS_RPT; k++)
             if (st[k] && bk[k] >= base && bk[k] - base < m) tile[bk[k] - base] = hv[k];
         __syncthreads();
-        for (uint32_t x = threadIdx.x; x < m; x += HEADS_TPB) head[base + x] = tile[x];
+        for (uint32_t x = threadIdx.x; x < m; x += HEADS_TPB) head[(base + x) << hsh] = tile[x];
         __syncthreads();
     }
 }
 
 #define IDX_MAX_BLOCKS 4096u
+
+// a text shorter than K: every head of this strand's table is empty
+__global__ void __launch_bounds__(256) k_heads_empty(ulonglong2 *__restrict__ head, uint64_t hs, uint32_t hsh) {
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < hs; h += (uint64_t)gridDim.x * blockDim.x)
+        head[h << hsh] = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
+}
 
 int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     const uint32_t K = (uint32_t)c->cp.K, k1 = (uint32_t)c->cp.k1;
@@ -153,11 +159,20 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     // (the match kernel addresses ent[] with 32-bit indices unless it runs its 64-bit-position variant, which a text
     //  with 2^32 or more sampled positions always does)
     int e;
-    if ((e = pgrc_buf_ensure(c, c->d_head, hs * 2 * sizeof(uint64_t)))) return e;
+    if (c->pair_build) {             // both strands' heads in one table of 32-byte slots (ctx.h)
+        if ((e = pgrc_buf_ensure(c, c->d_headpair, hs * 4 * sizeof(uint64_t)))) return e;
+        c->head_ptr = (ulonglong2 *)c->d_headpair.p + (strand ? 1 : 0);
+        c->head_sh = 1;
+    } else {
+        if ((e = pgrc_buf_ensure(c, c->d_head, hs * 2 * sizeof(uint64_t)))) return e;
+        c->head_ptr = (ulonglong2 *)c->d_head.p;
+        c->head_sh = 0;
+    }
     c->ent_ptr = nullptr;
     c->index_strand = strand;
     if (!npos) {
-        HIP_TRY(c, hipMemsetAsync(c->d_head.p, 0xFF, hs * 2 * sizeof(uint64_t), c->stream));
+        hipLaunchKernelGGL(k_heads_empty, dim3((uint32_t)std::min<uint64_t>((hs + 255) / 256, 65536ull)), dim3(256), 0, c->stream, c->head_ptr, hs, c->head_sh);
+        HIP_TRY(c, hipGetLastError());
         if ((e = pgrc_buf_ensure(c, c->d_sval[0], 64))) return e;
         c->ent_ptr = (const uint64_t *)c->d_sval[0].p;
         return PGRC_OK;
@@ -204,7 +219,7 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     if (he != hipSuccess) { c->err = std::string("index sort: ") + hipGetErrorString(he); return PGRC_E_DEVICE; }
     if (partition) return pgrc_ps_finish(c, keys.current(), vals.current(), (uint32_t)hbits, cb, vals.alternate());
     hipLaunchKernelGGL(k_copmem_index_heads, dim3((uint32_t)((npos + HEADS_REC - 1) / HEADS_REC)), dim3(HEADS_TPB), 0, c->stream,
-                       (const uint32_t *)keys.current(), (const uint64_t *)vals.current(), npos, hs, (ulonglong2 *)c->d_head.p);
+                       (const uint32_t *)keys.current(), (const uint64_t *)vals.current(), npos, hs, c->head_ptr, c->head_sh);
     HIP_TRY(c, hipGetLastError());
     c->ent_ptr = vals.current();
     return PGRC_OK;
@@ -215,16 +230,16 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
 #define SCAN_EPT 16
 #define SCAN_EPB (SCAN_TPB * SCAN_EPT)
 
-__global__ void __launch_bounds__(256) k_export_counts(const ulonglong2 *__restrict__ head, uint64_t hs, uint32_t *__restrict__ cnt) {
+__global__ void __launch_bounds__(256) k_export_counts(const ulonglong2 *__restrict__ head, uint32_t hsh, uint64_t hs, uint32_t *__restrict__ cnt) {
     for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < hs; h += (uint64_t)gridDim.x * blockDim.x)
-        cnt[h] = head_count(head[h]);
+        cnt[h] = head_count(head[h << hsh]);
 }
 
 __global__ void __launch_bounds__(256)
-k_export_positions(const ulonglong2 *__restrict__ head, const uint64_t *__restrict__ ent, const uint32_t *__restrict__ cumm,
+k_export_positions(const ulonglong2 *__restrict__ head, uint32_t hsh, const uint64_t *__restrict__ ent, const uint32_t *__restrict__ cumm,
                    uint64_t hs, uint32_t *__restrict__ positions) {
     for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < hs; h += (uint64_t)gridDim.x * blockDim.x) {
-        const ulonglong2 hd = head[h];
+        const ulonglong2 hd = head[h << hsh];
         const uint32_t c = head_count(hd), lo = cumm[h];
         for (uint32_t j = 0; j < c; j++) {
             const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (c == 2 ? hd.y : ent[(hd.y & W1_BASE_MASK) + j - 1]);
@@ -242,7 +257,7 @@ int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_po
     if ((e = pgrc_buf_ensure(c, cnt, (hs + 2) * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, cumm, (hs + 2) * sizeof(uint32_t)))) { cleanup(); return e; }
     HIP_TRY(c, hipMemsetAsync(cnt.p, 0, (hs + 2) * sizeof(uint32_t), c->stream));
     const uint32_t sgrid = (uint32_t)((hs + 255) / 256 < 65536u * 8u ? (hs + 255) / 256 : 65536u * 8u);
-    hipLaunchKernelGGL(k_export_counts, dim3(sgrid), dim3(256), 0, c->stream, (const ulonglong2 *)c->d_head.p, hs, (uint32_t *)cnt.p);
+    hipLaunchKernelGGL(k_export_counts, dim3(sgrid), dim3(256), 0, c->stream, (const ulonglong2 *)c->head_ptr, c->head_sh, hs, (uint32_t *)cnt.p);
     size_t tb = 0;
     hipError_t he = rocprim::exclusive_scan(nullptr, tb, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)(hs + 2), rocprim::plus<uint32_t>(), c->stream);
     if (he == hipSuccess && (e = pgrc_buf_ensure(c, temp, tb))) { cleanup(); return e; }
@@ -256,7 +271,7 @@ int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_po
     if (h_cumm && hipMemcpy(h_cumm, cumm.p, (hs + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return PGRC_E_DEVICE; }
     if (h_positions && total) {
         if ((e = pgrc_buf_ensure(c, pos, (size_t)total * sizeof(uint32_t)))) { cleanup(); return e; }
-        hipLaunchKernelGGL(k_export_positions, dim3(sgrid), dim3(256), 0, c->stream, (const ulonglong2 *)c->d_head.p,
+        hipLaunchKernelGGL(k_export_positions, dim3(sgrid), dim3(256), 0, c->stream, (const ulonglong2 *)c->head_ptr, c->head_sh,
                            c->ent_ptr, (const uint32_t *)cumm.p, hs, (uint32_t *)pos.p);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
             hipMemcpy(h_positions, pos.p, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
@@ -277,7 +292,8 @@ struct MatchArgs {
     const uint32_t *reads;
     uint64_t n, stride;
     const uint8_t *nflag;
-    const ulonglong2 *head;
+    const ulonglong2 *head;       // head of bucket h at head[h << hsh] (ctx.h: one table per strand, or the pair table)
+    uint32_t hsh;
     const uint64_t *ent;
     uint64_t *pos;
     uint8_t *rc, *mism;
@@ -576,7 +592,7 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
             {
                 const uint32_t h = hash_fp_window<KQ>(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
                                                       NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
-                hd = a.head[h];
+                hd = a.head[(uint64_t)h << a.hsh];
             }
 #if PROBE_AHEAD
             if (si + 1 < nseeds) {
@@ -586,7 +602,7 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
                 const uint32_t n2 = NW > 2 ? funnel_r(sh[2 % NW], NW > 3 ? sh[3 % NW] : 0u, sbits) : 0u;
                 const uint32_t n3 = NW > 3 ? funnel_r(sh[3 % NW], NW > 4 ? sh[4 % NW] : 0u, sbits) : 0u;
                 const uint32_t h2 = hash_fp_window<KQ>(n0, n1, n2, n3, a.K, lut, &fp2) & a.mask;
-                hd2 = a.head[h2];
+                hd2 = a.head[(uint64_t)h2 << a.hsh];
                 got2 = true;
             }
             have_n = false;
@@ -860,7 +876,7 @@ k_copmem_match_n(const MatchArgs a, const uint32_t *__restrict__ nidx, const uin
             }
             h &= a.mask;
             n_probe++;
-            const ulonglong2 hd = a.head[h];
+            const ulonglong2 hd = a.head[(uint64_t)h << a.hsh];
             const uint32_t cnt = head_count(hd);
             if (!cnt) continue;
             uint32_t nb = cnt;
@@ -942,7 +958,8 @@ struct DualArgs {
     const uint32_t *reads;
     uint64_t n, stride;
     const uint8_t *nflag;         // reads with N: the byte path of the ordinary passes
-    const ulonglong2 *head[2];
+    const ulonglong2 *head[2];    // head of bucket h of strand x at head[x][h << hsh]; hsh = 1: head[1] = head[0] + 1, the two
+    uint32_t hsh;                 // heads of a bucket number are the halves of one 32-byte slot (one 64-byte line for both gathers)
     const uint64_t *ent[2];
     uint64_t *pos;
     uint8_t *rc;
@@ -1091,8 +1108,8 @@ k_copmem_match_dual(const DualArgs a) {
             const uint32_t h = hash_fp_window<KQ>(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
                                                   NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
             ulonglong2 hr = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
-            if (fl & F_ACT0) hdF = a.head[0][h];
-            if (fl & F_ACT1) hr = a.head[1][h];
+            if (fl & F_ACT0) hdF = a.head[0][(uint64_t)h << a.hsh];
+            if (fl & F_ACT1) hr = a.head[1][(uint64_t)h << a.hsh];
             hdR_lds[threadIdx.x] = hr;
             nprobe_it = ((fl & F_ACT0) ? 1u : 0u) + ((fl & F_ACT1) ? 1u : 0u);
         } else if (m0 == M_ENTRY) {
@@ -1308,7 +1325,7 @@ static void launch_dual(pgrc_match_ctx *c, const DualArgs &a) {
 int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     const uint64_t lo = std::min<uint64_t>(c->range_lo, c->n), rn = std::min<uint64_t>(c->n - lo, c->range_n);   // (a block of a streamed run, or everything)
     if (rn == 0) return PGRC_OK;
-    if (c->index_strand != 1 || c->alt_index_strand != 0 || !c->ent_ptr || !c->alt_ent_ptr || !c->d_scr_pos.p) {
+    if (c->index_strand != 1 || c->alt_index_strand != 0 || !c->ent_ptr || !c->alt_ent_ptr || !c->d_scr_pos.p || c->head_sh != c->alt_head_sh) {
         c->err = "dual kernel without both indexes";
         return PGRC_E_STATE;
     }
@@ -1320,8 +1337,9 @@ int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     a.n = rn;
     a.stride = c->stride;
     a.nflag = (c->n_nreads || c->up_open) ? (const uint8_t *)c->nread_flag.p + lo : nullptr;   // (during an upload the side list is not final yet: the flags are)
-    a.head[0] = (const ulonglong2 *)c->alt_head.p;
-    a.head[1] = (const ulonglong2 *)c->d_head.p;
+    a.head[0] = (const ulonglong2 *)c->alt_head_ptr;
+    a.head[1] = (const ulonglong2 *)c->head_ptr;
+    a.hsh = c->head_sh;
     a.ent[0] = c->alt_ent_ptr;
     a.ent[1] = c->ent_ptr;
     a.pos = (uint64_t *)c->d_pos.p + lo;
@@ -1392,7 +1410,8 @@ int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase) {
     a.n = rn;
     a.stride = c->stride;
     a.nflag = (c->n_nreads || c->up_open) ? (const uint8_t *)c->nread_flag.p + lo : nullptr;   // (during an upload the side list is not final yet: the flags are)
-    a.head = (const ulonglong2 *)c->d_head.p;
+    a.head = (const ulonglong2 *)c->head_ptr;
+    a.hsh = c->head_sh;
     a.ent = c->ent_ptr;
     a.pos = (uint64_t *)c->d_pos.p + lo;
     a.rc = (uint8_t *)c->d_rc.p + lo;

@@ -85,7 +85,15 @@ struct pgrc_match_ctx {
     // copMEM index (rebuilt per pass, buffers reused)
     pgrc_copmem_params cp{};
     uint64_t npos = 0;
-    DevBuf d_head;                      // ulonglong2[hash_size] bucket heads
+    DevBuf d_head;                      // ulonglong2[hash_size] bucket heads (one strand's table of 16-byte heads)
+    // Where the ACTIVE set's heads really are: head h at head_ptr[h << head_sh].  head_sh = 0: d_head, one table per strand;
+    // head_sh = 1 (round 4, runs that keep both strands' indexes): the pair table d_headpair of 32-byte slots
+    // {forward head, RC head} per bucket number, head_ptr = slot base + strand -- the dual kernel's two gathers of a seed
+    // then fall into ONE 64-byte line (copmem.hip, "The dual kernel").
+    ulonglong2 *head_ptr = nullptr;
+    uint32_t head_sh = 0;
+    DevBuf d_headpair;                  // ulonglong2[2 * hash_size], shared by both index sets (never swapped)
+    bool pair_build = false;            // pgrc_copmem_build_index writes into d_headpair (set around the builds of both strands)
     DevBuf d_skey[2], d_sval[2], d_sorttmp; // (bucket, entry) records: radix sort ping-pong + rocPRIM scratch (grow-only)
     const uint64_t *ent_ptr = nullptr;  // the sorted entries (one of d_sval[]): ent[] of the match kernel
     int index_strand = -1;  // which strand the buffers currently describe
@@ -95,6 +103,8 @@ struct pgrc_match_ctx {
     DevBuf alt_head, alt_skey[2], alt_sval[2], alt_sorttmp;
     const uint64_t *alt_ent_ptr = nullptr;
     int alt_index_strand = -1;
+    ulonglong2 *alt_head_ptr = nullptr;
+    uint32_t alt_head_sh = 0;
     DevBuf d_scr_pos, d_scr_flag;
     bool screen_broken = false;         // no room for the second set: the passes run as the reference orders them
     hipStream_t build_stream = nullptr; // the RC index is built beside the forward one (screened schedule)

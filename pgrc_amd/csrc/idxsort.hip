@@ -377,7 +377,7 @@ __device__ __forceinline__ void ps_unpack(const PsRecFmt f, uint64_t rec, uint32
 template <int E, int PFF_TPB, int PFF_SUBBITS, int CAPI, bool PACKED>
 __global__ void __launch_bounds__(PFF_TPB)
 k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals, const uint32_t *__restrict__ pstart, uint32_t cb, uint32_t np,
-                 uint64_t *__restrict__ ent, ulonglong2 *__restrict__ head, uint32_t *__restrict__ slow_flag, const PsRecFmt fmt) {
+                 uint64_t *__restrict__ ent, ulonglong2 *__restrict__ head, uint32_t hsh, uint32_t *__restrict__ slow_flag, const PsRecFmt fmt) {
     constexpr uint32_t PFF_SUB = 1u << PFF_SUBBITS, PFF_CAP = (uint32_t)CAPI, BPT = PFF_SUB / PFF_TPB;
     static_assert(CAPI <= 8191 && (E == 8 || E == 16) && PFF_SUBBITS <= 13, "staging slots are 13-bit; ranks are packed 8 per register");
     __shared__ uint32_t pk[PFF_SUB + PFF_SUB / 16];
@@ -516,7 +516,7 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
             ulonglong2 hd;
             if (c <= 2) hd = make_ulonglong2(min(e0, e1), c == 2 ? max(e0, e1) : HEAD_EMPTY);      // (c == 0: both HEAD_EMPTY = all ones)
             else hd = make_ulonglong2(e0 | HEAD_OVF, (s + PFF_XOFF(w)) | ((uint64_t)c << 56));     // entries 1.. at ent[base + j - 1]
-            if (!(fmt.dbg & 8u)) head[((uint64_t)p << cb) + b] = hd;
+            if (!(fmt.dbg & 8u)) head[(((uint64_t)p << cb) + b) << hsh] = hd;
         }
         __syncthreads();                                      // (the next partition reuses counters and staging area)
         (void)xtotal;
@@ -540,7 +540,7 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
 template <bool PACKED>
 __global__ void __launch_bounds__(PF_TPB)
 k_ps_finish(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals, const uint32_t *__restrict__ pstart, uint32_t cb,
-            uint64_t *__restrict__ ent, ulonglong2 *__restrict__ head, const uint32_t *__restrict__ todo, const uint32_t *__restrict__ todo_count,
+            uint64_t *__restrict__ ent, ulonglong2 *__restrict__ head, uint32_t hsh, const uint32_t *__restrict__ todo, const uint32_t *__restrict__ todo_count,
             uint32_t np, const PsRecFmt fmt) {
     __shared__ uint32_t cnt[PF_NB];          // 1: count; from 2 on: first slot of the bucket (relative to this round's base)
     __shared__ uint8_t kept[PF_NB];          // min(count, 14): 14 = "more than 13"
@@ -667,7 +667,7 @@ k_ps_finish(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals
                         hd.y = (out + cnt[b] + 1) | ((uint64_t)c << 56);    // entries 1.. at ent[base + j - 1]
                     }
                 }
-                head[((uint64_t)p << cb) + r0 + b] = hd;
+                head[(((uint64_t)p << cb) + r0 + b) << hsh] = hd;
             }
             out += total;
         }
@@ -744,14 +744,15 @@ static int ps_launch_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uin
     fmt.dbg = dbg ? (uint32_t)atoi(dbg) : 0u;
     const bool packed = packed_sh != 0;
     uint32_t *todo = slow + np, *todo_count = todo + np;
-    ulonglong2 *head = (ulonglong2 *)c->d_head.p;
+    ulonglong2 *head = c->head_ptr;
+    const uint32_t hsh = c->head_sh;
     const uint32_t ggrid = std::min<uint32_t>(np, (uint32_t)c->num_cus * 2u);
     const char *gen = getenv("PGRC_INDEX_FINISH");   // "general": the general finish kernel for every partition (tests)
     // (the fast kernel takes a partition's 2^cb buckets in one round of at most 8192: the other front ends' partitions of
     //  tables beyond 2^29 buckets are larger and all go to the general kernel)
     if ((gen && !strcmp(gen, "general")) || cb > 13u) {
-        if (packed) hipLaunchKernelGGL(k_ps_finish<true>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, (const uint32_t *)nullptr, (const uint32_t *)nullptr, np, fmt);
-        else hipLaunchKernelGGL(k_ps_finish<false>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, (const uint32_t *)nullptr, (const uint32_t *)nullptr, np, fmt);
+        if (packed) hipLaunchKernelGGL(k_ps_finish<true>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, hsh, (const uint32_t *)nullptr, (const uint32_t *)nullptr, np, fmt);
+        else hipLaunchKernelGGL(k_ps_finish<false>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, hsh, (const uint32_t *)nullptr, (const uint32_t *)nullptr, np, fmt);
     } else {
         // registers per thread sized for the mean partition (uniform hash values); whatever is larger is flagged
         const uint64_t need = n / np + n / np / 4 + 512;
@@ -761,7 +762,7 @@ static int ps_launch_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uin
         // 256 x 32: 16.0, 256 x 32 with 2048-bucket rounds: 16.8, 512 x 16 with 2048-bucket rounds: 16.4, 1024 x 8: 13.5.
 #define PFF_LAUNCH(E, TPB, SB, CAP, PK)                                                                                   \
         hipLaunchKernelGGL((k_ps_finish_fast<E, TPB, SB, CAP, PK>), dim3(fgrid), dim3(TPB), 0, c->stream, d_keys, d_vals,  \
-                           pst2, cb, np, d_ent, head, slow, fmt)
+                           pst2, cb, np, d_ent, head, hsh, slow, fmt)
         // (one round of 2^cb <= 8192 buckets; staging area for 6144 entries -- the mean partition holds 0.7 * 8192 -- resp.
         //  8191 where partitions are larger: tables beyond 2^29 buckets)
         if (packed) {
@@ -773,8 +774,8 @@ static int ps_launch_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uin
         }
 #undef PFF_LAUNCH
         hipLaunchKernelGGL(k_ps_slow_list, dim3((np + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)slow, np, todo, todo_count);
-        if (packed) hipLaunchKernelGGL(k_ps_finish<true>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, (const uint32_t *)todo, (const uint32_t *)todo_count, np, fmt);
-        else hipLaunchKernelGGL(k_ps_finish<false>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, (const uint32_t *)todo, (const uint32_t *)todo_count, np, fmt);
+        if (packed) hipLaunchKernelGGL(k_ps_finish<true>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, hsh, (const uint32_t *)todo, (const uint32_t *)todo_count, np, fmt);
+        else hipLaunchKernelGGL(k_ps_finish<false>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, hsh, (const uint32_t *)todo, (const uint32_t *)todo_count, np, fmt);
     }
     HIP_TRY(c, hipGetLastError());
     c->ent_ptr = d_ent;

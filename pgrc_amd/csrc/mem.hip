@@ -99,7 +99,8 @@ struct MemArgs {
     const uint16_t *nmap;        // nullptr: the destination holds no 'N'
     uint64_t N, N2;
     uint64_t dest_words_alloc;
-    const ulonglong2 *head;
+    const ulonglong2 *head;      // head of bucket h at head[h << hsh] (ctx.h)
+    uint32_t hsh;
     const uint64_t *ent;
     uint32_t mask, K, k2;
     uint32_t LK2, KLK24;
@@ -176,7 +177,7 @@ k_mem_probe(const MemArgs a, unsigned long long *cursor, uint64_t *__restrict__ 
             }
         if (!has_n) {       // a window with an 'N' equals no source K-mer: it can produce no event
             const uint32_t h = copmem_hash32_fp(dw[0], dw[1], dw[2], dw[3], a.K, lut, &fp) & a.mask;
-            hd = a.head[h];
+            hd = a.head[(uint64_t)h << a.hsh];
             cnt = head_count(hd);
         }
     }
@@ -600,7 +601,7 @@ struct StaleWalk {
         pgrc_match_ctx *c = m->base;
         const uint32_t h = host_hash(m->K, dest + q) & (uint32_t)(c->cp.hash_size - 1);
         unsigned long long hd[2];
-        if (hipMemcpy(hd, (const char *)c->d_head.p + (size_t)h * 16, 16, hipMemcpyDeviceToHost) != hipSuccess) { lookup_err = 1; return 0; }
+        if (hipMemcpy(hd, (const char *)c->head_ptr + ((size_t)h << c->head_sh) * 16, 16, hipMemcpyDeviceToHost) != hipSuccess) { lookup_err = 1; return 0; }
         if (hd[0] == HEAD_EMPTY) return 0;
         pos[0] = (hd[0] & ENT_MASK) >> PGRC_FP_BITS;
         if (!(hd[0] & HEAD_OVF)) {
@@ -797,7 +798,8 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     a.src = (const uint32_t *)c->pg2[0].p;
     a.N = m->N;
     a.N2 = N2;
-    a.head = (const ulonglong2 *)c->d_head.p;
+    a.head = (const ulonglong2 *)c->head_ptr;
+    a.hsh = c->head_sh;
     a.ent = c->ent_ptr;
     a.mask = (uint32_t)(c->cp.hash_size - 1);
     a.K = (uint32_t)m->K;
@@ -809,7 +811,8 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     a.rev_compl = rev_compl ? 1 : 0;
     if (c->index_strand != 0) {          // (only if somebody rebuilt the base index in between)
         if ((e = pgrc_copmem_build_index(c, 0))) { m->err = c->err; return e; }
-        a.head = (const ulonglong2 *)c->d_head.p;
+        a.head = (const ulonglong2 *)c->head_ptr;
+        a.hsh = c->head_sh;
         a.ent = c->ent_ptr;
     }
 

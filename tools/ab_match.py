@@ -36,9 +36,9 @@ def main():
             _, _, _, hist, matched = ctx.get_results(arrays=False)
             if ref is None: ref = (hist.tolist(), matched)
             assert (hist.tolist(), matched) == ref, "variants disagree on results"
-            if r: res[i].append((c["ms_match"][0], c["ms_match"][1], c["ms_index"][0] + c["ms_index"][1], c["ms_total"]))
+            if r: res[i].append((c["ms_match"][0], c["ms_match"][1], c["ms_index"][0] + c["ms_index"][1], c["ms_total"], c["ms_screen"]))
     for i, v in enumerate(variants):
-        med = [statistics.median(x[k] for x in res[i]) for k in range(4)]
-        print(f"{a.variants[i]:40s} match_fwd {med[0]:7.2f}  match_rc {med[1]:7.2f}  index {med[2]:7.2f}  total {med[3]:7.2f} ms")
+        med = [statistics.median(x[k] for x in res[i]) for k in range(5)]
+        print(f"{a.variants[i]:40s} dual/screen {med[4]:7.2f}  match_fwd {med[0]:7.2f}  match_rc {med[1]:7.2f}  index {med[2]:7.2f}  total {med[3]:7.2f} ms")
 if __name__ == "__main__":
     main()
