@@ -720,6 +720,11 @@ static int pgrc_build_both_indexes(pgrc_match_ctx *c, bool *two_streams, F mark)
             else if (pe) return pe;
         }
         c->pair_build = pair;
+        // buckets per group (headfmt.h; PGRC_HEAD_PAIR=1..4: 1, 2, 4, 8): 4 -- measured at C3 in one context
+        // (profiles/r04_head_interleave_ab.txt): both gathers of a seed cost one request as long as they share a 128-BYTE line
+        // (groups of 1, 2, 4: dual kernel 79.5 -> 64.7 ms; groups of 8 = 256 bytes: 79.6), and the builds' head stores cost
+        // nothing extra only as whole 64-byte runs (groups of 1 and 2: index pair 16.2 -> 24.9 ms; groups of 4: 17.0)
+        c->pair_gm = (hp && hp[0] >= '1' && hp[0] <= '4') ? (1u << (hp[0] - '1')) - 1u : 3u;
     }
     if ((e = pgrc_copmem_build_index(c, 0))) { c->pair_build = false; return e; }
     if (!two) mark(); // 2
@@ -828,7 +833,7 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
             mark(); // 3
             if ((e = pgrc_copmem_match_pass(c, 0))) return e;
             mark(); // 4
-            c->pair_build = c->head_sh == 1;      // (the forward index sits in the pair table: the RC heads take its other half)
+            c->pair_build = c->head_sh != 0;      // (the forward index sits in the pair table: the RC heads take its other half)
             e = pgrc_copmem_build_index(c, 1);
             c->pair_build = false;
             if (e) return e;

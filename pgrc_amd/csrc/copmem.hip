@@ -138,7 +138,7 @@ k_copmem_index_heads(const uint32_t *__restrict__ sk, const uint64_t *__restrict
         for (int k = 0; k < HEADS_RPT; k++)
             if (st[k] && bk[k] >= base && bk[k] - base < m) tile[bk[k] - base] = hv[k];
         __syncthreads();
-        for (uint32_t x = threadIdx.x; x < m; x += HEADS_TPB) head[(base + x) << hsh] = tile[x];
+        for (uint32_t x = threadIdx.x; x < m; x += HEADS_TPB) head[head_slot(base + x, hsh)] = tile[x];
         __syncthreads();
     }
 }
@@ -148,7 +148,7 @@ k_copmem_index_heads(const uint32_t *__restrict__ sk, const uint64_t *__restrict
 // a text shorter than K: every head of this strand's table is empty
 __global__ void __launch_bounds__(256) k_heads_empty(ulonglong2 *__restrict__ head, uint64_t hs, uint32_t hsh) {
     for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < hs; h += (uint64_t)gridDim.x * blockDim.x)
-        head[h << hsh] = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
+        head[head_slot(h, hsh)] = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
 }
 
 int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
@@ -161,8 +161,8 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     int e;
     if (c->pair_build) {             // both strands' heads in one table of 32-byte slots (ctx.h)
         if ((e = pgrc_buf_ensure(c, c->d_headpair, hs * 4 * sizeof(uint64_t)))) return e;
-        c->head_ptr = (ulonglong2 *)c->d_headpair.p + (strand ? 1 : 0);
-        c->head_sh = 1;
+        c->head_ptr = (ulonglong2 *)c->d_headpair.p + (strand ? c->pair_gm + 1u : 0u);
+        c->head_sh = 1u | (c->pair_gm << 8);
     } else {
         if ((e = pgrc_buf_ensure(c, c->d_head, hs * 2 * sizeof(uint64_t)))) return e;
         c->head_ptr = (ulonglong2 *)c->d_head.p;
@@ -232,14 +232,14 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
 
 __global__ void __launch_bounds__(256) k_export_counts(const ulonglong2 *__restrict__ head, uint32_t hsh, uint64_t hs, uint32_t *__restrict__ cnt) {
     for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < hs; h += (uint64_t)gridDim.x * blockDim.x)
-        cnt[h] = head_count(head[h << hsh]);
+        cnt[h] = head_count(head[head_slot(h, hsh)]);
 }
 
 __global__ void __launch_bounds__(256)
 k_export_positions(const ulonglong2 *__restrict__ head, uint32_t hsh, const uint64_t *__restrict__ ent, const uint32_t *__restrict__ cumm,
                    uint64_t hs, uint32_t *__restrict__ positions) {
     for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < hs; h += (uint64_t)gridDim.x * blockDim.x) {
-        const ulonglong2 hd = head[h << hsh];
+        const ulonglong2 hd = head[head_slot(h, hsh)];
         const uint32_t c = head_count(hd), lo = cumm[h];
         for (uint32_t j = 0; j < c; j++) {
             const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (c == 2 ? hd.y : ent[(hd.y & W1_BASE_MASK) + j - 1]);
@@ -292,7 +292,7 @@ struct MatchArgs {
     const uint32_t *reads;
     uint64_t n, stride;
     const uint8_t *nflag;
-    const ulonglong2 *head;       // head of bucket h at head[h << hsh] (ctx.h: one table per strand, or the pair table)
+    const ulonglong2 *head;       // head of bucket h at head[head_slot(h, hsh)] (headfmt.h: one table per strand, or the pair table)
     uint32_t hsh;
     const uint64_t *ent;
     uint64_t *pos;
@@ -592,7 +592,7 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
             {
                 const uint32_t h = hash_fp_window<KQ>(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
                                                       NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
-                hd = a.head[(uint64_t)h << a.hsh];
+                hd = a.head[head_slot(h, a.hsh)];
             }
 #if PROBE_AHEAD
             if (si + 1 < nseeds) {
@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
                 const uint32_t n2 = NW > 2 ? funnel_r(sh[2 % NW], NW > 3 ? sh[3 % NW] : 0u, sbits) : 0u;
                 const uint32_t n3 = NW > 3 ? funnel_r(sh[3 % NW], NW > 4 ? sh[4 % NW] : 0u, sbits) : 0u;
                 const uint32_t h2 = hash_fp_window<KQ>(n0, n1, n2, n3, a.K, lut, &fp2) & a.mask;
-                hd2 = a.head[(uint64_t)h2 << a.hsh];
+                hd2 = a.head[head_slot(h2, a.hsh)];
                 got2 = true;
             }
             have_n = false;
@@ -876,7 +876,7 @@ k_copmem_match_n(const MatchArgs a, const uint32_t *__restrict__ nidx, const uin
             }
             h &= a.mask;
             n_probe++;
-            const ulonglong2 hd = a.head[(uint64_t)h << a.hsh];
+            const ulonglong2 hd = a.head[head_slot(h, a.hsh)];
             const uint32_t cnt = head_count(hd);
             if (!cnt) continue;
             uint32_t nb = cnt;
@@ -958,8 +958,8 @@ struct DualArgs {
     const uint32_t *reads;
     uint64_t n, stride;
     const uint8_t *nflag;         // reads with N: the byte path of the ordinary passes
-    const ulonglong2 *head[2];    // head of bucket h of strand x at head[x][h << hsh]; hsh = 1: head[1] = head[0] + 1, the two
-    uint32_t hsh;                 // heads of a bucket number are the halves of one 32-byte slot (one 64-byte line for both gathers)
+    const ulonglong2 *head[2];    // head of bucket h of strand x at head[x][head_slot(h, hsh)] (headfmt.h); the pair table: the two
+    uint32_t hsh;                 // heads of a bucket number share a line (one line request and one translation for both gathers)
     const uint64_t *ent[2];
     uint64_t *pos;
     uint8_t *rc;
@@ -1108,8 +1108,8 @@ k_copmem_match_dual(const DualArgs a) {
             const uint32_t h = hash_fp_window<KQ>(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
                                                   NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
             ulonglong2 hr = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
-            if (fl & F_ACT0) hdF = a.head[0][(uint64_t)h << a.hsh];
-            if (fl & F_ACT1) hr = a.head[1][(uint64_t)h << a.hsh];
+            if (fl & F_ACT0) hdF = a.head[0][head_slot(h, a.hsh)];
+            if (fl & F_ACT1) hr = a.head[1][head_slot(h, a.hsh)];
             hdR_lds[threadIdx.x] = hr;
             nprobe_it = ((fl & F_ACT0) ? 1u : 0u) + ((fl & F_ACT1) ? 1u : 0u);
         } else if (m0 == M_ENTRY) {

@@ -86,13 +86,14 @@ struct pgrc_match_ctx {
     pgrc_copmem_params cp{};
     uint64_t npos = 0;
     DevBuf d_head;                      // ulonglong2[hash_size] bucket heads (one strand's table of 16-byte heads)
-    // Where the ACTIVE set's heads really are: head h at head_ptr[h << head_sh].  head_sh = 0: d_head, one table per strand;
-    // head_sh = 1 (round 4, runs that keep both strands' indexes): the pair table d_headpair of 32-byte slots
-    // {forward head, RC head} per bucket number, head_ptr = slot base + strand -- the dual kernel's two gathers of a seed
-    // then fall into ONE 64-byte line (copmem.hip, "The dual kernel").
+    // Where the ACTIVE set's heads really are: head h at head_ptr[head_slot(h, head_sh)] (headfmt.h).  head_sh = 0: d_head,
+    // one table per strand; otherwise (round 4, runs that keep both strands' indexes) the pair table d_headpair, in which
+    // the forward and the RC head of a bucket number share a line -- the dual kernel's two gathers of a seed are then ONE
+    // line request and one translation (copmem.hip, "The dual kernel").
     ulonglong2 *head_ptr = nullptr;
     uint32_t head_sh = 0;
     DevBuf d_headpair;                  // ulonglong2[2 * hash_size], shared by both index sets (never swapped)
+    uint32_t pair_gm = 3;               // pair table: buckets per group - 1 (a power of two minus one; headfmt.h)
     bool pair_build = false;            // pgrc_copmem_build_index writes into d_headpair (set around the builds of both strands)
     DevBuf d_skey[2], d_sval[2], d_sorttmp; // (bucket, entry) records: radix sort ping-pong + rocPRIM scratch (grow-only)
     const uint64_t *ent_ptr = nullptr;  // the sorted entries (one of d_sval[]): ent[] of the match kernel

@@ -516,7 +516,7 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
             ulonglong2 hd;
             if (c <= 2) hd = make_ulonglong2(min(e0, e1), c == 2 ? max(e0, e1) : HEAD_EMPTY);      // (c == 0: both HEAD_EMPTY = all ones)
             else hd = make_ulonglong2(e0 | HEAD_OVF, (s + PFF_XOFF(w)) | ((uint64_t)c << 56));     // entries 1.. at ent[base + j - 1]
-            if (!(fmt.dbg & 8u)) head[(((uint64_t)p << cb) + b) << hsh] = hd;
+            if (!(fmt.dbg & 8u)) head[head_slot(((uint64_t)p << cb) + b, hsh)] = hd;
         }
         __syncthreads();                                      // (the next partition reuses counters and staging area)
         (void)xtotal;
@@ -667,7 +667,7 @@ k_ps_finish(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals
                         hd.y = (out + cnt[b] + 1) | ((uint64_t)c << 56);    // entries 1.. at ent[base + j - 1]
                     }
                 }
-                head[(((uint64_t)p << cb) + r0 + b) << hsh] = hd;
+                head[head_slot(((uint64_t)p << cb) + r0 + b, hsh)] = hd;
             }
             out += total;
         }

@@ -99,7 +99,7 @@ struct MemArgs {
     const uint16_t *nmap;        // nullptr: the destination holds no 'N'
     uint64_t N, N2;
     uint64_t dest_words_alloc;
-    const ulonglong2 *head;      // head of bucket h at head[h << hsh] (ctx.h)
+    const ulonglong2 *head;      // head of bucket h at head[head_slot(h, hsh)] (headfmt.h)
     uint32_t hsh;
     const uint64_t *ent;
     uint32_t mask, K, k2;
@@ -177,7 +177,7 @@ k_mem_probe(const MemArgs a, unsigned long long *cursor, uint64_t *__restrict__ 
             }
         if (!has_n) {       // a window with an 'N' equals no source K-mer: it can produce no event
             const uint32_t h = copmem_hash32_fp(dw[0], dw[1], dw[2], dw[3], a.K, lut, &fp) & a.mask;
-            hd = a.head[(uint64_t)h << a.hsh];
+            hd = a.head[head_slot(h, a.hsh)];
             cnt = head_count(hd);
         }
     }
@@ -601,7 +601,7 @@ struct StaleWalk {
         pgrc_match_ctx *c = m->base;
         const uint32_t h = host_hash(m->K, dest + q) & (uint32_t)(c->cp.hash_size - 1);
         unsigned long long hd[2];
-        if (hipMemcpy(hd, (const char *)c->head_ptr + ((size_t)h << c->head_sh) * 16, 16, hipMemcpyDeviceToHost) != hipSuccess) { lookup_err = 1; return 0; }
+        if (hipMemcpy(hd, (const char *)c->head_ptr + (size_t)head_slot(h, c->head_sh) * 16, 16, hipMemcpyDeviceToHost) != hipSuccess) { lookup_err = 1; return 0; }
         if (hd[0] == HEAD_EMPTY) return 0;
         pos[0] = (hd[0] & ENT_MASK) >> PGRC_FP_BITS;
         if (!(hd[0] & HEAD_OVF)) {
