@@ -31,7 +31,14 @@ WORKLOADS = {
     "C5-shard": (62_500_000, 250, 3_100_000_000, 38, 50, "c", False),  # one GPU's 1/8 of configs[4]
     "P64": (50_000_000, 150, 4_400_000_000, 38, 50, "c", False),  # Pg >= 4 Gi: the 64-bit-position kernels
     "tiny": (1_000_000, 150, 18_750_000, 38, 50, "c", False),
+    # C3 as the encoder really submits it (pgrc-encoder.cpp:349-352): the LQ set followed by the N set -- 98 M ACGT reads +
+    # 2 M reads holding 1-3 'N' (the generator's last reads), handed over in the reference's two packings before the timed region
+    "C3-N": (100_000_000, 150, 1_875_000_000, 38, 50, "c", False),
+    # C3 at PgRC's shipped mismatch limit (-M 3: k <= L / 3 = 50, pgrc-params.h:138-146)
+    "C3-M3": (100_000_000, 150, 1_875_000_000, 38, 3, "c", False),
+    "tiny-N": (1_000_000, 150, 18_750_000, 38, 50, "c", False),
 }
+N_FRACTION = {"C3-N": 0.02, "tiny-N": 0.02}     # share of the reads that hold an N (the reference's N read set)
 # measured random-request ceiling of the chip (tools/ubench/gather.hip): 51 G/s at a 4 GiB footprint, 48 G/s at the
 # 8-32 GiB footprints where the 8.6 GB bucket-head table of C3 lives (profiles/r01_ubench_gather_footprint.txt)
 GATHER_CEILING_GPS = 48.0
@@ -92,17 +99,35 @@ def main():
 
     # ---- inputs straight into HBM
     g = synth.pg_params(G, seed=12345)
-    rs = synth.reads_params(n_total, L, seed=12345, paired=paired)
-    d_pg = torch.zeros(pg_words + 64, dtype=torch.int32, device=dev)
-    synth.pg_device(g, d_pg.data_ptr())
-    d_reads = torch.empty(nw * stride, dtype=torch.int32, device=dev)
-    synth.reads_device(g, d_pg.data_ptr(), rs, first_read, n_per, d_reads.data_ptr(), stride)
-    torch.cuda.synchronize()
+    nfrac = N_FRACTION.get(args.workload, 0.0)
+    if nfrac:
+        # the LQ + N sum set: made on the device, brought to the host in the reference's two packings (tools/boundary_c3.py)
+        # and handed over through the boundary BEFORE the timed region -- the library keeps the N rows in its side list
+        if world > 1:
+            raise SystemExit("the workloads with N reads are single-GPU lines")
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import boundary_c3
+        pg_host, lq_rows, n_rows, n_lq, n_n = boundary_c3.make_host_inputs(n_per, L, G, nfrac)
+        rs = synth.reads_params(n_total, L, seed=12345, paired=paired, n_with_n=n_n)
+        _TEXT[G] = pg_host
+        ctx = MatchContext(L, seed_len, kmax, 0, mode, device=local_rank)
+        ctx.set_pg_ascii(pg_host)
+        ctx.set_reads_packed_sets([(lq_rows, n_lq, 4), (n_rows, n_n, 5)])
+        ctx._host_rows = (lq_rows, n_lq, n_rows, n_n)
+        ctx.set_profiling(True)
+        d_pg = None
+    else:
+        rs = synth.reads_params(n_total, L, seed=12345, paired=paired)
+        d_pg = torch.zeros(pg_words + 64, dtype=torch.int32, device=dev)
+        synth.pg_device(g, d_pg.data_ptr())
+        d_reads = torch.empty(nw * stride, dtype=torch.int32, device=dev)
+        synth.reads_device(g, d_pg.data_ptr(), rs, first_read, n_per, d_reads.data_ptr(), stride)
+        torch.cuda.synchronize()
 
-    ctx = MatchContext(L, seed_len, kmax, 0, mode, device=local_rank)
-    ctx.set_reads_device(d_reads.data_ptr(), n_per, stride, keep=d_reads)
-    ctx._keep_reads = d_reads
-    ctx.set_profiling(True)
+        ctx = MatchContext(L, seed_len, kmax, 0, mode, device=local_rank)
+        ctx.set_reads_device(d_reads.data_ptr(), n_per, stride, keep=d_reads)
+        ctx._keep_reads = d_reads
+        ctx.set_profiling(True)
 
     # multi-GPU: every rank owns 1/world of the packed Pg (what it would pack from its slice of the host text);
     # one all-gather per step rebuilds the replicated text
@@ -113,7 +138,7 @@ def main():
         if whi > wlo:
             d_slice[: whi - wlo] = d_pg[wlo:whi]
         del d_pg
-    else:
+    elif d_pg is not None:
         ctx.set_pg_packed_device(d_pg.data_ptr(), G)
 
     def step():
@@ -220,6 +245,7 @@ def main():
                                     f"{args.workload} (strong scaling): {n_total} x {L} bp {'PE' if paired else 'SE'} reads in total, split over {world} GPUs,")
                                    + f" vs Pg of {G} bp, mode {mode}, seed {seed_len}, -M {M} (k<={kmax}), both strands",
                        "symbols": "2-bit packed, 16 per u32 word (integer xor/popcount work, no floating point)",
+                       "reads_with_N": int(getattr(ctx, "_host_rows", (0, 0, 0, 0))[3]),
                        "reads_per_gpu": n_per, "read_len": L, "pg_len": G, "seed_len": seed_len, "max_mismatches": kmax,
                        "copmem": cp, "matched_fraction": matched / n_per,
                        "parallelism": f"reads sharded x{world}, Pg replicated" + (" (1 all-gather/step)" if world > 1 else "")},
@@ -307,6 +333,8 @@ def cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax):
     t_prep = time.perf_counter()
     pg = host_text(ctx, G)
     ns = min(args.cpu_sample_reads, n_per)
+    if hasattr(ctx, "_host_rows"):
+        ns = min(ns, int(ctx._host_rows[1]))       # (the sample stays inside the LQ set: the N set is the end of the sum set)
     reads = synth.reads_host(g, pg, rs, 0, ns)
     prep_s = time.perf_counter() - t_prep
     n_small = max(1000, ns // 100)
@@ -366,6 +394,22 @@ def reads_from_hbm(ctx_reads, idx, nw, stride, L):
     return np.frombuffer(b"ACGT", dtype=np.uint8)[sym.reshape(idx.size, nw * 16)[:, :L]]
 
 
+def rows_from_host_sets(host_rows, idx, L):
+    """the ASCII rows of reads `idx` of an LQ + N sum set held in the reference's two packings (SymbolsPackingFacility:
+    ACGT 4 symbols per byte, ACGNT 3 per byte as base-5 digits, first symbol most significant)"""
+    import numpy as np
+    lq_rows, n_lq, n_rows, n_n = host_rows
+    out = np.empty((idx.size, L), dtype=np.uint8)
+    is_lq = idx < n_lq
+    b = lq_rows[idx[is_lq]]                                             # (k, ceil(L/4))
+    sym = np.stack([(b >> 6) & 3, (b >> 4) & 3, (b >> 2) & 3, b & 3], axis=2).reshape(b.shape[0], -1)[:, :L]
+    out[is_lq] = np.frombuffer(b"ACGT", dtype=np.uint8)[sym]
+    c = n_rows[idx[~is_lq] - n_lq].astype(np.uint32)                    # (k, ceil(L/3))
+    sym = np.stack([c // 25, (c // 5) % 5, c % 5], axis=2).reshape(c.shape[0], -1)[:, :L]
+    out[~is_lq] = np.frombuffer(b"ACGNT", dtype=np.uint8)[sym]
+    return out
+
+
 def parity_sample(args, ctx, g, rs, n_per, L, G, seed_len, kmax):
     """Bit-parity evidence inside the bench line: a sample of the workload's reads -- a stride over ALL of them plus a
     stride over the reads the dual kernel had to do again in the reference's order (`redo_reads`: the ones in repeat
@@ -385,10 +429,12 @@ def parity_sample(args, ctx, g, rs, n_per, L, G, seed_len, kmax):
     idx = np.unique(np.concatenate([pick_all, pick_redo.astype(np.int64)]))
     pg = host_text(ctx, G)
     nw, stride = (L + 15) // 16, (n_per + 63) & ~63
-    reads = reads_from_hbm(ctx._keep_reads, idx, nw, stride, L)
+    reads = rows_from_host_sets(ctx._host_rows, idx, L) if hasattr(ctx, "_host_rows") else reads_from_hbm(ctx._keep_reads, idx, nw, stride, L)
+    # (the reads with N are the last of the set, hence of the sorted sample: the reference takes them as its N read set)
+    n_nset = int((idx >= ctx._host_rows[1]).sum()) if hasattr(ctx, "_host_rows") else 0
     t = time.perf_counter()
     if orc.have_ref():
-        r = orc.ref_match("c", pg, reads, seed_len, kmax, 0, True, 0, 1, 1)
+        r = orc.ref_match("c", pg, reads, seed_len, kmax, 0, True, n_nset, 1, 1)
         checker = "reference, serial index (PgHelpers::numberOfThreads = 1)"
     else:
         r = orc.oracle_match("c", pg, reads, seed_len, kmax, 0, True, max(1, min(args.cpu_threads, os.cpu_count() or 1)))
@@ -399,7 +445,7 @@ def parity_sample(args, ctx, g, rs, n_per, L, G, seed_len, kmax):
     d_rc = int((rc[idx] != r["rc"]).sum())
     d_mism = int((mism[idx] != r["mism"]).sum())
     return {"reads": int(idx.size), "drawn": f"stride over all {n_per} reads ({n_all}) + stride over the {redo.size} reads the dual kernel redid ({n_redo})",
-            "redo_in_sample": int(np.isin(idx, redo).sum()), "redo_reads": int(redo.size),
+            "redo_in_sample": int(np.isin(idx, redo).sum()), "redo_reads": int(redo.size), "reads_with_N_in_sample": n_nset,
             "checker": checker, "diff": d_pos + d_rc + d_mism, "diff_pos": d_pos, "diff_rc": d_rc,
             "diff_mism": d_mism, "matched_in_sample": int((r["mism"] != 255).sum()), "rc_in_sample": int(r["rc"].sum()), "checker_s": secs}
 

@@ -203,7 +203,10 @@ typedef struct {
  * original indexes, RC flags of SeparatedPseudoGenome::getReadsList(); it must carry no mismatches): in front of a new
  * entry go all old entries at SMALLER positions, an old entry at the same position follows it (:1004-1019). */
 typedef struct {
-    const uint32_t *order;        /* n_matched read indexes */
+    const uint32_t *order;        /* n_matched read indexes; NULL (round 4): the library makes the order on the device --
+                                   * ascending match position, reads matched at one position in ascending read index (a
+                                   * stable radix sort of (position, read) records; text below 2^32 symbols); n_matched is
+                                   * then ignored */
     uint64_t n_matched;
     const uint32_t *read_org_idx; /* original index of every READ (IndexesMapping::getReadOriginalIndex), NULL = identity */
     const uint8_t *list_off;      /* the old list: list_count offset deltas */

@@ -375,9 +375,9 @@ namespace PgTools {
             std::unique_ptr<PosIdx[]> byPos(new PosIdx[m ? m : 1]);
             {
                 PhaseLog log("  sort: (position, read) pairs");
-                #pragma omp parallel num_threads(T)
-                {
-                    const int t = omp_get_thread_num();
+                // (one iteration per slice: every slice is written whatever the size of the team OpenMP really delivers)
+                #pragma omp parallel for schedule(static, 1) num_threads(T)
+                for (int t = 0; t < T; t++) {
                     const uint64_t lo = n * t / T, hi = n * (t + 1) / T;
                     uint64_t at = first[t];
                     for (uint64_t i = lo; i < hi; i++)
@@ -407,9 +407,9 @@ namespace PgTools {
         const uint64_t n = readMatchPos.size();
         const int T = std::max(1, omp_get_max_threads());
         std::vector<uint64_t> first((size_t) T + 1, 0), top((size_t) T, 0);
-        #pragma omp parallel num_threads(T)
-        {
-            const int t = omp_get_thread_num();
+        // (one iteration per slice, not one slice per thread number: OpenMP may deliver fewer threads than asked for)
+        #pragma omp parallel for schedule(static, 1) num_threads(T)
+        for (int t = 0; t < T; t++) {
             const uint64_t lo = n * t / T, hi = n * (t + 1) / T;
             uint64_t cnt = 0, mx = 0;
             for (uint64_t i = lo; i < hi; i++)
@@ -432,8 +432,15 @@ namespace PgTools {
     // reads, then the merged streams from the device, appended to `builder`
     std::shared_ptr<void> HipReadsMatcher::makePgOrderStreams(SeparatedPseudoGenome *sPg, IndexesMapping *orgIndexesMapping,
                                                               bool revComplPairFile, SeparatedPseudoGenomeOutputBuilder *builder) {
+        // The order of the matched reads.  At -t 1 it is the reference's own: its sort leaves reads matched at one position in
+        // an order of its own that reaches the archive bytes, so the adapter repeats that sort (positionOrder).  At -t > 1 the
+        // reference's archive is not reproducible anyway (racy index build, parallel Pg generator: SURVEY 8c), so nothing
+        // depends on that tie order and the library makes the order on the device -- ascending position, ties by read index
+        // (round 4; C3 size: 0.67 s of host sort -> a few ms).  PGRC_DEVICE_SORT=0 / 1 forces the one or the other.
         std::vector<uint32_t> order;
-        {
+        const char *ds = getenv("PGRC_DEVICE_SORT");
+        const bool deviceSort = (ds ? ds[0] == '1' : PgHelpers::numberOfThreads > 1) && pgLength < (1ull << 32);
+        if (!deviceSort) {
             PhaseLog log("export: position sort");
             positionOrder(readMatchPos, matchedReadsCount, order);
         }
@@ -448,8 +455,8 @@ namespace PgTools {
         }
         ExtendedReadsListWithConstantAccessOption *rl = sPg->getReadsList();
         pgrc_export_pg_order_args a;
-        a.order = order.data();
-        a.n_matched = order.size();
+        a.order = deviceSort ? nullptr : order.data();
+        a.n_matched = deviceSort ? matchedReadsCount : order.size();
         a.read_org_idx = readOrg.data();
         a.list_off = rl->off.data();
         a.list_org_idx = rl->orgIdx.data();

@@ -233,7 +233,7 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
         (void)hipEventDestroy(c->build_ev[0]);
         (void)hipEventDestroy(c->build_ev[1]);
     }
-    DevBuf *bufs[] = {&c->pg2[0], &c->pg2[1], &c->reads_own, &c->nread_idx, &c->nread_ascii, &c->nread_flag, &c->d_pos,
+    DevBuf *bufs[] = {&c->pg2[0], &c->pg2[1], &c->reads_own, &c->nread_idx, &c->nread_ascii, &c->nread_flag, &c->nread_npos, &c->d_pos,
                       &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_head, &c->d_headpair, &c->d_skey[0], &c->d_skey[1], &c->d_sval[0], &c->d_sval[1], &c->d_sorttmp,
                       &c->alt_head, &c->alt_skey[0], &c->alt_skey[1], &c->alt_sval[0], &c->alt_sval[1], &c->alt_sorttmp, &c->d_scr_pos, &c->d_scr_flag,
                       &c->s_keys, &c->s_filter, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp, &c->s_sorted, &c->s_sorttmp, &c->s_mm, &c->s_rstart, &c->s_heavy, &c->s_nmask};
@@ -393,6 +393,7 @@ static int begin_reads(pgrc_match_ctx *c, uint64_t n, bool own) {
     if (n != c->n) c->screen_broken = false;     // another read set: the screen's per-read arrays may fit now
     c->n = n;
     c->n_nreads = 0;
+    c->n_many = 0;
     c->h_nidx.clear();
     c->have_reads = false;
     int e;
@@ -414,6 +415,7 @@ int pgrc_match_begin_reads(pgrc_match_ctx *c, uint64_t n) {
     int e = begin_reads(c, n, true);
     if (e) return e;
     if ((e = pgrc_buf_ensure(c, c->nread_flag, n))) return e;
+    if ((e = pgrc_buf_ensure(c, c->nread_npos, n * sizeof(uint32_t)))) return e;   // (only read where the flag says 3)
     // (cleared on a stream of its own and waited for: the main stream may hold index builds started ahead of the run --
     //  pgrc_match_prepare_index --, which neither this nor the uploads that follow should queue behind)
     if (!c->up_stream[0]) {
@@ -425,6 +427,7 @@ int pgrc_match_begin_reads(pgrc_match_ctx *c, uint64_t n) {
     HIP_TRY(c, hipStreamSynchronize(c->up_stream[0]));
     c->up_next = 0;
     c->up_nidx.clear();
+    c->up_nmany = 0;
     for (DevBuf &b : c->up_nchunks) pgrc_buf_free(b);
     c->up_nchunks.clear();
     c->up_nchunk_rows.clear();
@@ -481,6 +484,9 @@ static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, i
         else
             rcode = pgrc_launch_unpack_reads_acgnt(c, (const uint8_t *)stage, first, cnt, L, (uint32_t *)c->reads_own.p, c->stride,
                                                    (uint8_t *)c->nread_flag.p, (uint32_t *)flag.p);
+        // where the N's of the flagged reads are (flag 1 -> 3 for reads with at most 4 of them: the dual kernel's own)
+        if (rcode == PGRC_OK && symbols != 4)
+            rcode = pgrc_launch_npos_rows(c, (const uint8_t *)stage, symbols, first, cnt, L, (uint8_t *)c->nread_flag.p, (uint32_t *)c->nread_npos.p);
         c->stream = main_stream;
         // (the staging area is reused by the next chunk: its copy is queued behind this chunk's kernel on the same stream)
         if (symbols != 4) UP_MARK(c, "rows copied, unpack queued");
@@ -496,6 +502,7 @@ static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, i
             for (uint64_t k = 0; k < cnt; k++)
                 if (nf[k]) {
                     c->up_nidx.push_back((uint32_t)(first + k));
+                    if (nf[k] == 1) c->up_nmany++;
                     if (symbols == 0) hrows.insert(hrows.end(), rows + (off + k) * rb, rows + (off + k + 1) * rb);
                     else local.push_back((uint32_t)k);
                 }
@@ -552,6 +559,7 @@ int pgrc_match_end_reads(pgrc_match_ctx *c) {
     PGRC_ON_DEVICE(c);
     int e;
     c->n_nreads = c->up_nidx.size();
+    c->n_many = c->up_nmany;
     c->h_nidx = c->up_nidx;
     if (c->n_nreads) {
         const uint32_t L = c->prm.read_len;
@@ -846,13 +854,18 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
             mark(); // 3
             HIP_TRY(c, hipMemsetAsync(c->d_scr_flag.p, 0, c->n, c->stream));
             if (dual) {
+                // the reads with N: those with at most 4 N's are the dual kernel's own (its N-aware hash and verification);
+                // the others go the byte path on the side stream, a read's forward query and then its RC query in one lane,
+                // behind the dual kernel.  (PGRC_NREAD_BESIDE=1 launches that kernel first, as a small persistent grid: it
+                //  still only starts when the dual kernel's persistent blocks leave -- profiles/r04_nread_ab.txt)
+                const char *nb = getenv("PGRC_NREAD_BESIDE");
+                const bool beside = nb && nb[0] == '1';
+                if (beside && (e = pgrc_copmem_match_nreads(c, 0, 1, true, true))) return e;
                 if ((e = pgrc_copmem_match_dual(c))) return e;             // one query per read over both strands
                 mark(); // 4
-                swap_index_sets(c);
-                if ((e = pgrc_copmem_match_phase(c, 0, 4))) return e;      // what it left undecided, and the reads with N:
-                mark(); // 5
-                swap_index_sets(c);
-                if ((e = pgrc_copmem_match_phase(c, 1, 4))) return e;      // the two passes in the reference's order
+                if (!beside && (e = pgrc_copmem_match_nreads(c, 0, 1, false, true))) return e;
+                if ((e = pgrc_copmem_join_nreads(c))) return e;
+                mark(); // 5: what the reads with N took beyond the dual kernel
                 mark(); // 6
             } else {
                 if ((e = pgrc_copmem_match_phase(c, 1, 1))) return e;      // screen on the RC text

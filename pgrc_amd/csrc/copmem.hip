@@ -362,6 +362,45 @@ __device__ __forceinline__ uint32_t hash_fp_window(const uint32_t w0, const uint
     return h;
 }
 
+// The same for a window of a read that holds N's (npw: up to four read positions, one per byte, 0xFF = none; s = the
+// window's first read position).  The packed read carries code 0 = 'A' (0x41) where the read has an N, the reference
+// hashes the byte 'N' (0x4E): every N that falls on a hashed byte of step j adds 0x0D to that byte of the step's word --
+// no carry leaves the byte, so the patched word is exactly the reference's.  The fingerprint keeps the packed codes: a
+// difference it counts at an N position is a real mismatch (an N equals nothing), one it misses only weakens the lower
+// bound, which stays a lower bound.
+template <int KQ>
+__device__ __forceinline__ uint32_t hash_fp_window_n(const uint32_t w0, const uint32_t w1, const uint32_t w2, const uint32_t w3,
+                                                     uint32_t K, const uint32_t *lut, uint32_t *fp_out, uint32_t npw, uint32_t s) {
+    uint32_t qj[4], inc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t q = ((npw >> (8 * i)) & 0xFFu) - s;          // (none = 0xFF: 255 - s >= K, since s + K <= L <= 255)
+        const uint32_t j = q >> 2, b = q & 3u;
+        const bool hashed = q < K && b < (j < 3u ? 3u : 2u);
+        qj[i] = hashed ? j : 0xFFFFFFFFu;
+        inc[i] = 0x0Du << (8u * b);
+    }
+    const uint32_t w[4] = {w0, w1, w2, w3};
+    const uint32_t kq = KQ ? (uint32_t)KQ : (K >> 2);
+    uint32_t h = 4u * kq, fp = 0, fb = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < (KQ ? (uint32_t)KQ : 14u); j++) {
+        if (!KQ && j >= kq) break;
+        const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        uint32_t x = (j < 3) ? lut[b & 63u] : lut[64u + (b & 15u)];
+#pragma unroll
+        for (int i = 0; i < 4; i++) x += (qj[i] == j) ? inc[i] : 0u;
+        h = (h ^ (x + j)) * 171717u;
+        const uint32_t width = (j < 3) ? 2u : 4u;
+        if (fb + width <= PGRC_FP_BITS) {
+            fp |= ((j < 3) ? (b >> 6) : (b >> 4)) << fb;
+            fb += width;
+        }
+    }
+    *fp_out = fp;
+    return h;
+}
+
 #ifndef PROBE_AHEAD
 #define PROBE_AHEAD 1       // probing lanes fetch the next seed's bucket head together with their own
 #endif
@@ -380,9 +419,13 @@ __device__ __forceinline__ uint32_t hash_fp_window(const uint32_t w0, const uint
 // reads a wave reserves per visit to the global work counter: 1024 for a whole read set (256 / 512 / 1024: step +0 / -0.2 /
 // -0.4 % at C3), less for a short launch -- a block of a streamed run: 7 M reads over ~5000 resident waves are 1.35 chunks of
 // 1024 per wave, i.e. half the waves do two chunks while the others wait (10 ms per block instead of 6)
+// (Round 4, measured and dropped: "guided" reservation -- a wave that comes for reads near the end of the set takes
+//  (reads left) / (resident waves) of them, at least 128, so that the end is spread over all waves.  Whatever the parameters
+//  (profiles/r04_guided_ab.txt) the dual kernel ran 10 ms SLOWER at C3, 65.4 -> 75.4 ms.)
 static uint32_t pgrc_match_chunk(const pgrc_match_ctx *c, uint64_t n) {
     const uint64_t waves = (uint64_t)c->num_cus * 20u;           // (about what is resident)
     uint32_t chunk = MATCH_CHUNK;
+    if (const char *mc = getenv("PGRC_MATCH_CHUNK")) chunk = std::max(64, std::min(1 << 16, atoi(mc))) & ~63u;   // (experiments)
     while (chunk > 64u && n / chunk < waves * 8u) chunk >>= 1;
     return chunk;
 }
@@ -515,7 +558,7 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
 #pragma unroll
                     for (int k = 0; k < NW; k++) stg[wv][k][lane] = a.reads[(uint64_t)k * a.stride + wbeg + lane];
                     stg_c[wv][lane] = a.mism[wbeg + lane];
-                    stg_f[wv][lane] = (uint8_t)((a.nflag ? a.nflag[wbeg + lane] : 0) | (a.phase == 2u ? (a.scr_flag[wbeg + lane] & 1u) << 1 : 0u));
+                    stg_f[wv][lane] = (uint8_t)((a.nflag ? (a.nflag[wbeg + lane] & 1u) : 0u) | (a.phase == 2u ? (a.scr_flag[wbeg + lane] & 1u) << 1 : 0u));
                 }
                 __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // a wave's LDS accesses are served in order
             }
@@ -531,7 +574,7 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
                     idx = STAGE > 0 ? wbeg + sj : cnext + rank;
                     cin = STAGE > 0 ? stg_c[wv][sj] : a.mism[idx];
                     const uint32_t rflags = STAGE > 0 ? (uint32_t)stg_f[wv][sj]
-                                                      : (uint32_t)((a.nflag ? a.nflag[idx] : 0) | (a.phase == 2u ? (a.scr_flag[idx] & 1u) << 1 : 0u));
+                                                      : (uint32_t)((a.nflag ? (a.nflag[idx] & 1u) : 0u) | (a.phase == 2u ? (a.scr_flag[idx] & 1u) << 1 : 0u));
                     const bool skip = (rflags & 1u) || cin <= a.kmin;   // ReadsMatchers.cpp:430; 'N' reads: byte path
                     if (!skip) {
 #pragma unroll
@@ -796,141 +839,186 @@ __global__ void __launch_bounds__(MATCH_TPB) MATCH_OCCUPANCY_ATTR k_copmem_match
 // but on the same packed representation as the main kernel: the read as 2-bit words (N packs as code 0) plus a 16-bit
 // mask of its N positions per word, both in LDS.  Windows without an N hash through the LUT and use the fingerprint
 // shortcut exactly like k_copmem_match_sm; windows with an N rebuild the ASCII bytes for the hash and always verify.
+// Round 4: a PERSISTENT grid walks the side list in tiles of NREAD_TPB reads, and a lane takes its read through the
+// strands first .. last one after the other (the RC query of a read only needs that read's forward result:
+// ReadsMatchers.cpp:430-447) -- so a two-pass run needs ONE launch, small enough (a few waves per CU) to sit beside the
+// dual kernel from its start instead of running behind it.  The early-stop rule of k_copmem_match_sm applies unchanged:
+// an N of the read is a mismatch of every alignment, so a window that an alignment's mismatches leave untouched holds no N
+// and hashes like the text.
+struct NStrandArgs {
+    const uint32_t *pg;
+    const ulonglong2 *head;       // headfmt.h
+    uint32_t hsh;
+    const uint64_t *ent;
+    unsigned long long *counters; // [0] searched [1] candidates [2] probes (added to the strand's pass counters)
+};
+struct NReadArgs {
+    NStrandArgs st[2];
+    uint64_t G;
+    uint64_t *pos;
+    uint8_t *rc, *mism;
+    const uint32_t *nidx;         // the side list: read index, ASCII row
+    const uint8_t *nascii;
+    const uint8_t *skip_flag;     // not null: reads flagged 3 there were taken by the dual kernel
+    uint64_t nn;
+    uint32_t L, K, k1, k2, mask, kmax, kmin, early;
+    uint32_t first, last;         // strands to go through
+};
+
 #define NREAD_TPB 128
-__global__ void __launch_bounds__(NREAD_TPB)
-k_copmem_match_n(const MatchArgs a, const uint32_t *__restrict__ nidx, const uint8_t *__restrict__ nascii, uint64_t nn) {
+__global__ void __launch_bounds__(NREAD_TPB) k_copmem_match_n(const NReadArgs a) {
     __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
     // dynamic LDS, sized for this read length: rdw[NWr + 1][NREAD_TPB] = the packed read (+ one zero word: windows read
-    // one word ahead), nmw[NWr + 1][NREAD_TPB] = bit k of word w: symbol 16 w + k is an N
+    // one word ahead), nmw[NWr + 1][NREAD_TPB] = bit k of word w: symbol 16 w + k is an N.  A lane only ever touches its
+    // own column.
     extern __shared__ uint32_t nread_lds[];
     uint32_t (*rdw)[NREAD_TPB] = reinterpret_cast<uint32_t (*)[NREAD_TPB]>(nread_lds);
     uint32_t (*nmw)[NREAD_TPB] = reinterpret_cast<uint32_t (*)[NREAD_TPB]>(nread_lds + ((a.L + 15) / 16 + 1) * NREAD_TPB);
     hash_lut_init(lut);
-    const uint64_t t = (uint64_t)blockIdx.x * NREAD_TPB + threadIdx.x;
-    bool active = t < nn;
-    const uint64_t i = active ? nidx[t] : 0;
-    const uint32_t cin = active ? a.mism[i] : 0u;
-    if (cin <= a.kmin) active = false;                       // ReadsMatchers.cpp:430
-    const uint32_t NWr = (a.L + 15) / 16;
-    for (uint32_t w = 0; w <= NWr; w++) {
-        uint32_t pw = 0, nm = 0;
-        if (active && w < NWr) {
-            const uint8_t *row = nascii + t * a.L + 16 * w;
-            for (uint32_t k = 0; k < 16 && 16 * w + k < a.L; k++) {
-                const uint32_t ch = row[k];
-                uint32_t x = (ch >> 1) & 3u;
-                x ^= x >> 1;                                 // A0 C1 G2 T3
-                if (ch == 'N') { nm |= 1u << k; x = 0; }
-                pw |= x << (2 * k);
-            }
-        }
-        rdw[w][threadIdx.x] = pw;
-        nmw[w][threadIdx.x] = nm;
-    }
     __syncthreads();
-    uint64_t n_cand = 0, n_probe = 0;
-    if (active) {
-        const int H = ((int)a.L / 8) * 8;
-        uint32_t limit = (cin < a.kmax) ? cin - 1u : a.kmax;  // :488-489
-        const uint32_t budget = (a.L + 1u - a.K) / a.k2;
-        uint32_t falses = 0, cur = cin;
-        uint64_t best = PGRC_NOT_MATCHED_POS;
-        bool done = false;
-        for (uint32_t s = 0; s + a.K <= a.L && !done; s += a.k2) {
-            // the K-symbol window at s: four words of symbols and their N flags
-            const uint32_t q = s >> 4, sh2 = (s & 15u) * 2u, sh1 = s & 15u;
-            uint32_t ww[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t lo0 = (q + k <= NWr) ? rdw[q + k][threadIdx.x] : 0u, hi0 = (q + k + 1 <= NWr) ? rdw[q + k + 1][threadIdx.x] : 0u;
-                ww[k] = funnel_r(lo0, hi0, sh2);
-            }
-            // N flags of symbols s .. s+K-1 (K <= 56): bit x = symbol s + x
-            uint64_t nbits = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (q + k <= NWr) nbits |= (uint64_t)(nmw[q + k][threadIdx.x] & 0xFFFFu) << (16 * k);
-            if (sh1) {
-                const uint64_t top = (q + 4 <= NWr) ? (uint64_t)(nmw[q + 4][threadIdx.x] & 0xFFFFu) : 0ull;
-                nbits = (nbits >> sh1) | (top << (64 - sh1));
-            }
-            nbits &= (1ull << a.K) - 1ull;
-            const bool wn = nbits != 0;                        // the window holds an N
-            uint32_t fp_read = 0, h;
-            if (!wn) {
-                h = copmem_hash32_fp(ww[0], ww[1], ww[2], ww[3], a.K, lut, &fp_read);
-            } else {
-                // ASCII bytes of the window for maRushPrime1HashSparsified (Hashes.h:54-76): an N is the byte 0x4E
-                h = a.K;
-                for (uint32_t j = 0; j < a.K / 4; j++) {
-                    uint32_t w = 0;
-                    const uint32_t nby = (j < 3) ? 3u : 2u;
-                    for (uint32_t b = 0; b < nby; b++) {
-                        const uint32_t x = 4 * j + b;
-                        const uint32_t wsel = x < 16 ? ww[0] : x < 32 ? ww[1] : x < 48 ? ww[2] : ww[3];
-                        const uint32_t code = (wsel >> (2u * (x & 15u))) & 3u;
-                        w |= (((nbits >> x) & 1ull) ? (uint32_t)'N' : code2ascii(code)) << (8 * b);
-                    }
-                    h = (h ^ (w + j)) * 171717u;
+    const uint32_t NWr = (a.L + 15) / 16;
+    const int H = ((int)a.L / 8) * 8;
+    const uint32_t budget = (a.L + 1u - a.K) / a.k2;
+    const uint32_t rper = (a.K + a.k1 * a.k2 - 1u) / (a.k1 * a.k2) * a.k1;    // early stop: a round every rper seeds (k_copmem_match_sm)
+    uint64_t n_srch[2] = {0, 0}, n_cand[2] = {0, 0}, n_probe[2] = {0, 0};
+    for (uint64_t tile = blockIdx.x; tile * NREAD_TPB < a.nn; tile += gridDim.x) {
+        const uint64_t t = tile * NREAD_TPB + threadIdx.x;
+        if (t >= a.nn) continue;
+        const uint64_t i = a.nidx[t];
+        if (a.skip_flag && a.skip_flag[i] == 3) continue;
+        uint32_t cin = a.mism[i];
+        if (cin <= a.kmin) continue;                             // ReadsMatchers.cpp:430 (and nothing a later strand could improve)
+        for (uint32_t w = 0; w <= NWr; w++) {
+            uint32_t pw = 0, nm = 0;
+            if (w < NWr) {
+                const uint8_t *row = a.nascii + t * a.L + 16 * w;
+                for (uint32_t k = 0; k < 16 && 16 * w + k < a.L; k++) {
+                    const uint32_t ch = row[k];
+                    uint32_t x = (ch >> 1) & 3u;
+                    x ^= x >> 1;                                 // A0 C1 G2 T3
+                    if (ch == 'N') { nm |= 1u << k; x = 0; }
+                    pw |= x << (2 * k);
                 }
             }
-            h &= a.mask;
-            n_probe++;
-            const ulonglong2 hd = a.head[head_slot(h, a.hsh)];
-            const uint32_t cnt = head_count(hd);
-            if (!cnt) continue;
-            uint32_t nb = cnt;
-            if (falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET);          // :510-514
-            const uint32_t fpm = wn ? 0u : fp_head_mask(a.K, s, (uint32_t)H);
-            for (uint32_t j = 0; j < nb; j++) {
-                const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (cnt == 2 ? hd.y : a.ent[(hd.y & W1_BASE_MASK) + j - 1]);
-                const uint64_t sp = e >> PGRC_FP_BITS;
-                if ((uint64_t)s > sp) continue;                                 // :517-520
-                const uint64_t p = sp - s;
-                if (p + a.L > a.G) continue;
-                n_cand++;
-                if (!wn) {                                                      // certain head reject, as in k_copmem_match_sm
-                    const uint32_t x = ((uint32_t)e ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
-                    if ((uint32_t)__popc((x | (x >> 1)) & fpm) > limit) { falses += 1; continue; }
-                }
-                uint32_t mh = 0, mt = 0;
-                const uint32_t *src = a.pg + (p >> 4);
-                const uint32_t b = ((uint32_t)p & 15u) * 2u;
-                uint32_t lo = src[0];
-                for (uint32_t k = 0; k < NWr; k++) {
-                    const uint32_t hi = src[k + 1];
-                    const uint32_t x = funnel_r(lo, hi, b) ^ rdw[k][threadIdx.x];
-                    uint32_t nmb = nmw[k][threadIdx.x];                         // bit i -> bit 2 i
-                    nmb = (nmb | (nmb << 8)) & 0x00FF00FFu;
-                    nmb = (nmb | (nmb << 4)) & 0x0F0F0F0Fu;
-                    nmb = (nmb | (nmb << 2)) & 0x33333333u;
-                    nmb = (nmb | (nmb << 1)) & 0x55555555u;
-                    const uint32_t d = (x | (x >> 1) | nmb);
-                    mh += (uint32_t)__popc(d & sym_mask((int)k, 0, H));
-                    mt += (uint32_t)__popc(d & sym_mask((int)k, H, (int)a.L));
-                    lo = hi;
-                }
-                if (mh > limit) { falses += 1; continue; }                      // :536-539
-                const uint32_t m = mh + mt;
-                if (m > limit) { falses += 2; continue; }                       // :542-551 (counted twice)
-                cur = m;
-                best = p;
-                if (m <= a.kmin) { done = true; break; }
-                limit = m - 1u;
-            }
+            rdw[w][threadIdx.x] = pw;
+            nmw[w][threadIdx.x] = nm;
         }
-        if (best != PGRC_NOT_MATCHED_POS && cur < cin) {
-            a.pos[i] = a.strand ? a.G - (best + a.L) : best;
-            a.rc[i] = (uint8_t)a.strand;
-            a.mism[i] = (uint8_t)cur;
+        for (uint32_t strand = a.first; strand <= a.last && cin > a.kmin; strand++) {
+            const NStrandArgs &sa = a.st[strand];
+            n_srch[strand]++;
+            uint32_t limit = (cin < a.kmax) ? cin - 1u : a.kmax;  // :488-489
+            uint32_t falses = 0, cur = cin;
+            uint64_t best = PGRC_NOT_MATCHED_POS;
+            bool done = false;
+            uint32_t rq = 0, rclean = 0;
+            bool rdirty = false;
+            for (uint32_t s = 0; s + a.K <= a.L && !done; s += a.k2) {
+                // the K-symbol window at s: four words of symbols and their N flags
+                const uint32_t q = s >> 4, sh2 = (s & 15u) * 2u, sh1 = s & 15u;
+                uint32_t ww[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t lo0 = (q + k <= NWr) ? rdw[q + k][threadIdx.x] : 0u, hi0 = (q + k + 1 <= NWr) ? rdw[q + k + 1][threadIdx.x] : 0u;
+                    ww[k] = funnel_r(lo0, hi0, sh2);
+                }
+                // N flags of symbols s .. s+K-1 (K <= 56): bit x = symbol s + x
+                uint64_t nbits = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (q + k <= NWr) nbits |= (uint64_t)(nmw[q + k][threadIdx.x] & 0xFFFFu) << (16 * k);
+                if (sh1) {
+                    const uint64_t top = (q + 4 <= NWr) ? (uint64_t)(nmw[q + 4][threadIdx.x] & 0xFFFFu) : 0ull;
+                    nbits = (nbits >> sh1) | (top << (64 - sh1));
+                }
+                nbits &= (1ull << a.K) - 1ull;
+                const bool wn = nbits != 0;                        // the window holds an N
+                uint32_t fp_read = 0, h;
+                if (!wn) {
+                    h = copmem_hash32_fp(ww[0], ww[1], ww[2], ww[3], a.K, lut, &fp_read);
+                } else {
+                    // ASCII bytes of the window for maRushPrime1HashSparsified (Hashes.h:54-76): an N is the byte 0x4E
+                    h = a.K;
+                    for (uint32_t j = 0; j < a.K / 4; j++) {
+                        uint32_t w = 0;
+                        const uint32_t nby = (j < 3) ? 3u : 2u;
+                        for (uint32_t b = 0; b < nby; b++) {
+                            const uint32_t x = 4 * j + b;
+                            const uint32_t wsel = x < 16 ? ww[0] : x < 32 ? ww[1] : x < 48 ? ww[2] : ww[3];
+                            const uint32_t code = (wsel >> (2u * (x & 15u))) & 3u;
+                            w |= (((nbits >> x) & 1ull) ? (uint32_t)'N' : code2ascii(code)) << (8 * b);
+                        }
+                        h = (h ^ (w + j)) * 171717u;
+                    }
+                }
+                h &= a.mask;
+                n_probe[strand]++;
+                const ulonglong2 hd = sa.head[head_slot(h, sa.hsh)];
+                const uint32_t cnt = head_count(hd);
+                if (cnt) {
+                    uint32_t nb = cnt;
+                    if (falses > budget) nb = min(nb, PGRC_TRUNC_BUCKET);          // :510-514
+                    if (rq < a.k1 && (cnt >= PGRC_BUCKET_CAP || nb < cnt)) rdirty = true;   // not every position with this hash is looked at
+                    const uint32_t fpm = wn ? 0u : fp_head_mask(a.K, s, (uint32_t)H);
+                    for (uint32_t j = 0; j < nb; j++) {
+                        const uint64_t e = (j == 0) ? (hd.x & ENT_MASK) : (cnt == 2 ? hd.y : sa.ent[(hd.y & W1_BASE_MASK) + j - 1]);
+                        const uint64_t sp = e >> PGRC_FP_BITS;
+                        if ((uint64_t)s > sp) continue;                                 // :517-520
+                        const uint64_t p = sp - s;
+                        if (p + a.L > a.G) continue;
+                        n_cand[strand]++;
+                        if (!wn) {                                                      // certain head reject, as in k_copmem_match_sm
+                            const uint32_t x = ((uint32_t)e ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
+                            if ((uint32_t)__popc((x | (x >> 1)) & fpm) > limit) { falses += 1; continue; }
+                        }
+                        uint32_t mh = 0, mt = 0;
+                        const uint32_t *src = sa.pg + (p >> 4);
+                        const uint32_t b = ((uint32_t)p & 15u) * 2u;
+                        uint32_t lo = src[0];
+                        for (uint32_t k = 0; k < NWr; k++) {
+                            const uint32_t hi = src[k + 1];
+                            const uint32_t x = funnel_r(lo, hi, b) ^ rdw[k][threadIdx.x];
+                            uint32_t nmb = nmw[k][threadIdx.x];                         // bit i -> bit 2 i
+                            nmb = (nmb | (nmb << 8)) & 0x00FF00FFu;
+                            nmb = (nmb | (nmb << 4)) & 0x0F0F0F0Fu;
+                            nmb = (nmb | (nmb << 2)) & 0x33333333u;
+                            nmb = (nmb | (nmb << 1)) & 0x55555555u;
+                            const uint32_t d = (x | (x >> 1) | nmb);
+                            mh += (uint32_t)__popc(d & sym_mask((int)k, 0, H));
+                            mt += (uint32_t)__popc(d & sym_mask((int)k, H, (int)a.L));
+                            lo = hi;
+                        }
+                        if (mh > limit) { falses += 1; continue; }                      // :536-539
+                        const uint32_t m = mh + mt;
+                        if (m > limit) { falses += 2; continue; }                       // :542-551 (counted twice)
+                        cur = m;
+                        best = p;
+                        if (m <= a.kmin) { done = true; break; }
+                        limit = m - 1u;
+                    }
+                }
+                // a seed is behind this read: the early-stop rule, as in k_copmem_match_sm
+                if (rq == a.k1 - 1u) {
+                    rclean += rdirty ? 0u : 1u;
+                    rdirty = false;
+                }
+                rq = (rq + 1u == rper) ? 0u : rq + 1u;
+                if (a.early && rclean > limit) break;
+            }
+            if (best != PGRC_NOT_MATCHED_POS && cur < cin) {
+                a.pos[i] = strand ? a.G - (best + a.L) : best;
+                a.rc[i] = (uint8_t)strand;
+                a.mism[i] = (uint8_t)cur;
+                cin = cur;                                       // what the next strand's query has to beat
+            }
         }
     }
-    if (a.counters) {
-        const uint64_t s0 = wave_sum_u64(active ? 1ull : 0ull), s1 = wave_sum_u64(n_cand), s2 = wave_sum_u64(n_probe);
+    for (uint32_t strand = a.first; strand <= a.last; strand++) {
+        if (!a.st[strand].counters) continue;
+        const uint64_t s0 = wave_sum_u64(n_srch[strand]), s1 = wave_sum_u64(n_cand[strand]), s2 = wave_sum_u64(n_probe[strand]);
         if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&a.counters[0], (unsigned long long)s0);
-            atomicAdd(&a.counters[1], (unsigned long long)s1);
-            atomicAdd(&a.counters[2], (unsigned long long)s2);
+            atomicAdd(&a.st[strand].counters[0], (unsigned long long)s0);
+            atomicAdd(&a.st[strand].counters[1], (unsigned long long)s1);
+            atomicAdd(&a.st[strand].counters[2], (unsigned long long)s2);
         }
     }
 }
@@ -957,7 +1045,8 @@ struct DualArgs {
     uint64_t G;
     const uint32_t *reads;
     uint64_t n, stride;
-    const uint8_t *nflag;         // reads with N: the byte path of the ordinary passes
+    const uint8_t *nflag;         // reads with N: 1 = the byte path of the ordinary passes, 3 = taken here, its N positions in npos
+    const uint32_t *npos;         // (ctx.h nread_npos; nullptr: every flagged read goes the byte path)
     const ulonglong2 *head[2];    // head of bucket h of strand x at head[x][head_slot(h, hsh)] (headfmt.h); the pair table: the two
     uint32_t hsh;                 // heads of a bucket number share a line (one line request and one translation for both gathers)
     const uint64_t *ent[2];
@@ -968,6 +1057,8 @@ struct DualArgs {
     unsigned long long *work;
     uint8_t *redo_flag;           // per read: 2 = done again in the reference's order (F_SEQ); introspection only
     uint32_t L, K, k1, k2, mask, kmax;
+    uint32_t redo_above;          // a bucket of more entries than this, opened while U > budget, sends the read back (4; 0 = round 3's rule: any bucket)
+    uint32_t from_end;            // 1: chunks of reads are handed out from the end of the read set
     uint32_t chunk;               // reads a wave reserves per visit to the work counter (pgrc_match_chunk)
 };
 
@@ -984,6 +1075,7 @@ k_copmem_match_dual(const DualArgs a) {
     __shared__ uint32_t rd_lds[NW][MATCH_TPB];
     __shared__ uint32_t stg[MATCH_TPB / 64][NW][SW];
     __shared__ uint8_t stg_c[MATCH_TPB / 64][SW], stg_f[MATCH_TPB / 64][SW];
+    __shared__ uint32_t stg_n[MATCH_TPB / 64][SW];
     __shared__ ulonglong2 hdR_lds[MATCH_TPB];    // the RC head of a lane's current seed, waiting for the forward bucket to finish
     const uint32_t wv = threadIdx.x >> 6;
     uint32_t wbeg = 0, wend = 0, wnext = 0;
@@ -1012,6 +1104,7 @@ k_copmem_match_dual(const DualArgs a) {
            F_SEQ = 256, F_SEQ1 = 512 };
     uint32_t mode = M_NEED;
     uint32_t idx = 0, cin = 0, epoch = 0;
+    uint32_t npw = 0xFFFFFFFFu;   // the read's N positions, one per byte (0xFF = none): a read with 1-4 N's (hash_fp_window_n)
     uint32_t cnext = 0, cend = 0;
     uint32_t si = 0, rq = 0;
     // per strand (0 forward, 1 RC): own limit (-1 once an exact alignment is accepted), best count and position,
@@ -1042,8 +1135,12 @@ k_copmem_match_dual(const DualArgs a) {
                 unsigned long long base = 0;
                 if (lane == 0) base = atomicAdd(a.work, (unsigned long long)a.chunk);
                 base = __shfl(base, 0, 64);
-                cnext = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base, a.n));
-                cend = __builtin_amdgcn_readfirstlane((uint32_t)min((uint64_t)base + a.chunk, a.n));
+                const uint32_t lo_ = (uint32_t)min((uint64_t)base, a.n), hi_ = (uint32_t)min((uint64_t)base + a.chunk, a.n);
+                // a.from_end: the chunks are handed out from the END of the read set (each still walked upwards): PgRC's sum set
+                // ends with the N set, whose reads rarely match exactly and probe five times the buckets of an average read --
+                // taken last they are what the last waves still work on when the others have run dry
+                cnext = __builtin_amdgcn_readfirstlane(a.from_end ? (uint32_t)a.n - hi_ : lo_);
+                cend = __builtin_amdgcn_readfirstlane(a.from_end ? (uint32_t)a.n - lo_ : hi_);
             }
             if (wnext == wend && cnext != cend) {
                 const uint32_t nst = min((uint32_t)SW, cend - cnext);
@@ -1054,6 +1151,7 @@ k_copmem_match_dual(const DualArgs a) {
                     for (int k = 0; k < NW; k++) stg[wv][k][lane] = a.reads[(uint64_t)k * a.stride + wbeg + lane];
                     stg_c[wv][lane] = a.mism[wbeg + lane];
                     stg_f[wv][lane] = a.nflag ? a.nflag[wbeg + lane] : (uint8_t)0;
+                    stg_n[wv][lane] = a.npos ? a.npos[wbeg + lane] : 0xFFFFFFFFu;
                 }
                 __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
@@ -1068,7 +1166,9 @@ k_copmem_match_dual(const DualArgs a) {
                     const uint32_t sj = wnext - wbeg + rank;
                     idx = wbeg + sj;
                     cin = stg_c[wv][sj];
-                    if (!stg_f[wv][sj] && cin != 0u) {               // ReadsMatchers.cpp:430 with min_mismatches == 0
+                    const uint32_t nfl = stg_f[wv][sj];
+                    if ((nfl == 0u || (nfl == 3u && a.npos)) && cin != 0u) {   // ReadsMatchers.cpp:430 with min_mismatches == 0
+                        npw = nfl ? stg_n[wv][sj] : 0xFFFFFFFFu;
 #pragma unroll
                         for (int k = 0; k < NW; k++) rd_lds[k][threadIdx.x] = sh[k] = stg[wv][k][sj];
                         L0 = (cin < a.kmax) ? (int)cin - 1 : (int)a.kmax;   // :488-489
@@ -1105,8 +1205,13 @@ k_copmem_match_dual(const DualArgs a) {
         uint32_t ncand_it = 0, nprobe_it = 0;
         bool n_redo_it = false;
         if (m0 == M_PROBE) {
-            const uint32_t h = hash_fp_window<KQ>(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
-                                                  NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
+            uint32_t h;
+            if (__any(npw != 0xFFFFFFFFu))                           // (wave-uniform: only waves that hold a read with N's take the patched hash)
+                h = hash_fp_window_n<KQ>(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u, NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read,
+                                         npw, si * a.k2) & a.mask;
+            else
+                h = hash_fp_window<KQ>(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
+                                       NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
             ulonglong2 hr = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
             if (fl & F_ACT0) hdF = a.head[0][head_slot(h, a.hsh)];
             if (fl & F_ACT1) hr = a.head[1][head_slot(h, a.hsh)];
@@ -1183,14 +1288,17 @@ k_copmem_match_dual(const DualArgs a) {
         };
         // open the bucket of strand x for the current seed
         auto open_bucket = [&](const ulonglong2 hx) {
-            if (!(fl & F_SEQ) && (x == 0u ? U0 : U1) > budget) {     // some run could have cut a bucket by now: not decidable
-                fl |= F_REDO;                                        // this way -> the read again, in the reference's order
-                next = M_NEED;
-                return;
-            }
             const uint32_t cnt = head_count(hx);
             if (!cnt) {
                 bdone = true;
+                return;
+            }
+            // some run could have cut THIS bucket to its first 4 entries by now (:510-514 -- all the budget ever does; a bucket
+            // of at most 4 is the same bucket whatever the falses count): not decidable this way -> the read again, in the
+            // reference's order
+            if (!(fl & F_SEQ) && (x == 0u ? U0 : U1) > budget && cnt > a.redo_above) {
+                fl |= F_REDO;
+                next = M_NEED;
                 return;
             }
             nb = cnt;
@@ -1212,12 +1320,27 @@ k_copmem_match_dual(const DualArgs a) {
             }
             const uint32_t b = ((uint32_t)cand_p & 15u) * 2u;
             uint32_t mh = 0, mt = 0;
+            if (__any(npw != 0xFFFFFFFFu)) {                         // (wave-uniform) an N of the read equals no text symbol
 #pragma unroll
-            for (int k = 0; k < NW; k++) {
-                const uint32_t tw = funnel_r(pw[k], pw[k + 1], b);
-                const uint32_t rw = rd_lds[k][threadIdx.x];
-                mh += mism2(tw, rw, sym_mask(k, 0, H));
-                mt += mism2(tw, rw, sym_mask(k, H, (int)a.L));
+                for (int k = 0; k < NW; k++) {
+                    const uint32_t xr = funnel_r(pw[k], pw[k + 1], b) ^ rd_lds[k][threadIdx.x];
+                    uint32_t d = (xr | (xr >> 1)) & 0x55555555u;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t q = (npw >> (8 * i)) & 0xFFu;
+                        d |= ((q >> 4) == (uint32_t)k) ? 1u << (2u * (q & 15u)) : 0u;   // (none = 0xFF: symbol 255 lies beyond every read)
+                    }
+                    mh += (uint32_t)__popc(d & sym_mask(k, 0, H));
+                    mt += (uint32_t)__popc(d & sym_mask(k, H, (int)a.L));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NW; k++) {
+                    const uint32_t tw = funnel_r(pw[k], pw[k + 1], b);
+                    const uint32_t rw = rd_lds[k][threadIdx.x];
+                    mh += mism2(tw, rw, sym_mask(k, 0, H));
+                    mt += mism2(tw, rw, sym_mask(k, H, (int)a.L));
+                }
             }
             vcache[((uint32_t)cand_p * 0x9E3779B1u + x) >> (32 - VC_BITS)][threadIdx.x] =
                 make_uint2((uint32_t)cand_p, POS64 ? (mh | (mt << 8) | ((uint32_t)((uint64_t)cand_p >> 32) << 11) | (x << 19) | (epoch << 20))
@@ -1311,12 +1434,14 @@ static void launch_dual(pgrc_match_ctx *c, const DualArgs &a) {
     const char *f64 = getenv("PGRC_FORCE_POS64");
     const bool pos64 = c->G + 256 >= (1ull << 32) || (f64 && f64[0] == '1');
     const bool k28 = a.K == 28;
+    const char *xl = getenv("PGRC_EXTRA_LDS");    // experiment knob: extra dynamic LDS per block lowers the occupancy
+    const uint32_t dyn_lds = xl ? (uint32_t)atoi(xl) : 0u;
     if (pos64) {
-        if (k28) hipLaunchKernelGGL((k_copmem_match_dual<NW, 7, true>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_copmem_match_dual<NW, 0, true>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+        if (k28) hipLaunchKernelGGL((k_copmem_match_dual<NW, 7, true>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
+        else hipLaunchKernelGGL((k_copmem_match_dual<NW, 0, true>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
     } else {
-        if (k28) hipLaunchKernelGGL((k_copmem_match_dual<NW, 7, false>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_copmem_match_dual<NW, 0, false>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+        if (k28) hipLaunchKernelGGL((k_copmem_match_dual<NW, 7, false>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
+        else hipLaunchKernelGGL((k_copmem_match_dual<NW, 0, false>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
     }
 }
 
@@ -1337,6 +1462,10 @@ int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     a.n = rn;
     a.stride = c->stride;
     a.nflag = (c->n_nreads || c->up_open) ? (const uint8_t *)c->nread_flag.p + lo : nullptr;   // (during an upload the side list is not final yet: the flags are)
+    {
+        const char *ni = getenv("PGRC_NREAD_INLINE");              // 0: every read with an N goes the byte path (A/B runs, tests)
+        a.npos = (a.nflag && !(ni && ni[0] == '0') && c->nread_npos.p) ? (const uint32_t *)c->nread_npos.p + lo : nullptr;
+    }
     a.head[0] = (const ulonglong2 *)c->alt_head_ptr;
     a.head[1] = (const ulonglong2 *)c->head_ptr;
     a.hsh = c->head_sh;
@@ -1355,6 +1484,12 @@ int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     a.k2 = (uint32_t)c->cp.k2;
     a.mask = c->cp.hash_size - 1;
     a.kmax = c->prm.max_mismatches;
+    {
+        const char *ra = getenv("PGRC_REDO_ANY");                   // 1: round 3's rule (A/B runs)
+        a.redo_above = (ra && ra[0] == '1') ? 0u : PGRC_TRUNC_BUCKET;
+        const char *fe = getenv("PGRC_MATCH_FROM_END");             // 0: chunks from the start of the read set (A/B runs)
+        a.from_end = (fe && fe[0] == '0') ? 0u : 1u;
+    }
     switch (c->nw) {
 #define CASE_NW(N) case N: launch_dual<N>(c, a); break;
         CASE_NW(2) CASE_NW(3) CASE_NW(4) CASE_NW(5) CASE_NW(6) CASE_NW(7) CASE_NW(8) CASE_NW(9)
@@ -1394,6 +1529,92 @@ static void launch_match(pgrc_match_ctx *c, const MatchArgs &a) {
         else PGRC_LAUNCH_MATCH(0, false);
     }
 #undef PGRC_LAUNCH_MATCH
+}
+
+// The reads with N through the strands first .. last (k_copmem_match_n), on the side stream: it starts when what the main
+// stream holds so far is done (the indexes; a streamed run: when c->n_after says so) and the caller joins it later
+// (pgrc_copmem_join_nreads).  Every strand asked for must be one of the two index sets of the context.  beside_dual: a
+// persistent grid of a few waves per CU, launched BEFORE the dual kernel so that it holds its slots from the start (its
+// lanes are chains of dependent accesses: beside the dual kernel they cost that kernel a wave slot per SIMD for a while,
+// behind it 19 ms at C3 with nothing else to run).
+int pgrc_copmem_match_nreads(pgrc_match_ctx *c, int first, int last, bool beside_dual, bool only_many) {
+    if (!c->n_nreads) return PGRC_OK;
+    {
+        const char *ni = getenv("PGRC_NREAD_INLINE");
+        if (ni && ni[0] == '0') only_many = false;
+    }
+    if (only_many && !c->n_many) return PGRC_OK;                        // (the dual kernel takes every read with at most 4 N's)
+    NReadArgs a;
+    a.skip_flag = only_many ? (const uint8_t *)c->nread_flag.p : nullptr;
+    for (int s = first; s <= last; s++) {
+        const bool act = c->index_strand == s && c->ent_ptr, alt = !act && c->alt_index_strand == s && c->alt_ent_ptr;
+        if (!act && !alt) { c->err = "reads with N: no index of that strand"; return PGRC_E_STATE; }
+        a.st[s].pg = (const uint32_t *)c->pg2[s].p;
+        a.st[s].head = act ? c->head_ptr : c->alt_head_ptr;
+        a.st[s].hsh = act ? c->head_sh : c->alt_head_sh;
+        a.st[s].ent = act ? c->ent_ptr : c->alt_ent_ptr;
+        a.st[s].counters = (unsigned long long *)c->d_counters.p + 8 * s;
+    }
+    a.G = c->G;
+    a.pos = (uint64_t *)c->d_pos.p;
+    a.rc = (uint8_t *)c->d_rc.p;
+    a.mism = (uint8_t *)c->d_mism.p;
+    a.nidx = (const uint32_t *)c->nread_idx.p;
+    a.nascii = (const uint8_t *)c->nread_ascii.p;
+    a.nn = c->n_nreads;
+    a.L = c->prm.read_len;
+    a.K = (uint32_t)c->cp.K;
+    a.k1 = (uint32_t)c->cp.k1;
+    a.k2 = (uint32_t)c->cp.k2;
+    a.mask = c->cp.hash_size - 1;
+    a.kmax = c->prm.max_mismatches;
+    a.kmin = c->prm.min_mismatches;
+    {
+        const char *es = getenv("PGRC_EARLY_STOP");
+        a.early = (es && es[0] == '0') ? 0u : 1u;
+    }
+    a.first = (uint32_t)first;
+    a.last = (uint32_t)last;
+    if (!c->side_stream) {   // stream and both events, or nothing
+        hipStream_t st = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        hipError_t he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e0, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+        if (he != hipSuccess) {
+            if (e0) (void)hipEventDestroy(e0);
+            if (st) (void)hipStreamDestroy(st);
+            c->err = std::string("side stream: ") + hipGetErrorString(he);
+            return pgrc_hip_code(he);
+        }
+        c->side_stream = st;
+        c->side_ev[0] = e0;
+        c->side_ev[1] = e1;
+    }
+    if (c->n_after) {                                                   // (a streamed run: not behind the blocks still queued)
+        HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->n_after, 0));
+    } else {
+        HIP_TRY(c, hipEventRecord(c->side_ev[0], c->stream));           // the index (and the previous pass) are complete
+        HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->side_ev[0], 0));
+    }
+    const uint64_t tiles = (c->n_nreads + NREAD_TPB - 1) / NREAD_TPB;
+    uint32_t per_cu = 64u;                                              // alone or beside an ordinary pass: whatever fits
+    if (beside_dual) {
+        const char *ng = getenv("PGRC_NREAD_BLOCKS");                   // blocks of two waves per CU beside the dual kernel
+        per_cu = ng && atoi(ng) > 0 ? (uint32_t)atoi(ng) : 2u;
+    }
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, (uint64_t)c->num_cus * per_cu);
+    const uint32_t lds = 2u * ((uint32_t)c->nw + 1u) * NREAD_TPB * (uint32_t)sizeof(uint32_t);
+    hipLaunchKernelGGL(k_copmem_match_n, dim3(grid), dim3(NREAD_TPB), lds, c->side_stream, a);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->side_ev[1], c->side_stream));
+    return PGRC_OK;
+}
+
+// the main stream goes on when the reads with N are done
+int pgrc_copmem_join_nreads(pgrc_match_ctx *c) {
+    if (c->n_nreads && c->side_stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_ev[1], 0));
+    return PGRC_OK;
 }
 
 int pgrc_copmem_match_pass(pgrc_match_ctx *c, int strand) { return pgrc_copmem_match_phase(c, strand, 0); }
@@ -1442,34 +1663,8 @@ int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase) {
     //  count from read 0: it runs on whole-set launches only, never on a block of a streamed run)
     const bool with_n = c->n_nreads && phase != 1 && !c->range_skip_n && lo == 0 && rn == c->n;
     if (with_n) {
-        if (!c->side_stream) {   // stream and both events, or nothing
-            hipStream_t st = nullptr;
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            hipError_t he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&e0, hipEventDisableTiming);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&e1, hipEventDisableTiming);
-            if (he != hipSuccess) {
-                if (e0) (void)hipEventDestroy(e0);
-                if (st) (void)hipStreamDestroy(st);
-                c->err = std::string("side stream: ") + hipGetErrorString(he);
-                return pgrc_hip_code(he);
-            }
-            c->side_stream = st;
-            c->side_ev[0] = e0;
-            c->side_ev[1] = e1;
-        }
-        if (c->n_after) {                                                   // (a streamed run: not behind the blocks still queued)
-            HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->n_after, 0));
-        } else {
-            HIP_TRY(c, hipEventRecord(c->side_ev[0], c->stream));           // the index (and the previous pass) are complete
-            HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->side_ev[0], 0));
-        }
-        const uint32_t grid = (uint32_t)((c->n_nreads + NREAD_TPB - 1) / NREAD_TPB);
-        const uint32_t lds = 2u * ((uint32_t)c->nw + 1u) * NREAD_TPB * (uint32_t)sizeof(uint32_t);
-        hipLaunchKernelGGL(k_copmem_match_n, dim3(grid), dim3(NREAD_TPB), lds, c->side_stream, a,
-                           (const uint32_t *)c->nread_idx.p, (const uint8_t *)c->nread_ascii.p, c->n_nreads);
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipEventRecord(c->side_ev[1], c->side_stream));
+        const int ne = pgrc_copmem_match_nreads(c, strand, strand, false, false);
+        if (ne) return ne;
     }
     if (phase != 4)                  // (phase 4: the dual kernel has done every read without N)
     switch (c->nw) {
@@ -1482,6 +1677,6 @@ int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase) {
         return PGRC_E_PARAM;
     }
     HIP_TRY(c, hipGetLastError());
-    if (with_n) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_ev[1], 0));   // the pass ends when both kernels have
+    if (with_n) return pgrc_copmem_join_nreads(c);   // the pass ends when both kernels have
     return PGRC_OK;
 }

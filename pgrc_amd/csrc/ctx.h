@@ -66,13 +66,17 @@ struct pgrc_match_ctx {
     uint64_t n_nreads = 0;
     DevBuf nread_idx;       // u32[n_nreads] read index
     DevBuf nread_ascii;     // u8[n_nreads][read_len]
-    DevBuf nread_flag;      // u8[n] 1 = handled by the byte path
+    DevBuf nread_flag;      // u8[n] 0 = no N; 1 = N's, the byte path (k_copmem_match_n); 3 = at most 4 N's: their positions are in
+                            // nread_npos and the dual kernel takes the read itself (the other schedules treat 3 like 1)
+    DevBuf nread_npos;      // u32[n] four position bytes (0xFF = none) of the reads flagged 3 (pack.hip, k_npos_rows)
+    uint64_t n_many = 0;    // reads flagged 1: more N's than the dual kernel takes
     std::vector<uint32_t> h_nidx; // host copy of nread_idx (ascending): modes d/i/e cut it per batch of reads
 
     // chunked upload state (pgrc_match_begin_reads / _append_ / _end_)
     bool up_open = false;
     uint64_t up_next = 0;
     std::vector<uint32_t> up_nidx;                  // reads with N seen so far (ascending)
+    uint64_t up_nmany = 0;                          // ... of them with more than 4 N's
     std::vector<DevBuf> up_nchunks;                 // their ASCII rows, one device buffer per appended block that had some
     std::vector<uint64_t> up_nchunk_rows;
 
@@ -229,6 +233,8 @@ int pgrc_launch_repack_reads_ref(pgrc_match_ctx *c, const uint8_t *d_packed, uin
                                  uint32_t L, uint32_t *d_words, uint64_t stride);
 int pgrc_launch_unpack_reads_acgnt(pgrc_match_ctx *c, const uint8_t *d_packed, uint64_t first, uint64_t count,
                                    uint32_t L, uint32_t *d_words, uint64_t stride, uint8_t *d_nflag, uint32_t *d_errflag);
+int pgrc_launch_npos_rows(pgrc_match_ctx *c, const uint8_t *d_rows, int symbols, uint64_t first, uint64_t count, uint32_t L,
+                          uint8_t *d_nflag, uint32_t *d_npos);
 int pgrc_launch_nrows_ascii_acgnt(pgrc_match_ctx *c, const uint8_t *d_packed, const uint32_t *d_local_idx, uint64_t count,
                                   uint32_t L, uint8_t *d_ascii);
 
@@ -256,6 +262,8 @@ int pgrc_prepare_both_indexes(pgrc_match_ctx *c);
 bool pgrc_dual_applies(const pgrc_match_ctx *c);
 int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase);
 int pgrc_copmem_match_dual(pgrc_match_ctx *c);
+int pgrc_copmem_match_nreads(pgrc_match_ctx *c, int first, int last, bool beside_dual, bool only_many);
+int pgrc_copmem_join_nreads(pgrc_match_ctx *c);
 int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_positions, uint64_t *count);
 
 // seedidx.hip (modes d / i / e)

@@ -461,11 +461,64 @@ static int upload(pgrc_match_ctx *c, DevBuf &b, const void *src, size_t bytes) {
     return PGRC_OK;
 }
 
+// ---- the order of the matched reads made on the device (round 4): ascending match position, reads matched at one position
+// in ascending read index (the reference's order is its sort algorithm's -- std::sort / __gnu_parallel::sort leave equal
+// positions in an order of their own, ReadsMatchers.cpp:573-574 -- and only reproducible at -t 1; a caller that needs those
+// bytes passes its own order[]).  Records position << 32 | read of the matched reads, compacted in read order, then a stable
+// radix sort over the position bits (radix.hip): 4 passes for a text below 2^32.
+__global__ void __launch_bounds__(256) k_ord_flags(const uint64_t *__restrict__ pos, uint64_t n, uint8_t *__restrict__ flag) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        flag[i] = pos[i] != PGRC_NOT_MATCHED_POS ? 1 : 0;
+}
+__global__ void __launch_bounds__(256)
+k_ord_records(const uint64_t *__restrict__ pos, const uint64_t *__restrict__ slot, uint64_t n, uint64_t *__restrict__ rec) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        if (pos[i] != PGRC_NOT_MATCHED_POS) rec[slot[i]] = (pos[i] << 32) | i;
+}
+__global__ void __launch_bounds__(256) k_ord_reads(const uint64_t *__restrict__ rec, uint64_t m, uint32_t *__restrict__ order) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += (uint64_t)gridDim.x * blockDim.x)
+        order[k] = (uint32_t)rec[k];
+}
+
+int pgrc_radix_sort_u64(pgrc_match_ctx *c, uint64_t *d_a, uint64_t *d_b, uint64_t n, uint32_t bit_lo, uint32_t bit_hi, DevBuf &scratch,
+                        uint64_t **sorted);
+
+// -> b.order (device), *m_out = matched reads
+static int device_position_order(pgrc_match_ctx *c, Bufs &b, uint64_t *m_out) {
+    const uint64_t n = c->n;
+    if (c->G >= (1ull << 32)) { c->err = "export_pg_order: the device-made order needs a text below 2^32 symbols (pass order[])"; return PGRC_E_PARAM; }
+    DevBuf flag, slot, ra, rb, scratch;
+    auto done = [&](int e) { for (DevBuf *x : {&flag, &slot, &ra, &rb, &scratch}) pgrc_buf_free(*x); return e; };
+    int e;
+    if ((e = pgrc_buf_ensure(c, flag, n)) || (e = pgrc_buf_ensure(c, slot, (n + 1) * sizeof(uint64_t)))) return done(e);
+    if (n) hipLaunchKernelGGL(k_ord_flags, dim3(grid_for(n)), dim3(256), 0, c->stream, (const uint64_t *)c->d_pos.p, n, (uint8_t *)flag.p);
+    if ((e = device_scan<uint8_t, false>(c, (const uint8_t *)flag.p, n, (uint64_t *)slot.p, b.bs))) return done(e);
+    uint64_t m = 0;
+    if (hipMemcpyAsync(&m, (const uint64_t *)slot.p + n, sizeof m, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "export_pg_order: HIP error"; return done(PGRC_E_DEVICE); }
+    *m_out = m;
+    if ((e = pgrc_buf_ensure(c, b.order, m * sizeof(uint32_t)))) return done(e);
+    if (!m) return done(PGRC_OK);
+    if ((e = pgrc_buf_ensure(c, ra, m * sizeof(uint64_t))) || (e = pgrc_buf_ensure(c, rb, m * sizeof(uint64_t)))) return done(e);
+    hipLaunchKernelGGL(k_ord_records, dim3(grid_for(n)), dim3(256), 0, c->stream, (const uint64_t *)c->d_pos.p, (const uint64_t *)slot.p, n, (uint64_t *)ra.p);
+    uint32_t pbits = 1;
+    while (pbits < 32 && (c->G >> pbits)) pbits++;
+    uint64_t *sorted = nullptr;
+    if ((e = pgrc_radix_sort_u64(c, (uint64_t *)ra.p, (uint64_t *)rb.p, m, 32u, 32u + pbits, scratch, &sorted))) return done(e);
+    hipLaunchKernelGGL(k_ord_reads, dim3(grid_for(m)), dim3(256), 0, c->stream, (const uint64_t *)sorted, m, (uint32_t *)b.order.p);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "export_pg_order: HIP error"; return done(PGRC_E_DEVICE); }
+    return done(PGRC_OK);
+}
+
 static int export_pg_order(pgrc_match_ctx *c, const pgrc_export_pg_order_args *x, Bufs &b, pgrc_export_streams *out) {
-    const uint64_t m = x->n_matched, h = x->list_count, ne = m + h;
+    uint64_t m = x->n_matched;
+    const uint64_t h = x->list_count;
     const uint32_t width = x->byte_per_read_length ? 1u : 2u;
     int e;
-    if ((e = upload(c, b.order, x->order, m * sizeof(uint32_t)))) return e;
+    if (x->order) {
+        if ((e = upload(c, b.order, x->order, m * sizeof(uint32_t)))) return e;
+    } else if ((e = device_position_order(c, b, &m))) return e;
+    const uint64_t ne = m + h;
     if (x->read_org_idx && (e = upload(c, b.rorg, x->read_org_idx, c->n * sizeof(uint32_t)))) return e;
     if ((e = upload(c, b.loff, x->list_off, h)) || (e = upload(c, b.lorg, x->list_org_idx, h * sizeof(uint32_t)))) return e;
     if (x->list_rev_comp && (e = upload(c, b.lrc, x->list_rev_comp, h))) return e;
@@ -621,11 +674,11 @@ void pgrc_export_drop_view(pgrc_match_ctx *c) {
 }
 
 extern "C" int pgrc_match_export_pg_order(pgrc_match_ctx *c, const pgrc_export_pg_order_args *x, pgrc_export_streams *out) {
-    if (!c || !x || !out || (x->n_matched && !x->order) || (x->list_count && (!x->list_off || !x->list_org_idx))) return PGRC_E_PARAM;
+    if (!c || !x || !out || (x->list_count && (!x->list_off || !x->list_org_idx))) return PGRC_E_PARAM;
     memset(out, 0, sizeof *out);
     if (!c->have_results || !c->have_pg || !c->have_reads) { c->err = "export: run first"; return PGRC_E_STATE; }
     if (x->n_matched > c->n) { c->err = "export: more matched reads than reads"; return PGRC_E_PARAM; }
-    for (uint64_t j = 0; j < x->n_matched; j++)
+    for (uint64_t j = 0; x->order && j < x->n_matched; j++)
         if (x->order[j] >= c->n) { c->err = "export_pg_order: read index out of range"; return PGRC_E_PARAM; }
     pgrc_match_ctx *w = c;
     int ge = view_for(c, &w);

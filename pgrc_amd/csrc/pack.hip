@@ -251,3 +251,44 @@ int pgrc_launch_nrows_ascii_acgnt(pgrc_match_ctx *c, const uint8_t *d_packed, co
     HIP_TRY(c, hipGetLastError());
     return PGRC_OK;
 }
+
+// Where the N's of the reads flagged by the kernels above are.  One thread per read of the block; a flagged read with at
+// most 4 N's gets their positions as four bytes (0xFF = none; a read has at most 255 symbols) in npos[read] and the flag 3:
+// the dual kernel (copmem.hip) takes such a read like any other -- it patches the window hash where an N falls into a
+// window (the reference hashes the byte 'N') and counts every N as a mismatch.  More N's: the flag stays 1 and the read
+// goes the byte path (k_copmem_match_n).  rows: the block's rows as uploaded, ASCII (symbols = 0) or ACGNT-packed (5).
+__global__ void __launch_bounds__(256)
+k_npos_rows(const uint8_t *__restrict__ rows, int symbols, uint64_t first, uint64_t count, uint32_t L, uint32_t rb,
+            uint8_t *__restrict__ nflag, uint32_t *__restrict__ npos) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (!nflag[first + i]) continue;
+        const uint8_t *row = rows + i * rb;
+        uint32_t w = 0xFFFFFFFFu, cnt = 0;
+        for (uint32_t x = 0; x < L; x++) {
+            bool isn;
+            if (symbols == 0) isn = row[x] == 'N';
+            else {
+                const uint32_t v = row[x / 3];
+                isn = (x % 3 == 0 ? v / 25u : x % 3 == 1 ? (v / 5u) % 5u : v % 5u) == 3u;     // A0 C1 G2 N3 T4
+            }
+            if (isn) {
+                if (cnt < 4) w = (w & ~(0xFFu << (8 * cnt))) | (x << (8 * cnt));
+                cnt++;
+            }
+        }
+        if (cnt >= 1 && cnt <= 4) {
+            npos[first + i] = w;
+            nflag[first + i] = 3;
+        }
+    }
+}
+
+int pgrc_launch_npos_rows(pgrc_match_ctx *c, const uint8_t *d_rows, int symbols, uint64_t first, uint64_t count, uint32_t L,
+                          uint8_t *d_nflag, uint32_t *d_npos) {
+    if (!count) return PGRC_OK;
+    const uint32_t rb = symbols == 0 ? L : (L + 2) / 3;
+    const uint32_t grid = (uint32_t)((count + 255) / 256 < 65536 ? (count + 255) / 256 : 65536);
+    hipLaunchKernelGGL(k_npos_rows, dim3(grid), dim3(256), 0, c->stream, d_rows, symbols, first, count, L, rb, d_nflag, d_npos);
+    HIP_TRY(c, hipGetLastError());
+    return PGRC_OK;
+}

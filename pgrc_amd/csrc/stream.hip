@@ -192,10 +192,8 @@ extern "C" int pgrc_match_stream_end(pgrc_match_ctx *c, uint64_t hist[256], uint
     // blocks' kernels skip the reads with N, so the two write disjoint reads); the main stream joins it at its tail
     if (c->n_nreads) {
         c->n_after = c->st_ready;
-        pgrc_swap_index_sets(c);
-        e = pgrc_copmem_match_phase(c, 0, 4);
-        pgrc_swap_index_sets(c);
-        if (!e) e = pgrc_copmem_match_phase(c, 1, 4);
+        e = pgrc_copmem_match_nreads(c, 0, 1, false, c->st_dual);   // (the blocks' dual kernel took the reads with at most 4 N's)               // (one launch: a read's forward query, then its RC query)
+        if (!e) e = pgrc_copmem_join_nreads(c);
         c->n_after = nullptr;
     }
     if (timing_on()) { (void)hipStreamSynchronize(c->stream); ST_MARK(c, "all blocks matched, reads with N done"); }

@@ -254,11 +254,13 @@ class MatchContext:
 
     def export_pg_order(self, order, list_off, list_org_idx, list_rev_comp=None, read_org_idx=None,
                         rev_compl_pair_file: bool = False, byte_per_read_length: bool = True) -> dict:
-        """exportMatchesInPgOrder's streams (see pgrc_match_export_pg_order)."""
-        keep = [np.ascontiguousarray(order, dtype=np.uint32), np.ascontiguousarray(list_off, dtype=np.uint8),
+        """exportMatchesInPgOrder's streams (see pgrc_match_export_pg_order).  order=None: the library makes the order on the
+        device (ascending position, reads at one position by ascending index)."""
+        keep = [np.ascontiguousarray(order if order is not None else [], dtype=np.uint32), np.ascontiguousarray(list_off, dtype=np.uint8),
                 np.ascontiguousarray(list_org_idx, dtype=np.uint32)]
         a = _lib.ExportPgOrderArgs()
-        a.order, a.n_matched = keep[0].ctypes.data, keep[0].size
+        if order is not None:
+            a.order, a.n_matched = keep[0].ctypes.data, keep[0].size
         a.list_off, a.list_org_idx, a.list_count = keep[1].ctypes.data, keep[2].ctypes.data, keep[1].size
         if list_rev_comp is not None:
             keep.append(np.ascontiguousarray(list_rev_comp, dtype=np.uint8))

@@ -128,7 +128,7 @@ def main():
         else:
             write_fastq("in.fastq", reads, qseed)
             src, pair = b"in.fastq", b""
-        calls = lib.pgrc_ref_encode(src, pair, b"out.pgrc", 1, use_gpu, 1 if order else 0,
+        calls = lib.pgrc_ref_encode(src, pair, b"out.pgrc", int(os.environ.get("PGRC_E2E_THREADS", "1")), use_gpu, 1 if order else 0,
                                     (mode or "\0").encode(), seed, mcpm, (pre_mode or "\0").encode(), pre_seed)
         blob = open("out.pgrc", "rb").read()
         digests[leg] = hashlib.sha256(blob).hexdigest()

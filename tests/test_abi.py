@@ -34,6 +34,19 @@ def test_no_torch_types_in_the_abi_and_no_oracle_linkage():
     assert "pgrc_or_" not in syms and "pgrc_ref_" not in syms
 
 
+def test_library_exports_only_the_c_entry_points():
+    """pgrc_amd/csrc/exports.map: nothing but unmangled pgrc_* functions is visible to a host that links the library --
+    no mangled internals, no kernel stubs or kernel handles"""
+    import subprocess
+    from pgrc_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert names, "nm printed nothing"
+    stray = [n for n in names if not n.startswith("pgrc_")]
+    assert not stray, f"exported besides the C entry points: {stray[:8]} ({len(stray)} in all)"
+    assert set(header_symbols()) <= set(names)
+
+
 def test_parameter_derivation_matches_the_reference_rules():
     from pgrc_amd import _lib, copmem_params
     p = _lib.MatchParams()

@@ -124,3 +124,24 @@ def test_archive_identical_with_the_read_sets_made_on_the_device(tmp_path, case,
     r = _run(tmp_path, case, cpu_only=False, extra_env=dict(env, PGRC_E2E_GPU_STAGES="7", PGRC_DIVIDE_BATCH="7000", PGRC_FASTQ_PIECE="100000"))
     assert r["gpu_division_calls"] >= 1 and r["gpu_gpu_calls"] >= 1, r
     assert r["identical"] and r["roundtrip"], r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,threads", [("se", "1"), ("pe", "1"), ("se", "8"), ("pe_order", "8")])
+def test_archive_with_the_position_order_made_on_the_device(tmp_path, case, threads):
+    """Round 4: the Pg-order export with the matched reads ordered on the device (ascending position, reads at one position
+    by ascending index) instead of by the reference's sort, whose tie order only -t 1 reproduces.  HipReadsMatcher takes
+    it when PgHelpers::numberOfThreads > 1 (or PGRC_DEVICE_SORT=1): the archive must decode to the input and have the size
+    of the host-sort archive (the tie order moves a few bytes; at -t 8 the reference's parallel Pg generator and racy index
+    move more)."""
+    if not _have_e2e():
+        pytest.skip("oracle/_ref was built without the encoder harness")
+    env = {"PGRC_E2E_THREADS": threads}
+    if threads == "1":
+        env["PGRC_DEVICE_SORT"] = "1"
+    r = _run(tmp_path, case, cpu_only=False, extra_env=env)
+    assert r["gpu_gpu_calls"] >= 1 and r["roundtrip"], r
+    if case in ("se", "pe"):
+        assert r["gpu_device_exports"] >= 1, r
+    tol = 0.0005 if threads == "1" else 0.01
+    assert abs(r["gpu_bytes"] - r["cpu_bytes"]) <= tol * r["cpu_bytes"], r

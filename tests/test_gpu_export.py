@@ -46,6 +46,11 @@ def test_device_streams_equal_oracle_streams(name):
             for k in xu.STREAMS:
                 assert np.array_equal(got[k], want[k]), (name, byte_mode, with_org, k)
             assert got["last_pos"] == want["last_pos"]
+    # the order made on the device (order = NULL): ascending position, reads at one position by ascending index
+    want = xu.oracle_export_pg_order(case, res, order, pair_file=pair)
+    got = g["ctx"].export_pg_order(None, case["list_off"], case["list_org"], case["list_rc"], case["read_org"], pair, True)
+    for k in xu.STREAMS:
+        assert np.array_equal(got[k], want[k]), (name, "device-made order", k)
     # no RC stream on the old list
     c2 = dict(case, list_rc=None)
     want = xu.oracle_export_pg_order(c2, res, order, pair_file=pair)
@@ -150,3 +155,26 @@ def test_adapter_export_with_a_parallel_sort(tmp_path):
     got = xu.ref_export_run(case, str(tmp_path / "gpu"), 1, threads=8)
     for k in xu.STREAMS:
         assert got[k] == want[k], k
+
+
+@pytest.mark.parametrize("n,G,dups", [(70_000, 400_000, 30_000), (9_000, 3_000, 0), (8_192, 200_000, 100), (1, 1_000, 0)])
+def test_device_made_position_order(n, G, dups):
+    """The hand-written stable radix sort behind pgrc_match_export_pg_order(order = NULL) (radix.hip): several tiles, tile
+    edges, many reads at one position (copies of reads; a text shorter than the read count), one read.  The streams must be
+    those of the stable order (position, then read index)."""
+    L = 100 if G >= 1000 else 50
+    case = xu.export_case(seed=900 + n % 97, G=G, n=n, L=L, n_with_n=min(200, n // 10), dups=dups, list_gap=40)
+    g = gpu_match("c", case["pg"], case["reads"], 38, L // 3, 0, n_nset=case["n_n"])
+    res = {k: g[k] for k in ("pos", "rc", "mism")}
+    order = xu.stable_order(res["pos"])
+    if n > 1:
+        assert order.size > n // 2
+    want = xu.oracle_export_pg_order(case, res, order)
+    got = g["ctx"].export_pg_order(None, case["list_off"], case["list_org"], case["list_rc"], case["read_org"], False, True)
+    for k in xu.STREAMS:
+        assert np.array_equal(got[k], want[k]), (n, G, k)
+    assert got["last_pos"] == want["last_pos"]
+    many = gpu_match("c", case["pg"], case["reads"], 38, L // 3, 0, n_nset=case["n_n"], devices=[0, 0, 0])
+    got = many["ctx"].export_pg_order(None, case["list_off"], case["list_org"], case["list_rc"], case["read_org"], False, True)
+    for k in xu.STREAMS:
+        assert np.array_equal(got[k], want[k]), (n, G, k, "three shards")

@@ -239,6 +239,57 @@ def test_copmem_n_reads_take_the_byte_path():
         assert_same_results(g, r, "N reads vs reference")
 
 
+@pytest.mark.parametrize("L,kmax", [(150, 3), (150, 50), (100, 6), (250, 5)])
+@pytest.mark.parametrize("inline", ["1", "0"])
+def test_dual_kernel_takes_reads_with_few_ns(monkeypatch, L, kmax, inline):
+    """Round 4: a read with at most 4 N's is the dual kernel's own (nread_flag 3 + its N positions: the window hash is
+    patched where an N falls into a window, every N counts as a mismatch); more N's go the byte path behind it.
+    N's at the read's ends, several in one hash step, on fingerprint symbols, in every window; reads of N only; ASCII
+    rows and the reference's LQ + N sum set; PGRC_NREAD_INLINE=0 sends every read with an N down the byte path."""
+    monkeypatch.setenv("PGRC_DUAL", "1")
+    monkeypatch.setenv("PGRC_NREAD_INLINE", inline)
+    rng = np.random.default_rng(1000 + L + kmax)
+    pg, reads = make_inputs(400_000, 6000, L, seed=500 + L + kmax, n_with_n=0, pool_div=32)
+    n = reads.shape[0]
+    first_n = n - 1500
+    N = ord("N")
+    for i in range(first_n, n):
+        k = (i - first_n) % 12
+        if k < 4:                                      # 1..4 N's anywhere
+            for x in rng.choice(L, size=k + 1, replace=False):
+                reads[i, x] = N
+        elif k == 4:                                   # the read's first and last symbol
+            reads[i, 0] = N; reads[i, L - 1] = N
+        elif k == 5:                                   # several N's inside one 4-symbol hash step (hashed and fingerprint symbols)
+            x = int(rng.integers(0, L // 4 - 1)) * 4
+            reads[i, x:x + 4] = N
+        elif k == 6:                                   # N's every 40 symbols: (nearly) every window holds one
+            reads[i, 5::40][:4] = N
+        elif k == 7:                                   # 5..12 N's: the byte path
+            for x in rng.choice(L, size=int(rng.integers(5, 13)), replace=False):
+                reads[i, x] = N
+        elif k == 8:                                   # nothing but N
+            reads[i, :] = N
+        elif k == 9:                                   # an N in the tail part of the two-stage count
+            reads[i, L - 1 - int(rng.integers(0, L % 8 + 1))] = N
+        elif k == 10:                                  # an exact read from the text with one N
+            st = int(rng.integers(0, pg.size - L)); reads[i] = pg[st:st + L]; reads[i, int(rng.integers(0, L))] = N
+        else:                                          # its reverse complement with two
+            st = int(rng.integers(0, pg.size - L)); reads[i] = revcomp(pg[st:st + L]); reads[i, rng.choice(L, size=2, replace=False)] = N
+    o = orc.oracle_match("c", pg, reads, 38, kmax, 0)
+    assert (o["mism"][first_n:] != 255).sum() > 100          # (reads with N do get matched here)
+    g = gpu_match("c", pg, reads, 38, kmax, 0)
+    assert_same_results(g, o, f"ASCII rows, inline={inline}")
+    assert g["ctx"].counters()["screened"] == 2
+    g2 = gpu_match("c", pg, reads, 38, kmax, 0, n_nset=n - first_n)
+    assert_same_results(g2, o, f"LQ + N sum set, inline={inline}")
+    g3 = gpu_match("c", pg, reads, 38, kmax, 0, devices=[0, 0])
+    assert_same_results(g3, o, f"two shards, inline={inline}")
+    if orc.have_ref() and inline == "1":
+        r = orc.ref_match("c", pg, reads, 38, kmax, 0, n_nset=n - first_n)
+        assert_same_results(g, r, "vs real reference")
+
+
 def test_reference_packed_reads_entry_point():
     pg, reads = make_inputs(150000, 3000, 150, seed=8)
     o = orc.oracle_match("c", pg, reads, 38, 3, 0)
