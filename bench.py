@@ -40,7 +40,9 @@ WORKLOADS = {
 }
 N_FRACTION = {"C3-N": 0.02, "tiny-N": 0.02}     # share of the reads that hold an N (the reference's N read set)
 # measured random-request ceiling of the chip (tools/ubench/gather.hip): 51 G/s at a 4 GiB footprint, 48 G/s at the
-# 8-32 GiB footprints where the 8.6 GB bucket-head table of C3 lives (profiles/r01_ubench_gather_footprint.txt)
+# 8-32 GiB footprints where the bucket-head table of C3 lives (profiles/r01_ubench_gather_footprint.txt); the unit of a
+# request is a 128-BYTE line (round 4, profiles/r04_head_interleave_ab.txt): two 16-byte loads of one lane into one such
+# line cost 1.2 requests (41 G lines/s with two loads per line, profiles/r01_ubench_gather_same_line.txt)
 GATHER_CEILING_GPS = 48.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -53,6 +55,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("PGRC_BENCH_WORKLOAD", "C3"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--no-cpu-t1", action="store_true", help="skip the -t 1 leg of the CPU baseline (two more serial index builds)")
     ap.add_argument("--cpu-sample-reads", type=int, default=3_000_000)
     ap.add_argument("--parity-sample-reads", type=int, default=100_000,
                     help="reads checked bit for bit against the SERIAL-index reference (0 = skip)")
@@ -198,10 +201,12 @@ def main():
             kname = "k_copmem_match" + ("(fwd)" if dom == 0 else "(rc)")
         alg_bytes = kc["searched"] * (rb + 10) + kc["probes"] * 8 + kc["candidates"] * (5 + rb)
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        # random 64-B line requests issued by that launch: one per probed bucket head, one per fetched entry pair,
-        # and per verified text window the lines a (L/4)-byte window at a random 4-B offset spans on average
-        # (tools/ubench: the chip sustains ~51 G independent random requests per second, whatever their width)
-        gathers = int(kc["probes"] + kc["entry_fetches"] + kc["verifies"] * (1.0 + max(rb - 4, 0) / 64.0))
+        # random line requests issued by that launch: one per probed SEED under the pair table (round 4: a seed's forward and RC
+        # head share a 128-byte line; `dual_seed_probes`) -- one per probed head otherwise --, one per fetched entry pair, and
+        # per verified text window the 128-byte lines a (L/4)-byte window at a random 4-B offset spans on average
+        # (tools/ubench: the chip sustains ~48-51 G independent random requests per second, whatever their width)
+        head_lines = ctr.get("dual_seed_probes", 0) if (schedule == "dual" and ctr.get("dual_seed_probes", 0)) else kc["probes"]
+        gathers = int(head_lines + kc["entry_fetches"] + kc["verifies"] * (1.0 + max(rb - 4, 0) / 128.0))
         gather_rate = gathers / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         # the bytes THIS kernel's algorithm needs (its fingerprints reject 99.9 % of the false candidates without
         # touching the text, so the reference's text-window bytes above are mostly never moved): a 16-B head per
@@ -211,9 +216,9 @@ def main():
         # HBM traffic of that launch from the PMC counters (FETCH_SIZE + WRITE_SIZE): they cannot be read from inside
         # this process, so the value comes from the committed separate `rocprofv3 --pmc` passes of this very command
         # (tools/pmc_groups.sh + tools/pmc_traffic.py -> profiles/); null for workloads that were not profiled.
-        traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", f"r03_{args.workload.lower()}_traffic.json")
-        for older in (f"r02_{args.workload.lower()}_traffic.json", f"r01_final_{args.workload.lower()}_traffic.json"):
+        traffic, traffic_src, index_traffic = None, None, None
+        tp = os.path.join(ROOT, "profiles", f"r04_{args.workload.lower()}_traffic.json")
+        for older in (f"r03_{args.workload.lower()}_traffic.json", f"r02_{args.workload.lower()}_traffic.json", f"r01_final_{args.workload.lower()}_traffic.json"):
             if not os.path.exists(tp):
                 tp = os.path.join(ROOT, "profiles", older)
         if world == 1 and os.path.exists(tp):
@@ -225,6 +230,7 @@ def main():
                     raise KeyError("profile taken under another schedule")
                 traffic = tj["dispatches"][0 if schedule == "dual" else dom + (1 if schedule == "screened" else 0)]["hbm_bytes"]
                 traffic_src = os.path.relpath(tp, ROOT)
+                index_traffic = tj.get("index_per_strand", {}).get("hbm_bytes")
             except Exception:
                 traffic = None
         out = {
@@ -252,8 +258,9 @@ def main():
             # `bound` keeps to the two values the bench contract knows: the kernel is priced against the HBM byte roofline
             # (`frac`, SURVEY 8d bytes).  What it actually runs into is named in `binding_limit`: the rate of random 64-B line
             # requests / address translations (`gather_frac`), which caps any hash-probe design at 12.5-25 % of the byte roofline.
-            "roofline": {"bound": "hbm", "binding_limit": "random 64-B line requests / address translations (not HBM bytes)",
-                         "index": index_roofline(ctr, cp, G, n_strands=2),
+            "roofline": {"bound": "hbm", "binding_limit": "random 128-B line requests / address translations and, since the pair table, the number of requests the resident lanes keep in flight (not HBM bytes)",
+                         "index": dict(index_roofline(ctr, cp, G, n_strands=2), traffic=(2 * index_traffic if index_traffic else None),
+                                       traffic_note="HBM bytes of both strands' builds from the same committed PMC passes as `traffic`"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname, "schedule": schedule,
@@ -264,7 +271,8 @@ def main():
                          "match_launches_mean_ms": (ctr["ms_screen"] + sum(ctr["ms_match"])) / (3 if ctr["screened"] else 2),
                          "kernel_bytes": kernel_bytes, "achieved_kernel_bytes": kernel_gbs,
                          "frac_kernel_bytes": kernel_gbs / HBM_PEAK_GBS,
-                         "limiter": "random accesses (one per bucket head / entry pair / text window): each costs a 64-B line request and an address translation; the chip serves ~48 G lines/s and the UTCL2s ~43 G translations/s (DESIGN.md 9)",
+                         "limiter": "random accesses (one per probed seed -- its two heads share a 128-B line --, entry pair, text window): each costs a line request and an address translation; the chip serves ~48 G single-load lines/s (41 G/s with two loads per line) and the UTCL2s ~43 G translations/s; at 5 waves per SIMD with one request per lane in flight the kernel now sits at ~0.7 of that and responds to occupancy (DESIGN.md 4.2, 9)",
+                         "head_line_requests": int(head_lines), "heads_probed": int(kc["probes"]),
                          "random_gathers": gathers, "gather_rate_G_per_s": gather_rate,
                          "gather_ceiling_G_per_s": GATHER_CEILING_GPS, "gather_frac": gather_rate / GATHER_CEILING_GPS},
             "phases_ms": {"index_fwd": ctr["ms_index"][0], "match_fwd": ctr["ms_match"][0], "index_rc": ctr["ms_index"][1],
@@ -278,7 +286,7 @@ def main():
                           "index_note": ("both index builds run at once on two streams: index_fwd is the pair, index_rc ~ 0"
                                          if ctr["screened"] and ctr["ms_index"][1] < 0.1 * ctr["ms_index"][0] else None)},
             "dist_backend": args.dist_backend if world > 1 else None,
-            "counters": {k: ctr[k] for k in ("searched", "candidates", "probes", "entry_fetches", "verifies", "index_entries", "dual", "redo_reads")},
+            "counters": {k: ctr[k] for k in ("searched", "candidates", "probes", "entry_fetches", "verifies", "index_entries", "dual", "redo_reads", "dual_seed_probes")},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -364,7 +372,26 @@ def cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax):
     # (tests/fullscale_parity.py, tests/).
     pos, rc, mism, _, _ = ctx.get_results()
     diff = int((mism[:ns] != r["mism"]).sum())
-    return {"value": value, "unit": "reads/s", "cores": threads, "kind": kind, "extrapolated": True,
+    # the same path at -t 1 (BASELINE.md section 3 asks for both): serial index build, one thread in the per-read loop, on a
+    # smaller sample of the same reads (two runs again: the fixed cost is two serial index builds over the whole text)
+    t1 = None
+    if not args.no_cpu_t1 and kind == "reference":
+        n1s, n1b = 1000, min(50_000, ns)
+        run1 = lambda n: (lambda t0: (orc.ref_match("c", pg, reads[:n], seed_len, kmax, 0, True, 0, 1, 1), time.perf_counter() - t0)[1])(time.perf_counter())
+        ts, tb = run1(n1s), run1(n1b)
+        b1 = max((tb - ts) / (n1b - n1s), 1e-12)
+        a1 = max(ts - b1 * n1s, 0.0)
+        t1 = {"value": n_per / (a1 + b1 * n_per), "unit": "reads/s", "cores": 1, "extrapolated": True, "fixed_s": a1, "per_read_us": b1 * 1e6,
+              "sample": f"n={n1s}: {ts:.2f}s, n={n1b}: {tb:.2f}s (PgHelpers::numberOfThreads = 1, one OpenMP thread)"}
+    cpu_model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": value, "unit": "reads/s", "cores": threads, "nproc": os.cpu_count(), "cpu_model": cpu_model, "t1": t1, "kind": kind, "extrapolated": True,
             "sample": f"EXTRAPOLATED from a bounded sample: whole {G}-bp Pg, first {ns} reads of the workload, both strands incl. index builds; two runs "
                       f"(n={n_small}: {t_small:.2f}s, n={ns}: {t_big:.2f}s) => fixed {a:.2f}s + {b * 1e6:.3f}us/read, "
                       f"extrapolated to {n_per} reads; sample-only rate {ns / t_big:.0f} reads/s",

@@ -278,6 +278,8 @@ typedef struct {
                              * verifies (the per-strand counters above then describe the two ordinary passes after it) */
     uint32_t schedule_downgraded; /* 1 = the second index set (or the screen's arrays) did not fit in device memory: this
                              * context runs the two passes in turn until another text / read set is handed over */
+    uint64_t dual_seed_probes; /* screened == 2: seeds the dual kernel probed -- a seed's forward and RC head (dual[2] counts
+                             * both) lie in ONE 128-byte line of the pair table: this is the number of line requests for heads */
 } pgrc_match_counters;
 /* flags[i] != 0: read i was one of `redo_reads` -- the dual kernel met a bucket it could not judge without the
  * reference's own falses count and did the read again in the reference's order (tests and bench.py draw their parity

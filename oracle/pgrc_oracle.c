@@ -407,8 +407,14 @@ int pgrc_or_match_copmem(const char *pg, uint64_t pg_len, const char *reads, uin
  * order (return 1). */
 typedef struct { int limit; uint32_t cur; uint64_t best; uint64_t U; uint32_t rclean; int rdirty, active, found; } dual_side;
 
+/* Speculative first attempt (round 4, the HIP kernel's a.spec): spec = small limit + 1 (0: none).  The query starts both
+ * strands at min(L0, spec - 1) while U keeps bounding the falses of the run with the REAL starting limit L0; whatever it
+ * finds is final, a read that finds nothing is queried again with spec = 0 (pgrc_or_match_copmem_dual below). */
+static int g_dual_spec = 0;
+void pgrc_or_set_dual_spec(int small_limit_plus_1) { g_dual_spec = small_limit_plus_1; }
+
 static int dual_query(const pgrc_or_index *idx[2], const char *text[2], const char *read, uint32_t read_len,
-                      uint8_t kmax, uint8_t cin, int *strand_out, uint64_t *pos_out, uint8_t *m_out, uint64_t cands[2]) {
+                      uint8_t kmax, uint8_t cin, int spec, int *strand_out, uint64_t *pos_out, uint8_t *m_out, uint64_t cands[2]) {
     const int K = idx[0]->p.K, k2 = idx[0]->p.k2;
     const uint32_t k1 = (uint32_t)idx[0]->p.k1;
     const uint32_t mask = idx[0]->p.hash_size - 1;
@@ -418,7 +424,8 @@ static int dual_query(const pgrc_or_index *idx[2], const char *text[2], const ch
     const int L0 = cin < kmax ? (int)cin - 1 : (int)kmax;
     const uint32_t rper = ((uint32_t)K + k1 * (uint32_t)k2 - 1) / (k1 * (uint32_t)k2) * k1;
     dual_side sd[2];
-    for (int x = 0; x < 2; x++) { sd[x].limit = L0; sd[x].cur = cin; sd[x].best = PGRC_OR_NOT_MATCHED_POS; sd[x].U = 0; sd[x].rclean = 0; sd[x].rdirty = 0; sd[x].active = 1; sd[x].found = 0; }
+    const int Lstart = (spec && L0 >= spec) ? spec - 1 : L0;
+    for (int x = 0; x < 2; x++) { sd[x].limit = Lstart; sd[x].cur = cin; sd[x].best = PGRC_OR_NOT_MATCHED_POS; sd[x].U = 0; sd[x].rclean = 0; sd[x].rdirty = 0; sd[x].active = 1; sd[x].found = 0; }
     uint32_t rq = 0, probes = 0;
 #define DUAL_EFF(x) ((x) == 0 ? (sd[1].found && (int)sd[1].cur < sd[0].limit ? (int)sd[1].cur : sd[0].limit) \
                               : (sd[0].found && (int)sd[0].cur - 1 < sd[1].limit ? (int)sd[0].cur - 1 : sd[1].limit))
@@ -507,7 +514,10 @@ int pgrc_or_match_copmem_dual(const char *pg, uint64_t pg_len, const char *reads
         int strand = -1;
         uint64_t pos = 0, cd[2] = {0, 0};
         uint8_t m = 0;
-        if (!dual_query(idx, text, rd, read_len, kmax, res->mism[i], &strand, &pos, &m, cd)) {
+        int ab = dual_query(idx, text, rd, read_len, kmax, res->mism[i], g_dual_spec, &strand, &pos, &m, cd);
+        if (!ab && strand < 0 && g_dual_spec)          /* the first attempt found nothing: the read again with its real limit */
+            ab = dual_query(idx, text, rd, read_len, kmax, res->mism[i], 0, &strand, &pos, &m, cd);
+        if (!ab) {
             cands0 += cd[0]; cands1 += cd[1];
             if (strand >= 0) { res->pos[i] = strand ? pg_len - (pos + read_len) : pos; res->rc[i] = (uint8_t)strand; res->mism[i] = m; }
             continue;

@@ -73,6 +73,7 @@ void pgrc_or_index_free(pgrc_or_index *idx);
 /* test switch (default 0 = the reference's loops): stop a read once the HIP kernel's early-stop rule holds; and the
  * number of seed probes executed since the last reset */
 void pgrc_or_set_early_stop(int on);
+void pgrc_or_set_dual_spec(int small_limit_plus_1);   /* test switch: the dual scheme's speculative first attempt */
 uint64_t pgrc_or_probe_count(int reset);
 uint64_t pgrc_or_copmem_match_read(const pgrc_or_index *idx, const char *pg, const char *read,
                                    uint32_t read_len, uint8_t kmax, uint8_t kmin, uint8_t *cnt,

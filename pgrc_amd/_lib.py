@@ -40,7 +40,7 @@ class Counters(C.Structure):
                 ("entry_fetches", C.c_uint64 * 2), ("verifies", C.c_uint64 * 2), ("index_entries", C.c_uint64 * 2), ("ms_index", C.c_float * 2), ("ms_match", C.c_float * 2),
                 ("ms_other", C.c_float), ("ms_total", C.c_float), ("ms_allgather", C.c_float),
                 ("screened", C.c_uint32), ("ms_screen", C.c_float), ("redo_reads", C.c_uint64), ("dual", C.c_uint64 * 5),
-                ("schedule_downgraded", C.c_uint32)]
+                ("schedule_downgraded", C.c_uint32), ("dual_seed_probes", C.c_uint64)]
 
 
 class SynthPg(C.Structure):

@@ -910,6 +910,7 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
     if (screened && dual) {
         for (int k = 0; k < 5; k++) c->ctr.dual[k] = scr[k];
         c->ctr.redo_reads = scr[5];
+        c->ctr.dual_seed_probes = scr[6];
         c->ctr.screened = 2;
     } else if (screened) {           // the screen ran on the RC text: its work counts with that strand's (not "searched")
         c->ctr.candidates[1] += scr[1];

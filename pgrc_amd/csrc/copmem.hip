@@ -1053,10 +1053,11 @@ struct DualArgs {
     uint64_t *pos;
     uint8_t *rc;
     uint8_t *mism;
-    unsigned long long *counters; // [0] searched [1] candidates [2] heads probed [3] entry fetches [4] verifies [5] redo
+    unsigned long long *counters; // [0] searched [1] candidates [2] heads probed [3] entry fetches [4] verifies [5] redo [6] seeds probed
     unsigned long long *work;
     uint8_t *redo_flag;           // per read: 2 = done again in the reference's order (F_SEQ); introspection only
     uint32_t L, K, k1, k2, mask, kmax;
+    uint32_t spec;                // 0, or the small limit + 1 every read first tries (speculative first attempt)
     uint32_t redo_above;          // a bucket of more entries than this, opened while U > budget, sends the read back (4; 0 = round 3's rule: any bucket)
     uint32_t from_end;            // 1: chunks of reads are handed out from the end of the read set
     uint32_t chunk;               // reads a wave reserves per visit to the work counter (pgrc_match_chunk)
@@ -1089,7 +1090,7 @@ k_copmem_match_dual(const DualArgs a) {
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t n_search = 0, n_cand = 0, n_probe = 0, n_ent = 0, n_ver = 0, n_redo = 0;
+    uint32_t n_search = 0, n_cand = 0, n_probe = 0, n_ent = 0, n_ver = 0, n_redo = 0, n_seed = 0;
     uint32_t sh[NW];
 #pragma unroll
     for (int k = 0; k < NW; k++) sh[k] = 0u;
@@ -1100,8 +1101,9 @@ k_copmem_match_dual(const DualArgs a) {
     enum { M_PROBE = 0, M_ENTRY = 1, M_VERIFY = 2, M_NEED = 3, M_ADV = 4, M_DEAD = 5 };
     // F_SEQ: the falses bound ran out: the lane does this read again in the reference's order, right here (forward query
     // with its real falses count and bucket truncation, then -- F_SEQ1 -- the RC query from the forward result)
+    // F_SPEC (round 4): the read's first attempt, with both strands' limits cut to a.spec - 1 (see the launcher)
     enum { F_ACT0 = 1, F_ACT1 = 2, F_FOUND0 = 4, F_FOUND1 = 8, F_DIRTY0 = 16, F_DIRTY1 = 32, F_REDO = 64, F_FWDEXACT = 128,
-           F_SEQ = 256, F_SEQ1 = 512 };
+           F_SEQ = 256, F_SEQ1 = 512, F_SPEC = 1024 };
     uint32_t mode = M_NEED;
     uint32_t idx = 0, cin = 0, epoch = 0;
     uint32_t npw = 0xFFFFFFFFu;   // the read's N positions, one per byte (0xFF = none): a read with 1-4 N's (hash_fp_window_n)
@@ -1172,12 +1174,13 @@ k_copmem_match_dual(const DualArgs a) {
 #pragma unroll
                         for (int k = 0; k < NW; k++) rd_lds[k][threadIdx.x] = sh[k] = stg[wv][k][sj];
                         L0 = (cin < a.kmax) ? (int)cin - 1 : (int)a.kmax;   // :488-489
-                        lim0 = lim1 = L0;
+                        const bool spec = a.spec && L0 >= (int)a.spec;       // first with the small limit a.spec - 1
+                        lim0 = lim1 = spec ? (int)a.spec - 1 : L0;
                         cur0 = cur1 = cin;
                         best0 = best1 = POS_NONE;
                         U0 = U1 = 0;
                         rcl0 = rcl1 = 0;
-                        fl = F_ACT0 | F_ACT1;
+                        fl = F_ACT0 | F_ACT1 | (spec ? (uint32_t)F_SPEC : 0u);
                         si = 0;
                         rq = 0;
                         has_pend = false;
@@ -1397,7 +1400,27 @@ k_copmem_match_dual(const DualArgs a) {
             for (int kk = 0; kk < NW; kk++) sh[kk] = rd_lds[kk][threadIdx.x];
             next = M_PROBE;
         }
-        n_probe += (uint32_t)__popcll(__ballot(nprobe_it >= 1)) + (uint32_t)__popcll(__ballot(nprobe_it >= 2));
+        // ---- the first attempt with the small limit found nothing on either strand: the read again with its real limit
+        // (what the verify cache holds stays valid: counts do not depend on the limit)
+        if (next == M_NEED && m0 <= M_VERIFY && (fl & (F_SPEC | F_FOUND0 | F_FOUND1 | F_SEQ)) == F_SPEC) {
+            lim0 = lim1 = L0;
+            cur0 = cur1 = cin;
+            best0 = best1 = POS_NONE;
+            U0 = U1 = 0;
+            rcl0 = rcl1 = 0;
+            fl = F_ACT0 | F_ACT1;
+            si = 0;
+            rq = 0;
+            has_pend = false;
+#pragma unroll
+            for (int kk = 0; kk < NW; kk++) sh[kk] = rd_lds[kk][threadIdx.x];
+            next = M_PROBE;
+        }
+        {
+            const uint32_t seeds_it = (uint32_t)__popcll(__ballot(nprobe_it >= 1));
+            n_seed += seeds_it;
+            n_probe += seeds_it + (uint32_t)__popcll(__ballot(nprobe_it >= 2));
+        }
         n_ent += (uint32_t)__popcll(__ballot(counted_ent));
         n_ver += (uint32_t)__popcll(__ballot(m0 == M_VERIFY));
         n_cand += (uint32_t)__popcll(__ballot(ncand_it >= 1)) + (uint32_t)__popcll(__ballot(ncand_it >= 2));
@@ -1424,6 +1447,7 @@ k_copmem_match_dual(const DualArgs a) {
         atomicAdd(&a.counters[3], (unsigned long long)n_ent);
         atomicAdd(&a.counters[4], (unsigned long long)n_ver);
         atomicAdd(&a.counters[5], (unsigned long long)n_redo);
+        atomicAdd(&a.counters[6], (unsigned long long)n_seed);
     }
 }
 
@@ -1487,6 +1511,20 @@ int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     {
         const char *ra = getenv("PGRC_REDO_ANY");                   // 1: round 3's rule (A/B runs)
         a.redo_above = (ra && ra[0] == '1') ? 0u : PGRC_TRUNC_BUCKET;
+        // Speculative first attempt (round 4).  With a large limit (PgRC's -M 3: k <= 50 at 150 bp) the fingerprints reject
+        // nothing until a read has found its alignment, so every false candidate of its first seeds costs a text window:
+        // 14 verified windows per read at C3 against 3 at k <= 3.  A read therefore first runs its query with both strands'
+        // limits cut to a.spec - 1 (3): whatever that finds is the reference's result (the query is the same dual query with a
+        // smaller kmax, hence the reference's with that kmax; an alignment with m <= 3 mismatches found there is the first one
+        // with the smallest count on the winning strand under ANY larger limit too -- U keeps bounding the falses of the run
+        // with the REAL limit, so a bucket some run could have cut still sends the read back); a read that finds nothing
+        // starts again with its real limit (the tenth of C3's reads with more than 3 mismatches).  MEASURED, AND OFF BY DEFAULT:
+        // at C3 with k <= 50 the dual kernel takes 98.3 ms without it and 101.1 / 110.5 / 107.2 / 104.4 / 100.7 ms with a first
+        // attempt at 0 / 1 / 2 / 3 / 5 (profiles/r04_spec_limit_ab.txt): the second query of the reads that find nothing costs
+        // more than the windows the others save.  PGRC_SPEC_LIMIT = the small limit switches it on (tests).
+        const char *sl = getenv("PGRC_SPEC_LIMIT");
+        const int slv = sl ? atoi(sl) : -1;
+        a.spec = slv < 0 ? 0u : (uint32_t)slv + 1u;
         const char *fe = getenv("PGRC_MATCH_FROM_END");             // 0: chunks from the start of the read set (A/B runs)
         a.from_end = (fe && fe[0] == '0') ? 0u : 1u;
     }

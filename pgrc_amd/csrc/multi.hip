@@ -494,6 +494,7 @@ int pgrc_multi_get_counters(pgrc_match_ctx *f, pgrc_match_counters *out) {
         out->redo_reads += x.redo_reads;
         out->schedule_downgraded |= x.schedule_downgraded;
         for (int k = 0; k < 5; k++) out->dual[k] += x.dual[k];
+        out->dual_seed_probes += x.dual_seed_probes;
     }
     out->ms_allgather = m->ms_allgather;
     return PGRC_OK;

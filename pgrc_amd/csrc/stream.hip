@@ -214,6 +214,7 @@ extern "C" int pgrc_match_stream_end(pgrc_match_ctx *c, uint64_t hist[256], uint
     if (c->st_dual) {
         for (int k = 0; k < 5; k++) c->ctr.dual[k] = scr[k];
         c->ctr.redo_reads = scr[5];
+        c->ctr.dual_seed_probes = scr[6];
         c->ctr.screened = 2;
     }
     c->ctr.ms_total = (float)((now_s() - c->st_t0) * 1e3);           // (host clock: stream_begin .. here)

@@ -327,7 +327,7 @@ class MatchContext:
                 "entry_fetches": list(c.entry_fetches), "verifies": list(c.verifies), "index_entries": list(c.index_entries), "ms_index": list(c.ms_index), "ms_match": list(c.ms_match),
                 "ms_other": c.ms_other, "ms_total": c.ms_total, "ms_allgather": c.ms_allgather,
                 "screened": c.screened, "ms_screen": c.ms_screen, "redo_reads": c.redo_reads,
-                "schedule_downgraded": c.schedule_downgraded,
+                "schedule_downgraded": c.schedule_downgraded, "dual_seed_probes": c.dual_seed_probes,
                 "dual": dict(zip(("searched", "candidates", "probes", "entry_fetches", "verifies"), list(c.dual)))}
 
 

@@ -51,6 +51,7 @@ def oracle():
                                                   C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         lib.pgrc_or_copmem_match_read.restype = C.c_uint64
         lib.pgrc_or_set_early_stop.argtypes = [C.c_int]
+        lib.pgrc_or_set_dual_spec.argtypes = [C.c_int]
         lib.pgrc_or_match_copmem_dual.argtypes = [_P, C.c_uint64, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint8,
                                                   C.c_uint8, C.c_int, C.c_int, C.POINTER(Result), C.POINTER(C.c_uint64)]
         lib.pgrc_or_match_copmem_screened.argtypes = [_P, C.c_uint64, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint8,

@@ -42,6 +42,15 @@ def _both(pg, reads, seed_len, kmax, kmin, rev=True):
             for k in ("pos", "rc", "mism", "hist"):
                 assert np.array_equal(np.asarray(full[k]), np.asarray(du[k])), ("dual", k)
             assert full["matched"] == du["matched"]
+            # ... with a speculative first attempt at a small limit (round 4; 3 is the kernel's default, 0 = exact only)
+            for small in (3, 0, 1):
+                lib.pgrc_or_set_dual_spec(small + 1)
+                try:
+                    ds = orc.oracle_match_dual(pg, reads, seed_len, kmax)
+                finally:
+                    lib.pgrc_or_set_dual_spec(0)
+                for k in ("pos", "rc", "mism", "hist"):
+                    assert np.array_equal(np.asarray(full[k]), np.asarray(ds[k])), ("dual, first attempt at", small, k)
     return p_full, p_early
 
 

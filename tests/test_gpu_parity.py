@@ -290,6 +290,20 @@ def test_dual_kernel_takes_reads_with_few_ns(monkeypatch, L, kmax, inline):
         assert_same_results(g, r, "vs real reference")
 
 
+@pytest.mark.parametrize("small", ["0", "3"])
+def test_dual_kernel_speculative_first_attempt(monkeypatch, small):
+    """PGRC_SPEC_LIMIT (off by default: measured, no gain): every read first runs its query with both limits cut to the small
+    value and only starts again with the real limit (k <= 50: PgRC's -M 3) if that finds nothing.  Same results."""
+    monkeypatch.setenv("PGRC_DUAL", "1")
+    monkeypatch.setenv("PGRC_SPEC_LIMIT", small)
+    for L, n_with_n in ((150, 200), (100, 0)):
+        pg, reads = make_inputs(300_000, 5000, L, seed=70 + L, n_with_n=n_with_n, pool_div=32)
+        o = orc.oracle_match("c", pg, reads, 38, L // 3, 0)
+        g = gpu_match("c", pg, reads, 38, L // 3, 0)
+        assert_same_results(g, o, f"first attempt at {small}, L={L}")
+        assert g["ctx"].counters()["screened"] == 2
+
+
 def test_reference_packed_reads_entry_point():
     pg, reads = make_inputs(150000, 3000, 150, seed=8)
     o = orc.oracle_match("c", pg, reads, 38, 3, 0)

@@ -19,5 +19,24 @@ res = {"kernel": kern, "per_step": per_step, "schedule": schedule, "dispatches":
 for i in range(min(len(vals.get("FETCH_SIZE", [])), len(vals.get("WRITE_SIZE", [])))):
     res["dispatches"].append({"fetch_bytes": vals["FETCH_SIZE"][i], "write_bytes": vals["WRITE_SIZE"][i],
                               "hbm_bytes": vals["FETCH_SIZE"][i] + vals["WRITE_SIZE"][i]})
+# the index build of one strand (idxsweep.hip / idxsort.hip kernels): bytes over all their dispatches of the run, divided by
+# the strands built (2 per step; steps = launches of the dual kernel, or of the match kernel / 2).  Their reads are wide
+# coalesced streams, which gfx950's FETCH_SIZE reports at half their bytes (MI355X_MICROARCH.md, HBM): doubled here.
+idx = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+steps = 0
+for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+    rows = list(csv.DictReader(open(f)))
+    names = {r["Counter_Name"] for r in rows}
+    for cn in ("FETCH_SIZE", "WRITE_SIZE"):
+        if cn in names:
+            idx[cn] += sum(float(r["Counter_Value"]) * 1024.0 for r in rows if r["Counter_Name"] == cn and
+                           any(k in r["Kernel_Name"] for k in ("k_os_", "k_ps_", "k_psc_")))
+            if cn == "FETCH_SIZE":
+                nm = sum(1 for r in rows if r["Counter_Name"] == cn and kern in r["Kernel_Name"])
+                steps = nm // per_step if per_step else 0
+if steps:
+    res["index_per_strand"] = {"read_bytes": 2.0 * idx["FETCH_SIZE"] / (2 * steps), "write_bytes": idx["WRITE_SIZE"] / (2 * steps),
+                               "hbm_bytes": (2.0 * idx["FETCH_SIZE"] + idx["WRITE_SIZE"]) / (2 * steps), "steps": steps,
+                               "note": "FETCH_SIZE of the build's streaming reads doubled (gfx950 reports half); per strand"}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))
