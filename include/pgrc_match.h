@@ -285,6 +285,10 @@ typedef struct {
  * reference's own falses count and did the read again in the reference's order (tests and bench.py draw their parity
  * samples from these reads).  n bytes; all zero when the last run did not take the dual kernel. */
 int pgrc_match_get_redo_flags(pgrc_match_ctx *ctx, uint8_t *flags);
+/* Measurement only (tools/ubench_partjoin.py, pgrc_amd/csrc/ubench.hip): n probes of a table of 2^hash_bits 16-byte heads,
+ * once as random gathers and once partitioned by the top bucket bits and joined against heads staged in LDS.
+ * ms[0..3] = record generation, gather, partitioning, join; sums[0..1] = the two ways' checksums (must agree). */
+int pgrc_match_ubench_partjoin(uint64_t n_probes, uint32_t hash_bits, float ms[4], uint64_t sums[2]);
 /* enable per-kernel HIP-event timing + work counters for subsequent runs */
 int pgrc_match_set_profiling(pgrc_match_ctx *ctx, int enabled);
 int pgrc_match_get_counters(pgrc_match_ctx *ctx, pgrc_match_counters *out);

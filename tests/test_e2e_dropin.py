@@ -145,3 +145,14 @@ def test_archive_with_the_position_order_made_on_the_device(tmp_path, case, thre
         assert r["gpu_device_exports"] >= 1, r
     tol = 0.0005 if threads == "1" else 0.01
     assert abs(r["gpu_bytes"] - r["cpu_bytes"]) <= tol * r["cpu_bytes"], r
+
+
+@pytest.mark.gpu
+def test_archive_identical_without_the_libstdcxx_shortcuts(tmp_path):
+    """HipReadsMatcher's two libstdc++-dependent shortcuts (a string stream adopting the export arrays as its contents,
+    pages of reserved vector storage touched ahead) are optimisations with guarded fallbacks: PGRC_NO_ADOPT /
+    PGRC_NO_PRETOUCH take the fallbacks, the archive stays the same."""
+    if not _have_e2e():
+        pytest.skip("oracle/_ref was built without the encoder harness")
+    r = _run(tmp_path, "se", cpu_only=False, extra_env={"PGRC_NO_ADOPT": "1", "PGRC_NO_PRETOUCH": "1"})
+    assert r["gpu_gpu_calls"] >= 1 and r["gpu_device_exports"] >= 1 and r["identical"] and r["roundtrip"], r
