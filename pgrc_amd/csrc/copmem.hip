@@ -1053,11 +1053,10 @@ struct DualArgs {
     uint64_t *pos;
     uint8_t *rc;
     uint8_t *mism;
-    unsigned long long *counters; // [0] searched [1] candidates [2] heads probed [3] entry fetches [4] verifies [5] redo [6] seeds probed [7] next-seed head pairs fetched ahead and dropped
+    unsigned long long *counters; // [0] searched [1] candidates [2] heads probed [3] entry fetches [4] verifies [5] redo [6] seeds probed
     unsigned long long *work;
     uint8_t *redo_flag;           // per read: 2 = done again in the reference's order (F_SEQ); introspection only
     uint32_t L, K, k1, k2, mask, kmax;
-    uint32_t ahead;               // 1: probing lanes fetch their next seed's heads too and take two seeds per iteration
     uint32_t spec;                // 0, or the small limit + 1 every read first tries (speculative first attempt)
     uint32_t redo_above;          // a bucket of more entries than this, opened while U > budget, sends the read back (4; 0 = round 3's rule: any bucket)
     uint32_t from_end;            // 1: chunks of reads are handed out from the end of the read set
@@ -1091,7 +1090,7 @@ k_copmem_match_dual(const DualArgs a) {
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t n_search = 0, n_cand = 0, n_probe = 0, n_ent = 0, n_ver = 0, n_redo = 0, n_seed = 0, n_drop = 0;
+    uint32_t n_search = 0, n_cand = 0, n_probe = 0, n_ent = 0, n_ver = 0, n_redo = 0, n_seed = 0;
     uint32_t sh[NW];
 #pragma unroll
     for (int k = 0; k < NW; k++) sh[k] = 0u;
@@ -1204,9 +1203,6 @@ k_copmem_match_dual(const DualArgs a) {
         const uint32_t m0 = mode;
         // ---- this iteration's loads
         ulonglong2 hdF = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
-        ulonglong2 hdF2 = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY), hdR2 = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);   // the next seed's heads
-        uint32_t fp2 = 0, nprobe2_it = 0;
-        bool got2 = false;
         uint64_t v = 0;
         bool counted_ent = false;
         uint32_t ncand_it = 0, nprobe_it = 0;
@@ -1222,22 +1218,6 @@ k_copmem_match_dual(const DualArgs a) {
             ulonglong2 hr = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
             if (fl & F_ACT0) hdF = a.head[0][head_slot(h, a.hsh)];
             if (fl & F_ACT1) hr = a.head[1][head_slot(h, a.hsh)];
-            // Two seeds per iteration (round 4): the heads of this lane's NEXT seed come with the same wait -- four of every
-            // five seeds need nothing beyond their heads (empty buckets, fingerprint rejects), and such a lane then takes its
-            // next seed in this very iteration instead of idling through another round trip.  The heads of a next seed that
-            // cannot be used yet (the current one goes on to an entry or a text window) are dropped and fetched again.
-            if (a.ahead && si + 1u < nseeds) {
-                const uint32_t n0 = funnel_r(sh[0], NW > 1 ? sh[1 % NW] : 0u, sbits);
-                const uint32_t n1 = NW > 1 ? funnel_r(sh[1 % NW], NW > 2 ? sh[2 % NW] : 0u, sbits) : 0u;
-                const uint32_t n2 = NW > 2 ? funnel_r(sh[2 % NW], NW > 3 ? sh[3 % NW] : 0u, sbits) : 0u;
-                const uint32_t n3 = NW > 3 ? funnel_r(sh[3 % NW], NW > 4 ? sh[4 % NW] : 0u, sbits) : 0u;
-                uint32_t h2;
-                if (__any(npw != 0xFFFFFFFFu)) h2 = hash_fp_window_n<KQ>(n0, n1, n2, n3, a.K, lut, &fp2, npw, (si + 1u) * a.k2) & a.mask;
-                else h2 = hash_fp_window<KQ>(n0, n1, n2, n3, a.K, lut, &fp2) & a.mask;
-                if (fl & F_ACT0) hdF2 = a.head[0][head_slot(h2, a.hsh)];
-                if (fl & F_ACT1) hdR2 = a.head[1][head_slot(h2, a.hsh)];
-                got2 = true;
-            }
             hdR_lds[threadIdx.x] = hr;
             nprobe_it = ((fl & F_ACT0) ? 1u : 0u) + ((fl & F_ACT1) ? 1u : 0u);
         } else if (m0 == M_ENTRY) {
@@ -1384,7 +1364,7 @@ k_copmem_match_dual(const DualArgs a) {
             open_bucket(hdR_lds[threadIdx.x]);
         }
         if (bdone) next = M_ADV;
-        auto advance = [&]() {                                       // to the next seed
+        if (next == M_ADV) {                                         // to the next seed
             si++;
             has_pend = false;
             if (rq == a.k1 - 1u) {                                   // a round is behind this read
@@ -1399,23 +1379,6 @@ k_copmem_match_dual(const DualArgs a) {
             if ((fl & F_ACT0) && (int)rcl0 > eff(0u)) fl &= ~(uint32_t)F_ACT0;   // nothing acceptable is left on that strand
             if ((fl & F_ACT1) && (int)rcl1 > eff(1u)) fl &= ~(uint32_t)F_ACT1;
             next = (si < nseeds && (fl & (F_ACT0 | F_ACT1))) ? M_PROBE : M_NEED;
-        };
-        if (next == M_ADV) advance();
-        // ---- the seed just probed needed nothing beyond its heads: this lane's next seed, whose heads are here already
-        if (got2 && m0 == M_PROBE && next == M_PROBE) {
-            fp_read = fp2;
-            hdR_lds[threadIdx.x] = hdR2;
-            nprobe2_it = ((fl & F_ACT0) ? 1u : 0u) + ((fl & F_ACT1) ? 1u : 0u);
-            bdone = false;
-            x = (fl & F_ACT0) ? 0u : 1u;
-            open_bucket(x == 0u ? hdF2 : hdR2);
-            if (bdone && x == 0u && (fl & F_ACT1)) {
-                bdone = false;
-                x = 1u;
-                open_bucket(hdR2);
-            }
-            if (bdone) next = M_ADV;
-            if (next == M_ADV) advance();
         }
         // ---- the reference's order for a read whose falses bound ran out: restart it as a forward query, then an RC query
         if (next == M_NEED && m0 <= M_VERIFY && (((fl & F_REDO) != 0u) || ((fl & (F_SEQ | F_SEQ1 | F_FWDEXACT)) == F_SEQ))) {
@@ -1454,10 +1417,9 @@ k_copmem_match_dual(const DualArgs a) {
             next = M_PROBE;
         }
         {
-            const uint32_t seeds_it = (uint32_t)__popcll(__ballot(nprobe_it >= 1)) + (uint32_t)__popcll(__ballot(nprobe2_it >= 1));
+            const uint32_t seeds_it = (uint32_t)__popcll(__ballot(nprobe_it >= 1));
             n_seed += seeds_it;
-            n_probe += seeds_it + (uint32_t)__popcll(__ballot(nprobe_it >= 2)) + (uint32_t)__popcll(__ballot(nprobe2_it >= 2));
-            n_drop += (uint32_t)__popcll(__ballot(got2 && nprobe2_it == 0u));
+            n_probe += seeds_it + (uint32_t)__popcll(__ballot(nprobe_it >= 2));
         }
         n_ent += (uint32_t)__popcll(__ballot(counted_ent));
         n_ver += (uint32_t)__popcll(__ballot(m0 == M_VERIFY));
@@ -1486,7 +1448,6 @@ k_copmem_match_dual(const DualArgs a) {
         atomicAdd(&a.counters[4], (unsigned long long)n_ver);
         atomicAdd(&a.counters[5], (unsigned long long)n_redo);
         atomicAdd(&a.counters[6], (unsigned long long)n_seed);
-        atomicAdd(&a.counters[7], (unsigned long long)n_drop);
     }
 }
 
@@ -1564,8 +1525,11 @@ int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
         const char *sl = getenv("PGRC_SPEC_LIMIT");
         const int slv = sl ? atoi(sl) : -1;
         a.spec = slv < 0 ? 0u : (uint32_t)slv + 1u;
-        const char *ah = getenv("PGRC_DUAL_AHEAD");                 // 0: one seed per iteration (A/B runs)
-        a.ahead = (ah && ah[0] == '0') ? 0u : 1u;
+        // (Round 4, measured and removed: "two seeds per iteration" -- probing lanes also fetched their NEXT seed's two heads and,
+        //  when the current seed needed nothing beyond its heads (four of five do), took the next one in the same iteration;
+        //  heads that could not be used were dropped.  C3: 71.6 -> 74.8 ms, -M 3: 103.4 -> 114.0, C3-N: 74.3 -> 78.1
+        //  (profiles/r04_dual_ahead_ab.txt; that binary also spilled 9 registers, which cost the switched-off leg 5 ms against
+        //  66 ms without the code).  More requests per lane do not help: what the kernel responds to is resident waves.)
         const char *fe = getenv("PGRC_MATCH_FROM_END");             // 0: chunks from the start of the read set (A/B runs)
         a.from_end = (fe && fe[0] == '0') ? 0u : 1u;
     }
