@@ -345,6 +345,120 @@ __device__ __forceinline__ uint64_t lower_bound_u32(const uint32_t *v, uint64_t 
     return lo;
 }
 
+// ---- the order of the hits (round 4: hand-written, radix.hip).  What the replay needs is every read's hits together, in
+// ascending (text position, part) order -- the order in which the reference's scan meets them.  A full sort of the 63-bit
+// records is 8 radix passes; grouping by read is 4 stable passes over the read bits, and a read has a handful of hits, which
+// arrive nearly in position order already (the scan walks the text upwards): the first hit of every read puts its read's run
+// in order in place -- insertion sort for runs of up to SEED_RUN_SMALL, runs beyond that (repeats, tandem tracts) are listed
+// and sorted by a block each in LDS (bitonic, up to SEED_RUN_LDS records); a longer run raises a flag and the caller falls
+// back to the library's full sort.
+#define SEED_RUN_SMALL 48u
+#define SEED_RUN_WAVE 1024u      // runs up to this length: one WAVE each (k_seed_order_mid); longer: one block (k_seed_order_big)
+#define SEED_RUN_LDS 8192u
+
+__global__ void __launch_bounds__(256)
+k_seed_order_runs(uint64_t *__restrict__ hits, uint64_t nhits, uint64_t *__restrict__ mid, uint64_t *__restrict__ big,
+                  unsigned long long *__restrict__ counts /* [0] mid runs [1] big runs */, uint64_t mid_cap, uint64_t big_cap,
+                  uint32_t *__restrict__ overflow) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nhits) return;
+    const uint64_t i = hits[x] >> 36;
+    if (x != 0 && (hits[x - 1] >> 36) == i) return;              // not the first hit of its read
+    uint64_t len = 1;
+    while (x + len < nhits && (hits[x + len] >> 36) == i && len <= SEED_RUN_SMALL) len++;
+    if (len <= 1) return;
+    if (len > SEED_RUN_SMALL) {                                  // a long run: its end by bisection (the hits are grouped by read)
+        uint64_t lo = x + len, hi = nhits;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if ((hits[mid] >> 36) <= i) lo = mid + 1; else hi = mid;
+        }
+        len = lo - x;
+    }
+    if (len > SEED_RUN_LDS) { atomicOr(overflow, 1u); return; }
+    if (len > SEED_RUN_WAVE) {
+        const unsigned long long k = atomicAdd(&counts[1], 1ull);
+        if (k < big_cap) { big[2 * k] = x; big[2 * k + 1] = len; }
+        else atomicOr(overflow, 1u);
+        return;
+    }
+    if (len > SEED_RUN_SMALL) {
+        const unsigned long long k = atomicAdd(&counts[0], 1ull);
+        if (k < mid_cap) { mid[2 * k] = x; mid[2 * k + 1] = len; }
+        else atomicOr(overflow, 1u);
+        return;
+    }
+    for (uint64_t a = 1; a < len; a++) {                         // insertion sort, in place (nearly sorted on arrival)
+        const uint64_t y = hits[x + a];
+        uint64_t b = a;
+        while (b > 0 && hits[x + b - 1] > y) { hits[x + b] = hits[x + b - 1]; b--; }
+        if (b != a) hits[x + b] = y;
+    }
+}
+
+// one wave per listed run of medium length: bitonic sort in the wave's slice of LDS (a wave's LDS accesses are served in
+// order, so no barrier is needed between the stages)
+__global__ void __launch_bounds__(256)
+k_seed_order_mid(uint64_t *__restrict__ hits, const uint64_t *__restrict__ mid, const unsigned long long *__restrict__ counts, uint64_t mid_cap) {
+    __shared__ uint64_t vs[4][SEED_RUN_WAVE];
+    uint64_t *v = vs[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t nr = min((uint64_t)counts[0], mid_cap);
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4u;
+    for (uint64_t r = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); r < nr; r += nwaves) {
+        const uint64_t x0 = mid[2 * r], len = mid[2 * r + 1];
+        uint32_t m = 64;
+        while (m < len) m <<= 1;
+        for (uint32_t t = lane; t < m; t += 64) v[t] = t < len ? hits[x0 + t] : ~0ull;
+        __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        for (uint32_t k = 2; k <= m; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = lane; t < m; t += 64) {
+                    const uint32_t u = t ^ j;
+                    if (u > t) {
+                        const uint64_t p = v[t], q = v[u];
+                        const bool up = (t & k) == 0;
+                        if ((p > q) == up) { v[t] = q; v[u] = p; }
+                    }
+                }
+                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        for (uint32_t t = lane; t < len; t += 64) hits[x0 + t] = v[t];
+        __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// one block per listed long run: bitonic sort in LDS
+__global__ void __launch_bounds__(1024)
+k_seed_order_big(uint64_t *__restrict__ hits, const uint64_t *__restrict__ big, const unsigned long long *__restrict__ counts, uint64_t big_cap) {
+    __shared__ uint64_t v[SEED_RUN_LDS];
+    const uint64_t nb = min((uint64_t)counts[1], big_cap);
+    for (uint64_t r = blockIdx.x; r < nb; r += gridDim.x) {
+        const uint64_t x0 = big[2 * r], len = big[2 * r + 1];
+        uint32_t m = 64;
+        while (m < len) m <<= 1;                                 // power of two >= len (<= SEED_RUN_LDS), padded with all ones
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < m; t += 1024) v[t] = t < len ? hits[x0 + t] : ~0ull;
+        __syncthreads();
+        for (uint32_t k = 2; k <= m; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = threadIdx.x; t < m; t += 1024) {
+                    const uint32_t u = t ^ j;
+                    if (u > t) {
+                        const uint64_t p = v[t], q = v[u];
+                        const bool up = (t & k) == 0;
+                        if ((p > q) == up) { v[t] = q; v[u] = p; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t t = threadIdx.x; t < len; t += 1024) hits[x0 + t] = v[t];
+    }
+}
+
+int pgrc_radix_sort_u64(pgrc_match_ctx *c, uint64_t *d_a, uint64_t *d_b, uint64_t n, uint32_t bit_lo, uint32_t bit_hi, DevBuf &scratch,
+                        uint64_t **sorted);
+
 // Hamming count of EVERY hit, one thread per hit (the replay below only compares counts with the read's current limit,
 // ReadsMatchers.cpp:315-319, so the full count serves every limit), and the first hit of every read.
 __global__ void __launch_bounds__(256)
@@ -560,27 +674,69 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
         int ibits = 1;                                      // only the key bits that can be set take part in the sort
         while ((1ull << ibits) < a.n) ibits++;
         const int end_bit = 36 + ibits;
-        size_t temp_bytes = 0;
-        HIP_TRY(c, rocprim::radix_sort_keys(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)cap, 0, end_bit, c->stream));
         // scratch lives in the context (grow-only): no hipMalloc / hipFree (= device synchronisation) per pass
         DevBuf &sorted = c->s_sorted, &temp = c->s_sorttmp;
         if ((e = pgrc_buf_ensure(c, sorted, cap * sizeof(uint64_t)))) return e;       // sized like the hit buffer: no regrow
-        if ((e = pgrc_buf_ensure(c, temp, temp_bytes))) return e;
         if ((e = pgrc_buf_ensure(c, c->s_mm, cap))) return e;
         if ((e = pgrc_buf_ensure(c, c->s_rstart, a.n * sizeof(uint64_t)))) return e;
         if ((e = pgrc_buf_ensure(c, c->s_heavy, a.n * sizeof(uint32_t)))) return e;
-        hipError_t he = rocprim::radix_sort_keys(temp.p, temp_bytes, (uint64_t *)c->s_hits.p, (uint64_t *)sorted.p, (size_t)nhits, 0, end_bit, c->stream);
+        hipError_t he = hipSuccess;
+        const uint64_t *sorted_hits = nullptr;
+        // PGRC_SEED_SORT=own: the hand-written road (4 stable passes over the read bits + every read's run ordered in place).
+        // MEASURED AT C3, mode d, ~1.2 G hits per strand (profiles/r04_mode_d_own_sort_kernel_stats.csv): 4 x (k_rx_hist 4.7 +
+        // k_rx_scatter 6.4) + k_seed_order_runs 23 + k_seed_order_big 6.6 = 74 ms per sort against the library's 79 ms
+        // (8 onesweep passes of 8.8 ms + 9.4 ms of histograms): a tie, and reads with more than 8192 hits (tandem tracts) send
+        // the whole sort to the library anyway -- so the library's sort stays the default.
+        const char *ssel = getenv("PGRC_SEED_SORT");
+        bool own_sort = ssel && !strcmp(ssel, "own");
+        if (own_sort) {
+            // hits grouped by read (stable passes over the read bits only), then every read's run put in order in place
+            uint64_t *grouped = nullptr;
+            if ((e = pgrc_radix_sort_u64(c, (uint64_t *)c->s_hits.p, (uint64_t *)sorted.p, nhits, 36u, (uint32_t)end_bit, temp, &grouped))) return e;
+            const uint64_t mid_cap = std::max<uint64_t>(1024, nhits / SEED_RUN_SMALL + 1), big_cap = std::max<uint64_t>(1024, nhits / SEED_RUN_WAVE + 1);
+            DevBuf &runl = c->s_runs;                                 // (run lists: start, length; sized for the worst case)
+            if ((e = pgrc_buf_ensure(c, runl, (2 * (mid_cap + big_cap) + 4) * sizeof(uint64_t)))) return e;
+            uint64_t *midl = (uint64_t *)runl.p, *bigl = midl + 2 * mid_cap;
+            unsigned long long *counts = (unsigned long long *)(bigl + 2 * big_cap);
+            uint32_t *ovf = (uint32_t *)(counts + 2);
+            he = hipMemsetAsync(counts, 0, 24, c->stream);
+            if (he == hipSuccess) {
+                hipLaunchKernelGGL(k_seed_order_runs, dim3((uint32_t)((nhits + 255) / 256)), dim3(256), 0, c->stream, grouped, (uint64_t)nhits,
+                                   midl, bigl, counts, mid_cap, big_cap, ovf);
+                hipLaunchKernelGGL(k_seed_order_mid, dim3((uint32_t)c->num_cus * 4u), dim3(256), 0, c->stream, grouped, (const uint64_t *)midl,
+                                   (const unsigned long long *)counts, mid_cap);
+                hipLaunchKernelGGL(k_seed_order_big, dim3((uint32_t)c->num_cus), dim3(1024), 0, c->stream, grouped, (const uint64_t *)bigl,
+                                   (const unsigned long long *)counts, big_cap);
+                he = hipGetLastError();
+            }
+            uint32_t overflow = 0;
+            if (he == hipSuccess) he = hipMemcpyAsync(&overflow, ovf, sizeof overflow, hipMemcpyDeviceToHost, c->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+            if (he != hipSuccess) { c->err = std::string("seed-index hit order: ") + hipGetErrorString(he); return PGRC_E_DEVICE; }
+            sorted_hits = grouped;
+            if (overflow) {                                           // a read with more hits than a block sorts in LDS: the library's full sort
+                own_sort = false;
+                if (grouped != (uint64_t *)c->s_hits.p) HIP_TRY(c, hipMemcpyAsync(c->s_hits.p, grouped, nhits * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+            }
+        }
+        if (!own_sort) {
+            size_t temp_bytes = 0;
+            HIP_TRY(c, rocprim::radix_sort_keys(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)cap, 0, end_bit, c->stream));
+            if ((e = pgrc_buf_ensure(c, temp, temp_bytes))) return e;
+            he = rocprim::radix_sort_keys(temp.p, temp_bytes, (uint64_t *)c->s_hits.p, (uint64_t *)sorted.p, (size_t)nhits, 0, end_bit, c->stream);
+            sorted_hits = (const uint64_t *)sorted.p;
+        }
         if (he == hipSuccess) he = hipMemsetAsync(c->s_rstart.p, 0xFF, a.n * sizeof(uint64_t), c->stream);
         unsigned long long *nheavy = cursor + 1;
         if (he == hipSuccess) he = hipMemsetAsync(nheavy, 0, sizeof(unsigned long long), c->stream);
         if (he == hipSuccess) {
             hipLaunchKernelGGL(k_seed_hamming, dim3((uint32_t)((nhits + 255) / 256)), dim3(256), 0, c->stream, a,
-                               (const uint64_t *)sorted.p, (uint64_t)nhits, (uint8_t *)c->s_mm.p, (uint64_t *)c->s_rstart.p);
+                               sorted_hits, (uint64_t)nhits, (uint8_t *)c->s_mm.p, (uint64_t *)c->s_rstart.p);
             hipLaunchKernelGGL(k_seed_replay, dim3((uint32_t)((a.n + 255) / 256)), dim3(256), 0, c->stream, a,
-                               (const uint64_t *)sorted.p, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p,
+                               sorted_hits, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p,
                                (uint32_t *)c->s_heavy.p, nheavy);
             hipLaunchKernelGGL(k_seed_replay_heavy, dim3((uint32_t)c->num_cus * 8u), dim3(256), 0, c->stream, a,
-                               (const uint64_t *)sorted.p, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p,
+                               sorted_hits, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p,
                                (const uint32_t *)c->s_heavy.p, (const unsigned long long *)nheavy);
             he = hipGetLastError();
         }

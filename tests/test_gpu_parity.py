@@ -527,6 +527,25 @@ def test_seedindex_modes_parity(mode, L, seed_len, M, shortcut, G, n, n_with_n):
 
 
 @pytest.mark.parametrize("mode", ["d", "i", "e"])
+def test_seedindex_own_hit_order(monkeypatch, mode):
+    """PGRC_SEED_SORT=own (not the default: a measured tie with the library's sort): the hits grouped by read with the
+    library's own stable radix passes over the read bits, every read's run then ordered in place -- by its first hit's lane
+    (short runs), a wave (up to 1024 hits) or a block (up to 8192); longer runs fall back to the library's full sort."""
+    monkeypatch.setenv("PGRC_SEED_SORT", "own")
+    L, seed_len = (100, 25) if mode != "e" else (100, 100)
+    pg, reads = make_inputs(300_000, 9000, L, seed=4242, pool_div=4, tandem_every=2)      # repeat families: runs of dozens of hits
+    rng = np.random.default_rng(3)
+    unit = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=7)
+    pg[50_000:56_000] = np.tile(unit, 1000)[:6000]                                        # a tandem tract: runs of hundreds to thousands
+    for k in range(40):
+        st = 50_000 + int(rng.integers(0, 5000)); reads[k] = pg[st:st + L]
+    kmax = 0 if mode == "e" else L // seed_len - 1
+    o = orc.oracle_match(mode, pg, reads, seed_len, kmax, 0)
+    g = gpu_match(mode, pg, reads, seed_len, kmax, 0)
+    assert_same_results(g, o, f"own hit order, mode {mode}")
+
+
+@pytest.mark.parametrize("mode", ["d", "i", "e"])
 def test_seedindex_hit_floods_on_low_complexity_text(mode):
     """A poly-A tract and reads taken from it: every window of the tract hits every part of those reads (~1.4 M hits
     from 8 kbp of text), which overflows the scan kernel's block-local hit buffer and the first guess of the hit
