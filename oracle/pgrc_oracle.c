@@ -1155,7 +1155,8 @@ int pgrc_or_divide_reads(const char *reads, const char *quals, uint64_t n, uint3
         int high = 1;
         if (error_limit < 1) {                               /* isQualityHigh, DivisionReadsSetDecorators.cpp:30-38 */
             const char *q = quals + i * L;
-            if (simplified) high = q[suffix_pos] > '#';
+            /* quality[suffix_pos] of a std::string (signed chars); suffix_pos == L (error_limit 0) is its terminating 0 */
+            if (simplified) high = suffix_pos < (int)L ? (signed char)q[suffix_pos] > '#' : 0;
             else high = (1 - quality_arith_avg(q, L) <= error_limit);
         }
         if (error_limit < 1 && !high) {

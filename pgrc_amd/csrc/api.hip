@@ -72,6 +72,11 @@ void pgrc_buf_free(DevBuf &b) {
         int dev = -1;
         bool kept = false;
         if (b.bytes >= POOL_MIN && hipGetDevice(&dev) == hipSuccess) {
+            // A pooled buffer can be handed to any context, stream or thread at once: nothing may still be using it.  hipFree
+            // used to give that guarantee by waiting for the device; so does this (large buffers are only given back on
+            // destroy, on growth and on error paths -- never between the blocks of a streamed run, which keeps what it must free
+            // until its end).
+            (void)hipDeviceSynchronize();
             std::lock_guard<std::mutex> g(g_pool_mu);
             if (g_pool_bytes + b.bytes <= pool_cap()) {
                 g_pool.push_back({b.p, b.bytes, dev});

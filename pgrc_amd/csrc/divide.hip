@@ -104,7 +104,9 @@ k_dv_quality(const uint8_t *__restrict__ quals, uint64_t n, uint32_t L, int simp
              const float *__restrict__ lut, uint8_t *__restrict__ high, uint32_t *__restrict__ flags) {
     if (simplified) {
         const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (r < n) high[r] = quals[r * L + suffix_pos] > '#' ? 1 : 0;
+        // `quality[suffix_pos] > '#'` on a std::string of (signed) chars (DivisionReadsSetDecorators.cpp:33): a byte of 128 or
+        // more is negative there, and suffix_pos == L (error_limit 0) reads the string's terminating 0 -- never high
+        if (r < n) high[r] = ((uint32_t)suffix_pos < L && (int8_t)quals[r * L + suffix_pos] > (int8_t)'#') ? 1 : 0;
         return;
     }
     __shared__ uint32_t fx[256];                          // entry * 2^26; characters past the table: flagged, counted as 0
@@ -256,8 +258,29 @@ struct FqRowsArgs {
     uint32_t *err;
 };
 __device__ __forceinline__ bool fq_alpha(uint32_t ch) { return (ch - 'A') < 26u || (ch - 'a') < 26u; }
-// complementsLut for the letters a read may hold (utils/helper.cpp:263-276); anything else is reported by k_dv_symbols
-__device__ __forceinline__ uint32_t fq_complement(uint32_t ch) { return ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch; }
+// What PgHelpers' complement table does to a symbol of the second file's reads (utils/helper.cpp:261-282): both cases of
+// A C G T N U and of the IUPAC pairs Y/R K/M B/V D/H map to the UPPER-case complement (so a lower-case `a` comes out as a
+// valid `T`), every other byte to 0 -- which k_dv_symbols then reports as a symbol outside ACGNT, as the reference's
+// packing would.
+__device__ __forceinline__ uint32_t fq_complement(uint32_t ch) {
+    switch (ch | 0x20u) {                // (letters only: the cases below are lower-case letters)
+    case 'a': return 'T';
+    case 'c': return 'G';
+    case 'g': return 'C';
+    case 't': return 'A';
+    case 'n': return 'N';
+    case 'u': return 'A';
+    case 'y': return 'R';
+    case 'r': return 'Y';
+    case 'k': return 'M';
+    case 'm': return 'K';
+    case 'b': return 'V';
+    case 'd': return 'H';
+    case 'h': return 'D';
+    case 'v': return 'B';
+    default: return 0u;
+    }
+}
 
 // record k of the batch = record k (or k / 2 of file k % 2) of the text: column x < L copies symbol and quality character,
 // column L checks that the run of letters ends there (FASTQReadsSourceIterator::moveNext, :218-220)
@@ -327,7 +350,8 @@ int pgrc_divider_create(const pgrc_divide_params *p, pgrc_divider **out) {
     d->base.device = dev;
     // suffix_pos = read_length * (1 - error_level), a double truncated to int (DivisionReadsSetDecorators.cpp:14)
     d->suffix_pos = (int)((double)p->read_len * (1 - p->error_limit));
-    if (p->error_limit < 1 && p->simplified_suffix_mode && (d->suffix_pos < 0 || d->suffix_pos >= (int)p->read_len)) {
+    // (suffix_pos == read_len -- error_limit 0 -- is what the reference accepts too: it tests the quality string's terminator)
+    if (p->error_limit < 1 && p->simplified_suffix_mode && (d->suffix_pos < 0 || d->suffix_pos > (int)p->read_len)) {
         g_div_create_err = "simplified suffix mode: the tested position lies outside the read";
         delete d;
         return PGRC_E_PARAM;

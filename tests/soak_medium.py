@@ -40,12 +40,16 @@ def main():
         stage = "0" if rng.random() < 0.2 else ""        # ... and without staged refills
         dual = str(rng.choice(["", "1", "1", "0"]))         # one query per read over both strands: forced / where it pays / never
         screen = str(rng.choice(["", "", "0", "1"]))       # "" = the dual kernel where it applies       # ... and the two passes in the reference's order (no exact-match screen)
-        for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish), ("PGRC_EARLY_STOP", early), ("PGRC_MATCH_STAGE", stage), ("PGRC_SCREEN", screen), ("PGRC_DUAL", dual)):
+        pairk = str(rng.choice(["", "", "0", "1", "3", "4"]))       # round 4: the pair table by group size (0 = a table per strand)
+        inline = "0" if rng.random() < 0.3 else ""
+        from_end = "0" if rng.random() < 0.3 else ""
+        for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish), ("PGRC_EARLY_STOP", early), ("PGRC_MATCH_STAGE", stage), ("PGRC_SCREEN", screen), ("PGRC_DUAL", dual),
+                         ("PGRC_HEAD_PAIR", pairk), ("PGRC_NREAD_INLINE", inline), ("PGRC_MATCH_FROM_END", from_end)):
             if val:
                 os.environ[key] = val
             else:
                 os.environ.pop(key, None)
-        what = dict(L=L, seed_len=seed_len, kmax=kmax, kmin=kmin, G=G, n=n, nn=nn, seed=seed, shards=shards, variant=variant, finish=finish, early=early, stage=stage, screen=screen, dual=dual)
+        what = dict(L=L, seed_len=seed_len, kmax=kmax, kmin=kmin, G=G, n=n, nn=nn, seed=seed, shards=shards, variant=variant, finish=finish, early=early, stage=stage, screen=screen, dual=dual, pairk=pairk, inline=inline, from_end=from_end)
         o = orc.oracle_match("c", pg, reads, seed_len, kmax, kmin, True, 16)
         g = gpu_match("c", pg, reads, seed_len, kmax, kmin, True, devices=[0] * shards if shards else None)
         for k in ("pos", "rc", "mism", "hist"):

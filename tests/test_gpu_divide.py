@@ -77,8 +77,15 @@ def test_divide_edge_cases():
     assert g["n_n"] == 64 and same(g, oracle_divide(all_n, quals[:64], 1.0, True, True, False)) is None
     with pytest.raises(PgrcMatchError):
         DividedPCLReadsSets(0)
-    with pytest.raises(PgrcMatchError):
-        DividedPCLReadsSets(100, 0.0, True)                 # simplified mode would test the position past the read
+    # error_limit 0 in the simplified mode: the reference tests quality[L], the string's terminating 0 -- never "high":
+    # every read without an N goes to the LQ set (round 4: accepted like the reference, round 3 refused it); and a quality
+    # byte of 128 or more is a negative char there, never above '#'
+    g0 = gpu_divide(reads, quals, 0.0, True, True, False)
+    assert g0["n_hq"] == 0 and same(g0, oracle_divide(reads, quals, 0.0, True, True, False)) is None
+    hi = quals.copy()
+    hi[:, 90] = 200
+    gh = gpu_divide(reads, hi, 0.1, True, True, False)
+    assert same(gh, oracle_divide(reads, hi, 0.1, True, True, False)) is None and gh["n_hq"] == 0
 
 
 @pytest.mark.skipif(not HAVE_REF, reason="needs oracle/_ref")
