@@ -37,6 +37,9 @@ WORKLOADS = {
     # C3 at PgRC's shipped mismatch limit (-M 3: k <= L / 3 = 50, pgrc-params.h:138-146)
     "C3-M3": (100_000_000, 150, 1_875_000_000, 38, 3, "c", False),
     "tiny-N": (1_000_000, 150, 18_750_000, 38, 50, "c", False),
+    # short reads (few seeds per read): where the dual kernel's schedule stops paying (tools/ab_match.py, PGRC_DUAL=0 / 1)
+    "S75": (10_000_000, 75, 125_000_000, 38, 25, "c", False),
+    "S50": (10_000_000, 50, 125_000_000, 38, 25, "c", False),
 }
 N_FRACTION = {"C3-N": 0.02, "tiny-N": 0.02}     # share of the reads that hold an N (the reference's N read set)
 # measured random-request ceiling of the chip (tools/ubench/gather.hip): 51 G/s at a 4 GiB footprint, 48 G/s at the

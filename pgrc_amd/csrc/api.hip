@@ -692,9 +692,11 @@ static bool dual_wanted(const pgrc_match_ctx *c, int first, int last) {
     const char *sc = getenv("PGRC_SCREEN");
     if ((es && es[0] == '0') || (sc && (sc[0] == '0' || sc[0] == '1'))) return false;   // the older schedules were asked for
     if (v && v[0] == '1') return true;
-    // short reads: too few seeds to save, and the fixed cost of the extra launches shows (C2, 37 seeds: +19 %)
+    // Round 2 kept short reads (fewer than 48 seeds) on the two passes: the dual kernel cost C2 (100 bp, 37 seeds) +19 % then.
+    // With the pair table and nothing launched behind it, it wins at every length measured (round 4, one context each,
+    // profiles/r04_c2_dual_ab.txt): C2 16.3 -> 12.5 ms, 75 bp 13.4 -> 11.0, 50 bp 9.9 -> 8.6, 1 M x 150 bp 7.2 -> 4.6.
     const uint32_t K = (uint32_t)c->cp.K, k2 = (uint32_t)c->cp.k2;
-    return k2 && c->prm.read_len >= K && (c->prm.read_len - K) / k2 + 1 >= 48u;
+    return k2 && c->prm.read_len >= K;
 }
 
 } // extern "C" (a template, and helpers of stream.hip)
