@@ -68,8 +68,11 @@ int pgrc_divider_run(pgrc_divider *d, const char *reads, const char *quals, uint
  * record read with std::getline -- identifier, symbols, '+' line, qualities; the read is the leading run of letters of the
  * symbol line and must be read_len long, the quality string is cut or zero-padded to that length).  `text` is a piece of
  * the file, in file order; the call takes every COMPLETE record of it, divides them as pgrc_divider_run does and reports in
- * *consumed where the next piece has to start (the caller keeps the rest and appends what it reads next).  final_piece != 0:
- * nothing follows -- a last line without a newline counts; text that ends inside a record is PGRC_E_PARAM (what the
+ * *consumed where the next piece has to start (the caller keeps the rest and appends what it reads next).  final_piece:
+ * bit 0 (1) = nothing follows in either text; bit 1 (2) / bit 2 (4) = the first / the second text ends here while the other
+ * may go on (round 4: pair files of different lengths -- the reference stops at the first exhausted file, and so does this:
+ * pgrc_divider_last_was_terminal tells the caller when).  Where a text ends,
+ * a last line without a newline counts; text that ends inside a record is PGRC_E_PARAM (what the
  * reference makes of a cut-off last record depends on strings left over from the record before: not reproduced).
  * pair_text != NULL: the second file of a pair (ManagedReadsSetIterator, readsset/persistance/ReadsSetPersistence.cpp:20-56):
  * records are taken from the two texts in turn, the first file first, as many whole pairs as both pieces hold (at the final
@@ -80,6 +83,10 @@ int pgrc_divider_run(pgrc_divider *d, const char *reads, const char *quals, uint
 int pgrc_divider_run_fastq(pgrc_divider *d, const char *text, uint64_t bytes, const char *pair_text, uint64_t pair_bytes,
                            int32_t rev_compl_pair, int32_t final_piece, uint64_t *consumed, uint64_t *pair_consumed,
                            uint64_t *n_records, pgrc_divided_reads *out);
+
+/* 1 if the last pgrc_divider_run_fastq took the last records the reference's iteration would take (its source is through
+ * when its turn comes: one text ended and its records are used up) -- the caller stops; 0: hand over the next pieces */
+int pgrc_divider_last_was_terminal(const pgrc_divider *d);
 
 /* timing of the last run in milliseconds (upload [+ parsing], kernels, download) */
 int pgrc_divider_last_ms(const pgrc_divider *d, float ms[3]);

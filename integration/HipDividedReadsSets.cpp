@@ -166,10 +166,10 @@ namespace PgTools {
         size_t window[2] = {piece, piece};                  // grows when a window holds no whole record (or no mate for one)
         for (;;) {
             size_t len[2];
-            bool final = true;
+            int finalBits = 0;                              // bit 1 / bit 2: the first / the second file ends in this window
             for (int f = 0; f < (paired ? 2 : 1); f++) {
                 len[f] = std::min(window[f], in[f].bytes - in[f].at);
-                final = final && in[f].at + len[f] == in[f].bytes;
+                if (in[f].at + len[f] == in[f].bytes) finalBits |= 2 << f;
                 if (len[f] >= (1ull << 31)) {
                     fprintf(stderr, "HipDividedReadsSets: a FASTQ record or the lag between the two files exceeds 2 GiB\n");
                     exit(EXIT_FAILURE);
@@ -178,8 +178,11 @@ namespace PgTools {
             pgrc_divided_reads part;                        // (the divider's arrays: valid until its next run)
             uint64_t used[2] = {0, 0}, cnt = 0;
             failOn(pgrc_divider_run_fastq(divider, in[0].p + in[0].at, len[0], paired ? (in[1].p ? in[1].p + in[1].at : "") : nullptr,
-                                          paired ? len[1] : 0, revComplPairFile ? 1 : 0, final ? 1 : 0, &used[0], paired ? &used[1] : nullptr, &cnt,
+                                          paired ? len[1] : 0, revComplPairFile ? 1 : 0, finalBits, &used[0], paired ? &used[1] : nullptr, &cnt,
                                           &part), divider, "divider_run_fastq");
+            // the reference stops at the first exhausted file (pair files of different lengths included): so does this,
+            // without growing the other file's window to its end
+            const bool final = pgrc_divider_last_was_terminal(divider) != 0;
             batchesServed++;
             appendRows(readsSets->getHqReadsSet(), part.hq_rows, part.n_hq);
             appendRows(readsSets->getLqReadsSet(), part.lq_rows, part.n_lq);

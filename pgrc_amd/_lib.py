@@ -161,6 +161,7 @@ _PROTOS = [
     ("pgrc_divider_run_fastq", C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(DividedReads)]),
     ("pgrc_divider_last_ms", C.c_int, [_P, C.POINTER(C.c_float * 3)]),
+    ("pgrc_divider_last_was_terminal", C.c_int, [_P]),
 ]
 
 EXPORTED_SYMBOLS = [p[0] for p in _PROTOS]

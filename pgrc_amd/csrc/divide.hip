@@ -47,6 +47,7 @@ struct pgrc_divider {
     hipEvent_t ev[4]{};
     bool have_ev = false;
     float ms[3] = {0, 0, 0};
+    bool last_terminal = false;   // the last pgrc_divider_run_fastq took what the reference's iteration would take before it ends
 };
 
 static int dv_host_ensure(pgrc_divider *d, pgrc_divider::HostBuf &b, size_t bytes) {
@@ -393,6 +394,8 @@ void pgrc_divider_destroy(pgrc_divider *d) {
     delete d;
 }
 
+int pgrc_divider_last_was_terminal(const pgrc_divider *d) { return d && d->last_terminal ? 1 : 0; }
+
 int pgrc_divider_last_ms(const pgrc_divider *d, float ms[3]) {
     if (!d || !ms) return PGRC_E_PARAM;
     memcpy(ms, d->ms, sizeof d->ms);
@@ -547,6 +550,8 @@ int pgrc_divider_run_fastq(pgrc_divider *d, const char *text, uint64_t bytes, co
     hipStream_t s = c->stream;
     const char *src[2] = {text, pair_text};
     const uint64_t len[2] = {bytes, pair_bytes};
+    // final_piece: bit 0 = nothing follows in either text; bit 1 / bit 2 = the first / the second text ends here (the other may go on)
+    const bool fin[2] = {(final_piece & 3) != 0, (final_piece & 5) != 0};
     uint64_t lines[2] = {0, 0};
     uint32_t nls[2] = {0, 0};
     (void)hipEventRecord(d->ev[0], s);
@@ -566,7 +571,7 @@ int pgrc_divider_run_fastq(pgrc_divider *d, const char *text, uint64_t bytes, co
         DIV_TRY(d, hipStreamSynchronize(s));
         if (len[f]) last = (uint8_t)src[f][len[f] - 1];
         // std::getline: a last piece without its newline is a line too, once nothing more will come
-        lines[f] = nl + ((final_piece && len[f] && last != '\n') ? 1u : 0u);
+        lines[f] = nl + ((fin[f] && len[f] && last != '\n') ? 1u : 0u);
         nls[f] = nl;
         if ((e = pgrc_buf_ensure(c, d->d_ls[f], ((size_t)nl + 8) * sizeof(uint32_t)))) return e;
         hipLaunchKernelGGL(k_fq_starts, dim3((uint32_t)((n16 + 255) / 256 + 1)), dim3(256), 0, s, (const uint8_t *)d->d_text[f].p, len[f], n16,
@@ -577,10 +582,16 @@ int pgrc_divider_run_fastq(pgrc_divider *d, const char *text, uint64_t bytes, co
     const uint64_t rec[2] = {lines[0] / 4, lines[1] / 4};
     uint64_t n;                       // records taken: the two files in turn, first file first, until one of them has no more
     uint64_t take[2];
-    if (!paired) { n = rec[0]; take[0] = rec[0]; take[1] = 0; }
-    else if (final_piece) { n = rec[0] <= rec[1] ? 2 * rec[0] : 2 * rec[1] + 1; take[0] = (n + 1) / 2; take[1] = n / 2; }
-    else { const uint64_t m = std::min(rec[0], rec[1]); n = 2 * m; take[0] = take[1] = m; }
-    if (final_piece) {
+    // `terminal`: the reference's iteration ends with this call -- a source is through when its turn comes (it stops at the
+    // first exhausted file).  One text may end here while the other goes on (final_piece bits 2 / 4): the pairs its records
+    // form are taken as soon as the other piece holds their mates, whatever lies beyond them there.
+    bool terminal;
+    if (!paired) { n = rec[0]; take[0] = rec[0]; take[1] = 0; terminal = fin[0]; }
+    else if ((fin[0] && fin[1]) || (fin[0] && rec[1] >= rec[0]) || (fin[1] && rec[0] >= rec[1] + 1)) {
+        n = rec[0] <= rec[1] ? 2 * rec[0] : 2 * rec[1] + 1; take[0] = (n + 1) / 2; take[1] = n / 2; terminal = true;
+    } else { const uint64_t m = std::min(rec[0], rec[1]); n = 2 * m; take[0] = take[1] = m; terminal = false; }
+    d->last_terminal = terminal;
+    if (terminal && fin[paired ? (int)(n & 1) : 0]) {
         // The record the reference would read next: none (its source is through: it stops) -- or the beginning of one.  What it
         // makes of a cut-off last record depends on state left over in its iterator (a std::getline on a stream already at
         // its end leaves the string of the record BEFORE in place): not reproduced, reported instead.

@@ -73,8 +73,9 @@ class DividedPCLReadsSets:
                 "n_rows": arr(out.n_rows, out.n_n * out.n_row_bytes, np.uint8),
                 "lq_index": arr(out.lq_index, out.n_lq, np.uint32), "n_index": arr(out.n_index, out.n_n, np.uint32)}
 
-    def divide_fastq(self, text: bytes, pair_text: Optional[bytes] = None, rev_compl_pair: bool = False, final: bool = True):
-        """One piece of FASTQ text (and of the pair file's): (result dict, records taken, bytes consumed, pair bytes consumed)."""
+    def divide_fastq(self, text: bytes, pair_text: Optional[bytes] = None, rev_compl_pair: bool = False, final=True):
+        """One piece of FASTQ text (and of the pair file's): (result dict, records taken, bytes consumed, pair bytes consumed).
+        final: True / 1 = nothing follows in either text; 2 / 4 = only the first / the second text ends here."""
         out = _lib.DividedReads()
         used, pused, nrec = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         t = np.frombuffer(text, dtype=np.uint8) if len(text) else np.zeros(1, np.uint8)
@@ -83,9 +84,13 @@ class DividedPCLReadsSets:
             pt = np.frombuffer(pair_text, dtype=np.uint8) if len(pair_text) else np.zeros(1, np.uint8)
         self._ck(lib.pgrc_divider_run_fastq(self._h, t.ctypes.data_as(C.c_void_p), len(text),
                                             pt.ctypes.data_as(C.c_void_p) if pt is not None else None,
-                                            len(pair_text) if pair_text is not None else 0, int(bool(rev_compl_pair)), int(bool(final)),
+                                            len(pair_text) if pair_text is not None else 0, int(bool(rev_compl_pair)), int(final),
                                             C.byref(used), C.byref(pused), C.byref(nrec), C.byref(out)))
         return self._result(out), int(nrec.value), int(used.value), int(pused.value)
+
+    def last_was_terminal(self) -> bool:
+        """did the last divide_fastq take the last records the reference's iteration would take (pgrc_divider_last_was_terminal)"""
+        return bool(lib.pgrc_divider_last_was_terminal(self._h))
 
     def last_ms(self):
         ms = (C.c_float * 3)()

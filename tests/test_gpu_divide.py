@@ -182,6 +182,43 @@ def test_divide_fastq_text_parity(paired, rev, crlf, trailing):
         assert nrec == n and same(g, oracle_divide_fastq(a, b, rev, L, COMBOS[5])) is None, piece
 
 
+@pytest.mark.parametrize("n_a,n_b", [(20, 300), (300, 20), (150, 151), (0, 40)])
+def test_divide_fastq_pair_files_of_different_lengths(n_a, n_b):
+    """The reference stops at the first exhausted file of a pair.  Fed in pieces, the text of the shorter file ends while the
+    other goes on (final_piece bits 2 / 4): the call that takes the last records says so (pgrc_divider_last_was_terminal)
+    and the reader stops there -- it does not have to grow the longer file's window to its end (round 4)."""
+    from pgrc_amd import DividedPCLReadsSets
+    L = 80
+    reads, quals = make_records(seed=77, n=n_a + n_b, L=L)
+    a = make_fastq(reads[:n_a], quals[:n_a], seed=1) if n_a else b""
+    b = make_fastq(reads[n_a:], quals[n_a:], seed=2)
+    combo = COMBOS[5]
+    o = oracle_divide_fastq(a, b, True, L, combo)
+    for piece in (700, 4096, 1 << 20):
+        d = DividedPCLReadsSets(L, *combo)
+        parts, buf, at, src, calls = [], [b"", b""], [0, 0], [a, b], 0
+        while True:
+            bits = 0
+            for f in range(2):
+                buf[f] += src[f][at[f]: at[f] + piece]
+                at[f] += piece
+                if at[f] >= len(src[f]):
+                    bits |= 2 << f
+            res, nrec, used, pused = d.divide_fastq(buf[0], buf[1], True, final=bits)
+            parts.append((res, nrec))
+            buf[0], buf[1] = buf[0][used:], buf[1][pused:]
+            calls += 1
+            if d.last_was_terminal():
+                break
+            assert calls < 10_000
+        d.close()
+        g, nrec = _concat(parts)
+        assert nrec == (2 * n_a if n_a <= n_b else 2 * n_b + 1), (piece, nrec)
+        assert same(g, o) is None, (piece, same(g, o))
+        # the reader stopped about where the shorter file ended, not at the end of the longer one
+        assert max(at) <= (min(n_a, n_b) + 2) * (2 * L + 40) + 3 * piece, (piece, at)
+
+
 def test_divide_fastq_edges():
     from pgrc_amd import DividedPCLReadsSets, PgrcMatchError
     L = 64
