@@ -1064,7 +1064,10 @@ struct DualArgs {
 };
 
 template <int NW, int KQ, bool POS64>
-__global__ void __launch_bounds__(MATCH_TPB) __attribute__((amdgpu_waves_per_eu(NW <= 10 ? 5 : 4)))   // (97 registers without the hint: 4 waves)
+#ifndef DUAL_WAVES_PER_EU
+#define DUAL_WAVES_PER_EU 5      // (experiments: tools/variants.sh)
+#endif
+__global__ void __launch_bounds__(MATCH_TPB) __attribute__((amdgpu_waves_per_eu(NW <= 10 ? DUAL_WAVES_PER_EU : 4)))   // (97 registers without the hint: 4 waves)
 k_copmem_match_dual(const DualArgs a) {
     typedef typename std::conditional<POS64, uint64_t, uint32_t>::type pos_t;
     constexpr pos_t POS_NONE = (pos_t)~(pos_t)0;

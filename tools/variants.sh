@@ -5,7 +5,7 @@
 set -eu
 cd "$(dirname "$0")/.."
 V=pgrc_amd/variants
-declare -A DEFS=( [base]="" [w7]="-DMATCH_WAVES_PER_EU=7" [w8]="-DMATCH_WAVES_PER_EU=8" [w5]="-DMATCH_WAVES_PER_EU=5" [vc8]="-DVC_BITS=3" [vc2]="-DVC_BITS=1" [noahead]="-DPROBE_AHEAD=0" [chunk256]="-DMATCH_CHUNK=256u" )
+declare -A DEFS=( [base]="" [w7]="-DMATCH_WAVES_PER_EU=7" [w8]="-DMATCH_WAVES_PER_EU=8" [w5]="-DMATCH_WAVES_PER_EU=5" [vc8]="-DVC_BITS=3" [vc2]="-DVC_BITS=1" [noahead]="-DPROBE_AHEAD=0" [chunk256]="-DMATCH_CHUNK=256u" [d6]="-DDUAL_WAVES_PER_EU=6 -DMATCH_STAGE=16" [s16]="-DMATCH_STAGE=16" [vc2s16]="-DVC_BITS=1 -DMATCH_STAGE=16" [d6vc2]="-DDUAL_WAVES_PER_EU=6 -DMATCH_STAGE=16 -DVC_BITS=1" )
 ORDER="${VARIANTS:-base w7 w8 vc8}"
 if [ "${1:-build}" = build ]; then
   mkdir -p $V
