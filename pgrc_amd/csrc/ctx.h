@@ -40,7 +40,8 @@ struct pgrc_match_ctx {
     // several devices behind this object (pgrc_match_create_multi): it is then only the front, the work happens in
     // one child context per device
     pgrc_multi *multi = nullptr;
-    void *export_view = nullptr;        // multi-device front: the shards' reads and results gathered on the first device (export.hip)
+    void *export_view = nullptr;        // multi-device front: the shards' results gathered on the first device (export.hip)
+    pgrc_match_ctx *export_front = nullptr;   // set in that gathered view: the front whose shards hold the reads (mismatch lists per shard)
 
     pgrc_match_params prm{};
     int device = 0;
@@ -275,3 +276,5 @@ int pgrc_launch_init_results(pgrc_match_ctx *c);
 int pgrc_launch_hist(pgrc_match_ctx *c);
 int pgrc_extract_mismatches(pgrc_match_ctx *c, const uint8_t *reversed_flags, uint64_t *cum, uint8_t *codes,
                             uint16_t *offsets);
+int pgrc_extract_lists_device(pgrc_match_ctx *c, const uint8_t *d_revflags, bool lists, DevBuf &d_cum, DevBuf &d_codes, DevBuf &d_offs,
+                              uint64_t *total_out);

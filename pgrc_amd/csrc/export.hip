@@ -351,6 +351,43 @@ __global__ void __launch_bounds__(256) k_export_mismatches(const MisArgs a) {
     if (emitted) ro[o] = (OFF)(L - 1u - prev_off);
 }
 
+// ---- the same from per-read mismatch LISTS (round 4: a matcher over several devices).  Every shard makes the lists of its own
+// reads on its own device (results.hip, k_extract: codes + list offsets in the orientation updateEntry chooses) and only those
+// travel to the exporting device -- 8 bytes per read and 3 per mismatch instead of the packed reads and the N side lists.  An
+// entry then copies its read's codes and codes the offsets backwards, as above.
+__global__ void __launch_bounds__(256)
+k_ex_parity(const uint32_t *__restrict__ eread, const uint32_t *__restrict__ eorg, uint64_t ne, uint8_t *__restrict__ par) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < ne; r += (uint64_t)gridDim.x * blockDim.x)
+        if (eread[r] != EX_NONE) par[eread[r]] = (uint8_t)(eorg[r] & 1u);
+}
+__global__ void __launch_bounds__(256)
+k_ex_revflags(const uint8_t *__restrict__ rc, const uint8_t *__restrict__ par, uint64_t n, uint32_t pair_file, uint8_t *__restrict__ rev) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        rev[i] = (uint8_t)(pair_file ? ((rc[i] != 0) != (par[i] != 0)) : (rc[i] != 0));     // ReadsMatchers.cpp:553
+}
+__global__ void __launch_bounds__(256) k_ex_rebase(uint64_t *__restrict__ cum, uint64_t count, uint64_t base) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) cum[i] += base;
+}
+template <typename OFF>
+__global__ void __launch_bounds__(256)
+k_export_mismatches_lists(const uint32_t *__restrict__ eread, const uint8_t *__restrict__ emc, const uint64_t *__restrict__ mbase, uint64_t ne,
+                          const uint64_t *__restrict__ cum, const uint8_t *__restrict__ codes, const uint16_t *__restrict__ offs, uint32_t L,
+                          uint8_t *__restrict__ sym, OFF *__restrict__ ro) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ne) return;
+    const uint32_t cnt = emc[r];
+    if (!cnt) return;
+    const uint64_t src = cum[eread[r]], o = mbase[r];
+    uint32_t prev = 0;
+    for (uint32_t k = 0; k < cnt; k++) {
+        sym[o + k] = codes[src + k];
+        const uint32_t step = offs[src + k];
+        if (k) ro[o + cnt - k] = (OFF)(step - 1u - prev);
+        prev = step;
+    }
+    ro[o] = (OFF)(L - 1u - prev);
+}
+
 // ---------------------------------------------------------------- host side
 
 static uint32_t grid_for(uint64_t n) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>((n + 255) / 256, 1), 65536ull * 4); }
@@ -368,6 +405,74 @@ struct Bufs {
         for (DevBuf *b : {&order, &rorg, &loff, &lorg, &lrc, &lpos, &epos, &eread, &eorg, &erc, &emc, &off, &mbase, &sym, &roff, &bs, &flag}) pgrc_buf_free(*b);
     }
 };
+}
+
+// view = the gathered results of front f on its first device; b.eread / b.eorg / b.emc / b.mbase are there.  -> b.sym, b.roff
+static int mismatch_streams_from_shards(pgrc_match_ctx *view, Bufs &b, uint64_t ne, int pair_file, uint32_t width, uint64_t total) {
+    pgrc_match_ctx *f = view->export_front;
+    const std::vector<PgrcShardView> sh = pgrc_multi_shards(f);
+    const uint64_t n = view->n;
+    DevBuf par, rev, cumAll, codesAll, offsAll;
+    auto done = [&](int e) { for (DevBuf *x : {&par, &rev, &cumAll, &codesAll, &offsAll}) pgrc_buf_free(*x); return e; };
+    int e;
+    if ((e = pgrc_buf_ensure(view, par, n ? n : 1)) || (e = pgrc_buf_ensure(view, rev, n ? n : 1)) || (e = pgrc_buf_ensure(view, cumAll, (n + 1) * sizeof(uint64_t))) ||
+        (e = pgrc_buf_ensure(view, codesAll, total)) || (e = pgrc_buf_ensure(view, offsAll, total * sizeof(uint16_t))))
+        return done(e);
+    // the orientation of every read's list: rc, or rc != (its original index is odd) -- the parity comes from the entries
+    hipError_t he = hipMemsetAsync(par.p, 0, n ? n : 1, view->stream);
+    if (he == hipSuccess && ne) {
+        hipLaunchKernelGGL(k_ex_parity, dim3(grid_for(ne)), dim3(256), 0, view->stream, (const uint32_t *)b.eread.p, (const uint32_t *)b.eorg.p, ne, (uint8_t *)par.p);
+        if (n) hipLaunchKernelGGL(k_ex_revflags, dim3(grid_for(n)), dim3(256), 0, view->stream, (const uint8_t *)view->d_rc.p, (const uint8_t *)par.p, n,
+                                  pair_file ? 1u : 0u, (uint8_t *)rev.p);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(view->stream);
+    if (he != hipSuccess) { view->err = std::string("export: orientation flags: ") + hipGetErrorString(he); return done(pgrc_hip_code(he)); }
+    uint64_t base = 0;
+    for (const PgrcShardView &s : sh) {
+        const uint64_t cnt = s.hi - s.lo;
+        if (!cnt) continue;
+        pgrc_match_ctx *c = s.ctx;
+        DevBuf d_rev, d_cum, d_codes, d_offs;
+        uint64_t tot_s = 0;
+        int se;
+        {
+            PgrcDeviceScope cs(c->device);
+            if (!cs.ok) { view->err = "hipSetDevice failed"; return done(PGRC_E_NO_DEVICE); }
+            se = pgrc_buf_ensure(c, d_rev, cnt);
+            if (!se && hipMemcpyAsync(d_rev.p, (const uint8_t *)rev.p + s.lo, cnt, hipMemcpyDefault, c->stream) != hipSuccess) se = PGRC_E_DEVICE;
+            if (!se) se = pgrc_extract_lists_device(c, (const uint8_t *)d_rev.p, true, d_cum, d_codes, d_offs, &tot_s);
+            if (!se && hipStreamSynchronize(c->stream) != hipSuccess) se = PGRC_E_DEVICE;
+            if (se) view->err = c->err.empty() ? "export: a shard's mismatch lists" : c->err;
+        }
+        if (!se) {
+            // the shard's lists into the whole set's: offsets of its reads behind those of the shards before it
+            he = hipMemcpyAsync((uint64_t *)cumAll.p + s.lo, d_cum.p, cnt * sizeof(uint64_t), hipMemcpyDefault, view->stream);
+            if (he == hipSuccess && base) hipLaunchKernelGGL(k_ex_rebase, dim3(grid_for(cnt)), dim3(256), 0, view->stream, (uint64_t *)cumAll.p + s.lo, cnt, base);
+            if (he == hipSuccess && tot_s) he = hipMemcpyAsync((uint8_t *)codesAll.p + base, d_codes.p, tot_s, hipMemcpyDefault, view->stream);
+            if (he == hipSuccess && tot_s) he = hipMemcpyAsync((uint16_t *)offsAll.p + base, d_offs.p, tot_s * sizeof(uint16_t), hipMemcpyDefault, view->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(view->stream);
+            if (he != hipSuccess) { se = pgrc_hip_code(he); view->err = std::string("export: gathering a shard's mismatch lists: ") + hipGetErrorString(he); }
+        }
+        {
+            PgrcDeviceScope cs(c->device);
+            for (DevBuf *x : {&d_rev, &d_cum, &d_codes, &d_offs}) pgrc_buf_free(*x);
+        }
+        if (se) return done(se);
+        base += tot_s;
+    }
+    if (base != total) { view->err = "export: the shards' mismatch lists do not add up to the entries' counts"; return done(PGRC_E_STATE); }
+    const uint32_t grid = (uint32_t)((ne + 255) / 256);
+    if (width == 1)
+        hipLaunchKernelGGL(k_export_mismatches_lists<uint8_t>, dim3(grid), dim3(256), 0, view->stream, (const uint32_t *)b.eread.p, (const uint8_t *)b.emc.p,
+                           (const uint64_t *)b.mbase.p, ne, (const uint64_t *)cumAll.p, (const uint8_t *)codesAll.p, (const uint16_t *)offsAll.p, view->prm.read_len,
+                           (uint8_t *)b.sym.p, (uint8_t *)b.roff.p);
+    else
+        hipLaunchKernelGGL(k_export_mismatches_lists<uint16_t>, dim3(grid), dim3(256), 0, view->stream, (const uint32_t *)b.eread.p, (const uint8_t *)b.emc.p,
+                           (const uint64_t *)b.mbase.p, ne, (const uint64_t *)cumAll.p, (const uint8_t *)codesAll.p, (const uint16_t *)offsAll.p, view->prm.read_len,
+                           (uint8_t *)b.sym.p, (uint16_t *)b.roff.p);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(view->stream) != hipSuccess) { view->err = "export: mismatch streams from the lists"; return done(PGRC_E_DEVICE); }
+    return done(PGRC_OK);
 }
 
 // emc / eread / eorg (device) are filled: scan the counts, extract the mismatch streams, bring everything to the host
@@ -399,7 +504,10 @@ static int finish_export(pgrc_match_ctx *c, Bufs &b, uint64_t ne, int pair_file,
     uint64_t total = 0;
     HIP_TRY(c, hipMemcpyAsync(&total, (uint64_t *)b.mbase.p + ne, sizeof total, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (total) {
+    if (total && c->export_front) {                       // a matcher over several devices: the lists come from the shards
+        if ((e = pgrc_buf_ensure(c, b.sym, total)) || (e = pgrc_buf_ensure(c, b.roff, total * width))) return e;
+        if ((e = mismatch_streams_from_shards(c, b, ne, pair_file, width, total))) return e;
+    } else if (total) {
         if ((e = pgrc_buf_ensure(c, b.sym, total)) || (e = pgrc_buf_ensure(c, b.roff, total * width))) return e;
         MisArgs a;
         a.pg = (const uint32_t *)c->pg2[0].p;
@@ -569,35 +677,30 @@ static int export_pg_order(pgrc_match_ctx *c, const pgrc_export_pg_order_args *x
     return PGRC_OK;
 }
 
-// A multi-device context exports from ONE device: the per-read results, the packed reads and the side list of reads with
-// N of every shard are gathered (peer copies) into the layout of a single-device context on the first shard's device,
-// whose copy of the text serves; the export kernels then run on that view.  C3 over 8 devices: 0.9 GB of results and
-// 3.5 GB of reads travel once.
+// A multi-device context exports from ONE device: the per-read results of every shard are gathered (peer copies: 10 bytes per
+// read) into the layout of a single-device context on the first shard's device; the entry lists, offsets and counts are made
+// there.  The packed reads, the N side lists and the text stay where they are: the mismatch streams come from per-read lists
+// that every shard extracts on its own device (mismatch_streams_from_shards above; round 3 gathered the reads too: 3.5 GB of
+// them + 0.9 GB of results for C3 over 8 devices, now 0.9 GB + ~8 bytes per read and 3 per mismatch of lists).
 namespace {
 struct GatheredView {
     pgrc_match_ctx view;
-    DevBuf reads, nflag, nidx, nascii, pos, rc, mism;
+    DevBuf pos, rc, mism;
     ~GatheredView() {
-        for (DevBuf *b : {&reads, &nflag, &nidx, &nascii, &pos, &rc, &mism}) pgrc_buf_free(*b);
+        for (DevBuf *b : {&pos, &rc, &mism}) pgrc_buf_free(*b);
     }
     int build(pgrc_match_ctx *f) {
         const std::vector<PgrcShardView> sh = pgrc_multi_shards(f);
         pgrc_match_ctx *c0 = sh[0].ctx;
         PgrcDeviceScope scope(c0->device);
         if (!scope.ok) { f->err = "hipSetDevice failed"; return PGRC_E_NO_DEVICE; }
-        const uint64_t n = f->n, stride = (n + 63) & ~63ull;
-        const uint32_t nw = c0->nw, L = c0->prm.read_len;
-        uint64_t nn = 0;
-        for (const PgrcShardView &s : sh) nn += s.ctx->n_nreads;
+        const uint64_t n = f->n;
         int e;
         auto fail = [&](int code) { f->err = c0->err; return code; };
-        if ((e = pgrc_buf_ensure(c0, reads, (size_t)nw * std::max<uint64_t>(stride, 64) * 4)) || (e = pgrc_buf_ensure(c0, pos, n * 8)) ||
-            (e = pgrc_buf_ensure(c0, rc, n)) || (e = pgrc_buf_ensure(c0, mism, n)) || (e = pgrc_buf_ensure(c0, nflag, n)) ||
-            (e = pgrc_buf_ensure(c0, nidx, nn * 4)) || (e = pgrc_buf_ensure(c0, nascii, nn * L)))
+        if ((e = pgrc_buf_ensure(c0, pos, std::max<uint64_t>(n, 1) * 8)) || (e = pgrc_buf_ensure(c0, rc, std::max<uint64_t>(n, 1))) ||
+            (e = pgrc_buf_ensure(c0, mism, std::max<uint64_t>(n, 1))))
             return fail(e);
-        hipError_t he = hipMemsetAsync(nflag.p, 0, n ? n : 1, c0->stream);
-        uint64_t nat = 0;
-        std::vector<uint32_t> idx;
+        hipError_t he = hipSuccess;
         for (const PgrcShardView &s : sh) {
             const uint64_t cnt = s.hi - s.lo;
             if (!cnt || he != hipSuccess) continue;
@@ -609,33 +712,20 @@ struct GatheredView {
             if (he == hipSuccess) he = hipMemcpyAsync((uint64_t *)pos.p + s.lo, c->d_pos.p, cnt * 8, hipMemcpyDefault, c0->stream);
             if (he == hipSuccess) he = hipMemcpyAsync((uint8_t *)rc.p + s.lo, c->d_rc.p, cnt, hipMemcpyDefault, c0->stream);
             if (he == hipSuccess) he = hipMemcpyAsync((uint8_t *)mism.p + s.lo, c->d_mism.p, cnt, hipMemcpyDefault, c0->stream);
-            // word-major reads: row w of the shard (pitch = its stride) into columns [lo, hi) of row w of the view
-            if (he == hipSuccess)
-                he = hipMemcpy2DAsync((uint32_t *)reads.p + s.lo, stride * 4, c->reads2, c->stride * 4, cnt * 4, nw, hipMemcpyDefault, c0->stream);
-            if (c->n_nreads && he == hipSuccess) {
-                he = hipMemcpyAsync((uint8_t *)nflag.p + s.lo, c->nread_flag.p, cnt, hipMemcpyDefault, c0->stream);
-                if (he == hipSuccess) he = hipMemcpyAsync((uint8_t *)nascii.p + nat * L, c->nread_ascii.p, c->n_nreads * L, hipMemcpyDefault, c0->stream);
-                idx.resize(c->n_nreads);
-                if (he == hipSuccess) he = hipMemcpy(idx.data(), c->nread_idx.p, c->n_nreads * 4, hipMemcpyDefault);
-                for (uint32_t &v : idx) v += (uint32_t)s.lo;        // shard-local read index -> index in the whole set
-                if (he == hipSuccess) he = hipMemcpy((uint32_t *)nidx.p + nat, idx.data(), c->n_nreads * 4, hipMemcpyDefault);
-                nat += c->n_nreads;
-            }
         }
         if (he == hipSuccess) he = hipStreamSynchronize(c0->stream);
         if (he != hipSuccess) { f->err = std::string("export: gathering the shards: ") + hipGetErrorString(he); return pgrc_hip_code(he); }
         view.prm = c0->prm;
         view.device = c0->device;
         view.stream = c0->stream;
-        view.nw = nw;
+        view.num_cus = c0->num_cus;
+        view.nw = c0->nw;
         view.n = n;
-        view.stride = stride;
-        view.reads2 = (const uint32_t *)reads.p;
-        view.n_nreads = nn;
-        view.nread_flag = nflag;      // (DevBuf copies: the view never frees anything, this object does)
-        view.nread_idx = nidx;
-        view.nread_ascii = nascii;
-        view.d_pos = pos;
+        view.stride = 0;
+        view.reads2 = nullptr;            // (the reads stay on their shards)
+        view.n_nreads = 0;
+        view.export_front = f;
+        view.d_pos = pos;                 // (DevBuf copies: the view never frees anything, this object does)
         view.d_rc = rc;
         view.d_mism = mism;
         view.pg2[0] = c0->pg2[0];

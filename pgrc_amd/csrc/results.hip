@@ -185,15 +185,16 @@ __global__ void __launch_bounds__(256) k_extract(const ExtractArgs a) {
     }
 }
 
-int pgrc_extract_mismatches(pgrc_match_ctx *c, const uint8_t *reversed_flags, uint64_t *cum, uint8_t *codes,
-                            uint16_t *offsets) {
+// The lists on the device: d_cum (u64[n + 1], exclusive scan of the reads' mismatch counts), d_codes / d_offs (one entry per
+// mismatch), *total.  d_revflags: per-read orientation flags ON THE DEVICE (nullptr: reversed iff the read matched the RC strand).
+// Everything is queued on c->stream; the call returns after the scan's total is known (one synchronisation).
+int pgrc_extract_lists_device(pgrc_match_ctx *c, const uint8_t *d_revflags, bool lists, DevBuf &d_cum, DevBuf &d_codes, DevBuf &d_offs, uint64_t *total_out) {
     const uint64_t n = c->n;
-    DevBuf d_cum, d_bsum, d_codes, d_offs, d_flags;
+    DevBuf d_bsum;
     int e;
-    auto cleanup = [&]() { pgrc_buf_free(d_cum); pgrc_buf_free(d_bsum); pgrc_buf_free(d_codes); pgrc_buf_free(d_offs); pgrc_buf_free(d_flags); };
     const uint64_t nb = (n + XS_EPB - 1) / XS_EPB;
     if ((e = pgrc_buf_ensure(c, d_cum, (n + 1) * sizeof(uint64_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, d_bsum, (nb + 2) * sizeof(uint64_t)))) { cleanup(); return e; }
+    if ((e = pgrc_buf_ensure(c, d_bsum, (nb + 2) * sizeof(uint64_t)))) return e;
     if (n) {
         hipLaunchKernelGGL(k_xs_sums, dim3((uint32_t)nb), dim3(XS_TPB), 0, c->stream, (const uint8_t *)c->d_mism.p, n, (uint64_t *)d_bsum.p);
         hipLaunchKernelGGL(k_xs_bsums, dim3(1), dim3(64), 0, c->stream, (uint64_t *)d_bsum.p, nb);
@@ -202,19 +203,17 @@ int pgrc_extract_mismatches(pgrc_match_ctx *c, const uint8_t *reversed_flags, ui
     } else {
         (void)hipMemsetAsync(d_cum.p, 0, sizeof(uint64_t), c->stream);
     }
-    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(cum, d_cum.p, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+    uint64_t total = 0;
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&total, (const uint64_t *)d_cum.p + n, sizeof total, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) {
-        cleanup();
+        pgrc_buf_free(d_bsum);
         c->err = "extract: scan failed";
         return PGRC_E_DEVICE;
     }
-    const uint64_t total = cum[n];
-    if (!codes || !offsets || !total) { cleanup(); return PGRC_OK; }
-    if ((e = pgrc_buf_ensure(c, d_codes, total)) || (e = pgrc_buf_ensure(c, d_offs, total * sizeof(uint16_t)))) { cleanup(); return e; }
-    if (reversed_flags) {
-        if ((e = pgrc_buf_ensure(c, d_flags, n))) { cleanup(); return e; }
-        if (hipMemcpyAsync(d_flags.p, reversed_flags, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) { cleanup(); return PGRC_E_DEVICE; }
-    }
+    pgrc_buf_free(d_bsum);
+    *total_out = total;
+    if (!total || !lists) return PGRC_OK;                   // (lists = false: only the counts' scan was asked for)
+    if ((e = pgrc_buf_ensure(c, d_codes, total)) || (e = pgrc_buf_ensure(c, d_offs, total * sizeof(uint16_t)))) return e;
     ExtractArgs a;
     a.pg = (const uint32_t *)c->pg2[0].p;
     a.reads = c->reads2;
@@ -227,7 +226,7 @@ int pgrc_extract_mismatches(pgrc_match_ctx *c, const uint8_t *reversed_flags, ui
     a.pos = (const uint64_t *)c->d_pos.p;
     a.rc = (const uint8_t *)c->d_rc.p;
     a.mism = (const uint8_t *)c->d_mism.p;
-    a.revflags = reversed_flags ? (const uint8_t *)d_flags.p : nullptr;
+    a.revflags = d_revflags;
     a.cum = (const uint64_t *)d_cum.p;
     a.codes = (uint8_t *)d_codes.p;
     a.offsets = (uint16_t *)d_offs.p;
@@ -235,11 +234,29 @@ int pgrc_extract_mismatches(pgrc_match_ctx *c, const uint8_t *reversed_flags, ui
     hipLaunchKernelGGL(k_extract<false>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, a);
     if (c->n_nreads)
         hipLaunchKernelGGL(k_extract<true>, dim3((uint32_t)((c->n_nreads + 255) / 256)), dim3(256), 0, c->stream, a);
-    bool ok = hipGetLastError() == hipSuccess &&
-              hipMemcpyAsync(codes, d_codes.p, total, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
-              hipMemcpyAsync(offsets, d_offs.p, total * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
-              hipStreamSynchronize(c->stream) == hipSuccess;
+    if (hipGetLastError() != hipSuccess) { c->err = "extract: kernel failed"; return PGRC_E_DEVICE; }
+    return PGRC_OK;
+}
+
+int pgrc_extract_mismatches(pgrc_match_ctx *c, const uint8_t *reversed_flags, uint64_t *cum, uint8_t *codes,
+                            uint16_t *offsets) {
+    const uint64_t n = c->n;
+    DevBuf d_cum, d_codes, d_offs, d_flags;
+    int e;
+    auto cleanup = [&]() { pgrc_buf_free(d_cum); pgrc_buf_free(d_codes); pgrc_buf_free(d_offs); pgrc_buf_free(d_flags); };
+    if (reversed_flags && codes && offsets) {
+        if ((e = pgrc_buf_ensure(c, d_flags, n ? n : 1))) { cleanup(); return e; }
+        if (n && hipMemcpyAsync(d_flags.p, reversed_flags, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) { cleanup(); return PGRC_E_DEVICE; }
+    }
+    uint64_t total = 0;
+    const bool lists = codes && offsets;
+    if ((e = pgrc_extract_lists_device(c, (reversed_flags && lists) ? (const uint8_t *)d_flags.p : nullptr, lists, d_cum, d_codes, d_offs, &total))) { cleanup(); return e; }
+    bool ok = hipMemcpyAsync(cum, d_cum.p, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    if (ok && lists && total)
+        ok = hipMemcpyAsync(codes, d_codes.p, total, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+             hipMemcpyAsync(offsets, d_offs.p, total * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
     cleanup();
-    if (!ok) { c->err = "extract: kernel failed"; return PGRC_E_DEVICE; }
+    if (!ok) { c->err = "extract: copy failed"; return PGRC_E_DEVICE; }
     return PGRC_OK;
 }
