@@ -147,7 +147,6 @@ struct pgrc_match_ctx {
     DevBuf s_filter;        // modes d/i/e: one bit per slice of the key space (seedidx.hip)
     DevBuf s_nmask;                             // N masks of the reads with N (modes d/i/e)
     DevBuf s_heavy;                             // reads handed to the wave-per-read replay
-    DevBuf s_runs;                              // hit runs too long for one lane to order (seedidx.hip, k_seed_order_big)
     DevBuf s_sorted, s_sorttmp, s_mm, s_rstart; // sorted hits, rocPRIM scratch, Hamming count per hit, first hit per read
 
     // profiling

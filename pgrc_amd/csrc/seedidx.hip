@@ -345,117 +345,9 @@ __device__ __forceinline__ uint64_t lower_bound_u32(const uint32_t *v, uint64_t 
     return lo;
 }
 
-// ---- the order of the hits (round 4: hand-written, radix.hip).  What the replay needs is every read's hits together, in
-// ascending (text position, part) order -- the order in which the reference's scan meets them.  A full sort of the 63-bit
-// records is 8 radix passes; grouping by read is 4 stable passes over the read bits, and a read has a handful of hits, which
-// arrive nearly in position order already (the scan walks the text upwards): the first hit of every read puts its read's run
-// in order in place -- insertion sort for runs of up to SEED_RUN_SMALL, runs beyond that (repeats, tandem tracts) are listed
-// and sorted by a block each in LDS (bitonic, up to SEED_RUN_LDS records); a longer run raises a flag and the caller falls
-// back to the library's full sort.
-#define SEED_RUN_SMALL 48u
-#define SEED_RUN_WAVE 1024u      // runs up to this length: one WAVE each (k_seed_order_mid); longer: one block (k_seed_order_big)
-#define SEED_RUN_LDS 8192u
-
-__global__ void __launch_bounds__(256)
-k_seed_order_runs(uint64_t *__restrict__ hits, uint64_t nhits, uint64_t *__restrict__ mid, uint64_t *__restrict__ big,
-                  unsigned long long *__restrict__ counts /* [0] mid runs [1] big runs */, uint64_t mid_cap, uint64_t big_cap,
-                  uint32_t *__restrict__ overflow) {
-    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= nhits) return;
-    const uint64_t i = hits[x] >> 36;
-    if (x != 0 && (hits[x - 1] >> 36) == i) return;              // not the first hit of its read
-    uint64_t len = 1;
-    while (x + len < nhits && (hits[x + len] >> 36) == i && len <= SEED_RUN_SMALL) len++;
-    if (len <= 1) return;
-    if (len > SEED_RUN_SMALL) {                                  // a long run: its end by bisection (the hits are grouped by read)
-        uint64_t lo = x + len, hi = nhits;
-        while (lo < hi) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if ((hits[mid] >> 36) <= i) lo = mid + 1; else hi = mid;
-        }
-        len = lo - x;
-    }
-    if (len > SEED_RUN_LDS) { atomicOr(overflow, 1u); return; }
-    if (len > SEED_RUN_WAVE) {
-        const unsigned long long k = atomicAdd(&counts[1], 1ull);
-        if (k < big_cap) { big[2 * k] = x; big[2 * k + 1] = len; }
-        else atomicOr(overflow, 1u);
-        return;
-    }
-    if (len > SEED_RUN_SMALL) {
-        const unsigned long long k = atomicAdd(&counts[0], 1ull);
-        if (k < mid_cap) { mid[2 * k] = x; mid[2 * k + 1] = len; }
-        else atomicOr(overflow, 1u);
-        return;
-    }
-    for (uint64_t a = 1; a < len; a++) {                         // insertion sort, in place (nearly sorted on arrival)
-        const uint64_t y = hits[x + a];
-        uint64_t b = a;
-        while (b > 0 && hits[x + b - 1] > y) { hits[x + b] = hits[x + b - 1]; b--; }
-        if (b != a) hits[x + b] = y;
-    }
-}
-
-// one wave per listed run of medium length: bitonic sort in the wave's slice of LDS (a wave's LDS accesses are served in
-// order, so no barrier is needed between the stages)
-__global__ void __launch_bounds__(256)
-k_seed_order_mid(uint64_t *__restrict__ hits, const uint64_t *__restrict__ mid, const unsigned long long *__restrict__ counts, uint64_t mid_cap) {
-    __shared__ uint64_t vs[4][SEED_RUN_WAVE];
-    uint64_t *v = vs[threadIdx.x >> 6];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t nr = min((uint64_t)counts[0], mid_cap);
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4u;
-    for (uint64_t r = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); r < nr; r += nwaves) {
-        const uint64_t x0 = mid[2 * r], len = mid[2 * r + 1];
-        uint32_t m = 64;
-        while (m < len) m <<= 1;
-        for (uint32_t t = lane; t < m; t += 64) v[t] = t < len ? hits[x0 + t] : ~0ull;
-        __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        for (uint32_t k = 2; k <= m; k <<= 1)
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t t = lane; t < m; t += 64) {
-                    const uint32_t u = t ^ j;
-                    if (u > t) {
-                        const uint64_t p = v[t], q = v[u];
-                        const bool up = (t & k) == 0;
-                        if ((p > q) == up) { v[t] = q; v[u] = p; }
-                    }
-                }
-                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-        for (uint32_t t = lane; t < len; t += 64) hits[x0 + t] = v[t];
-        __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }
-}
-
-// one block per listed long run: bitonic sort in LDS
-__global__ void __launch_bounds__(1024)
-k_seed_order_big(uint64_t *__restrict__ hits, const uint64_t *__restrict__ big, const unsigned long long *__restrict__ counts, uint64_t big_cap) {
-    __shared__ uint64_t v[SEED_RUN_LDS];
-    const uint64_t nb = min((uint64_t)counts[1], big_cap);
-    for (uint64_t r = blockIdx.x; r < nb; r += gridDim.x) {
-        const uint64_t x0 = big[2 * r], len = big[2 * r + 1];
-        uint32_t m = 64;
-        while (m < len) m <<= 1;                                 // power of two >= len (<= SEED_RUN_LDS), padded with all ones
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t < m; t += 1024) v[t] = t < len ? hits[x0 + t] : ~0ull;
-        __syncthreads();
-        for (uint32_t k = 2; k <= m; k <<= 1)
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t t = threadIdx.x; t < m; t += 1024) {
-                    const uint32_t u = t ^ j;
-                    if (u > t) {
-                        const uint64_t p = v[t], q = v[u];
-                        const bool up = (t & k) == 0;
-                        if ((p > q) == up) { v[t] = q; v[u] = p; }
-                    }
-                }
-                __syncthreads();
-            }
-        for (uint32_t t = threadIdx.x; t < len; t += 1024) hits[x0 + t] = v[t];
-    }
-}
-
+// ---- the hits grouped by read: a stable radix sort over the read bits of the hit records (radix.hip; PGRC_SEED_SORT=lib: the
+// library's sort over the same bits).  Inside a read's run the hits stay in whatever order they arrived: the replay below takes a
+// minimum, not a walk.
 int pgrc_radix_sort_u64(pgrc_match_ctx *c, uint64_t *d_a, uint64_t *d_b, uint64_t n, uint32_t bit_lo, uint32_t bit_hi, DevBuf &scratch,
                         uint64_t **sorted);
 
@@ -478,62 +370,61 @@ k_seed_hamming(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhi
     mmv[x] = (uint8_t)min(mm, 255u);
 }
 
-// Reads with more than REPLAY_HEAVY candidates (tandem repeats: hundreds to thousands per read) would keep one lane --
-// and with it the whole wave -- looping alone: the per-thread replay hands them to k_seed_replay_heavy instead.
+// ---- 3b. what the reference's sequential rule leaves of a read's hits (ReadsMatchers.cpp:297-341, :198-230).  It walks the
+// hits in scan order -- ascending text position, at one position the parts in descending order: the low 36 bits of a hit
+// record, ascending -- and accepts a hit whose count is BELOW the read's current one (<= kmax for a read not matched yet),
+// until the count is <= kmin.  So it ends at the first hit with a count <= kmin if there is one, else at the first hit that
+// attains the smallest count: a lexicographic MINIMUM over the hits of (count <= kmin ? 0 : count, scan order), taken over the
+// hits with count <= the limit the read starts with.  A minimum needs the read's hits together, not in order (round 4: the
+// hit records are sorted by their read bits only -- 4 radix passes instead of 8).  The exact matcher (:198-230): the first hit
+// in scan order that equals the read.  (`stored == candidate -> skip`, :313-314, never changes the outcome: such a hit has the
+// stored alignment's own count, which is not below it.)
 #define REPLAY_HEAVY 64u
 
+__device__ __forceinline__ uint64_t replay_key(const SeedArgs &a, uint64_t hkey, uint32_t mm, uint32_t limit0, bool exact) {
+    const bool ok = exact ? mm == 0u : mm <= limit0;
+    if (!ok) return ~0ull;
+    return ((uint64_t)(mm <= a.kmin ? 0u : mm) << 56) | (hkey & ((1ull << 36) - 1ull));
+}
+
+__device__ __forceinline__ void replay_store(const SeedArgs &a, uint64_t i, uint64_t best_key, uint32_t best_mm) {
+    const uint64_t tp = a.tbase + ((best_key >> 4) & 0xFFFFFFFFull);
+    const uint32_t j = 15u - (uint32_t)(best_key & 15u);
+    const uint64_t p = tp - part_offset(a, j);
+    a.pos[i] = a.strand ? a.G - (p + a.L) : p;
+    a.rc[i] = (uint8_t)a.strand;
+    a.mism[i] = (uint8_t)best_mm;
+}
+
+// Reads with more than REPLAY_HEAVY hits (tandem repeats: hundreds to thousands per read) would keep one lane -- and with it
+// the whole wave -- looping alone: they are handed to k_seed_replay_heavy, one wave each.
 __global__ void __launch_bounds__(256)
 k_seed_replay(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhits, const uint8_t *__restrict__ mmv,
               const uint64_t *__restrict__ rstart, uint32_t *__restrict__ heavy, unsigned long long *__restrict__ nheavy) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    uint32_t c = a.mism[i];
-    uint64_t stored = a.pos[i];
-    uint32_t rcflag = a.rc[i];
+    const uint32_t c = a.mism[i];
     const bool exact = a.mode == 'e';
-    if (exact ? (stored != PGRC_NOT_MATCHED_POS) : (c <= a.kmin)) return;
-    bool changed = false;
+    if (exact ? (a.pos[i] != PGRC_NOT_MATCHED_POS) : (c <= a.kmin)) return;   // :304-305 resp. an exact match found before
+    const uint32_t limit0 = (c == PGRC_NOT_MATCHED_CNT) ? a.kmax : c - 1u;   // :315-316
     const uint64_t x0 = rstart[i];                              // all ones for a read without hits
+    uint64_t best = ~0ull;
+    uint32_t best_mm = 0;
     for (uint64_t x = x0; x < nhits; x++) {
         const uint64_t hkey = hits[x];
         if ((hkey >> 36) != i) break;
-        if (x - x0 >= REPLAY_HEAVY) {                 // too many candidates for one lane: a wave redoes this read
+        if (x - x0 >= REPLAY_HEAVY) {                 // too many hits for one lane: a wave does this read
             heavy[atomicAdd(nheavy, 1ull)] = (uint32_t)i;
             return;
         }
-        const uint64_t tp = a.tbase + ((hkey >> 4) & 0xFFFFFFFFull);
-        const uint32_t j = 15u - (uint32_t)(hkey & 15u);
-        const uint64_t p = tp - part_offset(a, j);
-        const uint64_t cand = a.strand ? a.G - (p + a.L) : p;
-        if (exact) {
-            if (mmv[x] != 0) continue;                                  // compareReadWithPattern == 0, :207
-            stored = cand;                                              // first hit in scan order wins, :209-212
-            rcflag = a.strand;
-            c = 0;
-            changed = true;
-            break;
-        }
-        if (c <= a.kmin) break;                                         // :304-305 (every later hit is skipped too)
-        if (stored == cand) continue;                                   // :313-314
-        const uint32_t limit = (c == PGRC_NOT_MATCHED_CNT) ? a.kmax : c - 1u; // :315-316
         const uint32_t mm = mmv[x];
-        if (mm <= limit) {                                              // got < count  (:319-328)
-            c = mm;
-            stored = cand;
-            rcflag = a.strand;
-            changed = true;
-        }
+        const uint64_t k = replay_key(a, hkey, mm, limit0, exact);
+        if (k < best) { best = k; best_mm = mm; }
     }
-    if (changed) {
-        a.pos[i] = stored;
-        a.rc[i] = (uint8_t)rcflag;
-        a.mism[i] = (uint8_t)c;
-    }
+    if (best != ~0ull) replay_store(a, i, best, best_mm);
 }
 
-// One wave per heavy read.  The sequential rule only changes state when a candidate is accepted (at most kmax + 1
-// times per read): between two acceptances the wave tests 64 candidates at a time against the current limit and
-// stored position and jumps to the first one that passes -- the same candidate the sequential loop would reach.
+// One wave per heavy read: 64 hits at a time, the minimum over the lanes at the end.
 __global__ void __launch_bounds__(256)
 k_seed_replay_heavy(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhits, const uint8_t *__restrict__ mmv,
                     const uint64_t *__restrict__ rstart, const uint32_t *__restrict__ heavy,
@@ -544,48 +435,30 @@ k_seed_replay_heavy(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_
     const bool exact = a.mode == 'e';
     for (uint64_t w = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < nh; w += nwaves) {
         const uint64_t i = heavy[w];
-        uint32_t c = a.mism[i];
-        uint64_t stored = a.pos[i];
-        bool changed = false;
-        uint64_t x = rstart[i];
-        bool more = true;
-        while (more) {
-            if (!exact && c <= a.kmin) break;                                   // :304-305
+        const uint32_t c = a.mism[i];
+        const uint32_t limit0 = (c == PGRC_NOT_MATCHED_CNT) ? a.kmax : c - 1u;
+        uint64_t best = ~0ull;
+        uint32_t best_mm = 0;
+        for (uint64_t x = rstart[i];; x += 64) {
             const uint64_t xi = x + lane;
-            bool ok = false, mine = false;
-            uint64_t cand = 0;
-            uint32_t mm = 0;
+            bool mine = false;
             if (xi < nhits) {
                 const uint64_t hkey = hits[xi];
                 mine = (hkey >> 36) == i;
                 if (mine) {
-                    const uint64_t tp = a.tbase + ((hkey >> 4) & 0xFFFFFFFFull);
-                    const uint32_t j = 15u - (uint32_t)(hkey & 15u);
-                    const uint64_t p = tp - part_offset(a, j);
-                    cand = a.strand ? a.G - (p + a.L) : p;
-                    mm = mmv[xi];
-                    if (exact) ok = mm == 0;                                    // :207
-                    else ok = cand != stored && mm <= ((c == PGRC_NOT_MATCHED_CNT) ? a.kmax : c - 1u);   // :313-319
+                    const uint32_t mm = mmv[xi];
+                    const uint64_t k = replay_key(a, hkey, mm, limit0, exact);
+                    if (k < best) { best = k; best_mm = mm; }
                 }
             }
-            const unsigned long long okm = __ballot(ok), minem = __ballot(mine);
-            if (okm) {
-                const int f = __ffsll((long long)okm) - 1;                      // the first candidate the sequential loop accepts
-                c = __shfl(mm, f, 64);
-                stored = __shfl(cand, f, 64);
-                changed = true;
-                if (exact) break;                                               // first hit in scan order wins, :209-212
-                x += (uint64_t)f + 1;
-            } else {
-                more = minem == ~0ull;                                          // all 64 were this read's: there may be more
-                x += 64;
-            }
+            if (__ballot(mine) != ~0ull) break;                                 // the run ended inside these 64
         }
-        if (changed && lane == 0) {
-            a.pos[i] = stored;
-            a.rc[i] = (uint8_t)a.strand;
-            a.mism[i] = (uint8_t)c;
+        for (int o = 32; o > 0; o >>= 1) {                                      // the smallest key of the wave, and its count
+            const uint64_t ok = __shfl_xor(best, o, 64);
+            const uint32_t om = __shfl_xor(best_mm, o, 64);
+            if (ok < best) { best = ok; best_mm = om; }
         }
+        if (lane == 0 && best != ~0ull) replay_store(a, i, best, best_mm);
     }
 }
 
@@ -682,48 +555,21 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
         if ((e = pgrc_buf_ensure(c, c->s_heavy, a.n * sizeof(uint32_t)))) return e;
         hipError_t he = hipSuccess;
         const uint64_t *sorted_hits = nullptr;
-        // PGRC_SEED_SORT=own: the hand-written road (4 stable passes over the read bits + every read's run ordered in place).
-        // MEASURED AT C3, mode d, ~1.2 G hits per strand (profiles/r04_mode_d_own_sort_kernel_stats.csv): 4 x (k_rx_hist 4.7 +
-        // k_rx_scatter 6.4) + k_seed_order_runs 23 + k_seed_order_big 6.6 = 74 ms per sort against the library's 79 ms
-        // (8 onesweep passes of 8.8 ms + 9.4 ms of histograms): a tie, and reads with more than 8192 hits (tandem tracts) send
-        // the whole sort to the library anyway -- so the library's sort stays the default.
+        // Round 4: only the read bits are sorted (4 passes of 27 bits at C3 instead of 8 of 63: the replay is a minimum over a
+        // read's hits).  PGRC_SEED_SORT=lib: rocPRIM's radix sort over the same bits instead of radix.hip's passes.
         const char *ssel = getenv("PGRC_SEED_SORT");
-        bool own_sort = ssel && !strcmp(ssel, "own");
+        bool own_sort = !(ssel && !strcmp(ssel, "lib"));
         if (own_sort) {
-            // hits grouped by read (stable passes over the read bits only), then every read's run put in order in place
             uint64_t *grouped = nullptr;
             if ((e = pgrc_radix_sort_u64(c, (uint64_t *)c->s_hits.p, (uint64_t *)sorted.p, nhits, 36u, (uint32_t)end_bit, temp, &grouped))) return e;
-            const uint64_t mid_cap = std::max<uint64_t>(1024, nhits / SEED_RUN_SMALL + 1), big_cap = std::max<uint64_t>(1024, nhits / SEED_RUN_WAVE + 1);
-            DevBuf &runl = c->s_runs;                                 // (run lists: start, length; sized for the worst case)
-            if ((e = pgrc_buf_ensure(c, runl, (2 * (mid_cap + big_cap) + 4) * sizeof(uint64_t)))) return e;
-            uint64_t *midl = (uint64_t *)runl.p, *bigl = midl + 2 * mid_cap;
-            unsigned long long *counts = (unsigned long long *)(bigl + 2 * big_cap);
-            uint32_t *ovf = (uint32_t *)(counts + 2);
-            he = hipMemsetAsync(counts, 0, 24, c->stream);
-            if (he == hipSuccess) {
-                hipLaunchKernelGGL(k_seed_order_runs, dim3((uint32_t)((nhits + 255) / 256)), dim3(256), 0, c->stream, grouped, (uint64_t)nhits,
-                                   midl, bigl, counts, mid_cap, big_cap, ovf);
-                hipLaunchKernelGGL(k_seed_order_mid, dim3((uint32_t)c->num_cus * 4u), dim3(256), 0, c->stream, grouped, (const uint64_t *)midl,
-                                   (const unsigned long long *)counts, mid_cap);
-                hipLaunchKernelGGL(k_seed_order_big, dim3((uint32_t)c->num_cus), dim3(1024), 0, c->stream, grouped, (const uint64_t *)bigl,
-                                   (const unsigned long long *)counts, big_cap);
-                he = hipGetLastError();
-            }
-            uint32_t overflow = 0;
-            if (he == hipSuccess) he = hipMemcpyAsync(&overflow, ovf, sizeof overflow, hipMemcpyDeviceToHost, c->stream);
-            if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-            if (he != hipSuccess) { c->err = std::string("seed-index hit order: ") + hipGetErrorString(he); return PGRC_E_DEVICE; }
             sorted_hits = grouped;
-            if (overflow) {                                           // a read with more hits than a block sorts in LDS: the library's full sort
-                own_sort = false;
-                if (grouped != (uint64_t *)c->s_hits.p) HIP_TRY(c, hipMemcpyAsync(c->s_hits.p, grouped, nhits * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
-            }
         }
         if (!own_sort) {
             size_t temp_bytes = 0;
-            HIP_TRY(c, rocprim::radix_sort_keys(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)cap, 0, end_bit, c->stream));
+            HIP_TRY(c, rocprim::radix_sort_keys(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)cap, 36, end_bit, c->stream));
             if ((e = pgrc_buf_ensure(c, temp, temp_bytes))) return e;
-            he = rocprim::radix_sort_keys(temp.p, temp_bytes, (uint64_t *)c->s_hits.p, (uint64_t *)sorted.p, (size_t)nhits, 0, end_bit, c->stream);
+            // (by the read bits only: the replay takes a minimum over a read's hits, their order inside a read does not matter)
+            he = rocprim::radix_sort_keys(temp.p, temp_bytes, (uint64_t *)c->s_hits.p, (uint64_t *)sorted.p, (size_t)nhits, 36, end_bit, c->stream);
             sorted_hits = (const uint64_t *)sorted.p;
         }
         if (he == hipSuccess) he = hipMemsetAsync(c->s_rstart.p, 0xFF, a.n * sizeof(uint64_t), c->stream);

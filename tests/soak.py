@@ -63,7 +63,7 @@ def main():
         redo_any = "1" if rng.random() < 0.2 else ""
         from_end = "0" if rng.random() < 0.3 else ""
         spec = str(rng.choice(["", "", "", "0", "1", "3"]))
-        seedsort = "own" if rng.random() < 0.5 else ""
+        seedsort = "lib" if rng.random() < 0.5 else ""
         for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish), ("PGRC_SEED_SEGMENT", seg), ("PGRC_SEED_READ_BATCH", batch),
                          ("PGRC_MATCH_STAGE", stage), ("PGRC_EARLY_STOP", early), ("PGRC_SCREEN", screen), ("PGRC_DUAL", dual),
                          ("PGRC_HEAD_PAIR", pairk), ("PGRC_NREAD_INLINE", inline), ("PGRC_REDO_ANY", redo_any), ("PGRC_MATCH_FROM_END", from_end),
