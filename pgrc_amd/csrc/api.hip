@@ -845,6 +845,12 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
             swap_index_sets(c);
             c->screen_broken = true;
             screened = false;
+            if (c->index_strand != 0 || !c->ent_ptr) {
+                // (it was already the FORWARD index that found no room, e.g. for the pair table's share of it: once more on its
+                //  own, into a table of its own -- if that does not fit either, the run fails with PGRC_E_ALLOC)
+                if (c->head_sh) { (void)hipStreamSynchronize(c->stream); pgrc_buf_free(c->d_headpair); c->head_ptr = c->alt_head_ptr = nullptr; c->head_sh = c->alt_head_sh = 0; }
+                if ((e = pgrc_copmem_build_index(c, 0))) return e;
+            }
             mark(); // 3
             if ((e = pgrc_copmem_match_pass(c, 0))) return e;
             mark(); // 4
