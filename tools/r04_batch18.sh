@@ -1,0 +1,5 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-.}
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py -x -q -m gpu -k "seed or golden or mode or exact" > gpurun_out/r04_batch18_tests.log 2>&1; tail -3 gpurun_out/r04_batch18_tests.log
+MODES_DIGEST=1 timeout -k 10 300 python tools/modes_c3.py d i e > gpurun_out/r04_modes_c3_fused.jsonl 2> gpurun_out/r04_modes_c3_fused.err; cut -c1-230 gpurun_out/r04_modes_c3_fused.jsonl
+MODES_DIGEST=1 PGRC_SEED_FUSED=0 timeout -k 10 300 python tools/modes_c3.py d i e > gpurun_out/r04_modes_c3_unfused.jsonl 2> gpurun_out/r04_modes_c3_unfused.err; cut -c1-230 gpurun_out/r04_modes_c3_unfused.jsonl
