@@ -241,7 +241,7 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
     DevBuf *bufs[] = {&c->pg2[0], &c->pg2[1], &c->reads_own, &c->nread_idx, &c->nread_ascii, &c->nread_flag, &c->nread_npos, &c->d_pos,
                       &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_head, &c->d_headpair, &c->d_skey[0], &c->d_skey[1], &c->d_sval[0], &c->d_sval[1], &c->d_sorttmp,
                       &c->alt_head, &c->alt_skey[0], &c->alt_skey[1], &c->alt_sval[0], &c->alt_sval[1], &c->alt_sorttmp, &c->d_scr_pos, &c->d_scr_flag,
-                      &c->s_keys, &c->s_filter, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp, &c->s_sorted, &c->s_sorttmp, &c->s_mm, &c->s_rstart, &c->s_heavy, &c->s_nmask};
+                      &c->s_keys, &c->s_filter, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp, &c->s_nmask, &c->s_best, &c->s_rows};
     for (DevBuf *b : bufs) pgrc_buf_free(*b);
     for (DevBuf &b : c->up_nchunks) pgrc_buf_free(b);
     if (c->have_events)

@@ -146,8 +146,7 @@ struct pgrc_match_ctx {
     DevBuf s_keys, s_vals, s_tab, s_hits, s_tmp;
     DevBuf s_filter;        // modes d/i/e: one bit per slice of the key space (seedidx.hip)
     DevBuf s_nmask;                             // N masks of the reads with N (modes d/i/e)
-    DevBuf s_heavy;                             // reads handed to the wave-per-read replay
-    DevBuf s_sorted, s_sorttmp, s_mm, s_rstart; // sorted hits, rocPRIM scratch, Hamming count per hit, first hit per read
+    DevBuf s_best, s_rows;                      // the atomic-minimum reduction: one key per read, the batch's reads row by row (seedidx.hip 3c)
 
     // profiling
     bool profiling = false;

@@ -15,16 +15,14 @@
 //
 // MI355X design: the read-part keys go into an open-addressing table in HBM (atomicCAS insert, chained duplicates);
 // one thread per text position computes its window key from the 2-bit text and emits a HIT record
-// (read << 36 | text position << 4 | 15 - part) for every chained pattern; the hits are radix-sorted
-// (rocPRIM device radix sort -- a plain library primitive) so that each read's candidates come out in exactly the
-// reference's order (ascending text position, equal positions in descending part index); one thread per read then
-// replays the reference's sequential rule over its candidates with popcount Hamming on 2-bit words.
+// (read << 36 | text position << 4 | 15 - part) for every chained pattern; one thread per hit takes its Hamming count
+// (popcount on 2-bit words) and the reference's sequential rule over a read's candidates -- walked in scan order: ascending
+// text position, equal positions in descending part index -- is taken as the lexicographic minimum it amounts to, one
+// atomicMin per acceptable hit on a 64-bit key per read (section 3).  No sort, no library kernel.
 #include <cstdlib>
 #include <cstring>
 
 #include <algorithm>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "ctx.h"
 #include "devutil.h"
@@ -286,23 +284,7 @@ k_seed_scan(const SeedArgs a, uint64_t nwin, uint64_t pg_words_alloc, unsigned l
         if (off + x < cap) hits[off + x] = lbuf[wave][x];
 }
 
-// ---- 3. per-read sequential replay over its sorted candidates
-__device__ __forceinline__ uint32_t hamming_vs_text(const SeedArgs &a, uint64_t i, uint64_t p) {
-    uint32_t mm = 0;
-    const uint32_t *src = a.pg + (p >> 4);
-    const uint32_t b = ((uint32_t)p & 15u) * 2u;
-    const uint32_t nw = (a.L + 15) / 16;
-    uint32_t lo = src[0];
-    for (uint32_t w = 0; w < nw; w++) {
-        const uint32_t hi = src[w + 1];
-        const uint32_t tw = funnel_r(lo, hi, b);
-        const uint32_t rw = a.reads[(uint64_t)w * a.stride + i];
-        mm += mism2(tw, rw, sym_mask((int)w, 0, (int)a.L));
-        lo = hi;
-    }
-    return mm;
-}
-
+// ---- 3. the hits' Hamming counts and what the reference's rule leaves of them
 // reads with N: their packed words hold code 0 at the N positions; a 16-bit mask per word forces those symbols to count
 // as mismatches (an N equals no text symbol)
 __global__ void __launch_bounds__(256)
@@ -345,122 +327,123 @@ __device__ __forceinline__ uint64_t lower_bound_u32(const uint32_t *v, uint64_t 
     return lo;
 }
 
-// ---- the hits grouped by read: a stable radix sort over the read bits of the hit records (radix.hip; PGRC_SEED_SORT=lib: the
-// library's sort over the same bits).  Inside a read's run the hits stay in whatever order they arrived: the replay below takes a
-// minimum, not a walk.
-int pgrc_radix_sort_u64(pgrc_match_ctx *c, uint64_t *d_a, uint64_t *d_b, uint64_t n, uint32_t bit_lo, uint32_t bit_hi, DevBuf &scratch,
-                        uint64_t **sorted);
-
-// Hamming count of EVERY hit, one thread per hit (the replay below only compares counts with the read's current limit,
-// ReadsMatchers.cpp:315-319, so the full count serves every limit), and the first hit of every read.
-__global__ void __launch_bounds__(256)
-k_seed_hamming(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhits, uint8_t *__restrict__ mmv,
-               uint64_t *__restrict__ rstart) {
-    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= nhits) return;
-    const uint64_t hkey = hits[x];
-    const uint64_t i = hkey >> 36;
-    if (x == 0 || (hits[x - 1] >> 36) != i) rstart[i] = x;
-    const uint64_t tp = a.tbase + ((hkey >> 4) & 0xFFFFFFFFull);
-    const uint32_t j = 15u - (uint32_t)(hkey & 15u);
-    const uint64_t p = tp - part_offset(a, j);
-    uint32_t mm;
-    if (a.nflag && a.nflag[i]) mm = hamming_vs_text_n(a, i, lower_bound_u32(a.nidx, a.nn, (uint32_t)(i + a.ibase)), p);   // a read with N
-    else mm = hamming_vs_text(a, i, p);
-    mmv[x] = (uint8_t)min(mm, 255u);
-}
-
 // ---- 3b. what the reference's sequential rule leaves of a read's hits (ReadsMatchers.cpp:297-341, :198-230).  It walks the
 // hits in scan order -- ascending text position, at one position the parts in descending order: the low 36 bits of a hit
 // record, ascending -- and accepts a hit whose count is BELOW the read's current one (<= kmax for a read not matched yet),
 // until the count is <= kmin.  So it ends at the first hit with a count <= kmin if there is one, else at the first hit that
 // attains the smallest count: a lexicographic MINIMUM over the hits of (count <= kmin ? 0 : count, scan order), taken over the
-// hits with count <= the limit the read starts with.  A minimum needs the read's hits together, not in order (round 4: the
-// hit records are sorted by their read bits only -- 4 radix passes instead of 8).  The exact matcher (:198-230): the first hit
-// in scan order that equals the read.  (`stored == candidate -> skip`, :313-314, never changes the outcome: such a hit has the
-// stored alignment's own count, which is not below it.)
-#define REPLAY_HEAVY 64u
+// hits with count <= the limit the read starts with.  The exact matcher (:198-230): the first hit in scan order that equals the
+// read.  (`stored == candidate -> skip`, :313-314, never changes the outcome: such a hit has the stored alignment's own count,
+// which is not below it.)  A minimum does not need a read's hits together, let alone in order (rounds 1-3 sorted all 63 bits of
+// the hit records with the library and replayed the rule; round 4 first sorted the read bits only, then nothing at all):
+// it is one 64-bit atomicMin per acceptable hit on a key per read,
+//     count' (8 bits) | strand (1) | window start in the strand's text (40) | 15 - part (4) | unused (3) | count (8)
+// (count' = 0 for a count <= kmin; the count itself rides in the low bits, below everything that orders).  The strand bit makes
+// the two passes one minimum as well: the RC pass of the reference accepts a hit only with a count BELOW the forward result's
+// (ReadsMatchers.cpp:315-316 with the count the first pass left), i.e. at equal count' the forward hit wins, and a forward count
+// <= kmin (count' 0) is beaten by nothing.  A read's state before the run (a second-phase run, :304-305) is its start key:
+// all ones = not matched, count' << 56 with nothing below = matched with that count -- no hit has a smaller key at the same count',
+// a hit's low bits are never all zero (15 - part >= 1).  So: start keys, every strand and segment of the text scanned with the
+// hits' Hamming counts taken in whatever order the scan left them, one pass over the reads at the end.  The hits arrive in text
+// order, their reads are random: the Hamming kernel takes a read's words from a ROW-major copy of the batch (one or two lines per
+// hit instead of one per word).  The hits of one read alignment (one per part that matches) sit next to each other in the hit
+// buffer: a hit does not go to memory when a neighbouring lane holds a smaller key of the same read, nor when the key in
+// memory is already no larger (a plain load: the key only ever falls) -- random 64-bit atomics run at a sixth of the rate of
+// random loads.  C3, mode d (830 M hits per strand): sort + counts + replay 75 ms per strand -> 22 ms, 372 -> 260 ms per run
+// (profiles/r04_modes_c3.txt).
+#define BK_NONE 0xFFFFFFFFFFFFFFFFull
+#define BK_HITBITS ((1ull << 55) - 1ull)
 
-__device__ __forceinline__ uint64_t replay_key(const SeedArgs &a, uint64_t hkey, uint32_t mm, uint32_t limit0, bool exact) {
-    const bool ok = exact ? mm == 0u : mm <= limit0;
-    if (!ok) return ~0ull;
-    return ((uint64_t)(mm <= a.kmin ? 0u : mm) << 56) | (hkey & ((1ull << 36) - 1ull));
-}
-
-__device__ __forceinline__ void replay_store(const SeedArgs &a, uint64_t i, uint64_t best_key, uint32_t best_mm) {
-    const uint64_t tp = a.tbase + ((best_key >> 4) & 0xFFFFFFFFull);
-    const uint32_t j = 15u - (uint32_t)(best_key & 15u);
-    const uint64_t p = tp - part_offset(a, j);
-    a.pos[i] = a.strand ? a.G - (p + a.L) : p;
-    a.rc[i] = (uint8_t)a.strand;
-    a.mism[i] = (uint8_t)best_mm;
-}
-
-// Reads with more than REPLAY_HEAVY hits (tandem repeats: hundreds to thousands per read) would keep one lane -- and with it
-// the whole wave -- looping alone: they are handed to k_seed_replay_heavy, one wave each.
-__global__ void __launch_bounds__(256)
-k_seed_replay(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhits, const uint8_t *__restrict__ mmv,
-              const uint64_t *__restrict__ rstart, uint32_t *__restrict__ heavy, unsigned long long *__restrict__ nheavy) {
+__global__ void __launch_bounds__(256) k_seed_best_init(const SeedArgs a, uint64_t *__restrict__ best) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const uint32_t c = a.mism[i];
-    const bool exact = a.mode == 'e';
-    if (exact ? (a.pos[i] != PGRC_NOT_MATCHED_POS) : (c <= a.kmin)) return;   // :304-305 resp. an exact match found before
-    const uint32_t limit0 = (c == PGRC_NOT_MATCHED_CNT) ? a.kmax : c - 1u;   // :315-316
-    const uint64_t x0 = rstart[i];                              // all ones for a read without hits
-    uint64_t best = ~0ull;
-    uint32_t best_mm = 0;
-    for (uint64_t x = x0; x < nhits; x++) {
-        const uint64_t hkey = hits[x];
-        if ((hkey >> 36) != i) break;
-        if (x - x0 >= REPLAY_HEAVY) {                 // too many hits for one lane: a wave does this read
-            heavy[atomicAdd(nheavy, 1ull)] = (uint32_t)i;
-            return;
-        }
-        const uint32_t mm = mmv[x];
-        const uint64_t k = replay_key(a, hkey, mm, limit0, exact);
-        if (k < best) { best = k; best_mm = mm; }
-    }
-    if (best != ~0ull) replay_store(a, i, best, best_mm);
+    uint64_t k;
+    if (a.mode == 'e') k = a.pos[i] != PGRC_NOT_MATCHED_POS ? 0ull : BK_NONE;      // :198-230: a read matched before is left alone
+    else k = c == PGRC_NOT_MATCHED_CNT ? BK_NONE : (uint64_t)(c <= a.kmin ? 0u : c) << 56;
+    best[i] = k;
 }
 
-// One wave per heavy read: 64 hits at a time, the minimum over the lanes at the end.
-__global__ void __launch_bounds__(256)
-k_seed_replay_heavy(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhits, const uint8_t *__restrict__ mmv,
-                    const uint64_t *__restrict__ rstart, const uint32_t *__restrict__ heavy,
-                    const unsigned long long *__restrict__ nheavy) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    const unsigned long long nh = *nheavy;
-    const bool exact = a.mode == 'e';
-    for (uint64_t w = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < nh; w += nwaves) {
-        const uint64_t i = heavy[w];
-        const uint32_t c = a.mism[i];
-        const uint32_t limit0 = (c == PGRC_NOT_MATCHED_CNT) ? a.kmax : c - 1u;
-        uint64_t best = ~0ull;
-        uint32_t best_mm = 0;
-        for (uint64_t x = rstart[i];; x += 64) {
-            const uint64_t xi = x + lane;
-            bool mine = false;
-            if (xi < nhits) {
-                const uint64_t hkey = hits[xi];
-                mine = (hkey >> 36) == i;
-                if (mine) {
-                    const uint32_t mm = mmv[xi];
-                    const uint64_t k = replay_key(a, hkey, mm, limit0, exact);
-                    if (k < best) { best = k; best_mm = mm; }
-                }
-            }
-            if (__ballot(mine) != ~0ull) break;                                 // the run ended inside these 64
-        }
-        for (int o = 32; o > 0; o >>= 1) {                                      // the smallest key of the wave, and its count
-            const uint64_t ok = __shfl_xor(best, o, 64);
-            const uint32_t om = __shfl_xor(best_mm, o, 64);
-            if (ok < best) { best = ok; best_mm = om; }
-        }
-        if (lane == 0 && best != ~0ull) replay_store(a, i, best, best_mm);
-    }
+// word-major words of the batch -> rows of rw words (rw = words of a read rounded up to 4: 16-byte loads)
+#define ROWS_TPB 256
+__global__ void __launch_bounds__(ROWS_TPB) k_seed_rows(const SeedArgs a, uint32_t rw, uint32_t *__restrict__ rows) {
+    extern __shared__ uint32_t rt[];                       // [rw][ROWS_TPB + 1]
+    const uint64_t i0 = (uint64_t)blockIdx.x * ROWS_TPB;
+    const uint64_t i = i0 + threadIdx.x;
+    for (uint32_t w = 0; w < rw; w++) rt[w * (ROWS_TPB + 1) + threadIdx.x] = (w < a.nwr && i < a.n) ? a.reads[(uint64_t)w * a.stride + i] : 0u;
+    __syncthreads();
+    const uint64_t nrows = a.n - i0 < ROWS_TPB ? a.n - i0 : ROWS_TPB;
+    for (uint64_t k = threadIdx.x; k < nrows * rw; k += ROWS_TPB) rows[i0 * rw + k] = rt[(k % rw) * (ROWS_TPB + 1) + k / rw];
 }
+
+template <int RW4>   // rw / 4
+__device__ __forceinline__ uint32_t hamming_row_vs_text(const SeedArgs &a, const uint32_t *__restrict__ rows, uint64_t i, uint64_t p) {
+    const uint4 *row = (const uint4 *)(rows + i * (uint64_t)(RW4 * 4));
+    uint32_t r[RW4 * 4];
+#pragma unroll
+    for (int q = 0; q < RW4; q++) {
+        const uint4 v = row[q];
+        r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+    }
+    const uint32_t *src = a.pg + (p >> 4);
+    const uint32_t b = ((uint32_t)p & 15u) * 2u;
+    uint32_t mm = 0, lo = src[0];
+#pragma unroll
+    for (int w = 0; w < RW4 * 4; w++) {
+        if ((uint32_t)w < a.nwr) {
+            const uint32_t hi = src[w + 1];
+            mm += mism2(funnel_r(lo, hi, b), r[w], sym_mask(w, 0, (int)a.L));
+            lo = hi;
+        }
+    }
+    return mm;
+}
+
+template <int RW4>
+__global__ void __launch_bounds__(256)
+k_seed_hamming_min(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhits, const uint32_t *__restrict__ rows,
+                   uint64_t *__restrict__ best) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i = ~0ull, key = BK_NONE;                      // key == BK_NONE: nothing to offer
+    if (x < nhits) {
+        const uint64_t hkey = hits[x];
+        i = hkey >> 36;
+        const uint64_t tp = a.tbase + ((hkey >> 4) & 0xFFFFFFFFull);
+        const uint32_t j = 15u - (uint32_t)(hkey & 15u);
+        const uint64_t p = tp - part_offset(a, j);
+        uint32_t mm;
+        if (a.nflag && a.nflag[i]) mm = hamming_vs_text_n(a, i, lower_bound_u32(a.nidx, a.nn, (uint32_t)(i + a.ibase)), p);   // a read with N
+        else mm = hamming_row_vs_text<RW4>(a, rows, i, p);
+        if (a.mode == 'e' ? mm == 0u : mm <= a.kmax)        // ReadsMatchers.cpp:315-319 / :214: no limit a read can have lets the others in
+            key = ((uint64_t)(mm <= a.kmin ? 0u : mm) << 56) | ((uint64_t)a.strand << 55) | (tp << 15) | ((hkey & 15ull) << 11) | mm;
+    }
+    // a neighbour (two lanes either way) with a smaller key of the same read takes this hit's place; keys of one read differ
+    bool mine = key != BK_NONE;
+#pragma unroll
+    for (int d = 1; d <= 2; d++) {
+        const uint64_t iu = __shfl_up(i, d, 64), ku = __shfl_up(key, d, 64), id = __shfl_down(i, d, 64), kd = __shfl_down(key, d, 64);
+        const uint32_t lane = threadIdx.x & 63u;
+        if (lane >= (uint32_t)d && iu == i && ku < key) mine = false;
+        if (lane + (uint32_t)d < 64u && id == i && kd < key) mine = false;
+    }
+    if (!mine || best[i] <= key) return;
+    atomicMin((unsigned long long *)&best[i], (unsigned long long)key);
+}
+
+__global__ void __launch_bounds__(256) k_seed_best_store(const SeedArgs a, const uint64_t *__restrict__ best) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const uint64_t k = best[i];
+    if (k == BK_NONE || (k & BK_HITBITS) == 0ull) return;             // no acceptable hit: the read keeps what it had
+    const uint32_t strand = (uint32_t)(k >> 55) & 1u;
+    const uint64_t tp = (k >> 15) & ((1ull << 40) - 1ull);
+    const uint32_t j = 15u - (uint32_t)((k >> 11) & 15u);
+    const uint64_t p = tp - part_offset(a, j);
+    a.pos[i] = strand ? a.G - (p + a.L) : p;
+    a.rc[i] = (uint8_t)strand;
+    a.mism[i] = (uint8_t)(k & 0xFFu);
+}
+
 
 __global__ void __launch_bounds__(256) k_seed_table_init(uint64_t *keys, uint32_t *heads, uint64_t n) {
     for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (uint64_t)gridDim.x * blockDim.x) {
@@ -517,6 +500,16 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
         hipLaunchKernelGGL(k_seed_insert_ascii, dim3((uint32_t)((a.nn * a.P + 255) / 256)), dim3(256), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
 
+    // a read's hits become its result by the atomic minimum of section 3b: a start key per read, the batch's reads row by row
+    const uint32_t rw = (a.nwr + 3u) & ~3u;                 // <= 16: reads have at most 255 symbols (pgrc_match_create)
+    if (c->G >= (1ull << 40)) { c->err = "modes d/i/e: texts below 2^40 symbols"; return PGRC_E_PARAM; }
+    if ((e = pgrc_buf_ensure(c, c->s_best, a.n * sizeof(uint64_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->s_rows, a.n * rw * sizeof(uint32_t)))) return e;
+    hipLaunchKernelGGL(k_seed_best_init, dim3((uint32_t)((a.n + 255) / 256)), dim3(256), 0, c->stream, a, (uint64_t *)c->s_best.p);
+    hipLaunchKernelGGL(k_seed_rows, dim3((uint32_t)((a.n + ROWS_TPB - 1) / ROWS_TPB)), dim3(ROWS_TPB), rw * (ROWS_TPB + 1) * sizeof(uint32_t),
+                       c->stream, a, rw, (uint32_t *)c->s_rows.p);
+    HIP_TRY(c, hipGetLastError());
+
     unsigned long long *cursor = (unsigned long long *)c->s_tmp.p;
     for (int pass = first_strand; pass <= last_strand; pass++) {
         a.pg = (const uint32_t *)c->pg2[pass].p;
@@ -544,54 +537,26 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
                                                             // (growing these multi-GB buffers again costs more than the pass itself)
         }
         if (nhits == 0) continue;
-        int ibits = 1;                                      // only the key bits that can be set take part in the sort
-        while ((1ull << ibits) < a.n) ibits++;
-        const int end_bit = 36 + ibits;
-        // scratch lives in the context (grow-only): no hipMalloc / hipFree (= device synchronisation) per pass
-        DevBuf &sorted = c->s_sorted, &temp = c->s_sorttmp;
-        if ((e = pgrc_buf_ensure(c, sorted, cap * sizeof(uint64_t)))) return e;       // sized like the hit buffer: no regrow
-        if ((e = pgrc_buf_ensure(c, c->s_mm, cap))) return e;
-        if ((e = pgrc_buf_ensure(c, c->s_rstart, a.n * sizeof(uint64_t)))) return e;
-        if ((e = pgrc_buf_ensure(c, c->s_heavy, a.n * sizeof(uint32_t)))) return e;
-        hipError_t he = hipSuccess;
-        const uint64_t *sorted_hits = nullptr;
-        // Round 4: only the read bits are sorted (4 passes of 27 bits at C3 instead of 8 of 63: the replay is a minimum over a
-        // read's hits).  PGRC_SEED_SORT=lib: rocPRIM's radix sort over the same bits instead of radix.hip's passes.
-        const char *ssel = getenv("PGRC_SEED_SORT");
-        bool own_sort = !(ssel && !strcmp(ssel, "lib"));
-        if (own_sort) {
-            uint64_t *grouped = nullptr;
-            if ((e = pgrc_radix_sort_u64(c, (uint64_t *)c->s_hits.p, (uint64_t *)sorted.p, nhits, 36u, (uint32_t)end_bit, temp, &grouped))) return e;
-            sorted_hits = grouped;
+        // counts in scan order, one atomicMin per acceptable hit (the host does not wait for it: the next scan follows on the stream)
+        const dim3 hg((uint32_t)((nhits + 255) / 256));
+        const uint64_t *h = (const uint64_t *)c->s_hits.p;
+        const uint32_t *rows = (const uint32_t *)c->s_rows.p;
+        uint64_t *best = (uint64_t *)c->s_best.p;
+        switch (rw / 4u) {
+        case 1: hipLaunchKernelGGL(k_seed_hamming_min<1>, hg, dim3(256), 0, c->stream, a, h, (uint64_t)nhits, rows, best); break;
+        case 2: hipLaunchKernelGGL(k_seed_hamming_min<2>, hg, dim3(256), 0, c->stream, a, h, (uint64_t)nhits, rows, best); break;
+        case 3: hipLaunchKernelGGL(k_seed_hamming_min<3>, hg, dim3(256), 0, c->stream, a, h, (uint64_t)nhits, rows, best); break;
+        default: hipLaunchKernelGGL(k_seed_hamming_min<4>, hg, dim3(256), 0, c->stream, a, h, (uint64_t)nhits, rows, best); break;
         }
-        if (!own_sort) {
-            size_t temp_bytes = 0;
-            HIP_TRY(c, rocprim::radix_sort_keys(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)cap, 36, end_bit, c->stream));
-            if ((e = pgrc_buf_ensure(c, temp, temp_bytes))) return e;
-            // (by the read bits only: the replay takes a minimum over a read's hits, their order inside a read does not matter)
-            he = rocprim::radix_sort_keys(temp.p, temp_bytes, (uint64_t *)c->s_hits.p, (uint64_t *)sorted.p, (size_t)nhits, 36, end_bit, c->stream);
-            sorted_hits = (const uint64_t *)sorted.p;
-        }
-        if (he == hipSuccess) he = hipMemsetAsync(c->s_rstart.p, 0xFF, a.n * sizeof(uint64_t), c->stream);
-        unsigned long long *nheavy = cursor + 1;
-        if (he == hipSuccess) he = hipMemsetAsync(nheavy, 0, sizeof(unsigned long long), c->stream);
-        if (he == hipSuccess) {
-            hipLaunchKernelGGL(k_seed_hamming, dim3((uint32_t)((nhits + 255) / 256)), dim3(256), 0, c->stream, a,
-                               sorted_hits, (uint64_t)nhits, (uint8_t *)c->s_mm.p, (uint64_t *)c->s_rstart.p);
-            hipLaunchKernelGGL(k_seed_replay, dim3((uint32_t)((a.n + 255) / 256)), dim3(256), 0, c->stream, a,
-                               sorted_hits, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p,
-                               (uint32_t *)c->s_heavy.p, nheavy);
-            hipLaunchKernelGGL(k_seed_replay_heavy, dim3((uint32_t)c->num_cus * 8u), dim3(256), 0, c->stream, a,
-                               sorted_hits, (uint64_t)nhits, (const uint8_t *)c->s_mm.p, (const uint64_t *)c->s_rstart.p,
-                               (const uint32_t *)c->s_heavy.p, (const unsigned long long *)nheavy);
-            he = hipGetLastError();
-        }
-        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-        if (he != hipSuccess) { c->err = std::string("seed-index pass: ") + hipGetErrorString(he); return PGRC_E_DEVICE; }
+        HIP_TRY(c, hipGetLastError());
         c->ctr.candidates[pass] += nhits;
         }
         c->ctr.searched[pass] += a.n;
     }
+    // the keys that a hit has lowered become the reads' results
+    hipLaunchKernelGGL(k_seed_best_store, dim3((uint32_t)((a.n + 255) / 256)), dim3(256), 0, c->stream, a, (const uint64_t *)c->s_best.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return PGRC_OK;
 }
 

@@ -57,17 +57,16 @@ def main():
         dual = str(rng.choice(["", "1", "1", "0"]))         # one query per read over both strands: forced / where it pays / never
         screen = str(rng.choice(["", "", "0", "1"]))       # "" = the dual kernel where it applies       # ... the two passes in the reference's order (no exact-match screen)
         # round 4: the pair table by group size (0 = a table per strand), reads with few N's inside the dual kernel or not, the redo
-        # rule, chunks from the end or the start, the speculative first attempt, the hand-written hit order of modes d / i / e
+        # rule, chunks from the end or the start, the speculative first attempt
         pairk = str(rng.choice(["", "", "0", "1", "2", "3", "4"]))
         inline = "0" if rng.random() < 0.3 else ""
         redo_any = "1" if rng.random() < 0.2 else ""
         from_end = "0" if rng.random() < 0.3 else ""
         spec = str(rng.choice(["", "", "", "0", "1", "3"]))
-        seedsort = "lib" if rng.random() < 0.5 else ""
         for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish), ("PGRC_SEED_SEGMENT", seg), ("PGRC_SEED_READ_BATCH", batch),
                          ("PGRC_MATCH_STAGE", stage), ("PGRC_EARLY_STOP", early), ("PGRC_SCREEN", screen), ("PGRC_DUAL", dual),
                          ("PGRC_HEAD_PAIR", pairk), ("PGRC_NREAD_INLINE", inline), ("PGRC_REDO_ANY", redo_any), ("PGRC_MATCH_FROM_END", from_end),
-                         ("PGRC_SPEC_LIMIT", spec), ("PGRC_SEED_SORT", seedsort)):
+                         ("PGRC_SPEC_LIMIT", spec)):
             if val:
                 os.environ[key] = val
             else:
@@ -76,7 +75,7 @@ def main():
                       n_nset=nn if packed else None)
         what = dict(mode=mode, L=L, seed_len=seed_len, M=M, kmin=kmin, G=G, n=n, nn=nn, rev=rev, seed=seed, shards=shards,
                     packed=packed, variant=variant, finish=finish, seg=seg, batch=batch, stage=stage, early=early, screen=screen, dual=dual,
-                    pairk=pairk, inline=inline, redo_any=redo_any, from_end=from_end, spec=spec, seedsort=seedsort)
+                    pairk=pairk, inline=inline, redo_any=redo_any, from_end=from_end, spec=spec)
         for k in ("pos", "rc", "mism", "hist"):
             if not np.array_equal(np.asarray(g[k]), np.asarray(o[k])):
                 print("READS MISMATCH", what, k, flush=True)

@@ -526,14 +526,12 @@ def test_seedindex_modes_parity(mode, L, seed_len, M, shortcut, G, n, n_with_n):
         assert_same_results(g, r, "vs real reference")
 
 
-@pytest.mark.parametrize("sort", ["own", "lib"])
 @pytest.mark.parametrize("mode", ["d", "i", "e"])
-def test_seedindex_hits_grouped_by_read_and_reduced(monkeypatch, mode, sort):
-    """Round 4: the hit records are sorted by their read bits only (radix.hip's passes, or the library's sort over the same
-    bits) and the reference's sequential rule over a read's hits is taken as what it amounts to -- a lexicographic minimum of
-    (count <= kmin ? 0 : count, scan order) -- by one lane (up to 64 hits) or one wave per read.  Repeat families and a
-    tandem tract: runs of dozens to thousands of hits, in arbitrary order inside a read."""
-    monkeypatch.setenv("PGRC_SEED_SORT", sort)
+def test_seedindex_hits_reduced_by_atomic_minimum(mode):
+    """Round 4: the reference's sequential rule over a read's hits is taken as what it amounts to -- a lexicographic minimum of
+    (count <= kmin ? 0 : count, strand, scan order) -- one atomicMin per acceptable hit on a key per read, no sort at all
+    (seedidx.hip section 3b).  Repeat families and a tandem tract: runs of dozens to thousands of hits per read, arriving in
+    arbitrary order, many of them on the same key at once."""
     L, seed_len = (100, 25) if mode != "e" else (100, 100)
     pg, reads = make_inputs(300_000, 9000, L, seed=4242, pool_div=4, tandem_every=2)      # repeat families: runs of dozens of hits
     rng = np.random.default_rng(3)
@@ -544,12 +542,12 @@ def test_seedindex_hits_grouped_by_read_and_reduced(monkeypatch, mode, sort):
     kmax = 0 if mode == "e" else L // seed_len - 1
     o = orc.oracle_match(mode, pg, reads, seed_len, kmax, 0)
     g = gpu_match(mode, pg, reads, seed_len, kmax, 0)
-    assert_same_results(g, o, f"hits grouped by read ({sort}), mode {mode}")
+    assert_same_results(g, o, f"hits reduced by minimum, mode {mode}")
     if mode != "e":                                   # ... and with a lower bound on the count that ends a read's walk (upper-case modes)
         o2 = orc.oracle_match(mode, pg, reads, seed_len, kmax, kmax)
-        assert_same_results(gpu_match(mode, pg, reads, seed_len, kmax, kmax), o2, f"kmin = kmax ({sort}), mode {mode}")
+        assert_same_results(gpu_match(mode, pg, reads, seed_len, kmax, kmax), o2, f"kmin = kmax, mode {mode}")
         o3 = orc.oracle_match(mode, pg, reads, seed_len, kmax, 1)
-        assert_same_results(gpu_match(mode, pg, reads, seed_len, kmax, 1), o3, f"kmin = 1 ({sort}), mode {mode}")
+        assert_same_results(gpu_match(mode, pg, reads, seed_len, kmax, 1), o3, f"kmin = 1, mode {mode}")
 
 
 @pytest.mark.parametrize("mode", ["d", "i", "e"])

@@ -25,5 +25,5 @@ for mode in (sys.argv[1:] or ["d", "i", "c"]):
         dig = None
         _, _, _, hist, matched = ctx.get_results(arrays=False)
     print(json.dumps({"mode": mode, "digest": dig, "n": n, "L": L, "G": G, "seed": seed_len, "kmax": kmax, "best_s": min(ts), "first_s": ts[0],
-                      "reads_per_s": n / min(ts), "matched": matched, "free_gb": torch.cuda.mem_get_info()[0] / 2**30}), flush=True)
+                      "reads_per_s": n / min(ts), "matched": matched, "candidates": ctx.counters()["candidates"], "free_gb": torch.cuda.mem_get_info()[0] / 2**30}), flush=True)
     del ctx
