@@ -1,7 +1,8 @@
 // radix.hip -- a stable LSD radix sort of 64-bit records by a bit field, hand-written for gfx950 (no library call).
 //
 // Who sorts with it (round 4): the position order of the Pg-order export (export.hip: records = position << 32 | read,
-// ReadsMatchers.cpp:563-574), the hits of modes d / i / e (seedidx.hip) and the events of the Pg-vs-Pg matcher (mem.hip).
+// ReadsMatchers.cpp:563-574).  (The hits of modes d / i / e were sorted with it for part of round 4; they are reduced without
+// any sort now, seedidx.hip.  The events of the Pg-vs-Pg matcher, mem.hip, still take the library's pair sort.)
 //
 // One pass over `dbits` <= 8 key bits, tiles of RX_TILE consecutive records:
 //   k_rx_hist     every tile counts its records per digit (LDS atomics)        -> cnt[digit][tile]

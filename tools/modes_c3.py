@@ -24,6 +24,17 @@ for mode in (sys.argv[1:] or ["d", "i", "c"]):
     else:
         dig = None
         _, _, _, hist, matched = ctx.get_results(arrays=False)
-    print(json.dumps({"mode": mode, "digest": dig, "n": n, "L": L, "G": G, "seed": seed_len, "kmax": kmax, "best_s": min(ts), "first_s": ts[0],
+    # a roofline line for rows a5-a7 (SURVEY 8d's style of counting: the bytes the algorithm has to touch, whatever the design moves):
+    # per window start and strand one 8-byte table key; per hit the entry (4 B), the read's and the window's L symbols at 2 bits,
+    # the read's 8-byte key; per read its packed words and its three result fields.  The binding limit is the same as the dual
+    # kernel's: random line requests (one per window probe, ~3 per hit), not bytes.
+    P = 1 if mode == "e" else L // seed_len
+    nwin = G - (L if mode == "e" else seed_len * (P if mode == "i" else 1)) + 1
+    cand = ctx.counters()["candidates"]; hits = (cand[0] + cand[1]) // len(ts)      # (the counters add up over the runs)
+    alg_bytes = 2 * nwin * 8 + hits * (4 + 2 * ((L + 3) // 4) + 8) + n * (4 * nw + 10)
+    roof = {"bound": "hbm", "achieved": alg_bytes / min(ts) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg_bytes / min(ts) / 1e9 / 8000.0,
+            "algorithmic_bytes": alg_bytes, "windows_per_strand": nwin, "hits_per_run": hits,
+            "random_requests_estimate": 2 * nwin + 3 * hits + n * P, "requests_G_per_s": (2 * nwin + 3 * hits + n * P) / min(ts) / 1e9}
+    print(json.dumps({"mode": mode, "digest": dig, "roofline": roof, "n": n, "L": L, "G": G, "seed": seed_len, "kmax": kmax, "best_s": min(ts), "first_s": ts[0],
                       "reads_per_s": n / min(ts), "matched": matched, "candidates": ctx.counters()["candidates"], "free_gb": torch.cuda.mem_get_info()[0] / 2**30}), flush=True)
     del ctx
