@@ -538,8 +538,9 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
         }
         if (nhits == 0) continue;
         // counts in scan order, one atomicMin per acceptable hit (the host does not wait for it: the next scan follows on the stream)
-        // (launches of at most 2^30 hits: a grid of more than 2^31 threads came back with wrong results on this stack -- 3.7 G hits
-        //  in one launch, an experiment of round 4, profiles/r04_seed_scan_experiments.txt)
+        // (launches of at most 2^30 hits.  In an experiment of round 4 ONE launch of this kernel over 3.7 G hits gave wrong results
+        //  where the same hits in launches of 2^30 were right -- profiles/r04_seed_scan_experiments.txt; the cause was not found:
+        //  plain grids of up to 2^32 - 256 threads execute correctly, tools/ubench/biggrid.hip.  Kept as the tested shape.)
         const uint32_t *rows = (const uint32_t *)c->s_rows.p;
         uint64_t *best = (uint64_t *)c->s_best.p;
         for (uint64_t h0 = 0; h0 < nhits; h0 += 1ull << 30) {
@@ -591,7 +592,7 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
     }
     // limits of the 64-bit hit record (read 28 bits | position in the segment 32 bits | part 4 bits); the knobs force
     // small batches / segments so that tests cover the loops on small inputs
-    uint64_t batch = std::min<uint64_t>((1ull << 28) - 1, (1ull << 30) / a.P), seg = (1ull << 32) - 65536;   // (at most 2^30 (read, part) entries: one thread each, see the note on large grids in seedidx_batch)
+    uint64_t batch = std::min<uint64_t>((1ull << 28) - 1, (1ull << 30) / a.P), seg = (1ull << 32) - 65536;   // (at most 2^30 (read, part) entries per batch: the sizes the tests and the C3 runs cover)
     if (const char *k = getenv("PGRC_SEED_READ_BATCH")) batch = std::max<uint64_t>(1, strtoull(k, nullptr, 10));
     if (const char *k = getenv("PGRC_SEED_SEGMENT")) seg = std::max<uint64_t>(4096, strtoull(k, nullptr, 10));
     const uint32_t *d_nidx = (const uint32_t *)c->nread_idx.p;
