@@ -13,12 +13,20 @@
 //             DefaultReadsApproxMatcher :297-341, InterleavedReadsApproxMatcher :364-409 (strict improvement, the
 //             stored-position skip, limit = count-1), countSequenceMismatchesVsUnpacked SymbolsPackingFacility.cpp:344-374
 //
-// MI355X design: the read-part keys go into an open-addressing table in HBM (atomicCAS insert, chained duplicates);
-// one thread per text position computes its window key from the 2-bit text and emits a HIT record
-// (read << 36 | text position << 4 | 15 - part) for every chained pattern; one thread per hit takes its Hamming count
-// (popcount on 2-bit words) and the reference's sequential rule over a read's candidates -- walked in scan order: ascending
-// text position, equal positions in descending part index -- is taken as the lexicographic minimum it amounts to, one
-// atomicMin per acceptable hit on a 64-bit key per read (section 3).  No sort, no library kernel.
+// MI355X design (round 4, its fourth form; the measurements that led here: profiles/r04_seed_scan_experiments.txt).
+//   1. The read-part keys go into an open-addressing table in HBM whose slots own a contiguous RANGE of an entry array (counts by
+//      atomicAdd while inserting, one exclusive scan, one placement pass) -- no chains: what a text window matches is read as a
+//      stream, by any lane.
+//   2. ONE scan of the forward text serves both strands (canonical keys, SeedArgs), in two kernels: k_seed_probe finds every
+//      window's range (one 8-byte word per window start); k_seed_expand shares the entries of the windows of its stretch among its
+//      lanes (prefix sums over the range lengths, a binary search per entry), and the windows with many entries -- repeats, tandem
+//      tracts: whole runs of them in one stretch -- go to a list that k_seed_heavy's waves take from all over the chip.
+//   3. Every (window, entry) pair is a HIT: its Hamming count (popcount on 2-bit words, the read taken from a row-major copy) is
+//      computed on the spot, and the reference's sequential rule over a read's hits -- walked in scan order: ascending text
+//      position, equal positions in descending part index -- is taken as the lexicographic minimum it amounts to, one atomicMin
+//      per acceptable hit on a 64-bit key per read (section 3b).
+// No hit records, no sort, no guess of a buffer size (the first run of a context is as fast as the next), no library kernel, and
+// the host waits once per batch of reads.
 #include <cstdlib>
 #include <cstring>
 
@@ -28,7 +36,6 @@
 #include "devutil.h"
 
 #define SX_EMPTY 0xFFFFFFFFFFFFFFFFull
-#define SX_NIL 0xFFFFFFFFu
 
 // two fixed 32-bit tables over the symbol values A0 C1 G2 T3 N4
 __device__ __forceinline__ uint32_t cyc_t0(uint32_t v) {
@@ -38,6 +45,12 @@ __device__ __forceinline__ uint32_t cyc_t1(uint32_t v) {
     return v == 0 ? 0xBF58476Du : v == 1 ? 0x1CE4E5B9u : v == 2 ? 0x94D049BBu : v == 3 ? 0x133111EBu : 0x2545F491u;
 }
 __device__ __forceinline__ uint32_t rotl1(uint32_t x) { return (x << 1) | (x >> 31); }
+__device__ __forceinline__ uint32_t rotr1(uint32_t x) { return (x >> 1) | (x << 31); }
+__device__ __forceinline__ uint32_t rotlk(uint32_t x, uint32_t k) { k &= 31u; return k ? (x << k) | (x >> (32u - k)) : x; }
+// the same tables over the COMPLEMENT of a symbol (N is its own): key of the reverse complement of s[0 .. m) =
+// XOR_k rotl(table(comp(s[k])), k) -- the cyclic polynomial of the reversed, complemented sequence
+__device__ __forceinline__ uint32_t cyc_c0(uint32_t v) { return cyc_t0(v < 4u ? 3u - v : 4u); }
+__device__ __forceinline__ uint32_t cyc_c1(uint32_t v) { return cyc_t1(v < 4u ? 3u - v : 4u); }
 __device__ __forceinline__ uint64_t mix64d(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -49,7 +62,8 @@ __device__ __forceinline__ uint64_t key_fix(uint32_t h0, uint32_t h1) {
 }
 
 struct SeedArgs {
-    const uint32_t *pg;
+    const uint32_t *pg;        // the forward text
+    const uint32_t *pg_rc;     // the RC text (Hamming counts of the RC strand's hits)
     uint64_t G;
     const uint32_t *reads;
     uint64_t n, stride;
@@ -61,18 +75,35 @@ struct SeedArgs {
     uint64_t nn;
     uint32_t L, m, P, cstride; // m = pattern length, P = parts, cstride = symbol stride inside a part (P for mode i)
     uint32_t mode;             // 'd', 'i', 'e'
-    uint32_t kmax, kmin, strand;
-    uint64_t tbase;            // first window start of the text segment being scanned (hit records keep 32-bit offsets from it)
+    uint32_t kmax, kmin;
     uint64_t ibase;            // first read of the batch (reads / result pointers are already offset; nidx holds set-wide indexes)
+    // the table: slot s holds a key and owns the entries ent[toff[s] .. toff[s + 1])
     uint64_t *tkeys;
-    uint32_t *theads;
+    uint32_t *toff;            // while inserting: entries per slot; after the scan: first entry of the slot (tsize + 1 words)
     uint64_t tmask;
+    uint32_t *eslot, *erank;   // per entry (read, part): its slot (bit 31: the flag below) and its rank among the slot's entries
+    uint32_t *ent;             // entry index | flag << 31, grouped by slot
     uint32_t *filter;          // one bit per 2^-fbits of the key space: set iff some indexed key falls there
     uint32_t fshift;           // 64 - fbits: the filter takes the TOP bits of the mixed key, the table its low bits
-    uint32_t *next;
+    // Both strands in ONE scan of the forward text.  A part is indexed under its CANONICAL key: the smaller of the key of the
+    // part and the key of its reverse complement, with a flag saying which.  A window of the forward text has both keys as well
+    // (each rolls in O(1)), probes once with the smaller one and carries the same flag: equal flags = the window equals the part,
+    // a hit of the forward strand at its start t; different flags = it equals the part's reverse complement, i.e. the part occurs
+    // in the RC text at window start rc_top - t, rc_top = G - 1 - (m - 1) * cstride (the window's last symbol is the RC window's
+    // first).  "Equals" is the equivalence of the header: the rotation classes of the forward and of the reverse-complement
+    // polynomial are the same sets of positions and complementing is a bijection of the symbols, so two sequences collide under
+    // one iff they collide under the other, and u ~ v iff rc(u) ~ rc(v): the candidates of either strand are exactly the
+    // reference's.  A window whose two keys are equal (it is equivalent to its own reverse complement) is a hit of BOTH strands for
+    // the parts with equal keys -- flag 0 -- and of neither for the others under that key (which only a chance collision of all 64
+    // bits puts there).  Each strand has the window starts [0, nwin_all); with cstride > 1 the extent the reference gives a window
+    // (m * cstride) is cstride - 1 more than it covers, so the scan walks the starts [0, rc_top] and each strand takes its own range.
+    uint32_t want;             // bit 0: hits of the forward strand wanted, bit 1: of the RC strand
+    uint64_t nwin_all, rc_top;
     uint64_t *pos;
     uint8_t *rc, *mism;
 };
+
+#define SX_FLAG 0x80000000u
 
 __device__ __forceinline__ uint32_t read_code(const SeedArgs &a, uint64_t i, uint32_t x) {
     return (a.reads[(uint64_t)(x >> 4) * a.stride + i] >> (2u * (x & 15u))) & 3u;
@@ -80,8 +111,11 @@ __device__ __forceinline__ uint32_t read_code(const SeedArgs &a, uint64_t i, uin
 __device__ __forceinline__ uint32_t ascii_val(uint8_t ch) { return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u; }
 __device__ __forceinline__ uint32_t part_offset(const SeedArgs &a, uint32_t j) { return a.mode == 'i' ? j : j * a.m; }
 
-// ---- 1. insert every (read, part) key
-__device__ __forceinline__ void table_insert(const SeedArgs &a, uint64_t key, uint32_t e) {
+// ---- 1. the table: every (read, part) entry finds the slot of its canonical key and takes a rank there; the counts become
+// the slots' ranges; the entries go to their places
+__device__ __forceinline__ void table_insert(const SeedArgs &a, uint64_t kf, uint64_t kr, uint32_t e) {
+    const uint64_t key = kr < kf ? kr : kf;                       // canonical (SeedArgs)
+    const uint32_t flag = kr < kf ? SX_FLAG : 0u;
     const uint64_t mixed = mix64d(key);
     if (a.filter) {
         const uint64_t fb = mixed >> a.fshift;
@@ -91,7 +125,8 @@ __device__ __forceinline__ void table_insert(const SeedArgs &a, uint64_t key, ui
     for (;;) {
         const unsigned long long prev = atomicCAS((unsigned long long *)&a.tkeys[slot], (unsigned long long)SX_EMPTY, (unsigned long long)key);
         if (prev == SX_EMPTY || prev == key) {
-            a.next[e] = atomicExch(&a.theads[slot], e);
+            a.erank[e] = atomicAdd(&a.toff[slot], 1u);
+            a.eslot[e] = (uint32_t)slot | flag;
             return;
         }
         slot = (slot + 1) & a.tmask;
@@ -105,13 +140,15 @@ __global__ void __launch_bounds__(256) k_seed_insert(const SeedArgs a) {
     const uint32_t j = (uint32_t)(e % a.P);
     if (a.nflag && a.nflag[i]) return; // byte-path reads are inserted by k_seed_insert_ascii
     const uint32_t off = part_offset(a, j);
-    uint32_t h0 = 0, h1 = 0;
+    uint32_t h0 = 0, h1 = 0, g0 = 0, g1 = 0;
     for (uint32_t k = 0; k < a.m; k++) {
         const uint32_t c = read_code(a, i, off + k * a.cstride);
         h0 = rotl1(h0) ^ cyc_t0(c);
         h1 = rotl1(h1) ^ cyc_t1(c);
+        g0 ^= rotlk(cyc_c0(c), k);
+        g1 ^= rotlk(cyc_c1(c), k);
     }
-    table_insert(a, key_fix(h0, h1), (uint32_t)e);
+    table_insert(a, key_fix(h0, h1), key_fix(g0, g1), (uint32_t)e);
 }
 
 __global__ void __launch_bounds__(256) k_seed_insert_ascii(const SeedArgs a) {
@@ -122,166 +159,22 @@ __global__ void __launch_bounds__(256) k_seed_insert_ascii(const SeedArgs a) {
     const uint64_t i = a.nidx[t] - a.ibase;
     const uint8_t *row = a.nascii + t * a.L;
     const uint32_t off = part_offset(a, j);
-    uint32_t h0 = 0, h1 = 0;
+    uint32_t h0 = 0, h1 = 0, g0 = 0, g1 = 0;
     for (uint32_t k = 0; k < a.m; k++) {
         const uint32_t c = ascii_val(row[off + k * a.cstride]);
         h0 = rotl1(h0) ^ cyc_t0(c);
         h1 = rotl1(h1) ^ cyc_t1(c);
+        g0 ^= rotlk(cyc_c0(c), k);
+        g1 ^= rotlk(cyc_c1(c), k);
     }
-    table_insert(a, key_fix(h0, h1), (uint32_t)(i * a.P + j));
+    table_insert(a, key_fix(h0, h1), key_fix(g0, g1), (uint32_t)(i * a.P + j));
 }
 
-// ---- 2. stream the text past the table.  A block stages its stretch of the text in LDS; a thread walks SCAN_R window
-// starts that are cstride apart with the O(1) rolling update of the cyclic polynomial (the reference's own scan,
-// cyclichash.h:110-118) and probes the table for each; hits are appended with ONE atomic per wave and iteration
-// into per-wave LDS buffers (the fill count is wave-uniform: a register, no LDS atomic) that are flushed with one
-// global atomic per block at the end -- or per wave and 512 hits when a buffer fills up (tandem repeats).  Same-address
-// returning atomics serialise at ~90 M/s: one per hit, or even one per wave and iteration (4 M at C2), made the
-// cursor the whole cost of this kernel, and a spill path that did so turned C3-size runs into seconds.  Single pass: the hit buffer is sized by a guess, the cursor keeps counting past its end, and
-// the host reruns the pass with the exact size if it overflowed.
-#define SCAN_TPB 256
-#define SCAN_R 16
-#define SCAN_TILE_WORDS (SCAN_TPB * SCAN_R / 16 + 24)
-#define SCAN_WCAP 512u     // hit records per wave buffer
-#define SCAN_B 8
-__global__ void __launch_bounds__(SCAN_TPB)
-k_seed_scan(const SeedArgs a, uint64_t nwin, uint64_t pg_words_alloc, unsigned long long *cursor, uint64_t *hits, uint64_t cap) {
-    // windows [a.tbase, nwin) of the text: one segment of fewer than 2^32 window starts
-    __shared__ uint32_t tile[SCAN_TILE_WORDS];
-    __shared__ uint64_t lbuf[SCAN_TPB / 64][SCAN_WCAP];
-    __shared__ uint32_t wtotal[SCAN_TPB / 64];
-    __shared__ unsigned long long gbase;
-    const uint32_t wave = threadIdx.x >> 6;
-    uint32_t wcount = 0;                                  // records in this wave's buffer (wave-uniform)
-    const uint32_t cs = a.cstride, m = a.m;
-    const uint32_t groups = SCAN_TPB / cs;               // runs of SCAN_R * cs consecutive starts, one thread per phase
-    const uint32_t per_block = groups * cs * SCAN_R;
-    const uint64_t b0 = a.tbase + (uint64_t)blockIdx.x * per_block;
-    const uint64_t w0 = b0 >> 4;
-    const uint32_t need = (uint32_t)(((b0 & 15) + per_block + (uint64_t)m * cs + 15) >> 4) + 1;   // <= SCAN_TILE_WORDS
-    for (uint32_t w = threadIdx.x; w < need; w += SCAN_TPB) tile[w] = (w0 + w < pg_words_alloc) ? a.pg[w0 + w] : 0u;
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u;
-    const bool worker = threadIdx.x < groups * cs;
-    const uint32_t g = threadIdx.x / cs, phase = threadIdx.x % cs;
-    const uint64_t s0 = b0 + (uint64_t)g * cs * SCAN_R + phase;
-    const uint32_t x0 = (uint32_t)(s0 - (w0 << 4));       // tile-relative symbol index of s0
-    auto sym = [&](uint32_t x) -> uint32_t { return (tile[x >> 4] >> (2u * (x & 15u))) & 3u; };
-    uint32_t h0 = 0, h1 = 0;
-    if (worker)
-        for (uint32_t k = 0; k < m; k++) {
-            const uint32_t c = sym(x0 + k * cs);
-            h0 = rotl1(h0) ^ cyc_t0(c);
-            h1 = rotl1(h1) ^ cyc_t1(c);
-        }
-    const uint32_t mr = m & 31u;
-    // batches of SCAN_B window starts: all keys of a batch first (rolling), then their table probes as independent
-    // loads, then the heads of the keys found -- a dependent round trip per batch instead of one per start
-    for (uint32_t r0 = 0; r0 < SCAN_R; r0 += SCAN_B) {
-        uint64_t keyv[SCAN_B], slotv[SCAN_B], kv[SCAN_B];
-        uint32_t ev[SCAN_B], fw[SCAN_B], fbit[SCAN_B];
-#pragma unroll
-        for (int b = 0; b < SCAN_B; b++) {
-            keyv[b] = key_fix(h0, h1);
-            const uint64_t mixed = mix64d(keyv[b]);
-            slotv[b] = mixed & a.tmask;
-            fbit[b] = (uint32_t)((mixed >> a.fshift) & 31u);
-            fw[b] = (uint32_t)(mixed >> a.fshift >> 5);
-            if (worker) {                                     // roll to the next start (cyclichash.h:110-118)
-                const uint32_t xo = x0 + (r0 + b) * cs;
-                const uint32_t co = sym(xo), cn = sym(xo + m * cs);
-                const uint32_t o0 = cyc_t0(co), o1 = cyc_t1(co);
-                h0 = rotl1(h0) ^ ((o0 << mr) | (mr ? o0 >> (32u - mr) : 0u)) ^ cyc_t0(cn);
-                h1 = rotl1(h1) ^ ((o1 << mr) | (mr ? o1 >> (32u - mr) : 0u)) ^ cyc_t1(cn);
-            }
-        }
-        // the filter first: a window whose bit is clear equals no indexed key -- one 4-byte gather in a bitmap of a thirty-second
-        // of the table's bytes; only the windows that pass (the hits and ~3 % more) go on to the table, whose probes each
-        // cost a random line of their own, collision steps included (the line of the previous slot is long gone from L1 / L2)
-#pragma unroll
-        for (int b = 0; b < SCAN_B; b++) {
-            const uint64_t t = s0 + (uint64_t)(r0 + b) * cs;
-            fw[b] = (worker && t < nwin) ? (a.filter ? a.filter[fw[b]] : 0xFFFFFFFFu) : 0u;
-        }
-#pragma unroll
-        for (int b = 0; b < SCAN_B; b++) kv[b] = ((fw[b] >> fbit[b]) & 1u) ? a.tkeys[slotv[b]] : SX_EMPTY;
-        // collisions (the slot holds another key) of the whole batch are resolved together: every round issues the
-        // next-slot loads of all starts still searching before any of them is looked at
-        uint32_t srch = 0, fnd = 0;
-#pragma unroll
-        for (int b = 0; b < SCAN_B; b++) {
-            if (kv[b] == keyv[b]) fnd |= 1u << b;
-            else if (kv[b] != SX_EMPTY) srch |= 1u << b;
-        }
-        while (__any(srch != 0)) {
-#pragma unroll
-            for (int b = 0; b < SCAN_B; b++)
-                if (srch & (1u << b)) {
-                    slotv[b] = (slotv[b] + 1) & a.tmask;
-                    kv[b] = a.tkeys[slotv[b]];
-                }
-#pragma unroll
-            for (int b = 0; b < SCAN_B; b++)
-                if (srch & (1u << b)) {
-                    if (kv[b] == SX_EMPTY) srch &= ~(1u << b);
-                    else if (kv[b] == keyv[b]) { fnd |= 1u << b; srch &= ~(1u << b); }
-                }
-        }
-#pragma unroll
-        for (int b = 0; b < SCAN_B; b++) ev[b] = (fnd & (1u << b)) ? a.theads[slotv[b]] : SX_NIL;
-        // the chains of the batch are walked together as well (one round = the next link of every live chain)
-        for (;;) {
-            uint32_t live = 0;
-#pragma unroll
-            for (int b = 0; b < SCAN_B; b++) live |= (ev[b] != SX_NIL) ? 1u << b : 0u;
-            if (!__any(live != 0)) break;
-            uint32_t nx[SCAN_B];
-#pragma unroll
-            for (int b = 0; b < SCAN_B; b++) nx[b] = (live & (1u << b)) ? a.next[ev[b]] : SX_NIL;
-#pragma unroll
-            for (int b = 0; b < SCAN_B; b++) {
-                const uint64_t t = s0 + (uint64_t)(r0 + b) * cs;
-                bool emit = false;
-                uint64_t rec = 0;
-                if (live & (1u << b)) {
-                    const uint32_t e = ev[b];
-                    const uint64_t i = e / a.P;
-                    const uint32_t j = e % a.P;
-                    const uint64_t shift = part_offset(a, j);
-                    // ReadsMatchers.cpp:308-309 / :375-376 and :311-312 / :378-379
-                    if (shift <= t && t - shift + a.L <= a.G) { emit = true; rec = (i << 36) | ((t - a.tbase) << 4) | (15u - j); }
-                }
-                const unsigned long long mk = __ballot(emit);
-                if (mk) {
-                    const uint32_t cnt = (uint32_t)__popcll(mk);
-                    if (wcount + cnt > SCAN_WCAP) {              // buffer full: this wave flushes it (one atomic per 512 hits)
-                        unsigned long long base = 0;
-                        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)wcount);
-                        base = __shfl(base, 0, 64);
-                        for (uint32_t x = lane; x < wcount; x += 64)
-                            if (base + x < cap) hits[base + x] = lbuf[wave][x];
-                        wcount = 0;
-                    }
-                    if (emit) lbuf[wave][wcount + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = rec;
-                    wcount += cnt;
-                }
-                ev[b] = nx[b];
-            }
-        }
-    }
-    // what is left in the wave buffers leaves with one global atomic per block
-    if (lane == 0) wtotal[wave] = wcount;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (uint32_t w = 0; w < SCAN_TPB / 64; w++) tot += wtotal[w];
-        gbase = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
-    }
-    __syncthreads();
-    unsigned long long off = gbase;
-    for (uint32_t w = 0; w < wave; w++) off += wtotal[w];
-    for (uint32_t x = lane; x < wcount; x += 64)
-        if (off + x < cap) hits[off + x] = lbuf[wave][x];
+__global__ void __launch_bounds__(256) k_seed_place(const SeedArgs a, uint64_t nent) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nent) return;
+    const uint32_t w = a.eslot[e];
+    a.ent[a.toff[w & ~SX_FLAG] + a.erank[e]] = (uint32_t)e | (w & SX_FLAG);
 }
 
 // ---- 3. the hits' Hamming counts and what the reference's rule leaves of them
@@ -299,9 +192,9 @@ k_seed_nmask(const uint8_t *__restrict__ nascii, uint64_t nn, uint32_t L, uint32
     nmask[x] = (uint16_t)m;
 }
 
-__device__ __forceinline__ uint32_t hamming_vs_text_n(const SeedArgs &a, uint64_t i, uint64_t trow, uint64_t p) {
+__device__ __forceinline__ uint32_t hamming_vs_text_n(const SeedArgs &a, const uint32_t *__restrict__ text, uint64_t i, uint64_t trow, uint64_t p) {
     uint32_t mm = 0;
-    const uint32_t *src = a.pg + (p >> 4);
+    const uint32_t *src = text + (p >> 4);
     const uint32_t b = ((uint32_t)p & 15u) * 2u;
     uint32_t lo = src[0];
     for (uint32_t w = 0; w < a.nwr; w++) {
@@ -343,14 +236,11 @@ __device__ __forceinline__ uint64_t lower_bound_u32(const uint32_t *v, uint64_t 
 // (ReadsMatchers.cpp:315-316 with the count the first pass left), i.e. at equal count' the forward hit wins, and a forward count
 // <= kmin (count' 0) is beaten by nothing.  A read's state before the run (a second-phase run, :304-305) is its start key:
 // all ones = not matched, count' << 56 with nothing below = matched with that count -- no hit has a smaller key at the same count',
-// a hit's low bits are never all zero (15 - part >= 1).  So: start keys, every strand and segment of the text scanned with the
-// hits' Hamming counts taken in whatever order the scan left them, one pass over the reads at the end.  The hits arrive in text
-// order, their reads are random: the Hamming kernel takes a read's words from a ROW-major copy of the batch (one or two lines per
-// hit instead of one per word).  The hits of one read alignment (one per part that matches) sit next to each other in the hit
-// buffer: a hit does not go to memory when a neighbouring lane holds a smaller key of the same read, nor when the key in
-// memory is already no larger (a plain load: the key only ever falls) -- random 64-bit atomics run at a sixth of the rate of
-// random loads.  C3, mode d (830 M hits per strand): sort + counts + replay 75 ms per strand -> 22 ms, 372 -> 260 ms per run
-// (profiles/r04_modes_c3.txt).
+// a hit's low bits are never all zero (15 - part >= 1).  So: start keys, the text scanned in any number of launches, in any order,
+// every hit's Hamming count taken where the hit is found, one pass over the reads at the end.  A hit's read is random: its words
+// come from a ROW-major copy of the batch (one or two lines per hit instead of one per word).  A hit does not go to memory when
+// the key in memory is already no larger (a plain load: the key only ever falls) -- random 64-bit atomics run at a sixth of the
+// rate of random loads, and the parts of one alignment bring the same key up to P times.
 #define BK_NONE 0xFFFFFFFFFFFFFFFFull
 #define BK_HITBITS ((1ull << 55) - 1ull)
 
@@ -377,7 +267,7 @@ __global__ void __launch_bounds__(ROWS_TPB) k_seed_rows(const SeedArgs a, uint32
 }
 
 template <int RW4>   // rw / 4
-__device__ __forceinline__ uint32_t hamming_row_vs_text(const SeedArgs &a, const uint32_t *__restrict__ rows, uint64_t i, uint64_t p) {
+__device__ __forceinline__ uint32_t hamming_row_vs_text(const SeedArgs &a, const uint32_t *__restrict__ text, const uint32_t *__restrict__ rows, uint64_t i, uint64_t p) {
     const uint4 *row = (const uint4 *)(rows + i * (uint64_t)(RW4 * 4));
     uint32_t r[RW4 * 4];
 #pragma unroll
@@ -385,7 +275,7 @@ __device__ __forceinline__ uint32_t hamming_row_vs_text(const SeedArgs &a, const
         const uint4 v = row[q];
         r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
     }
-    const uint32_t *src = a.pg + (p >> 4);
+    const uint32_t *src = text + (p >> 4);
     const uint32_t b = ((uint32_t)p & 15u) * 2u;
     uint32_t mm = 0, lo = src[0];
 #pragma unroll
@@ -399,35 +289,288 @@ __device__ __forceinline__ uint32_t hamming_row_vs_text(const SeedArgs &a, const
     return mm;
 }
 
-template <int RW4>
-__global__ void __launch_bounds__(256)
-k_seed_hamming_min(const SeedArgs a, const uint64_t *__restrict__ hits, uint64_t nhits, const uint32_t *__restrict__ rows,
-                   uint64_t *__restrict__ best) {
-    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t i = ~0ull, key = BK_NONE;                      // key == BK_NONE: nothing to offer
-    if (x < nhits) {
-        const uint64_t hkey = hits[x];
-        i = hkey >> 36;
-        const uint64_t tp = a.tbase + ((hkey >> 4) & 0xFFFFFFFFull);
-        const uint32_t j = 15u - (uint32_t)(hkey & 15u);
-        const uint64_t p = tp - part_offset(a, j);
-        uint32_t mm;
-        if (a.nflag && a.nflag[i]) mm = hamming_vs_text_n(a, i, lower_bound_u32(a.nidx, a.nn, (uint32_t)(i + a.ibase)), p);   // a read with N
-        else mm = hamming_row_vs_text<RW4>(a, rows, i, p);
-        if (a.mode == 'e' ? mm == 0u : mm <= a.kmax)        // ReadsMatchers.cpp:315-319 / :214: no limit a read can have lets the others in
-            key = ((uint64_t)(mm <= a.kmin ? 0u : mm) << 56) | ((uint64_t)a.strand << 55) | (tp << 15) | ((hkey & 15ull) << 11) | mm;
-    }
-    // a neighbour (two lanes either way) with a smaller key of the same read takes this hit's place; keys of one read differ
-    bool mine = key != BK_NONE;
+// ---- 2. stream the text past the table, in two kernels.
+// k_seed_probe: a block stages its stretch of the text in LDS; a thread walks SCAN_R window starts that are cstride apart with
+// the O(1) rolling update of the cyclic polynomial (the reference's own scan, cyclichash.h:110-118) -- both keys of a window --
+// and probes the table for each: all keys of the thread first, then their probes as independent loads, collisions of all of them
+// resolved together.  What a window found goes out as ONE 8-byte word per window start, found or not:
+//     first entry (30 bits) | entries (31) | the RC key is the canonical one (bit 62) | equal keys (bit 63);   0 = no key found.
+// k_seed_expand: a block takes the words of EXP_WIN consecutive window starts, lists the windows that found a key in LDS, and its
+// threads take the list's (window, entry) pairs in turn, whoever found them: pair o belongs to the window f with
+// prefix[f] <= o < prefix[f + 1] (binary search in LDS), entry o - prefix[f] of its range -- a read's index and part, a strand, an
+// alignment, its Hamming count, its key, one atomicMin.  Why two kernels: the probing needs its registers for loads in flight
+// (8 windows per lane), a hit needs few and thrives on resident threads -- fused in one kernel (110 registers, 1024 threads per CU)
+// the hits took 118 ms at C3 where they take half of that with 2048 threads per CU; and why ranges instead of the chains of a
+// node-based table: a chain costs a dependent gather per entry and leaves a wave waiting for its longest one (the planted repeats
+// of the synthetic Pg: 0.9 entries per window on average, dozens for some); ranges are read as streams, by any lane.
+#define SCAN_TPB 256
+#define SCAN_R 8
+#define SCAN_TILE_WORDS (SCAN_TPB * SCAN_R / 16 + 24)
+#define WREC_CNT_SH 30u
+#define WREC_OFF_MASK ((1ull << WREC_CNT_SH) - 1ull)
+#define WREC_CNT_MASK ((1ull << 31) - 1ull)
+template <bool FILTER>
+__global__ void __launch_bounds__(SCAN_TPB)
+k_seed_probe(const SeedArgs a, uint64_t wbase, uint64_t nwin, uint64_t pg_words_alloc, uint64_t *__restrict__ wrec) {
+    // window starts [wbase, nwin) of the FORWARD text; wrec[t - wbase] for every one of them
+    __shared__ uint32_t tile[SCAN_TILE_WORDS];
+    __shared__ uint64_t wst[SCAN_TPB * SCAN_R];
+    const uint32_t cs = a.cstride, m = a.m;
+    const uint32_t groups = SCAN_TPB / cs;               // runs of SCAN_R * cs consecutive starts, one thread per phase
+    const uint32_t per_block = groups * cs * SCAN_R;
+    const uint64_t b0 = wbase + (uint64_t)blockIdx.x * per_block;
+    const uint64_t w0 = b0 >> 4;
+    const uint32_t need = (uint32_t)(((b0 & 15) + per_block + (uint64_t)m * cs + 15) >> 4) + 1;   // <= SCAN_TILE_WORDS
+    for (uint32_t w = threadIdx.x; w < need; w += SCAN_TPB) tile[w] = (w0 + w < pg_words_alloc) ? a.pg[w0 + w] : 0u;
+    __syncthreads();
+    const bool worker = threadIdx.x < groups * cs;
+    const uint32_t g = threadIdx.x / cs, phase = threadIdx.x % cs;
+    const uint32_t so = g * cs * SCAN_R + phase;          // this thread's first start, relative to b0
+    const uint32_t x0 = (uint32_t)(b0 + so - (w0 << 4));  // its tile-relative symbol index
+    auto sym = [&](uint32_t x) -> uint32_t { return (tile[x >> 4] >> (2u * (x & 15u))) & 3u; };
+    uint32_t h0 = 0, h1 = 0, g0 = 0, g1 = 0;              // key of the window, key of its reverse complement
+    if (worker)
+        for (uint32_t k = 0; k < m; k++) {
+            const uint32_t c = sym(x0 + k * cs);
+            h0 = rotl1(h0) ^ cyc_t0(c);
+            h1 = rotl1(h1) ^ cyc_t1(c);
+            g0 ^= rotlk(cyc_t0(3u - c), k);
+            g1 ^= rotlk(cyc_t1(3u - c), k);
+        }
+    const uint32_t mr = m & 31u, mr1 = (m - 1u) & 31u;
+    uint64_t keyv[SCAN_R], kv[SCAN_R];
+    uint32_t slotv[SCAN_R], fw[SCAN_R], fbit[SCAN_R];      // (slots: the table has at most 2^31, seedidx_batch)
+    uint32_t wflag = 0, pal = 0;                          // per start: the RC key is the canonical one; both keys are equal
 #pragma unroll
-    for (int d = 1; d <= 2; d++) {
-        const uint64_t iu = __shfl_up(i, d, 64), ku = __shfl_up(key, d, 64), id = __shfl_down(i, d, 64), kd = __shfl_down(key, d, 64);
-        const uint32_t lane = threadIdx.x & 63u;
-        if (lane >= (uint32_t)d && iu == i && ku < key) mine = false;
-        if (lane + (uint32_t)d < 64u && id == i && kd < key) mine = false;
+    for (int b = 0; b < SCAN_R; b++) {
+        const uint64_t kf = key_fix(h0, h1), kr = key_fix(g0, g1);
+        keyv[b] = kr < kf ? kr : kf;
+        wflag |= kr < kf ? 1u << b : 0u;
+        pal |= kr == kf ? 1u << b : 0u;
+        const uint64_t mixed = mix64d(keyv[b]);
+        slotv[b] = (uint32_t)(mixed & a.tmask);
+        fbit[b] = FILTER ? (uint32_t)((mixed >> a.fshift) & 31u) : 0u;
+        fw[b] = FILTER ? (uint32_t)(mixed >> a.fshift >> 5) : 0u;
+        if (worker) {                                     // roll to the next start (cyclichash.h:110-118)
+            const uint32_t xo = x0 + (uint32_t)b * cs;
+            const uint32_t co = sym(xo), cn = sym(xo + m * cs);
+            const uint32_t o0 = cyc_t0(co), o1 = cyc_t1(co);
+            h0 = rotl1(h0) ^ ((o0 << mr) | (mr ? o0 >> (32u - mr) : 0u)) ^ cyc_t0(cn);
+            h1 = rotl1(h1) ^ ((o1 << mr) | (mr ? o1 >> (32u - mr) : 0u)) ^ cyc_t1(cn);
+            g0 = rotr1(g0 ^ cyc_t0(3u - co)) ^ rotlk(cyc_t0(3u - cn), mr1);     // the RC key drops its symbol 0, takes symbol m - 1
+            g1 = rotr1(g1 ^ cyc_t1(3u - co)) ^ rotlk(cyc_t1(3u - cn), mr1);
+        }
     }
-    if (!mine || best[i] <= key) return;
+    // the filter first: a window whose bit is clear equals no indexed key -- one 4-byte gather in a bitmap of a thirty-second
+    // of the table's bytes; only the windows that pass (the hits and ~3 % more) go on to the table, whose probes each
+    // cost a random line of their own
+#pragma unroll
+    for (int b = 0; b < SCAN_R; b++) {
+        const uint64_t t = b0 + so + (uint64_t)b * cs;
+        fw[b] = (worker && t < nwin) ? (FILTER ? a.filter[fw[b]] : 1u) : 0u;
+    }
+#pragma unroll
+    for (int b = 0; b < SCAN_R; b++) kv[b] = ((fw[b] >> fbit[b]) & 1u) ? a.tkeys[slotv[b]] : SX_EMPTY;
+    // collisions (the slot holds another key) are resolved together: every round issues the next-slot loads of all starts
+    // still searching before any of them is looked at
+    uint32_t srch = 0, fnd = 0;
+#pragma unroll
+    for (int b = 0; b < SCAN_R; b++) {
+        if (kv[b] == keyv[b]) fnd |= 1u << b;
+        else if (kv[b] != SX_EMPTY) srch |= 1u << b;
+    }
+    while (__any(srch != 0)) {
+#pragma unroll
+        for (int b = 0; b < SCAN_R; b++)
+            if (srch & (1u << b)) {
+                slotv[b] = (uint32_t)((slotv[b] + 1ull) & a.tmask);
+                kv[b] = a.tkeys[slotv[b]];
+            }
+#pragma unroll
+        for (int b = 0; b < SCAN_R; b++)
+            if (srch & (1u << b)) {
+                if (kv[b] == SX_EMPTY) srch &= ~(1u << b);
+                else if (kv[b] == keyv[b]) { fnd |= 1u << b; srch &= ~(1u << b); }
+            }
+    }
+    // the ranges of the keys found (two adjacent words), one word per window start
+    uint32_t lo[SCAN_R], hi[SCAN_R];
+#pragma unroll
+    for (int b = 0; b < SCAN_R; b++) {
+        lo[b] = hi[b] = 0;
+        if (fnd & (1u << b)) { lo[b] = a.toff[slotv[b]]; hi[b] = a.toff[slotv[b] + 1ull]; }
+    }
+    // (through LDS: a thread's starts are cstride apart -- written directly, a wave's store would touch 64 lines 8 bytes at a time)
+#pragma unroll
+    for (int b = 0; b < SCAN_R; b++)
+        if (worker)
+            wst[so + (uint32_t)b * cs] = hi[b] > lo[b] ? (uint64_t)lo[b] | ((uint64_t)(hi[b] - lo[b]) << WREC_CNT_SH) | ((uint64_t)((wflag >> b) & 1u) << 62) | ((uint64_t)((pal >> b) & 1u) << 63)
+                                                        : 0ull;
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < per_block && b0 + x < nwin; x += SCAN_TPB) wrec[b0 + x - wbase] = wst[x];
+}
+
+// One hit: entry word `ew` of a window of the forward text at start tf (wflag: the window's RC key is the canonical one; pal: its
+// two keys are equal; rep: the second turn of such a window, for the other strand).
+template <int RW4>
+__device__ __forceinline__ void seed_hit(const SeedArgs &a, uint32_t ew, uint32_t wflag, uint32_t pal, uint32_t rep, uint64_t tf,
+                                         const uint32_t *__restrict__ rows, uint64_t *__restrict__ best, uint32_t &cnt0, uint32_t &cnt1) {
+    const uint32_t e = ew & ~SX_FLAG, ef = ew >> 31;
+    if (pal && ef) return;                                // (not a candidate: SeedArgs)
+    const uint64_t i = e / a.P;
+    const uint32_t j = e % a.P;
+    const uint64_t shift = part_offset(a, j);
+    const uint32_t strand = wflag ^ ef ^ rep;             // the flags of part and window agree = forward
+    const uint64_t t = strand ? a.rc_top - tf : tf;       // (tf <= rc_top: the scanned range; wraps otherwise)
+    // ReadsMatchers.cpp:308-309 / :375-376 and :311-312 / :378-379: the alignment the hit stands for lies inside the text
+    if (!((a.want >> strand) & 1u) || t >= a.nwin_all || shift > t || t - shift + a.L > a.G) return;
+    if (strand) cnt1++; else cnt0++;
+    const uint64_t p = t - shift;
+    const uint32_t *text = strand ? a.pg_rc : a.pg;
+    uint32_t mm;
+    if (a.nflag && a.nflag[i]) mm = hamming_vs_text_n(a, text, i, lower_bound_u32(a.nidx, a.nn, (uint32_t)(i + a.ibase)), p);   // a read with N
+    else mm = hamming_row_vs_text<RW4>(a, text, rows, i, p);
+    if (a.mode == 'e' ? mm != 0u : mm > a.kmax) return;   // ReadsMatchers.cpp:315-319 / :214: no limit a read can have lets it in
+    const uint64_t key = ((uint64_t)(mm <= a.kmin ? 0u : mm) << 56) | ((uint64_t)strand << 55) | (t << 15) | ((uint64_t)(15u - j) << 11) | mm;
+    if (best[i] <= key) return;                           // (a plain load: the key only ever falls; random 64-bit atomics run at a sixth of the rate of loads)
     atomicMin((unsigned long long *)&best[i], (unsigned long long)key);
+}
+
+#define EXP_TPB 256
+#define EXP_R 8
+#define EXP_WIN (EXP_TPB * EXP_R)
+#define EXP_HEAVY 32u                    // entries of a window above which it goes to k_seed_heavy
+template <int RW4>
+__global__ void __launch_bounds__(EXP_TPB)
+k_seed_expand(const SeedArgs a, uint64_t wbase, uint64_t nwin, const uint64_t *__restrict__ wrec, const uint32_t *__restrict__ rows,
+              uint64_t *__restrict__ best, unsigned long long *__restrict__ counters, uint32_t *__restrict__ hlist, uint32_t heavy_thr) {
+    // the windows [wbase, nwin) that k_seed_probe described; counters[0 / 1]: hits of the forward / the RC strand
+    __shared__ uint32_t f_pre[EXP_WIN + 1];               // entries of a found window (twice that for a window with equal keys; at most 2 * 4096), then their exclusive prefix sums
+    __shared__ uint32_t f_off[EXP_WIN];                   // its first entry
+    __shared__ uint16_t f_meta[EXP_WIN];                  // window start - the block's first (11 bits) | bit 14: the RC key is the canonical one | bit 15: equal keys
+    __shared__ uint32_t scan_tmp[EXP_TPB / 64];
+    __shared__ uint16_t h_win[EXP_WIN];                   // the block's heavy windows (below), as offsets from its first window
+    __shared__ uint32_t nfound, nheavy, hbase, hitcnt[2];
+    if (threadIdx.x == 0) { nfound = 0; nheavy = 0; hitcnt[0] = 0; hitcnt[1] = 0; }
+    __syncthreads();
+    const uint64_t b0 = wbase + (uint64_t)blockIdx.x * EXP_WIN;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t rv[EXP_R];
+#pragma unroll
+    for (int q = 0; q < EXP_R; q++) {                                     // (coalesced; all loads first)
+        const uint32_t wo = (uint32_t)q * EXP_TPB + threadIdx.x;
+        rv[q] = b0 + wo < nwin ? wrec[b0 + wo - wbase] : 0ull;
+    }
+#pragma unroll
+    for (int q = 0; q < EXP_R; q++) {
+        const uint32_t wo = (uint32_t)q * EXP_TPB + threadIdx.x;
+        const uint64_t r = rv[q];
+        // A window with many entries (repeats, tandem tracts: the windows of one tract share a handful of keys with thousands of
+        // entries each, and they all lie in ONE block's stretch) is not this block's to expand: it goes on the list of heavy windows
+        // that k_seed_heavy's blocks take one at a time, from all over the chip.
+        if (r && ((r >> WREC_CNT_SH) & WREC_CNT_MASK) > heavy_thr) {
+            h_win[atomicAdd(&nheavy, 1u)] = (uint16_t)wo;
+        } else if (r) {
+            const uint32_t f = atomicAdd(&nfound, 1u);
+            const uint32_t p2 = (uint32_t)(r >> 63);
+            f_off[f] = (uint32_t)(r & WREC_OFF_MASK);
+            f_pre[f] = (uint32_t)((r >> WREC_CNT_SH) & WREC_CNT_MASK) << p2;
+            f_meta[f] = (uint16_t)(wo | ((uint32_t)((r >> 62) & 1u) << 14) | (p2 << 15));
+        }
+    }
+    __syncthreads();
+    if (nheavy) {                                         // (one global atomic per block that has any: counters[2] = heavy windows listed)
+        if (threadIdx.x == 0) hbase = (uint32_t)atomicAdd(counters + 2, (unsigned long long)nheavy);
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < nheavy; x += EXP_TPB) hlist[hbase + x] = (uint32_t)(b0 - wbase) + h_win[x];
+    }
+    // exclusive prefix sums of the list's lengths (EXP_R consecutive entries per thread)
+    const uint32_t nf = nfound;
+    uint32_t total;
+    {
+        uint32_t v[EXP_R], s = 0;
+#pragma unroll
+        for (int q = 0; q < EXP_R; q++) {
+            const uint32_t f = threadIdx.x * EXP_R + q;
+            v[q] = f < nf ? f_pre[f] : 0u;
+            s += v[q];
+        }
+        uint32_t inc = s;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(inc, o, 64);
+            if (lane >= (uint32_t)o) inc += u;
+        }
+        if (lane == 63) scan_tmp[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (uint32_t k = 0; k < EXP_TPB / 64; k++) {
+            const uint32_t x = scan_tmp[k];
+            if (k < (threadIdx.x >> 6)) woff += x;
+            tot += x;
+        }
+        total = tot;
+        uint32_t run = woff + inc - s;
+#pragma unroll
+        for (int q = 0; q < EXP_R; q++) {
+            const uint32_t f = threadIdx.x * EXP_R + q;
+            if (f < nf) f_pre[f] = run;
+            run += v[q];
+        }
+        if (threadIdx.x == 0) f_pre[nf] = tot;            // the end of the last range
+    }
+    __syncthreads();
+    // the hits: pair o of the block = entry (o - prefix[f]) of the window f that holds it
+    uint32_t cnt0 = 0, cnt1 = 0;
+    for (uint32_t o = threadIdx.x; o < total; o += EXP_TPB) {
+        uint32_t flo = 0, fhi = nf;                       // f_pre[flo] <= o < f_pre[fhi]
+        while (fhi - flo > 1u) {
+            const uint32_t mid = (flo + fhi) >> 1;
+            if (f_pre[mid] <= o) flo = mid;
+            else fhi = mid;
+        }
+        const uint32_t meta = f_meta[flo];
+        uint32_t k = o - f_pre[flo];
+        uint32_t rep = 0;                                 // a window with equal keys: its entries once more, for the other strand
+        if (meta >> 15) {
+            const uint32_t half = (f_pre[flo + 1] - f_pre[flo]) >> 1;
+            if (k >= half) { k -= half; rep = 1; }
+        }
+        seed_hit<RW4>(a, a.ent[f_off[flo] + k], (meta >> 14) & 1u, meta >> 15, rep, b0 + (meta & 0x3FFFu), rows, best, cnt0, cnt1);
+    }
+    if (cnt0) atomicAdd(&hitcnt[0], cnt0);
+    if (cnt1) atomicAdd(&hitcnt[1], cnt1);
+    __syncthreads();
+    if (threadIdx.x < 2 && hitcnt[threadIdx.x]) atomicAdd(counters + threadIdx.x, (unsigned long long)hitcnt[threadIdx.x]);
+}
+
+// The heavy windows of a launch (k_seed_expand): a persistent grid whose WAVES take them one at a time (counters[3] = the next
+// one) and walk a window's entries with their 64 lanes.
+template <int RW4>
+__global__ void __launch_bounds__(EXP_TPB)
+k_seed_heavy(const SeedArgs a, uint64_t wbase, const uint64_t *__restrict__ wrec, const uint32_t *__restrict__ hlist, const uint32_t *__restrict__ rows,
+             uint64_t *__restrict__ best, unsigned long long *__restrict__ counters) {
+    __shared__ uint32_t hitcnt[2];
+    if (threadIdx.x == 0) { hitcnt[0] = 0; hitcnt[1] = 0; }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long nh = counters[2];
+    uint32_t cnt0 = 0, cnt1 = 0;
+    for (;;) {
+        unsigned long long it = 0;
+        if (lane == 0) it = atomicAdd(counters + 3, 1ull);
+        it = __shfl(it, 0, 64);
+        if (it >= nh) break;
+        const uint32_t w = hlist[it];
+        const uint64_t r = wrec[w];
+        const uint32_t off = (uint32_t)(r & WREC_OFF_MASK), pal = (uint32_t)(r >> 63), wflag = (uint32_t)(r >> 62) & 1u;
+        const uint32_t cnt = (uint32_t)((r >> WREC_CNT_SH) & WREC_CNT_MASK);
+        for (uint32_t rep = 0; rep <= pal; rep++)
+            for (uint32_t k = lane; k < cnt; k += 64u) seed_hit<RW4>(a, a.ent[off + k], wflag, pal, rep, wbase + w, rows, best, cnt0, cnt1);
+    }
+    if (cnt0) atomicAdd(&hitcnt[0], cnt0);
+    if (cnt1) atomicAdd(&hitcnt[1], cnt1);
+    __syncthreads();
+    if (threadIdx.x < 2 && hitcnt[threadIdx.x]) atomicAdd(counters + threadIdx.x, (unsigned long long)hitcnt[threadIdx.x]);
 }
 
 __global__ void __launch_bounds__(256) k_seed_best_store(const SeedArgs a, const uint64_t *__restrict__ best) {
@@ -445,29 +588,30 @@ __global__ void __launch_bounds__(256) k_seed_best_store(const SeedArgs a, const
 }
 
 
-__global__ void __launch_bounds__(256) k_seed_table_init(uint64_t *keys, uint32_t *heads, uint64_t n) {
-    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (uint64_t)gridDim.x * blockDim.x) {
-        keys[s] = SX_EMPTY;
-        heads[s] = SX_NIL;
+__global__ void __launch_bounds__(256) k_seed_table_init(uint64_t *keys, uint32_t *counts, uint64_t n) {
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= n; s += (uint64_t)gridDim.x * blockDim.x) {
+        if (s < n) keys[s] = SX_EMPTY;
+        counts[s] = 0u;                                   // (n + 1 words: the scan leaves the number of entries in the last)
     }
 }
 
-// One batch of reads (fewer than 2^28: the hit records keep 28 bits for the read) against both strands, the text
-// scanned in segments of fewer than 2^32 window starts (32 bits for the position inside the segment).  A read's
-// candidates come in ascending text position, so segment after segment with the per-read state carried in the result
-// arrays IS the reference's sequential scan; reads are independent, so batch after batch is its loop over the reads.
+
+// One batch of reads (at most 2^30 entries: an entry index and a slot number leave a bit for the flag) against both strands.
+// Reads are independent, so batch after batch is the reference's loop over the reads; the reduction is a minimum over all
+// hits of a read (section 3b), so the text is scanned in launches of at most seg_windows window starts (8 + 4 bytes of scratch
+// per start), in any order.
 static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, int first_strand, int last_strand) {
     const uint64_t span = (uint64_t)a.m * a.cstride;  // extent of a text window
     const uint32_t L = a.L;
-    // read-part table
     const uint64_t nent = a.n * a.P;
     uint64_t tsize = 1024;
     while (tsize < 2 * nent) tsize <<= 1;   // (4 / 8 * nent: the exact matcher at C3 12 / 16 % faster, modes d / i unchanged; the filter below does better)
+    const uint64_t nbs = pgrc_ps_scan_blocks(tsize + 1) + 2;
     int e;
     if ((e = pgrc_buf_ensure(c, c->s_keys, tsize * sizeof(uint64_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->s_vals, tsize * sizeof(uint32_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->s_tab, nent * sizeof(uint32_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->s_tmp, 64))) return e;
+    if ((e = pgrc_buf_ensure(c, c->s_vals, (tsize + 1) * sizeof(uint32_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->s_tab, 3 * nent * sizeof(uint32_t)))) return e;          // slot, rank, place of every entry
+    if ((e = pgrc_buf_ensure(c, c->s_tmp, 64 + nbs * sizeof(uint32_t)))) return e;        // four counters, the scan's block sums
     // the filter: 32 bits per indexed key (3 % of the windows of a random text pass it by chance), at most 2^36 bits.  It
     // pays when most windows of the text equal no key -- the exact matcher at C3: 100 M keys against 1.9 G windows, 0.20 ->
     // 0.16 s -- and costs a dependent round trip where many do (modes d / i with four parts per read: 0.42 -> 0.43 s): used
@@ -485,20 +629,27 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
         a.fshift = 64u - (uint32_t)fbits;
     }
     a.tkeys = (uint64_t *)c->s_keys.p;
-    a.theads = (uint32_t *)c->s_vals.p;
+    a.toff = (uint32_t *)c->s_vals.p;
     a.tmask = tsize - 1;
-    a.next = (uint32_t *)c->s_tab.p;
+    a.eslot = (uint32_t *)c->s_tab.p;
+    a.erank = a.eslot + nent;
+    a.ent = a.erank + nent;
     if (a.nn) {
         if ((e = pgrc_buf_ensure(c, c->s_nmask, a.nn * a.nwr * sizeof(uint16_t)))) return e;
         a.nmask = (const uint16_t *)c->s_nmask.p;
         hipLaunchKernelGGL(k_seed_nmask, dim3((uint32_t)((a.nn * a.nwr + 255) / 256)), dim3(256), 0, c->stream, a.nascii, a.nn, L,
                            a.nwr, (uint16_t *)c->s_nmask.p);
     }
-    hipLaunchKernelGGL(k_seed_table_init, dim3(4096), dim3(256), 0, c->stream, a.tkeys, a.theads, tsize);
+    unsigned long long *counters = (unsigned long long *)c->s_tmp.p;   // [0 / 1] hits of the forward / the RC strand
+    uint32_t *bsum = (uint32_t *)((char *)c->s_tmp.p + 64);
+    HIP_TRY(c, hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_seed_table_init, dim3(4096), dim3(256), 0, c->stream, a.tkeys, a.toff, tsize);
     hipLaunchKernelGGL(k_seed_insert, dim3((uint32_t)((nent + 255) / 256)), dim3(256), 0, c->stream, a);
     if (a.nn)
         hipLaunchKernelGGL(k_seed_insert_ascii, dim3((uint32_t)((a.nn * a.P + 255) / 256)), dim3(256), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
+    if ((e = pgrc_ps_scan_u32(c, a.toff, tsize + 1, bsum))) return e;
+    hipLaunchKernelGGL(k_seed_place, dim3((uint32_t)((nent + 255) / 256)), dim3(256), 0, c->stream, a, nent);
 
     // a read's hits become its result by the atomic minimum of section 3b: a start key per read, the batch's reads row by row
     const uint32_t rw = (a.nwr + 3u) & ~3u;                 // <= 16: reads have at most 255 symbols (pgrc_match_create)
@@ -510,59 +661,51 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
                        c->stream, a, rw, (uint32_t *)c->s_rows.p);
     HIP_TRY(c, hipGetLastError());
 
-    unsigned long long *cursor = (unsigned long long *)c->s_tmp.p;
-    for (int pass = first_strand; pass <= last_strand; pass++) {
-        a.pg = (const uint32_t *)c->pg2[pass].p;
-        a.strand = (uint32_t)pass;
-        if (c->G < span) continue; // no window fits (the reference's scan loops are empty / undefined there)
-        const uint64_t nwin_all = c->G - span + 1;
-        const uint32_t per_block = (SCAN_TPB / a.cstride) * a.cstride * SCAN_R;
-        for (uint64_t w0 = 0; w0 < nwin_all; w0 += seg_windows) {
-        a.tbase = w0;
-        const uint64_t nwin = std::min(nwin_all, w0 + seg_windows);      // this segment: window starts [w0, nwin)
-        const uint32_t grid = (uint32_t)((nwin - w0 + per_block - 1) / per_block);
-        // hit buffer: a guess (two hits per indexed part, or whatever an earlier pass needed); exact size on overflow
-        uint64_t cap = std::max<uint64_t>(2 * nent + 4096, c->s_hits.bytes / sizeof(uint64_t));
-        unsigned long long nhits = 0;
-        for (int attempt = 0; attempt < 2; attempt++) {
-            if ((e = pgrc_buf_ensure(c, c->s_hits, cap * sizeof(uint64_t)))) return e;
-            HIP_TRY(c, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream));
-            hipLaunchKernelGGL(k_seed_scan, dim3(grid), dim3(SCAN_TPB), 0, c->stream, a, nwin, c->pg_words + PGRC_PG_PAD_WORDS,
-                               cursor, (uint64_t *)c->s_hits.p, cap);
-            HIP_TRY(c, hipGetLastError());
-            HIP_TRY(c, hipMemcpyAsync(&nhits, cursor, sizeof nhits, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (nhits <= cap) break;
-            cap = nhits + nhits / 4;                        // the guess was too small: once more, with headroom for the other strand
-                                                            // (growing these multi-GB buffers again costs more than the pass itself)
+    // ONE scan of the forward text finds the hits of both strands (SeedArgs), in launches of at most seg_windows window starts
+    a.pg = (const uint32_t *)c->pg2[0].p;
+    a.pg_rc = (const uint32_t *)c->pg2[1].p;
+    a.want = (first_strand == 0 ? 1u : 0u) | (last_strand == 1 ? 2u : 0u);
+    const uint64_t nwin_all = c->G >= span ? c->G - span + 1 : 0;       // window starts of either strand (none: the reference's scan loops are empty / undefined there)
+    a.nwin_all = nwin_all;
+    a.rc_top = nwin_all ? nwin_all - 1u + (a.cstride - 1u) : 0;
+    const uint64_t nscan = !nwin_all ? 0 : (a.want & 2u) ? a.rc_top + 1u : nwin_all;
+    const uint32_t per_block = (SCAN_TPB / a.cstride) * a.cstride * SCAN_R;
+    const uint32_t *rows = (const uint32_t *)c->s_rows.p;
+    uint64_t *best = (uint64_t *)c->s_best.p;
+    const uint64_t pgw = c->pg_words + PGRC_PG_PAD_WORDS;
+    const uint64_t seg = std::min<uint64_t>(seg_windows, nscan);
+    if ((e = pgrc_buf_ensure(c, c->s_hits, std::max<uint64_t>(seg, 1) * (sizeof(uint64_t) + sizeof(uint32_t))))) return e;     // one word per window start of a launch + the list of the heavy ones
+    uint64_t *wrec = (uint64_t *)c->s_hits.p;
+    uint32_t *hlist = (uint32_t *)(wrec + std::max<uint64_t>(seg, 1));
+    for (uint64_t w0 = 0; w0 < nscan; w0 += seg) {
+        const uint64_t nwin = std::min(nscan, w0 + seg);
+        const dim3 pgrid((uint32_t)((nwin - w0 + per_block - 1) / per_block)), egrid((uint32_t)((nwin - w0 + EXP_WIN - 1) / EXP_WIN));
+        if (a.filter) hipLaunchKernelGGL(k_seed_probe<true>, pgrid, dim3(SCAN_TPB), 0, c->stream, a, w0, nwin, pgw, wrec);
+        else hipLaunchKernelGGL(k_seed_probe<false>, pgrid, dim3(SCAN_TPB), 0, c->stream, a, w0, nwin, pgw, wrec);
+        HIP_TRY(c, hipMemsetAsync(counters + 2, 0, 2 * sizeof(unsigned long long), c->stream));       // heavy windows listed / taken
+        const dim3 hgrid((uint32_t)c->num_cus * 8u);
+        const uint32_t heavy_thr = getenv("PGRC_SEED_HEAVY") ? (uint32_t)std::min(4096, std::max(1, atoi(getenv("PGRC_SEED_HEAVY")))) : EXP_HEAVY;
+#define EXP_LAUNCH(R)                                                                                                                                       \
+        hipLaunchKernelGGL((k_seed_expand<R>), egrid, dim3(EXP_TPB), 0, c->stream, a, w0, nwin, (const uint64_t *)wrec, rows, best, counters, hlist, heavy_thr); \
+        hipLaunchKernelGGL((k_seed_heavy<R>), hgrid, dim3(EXP_TPB), 0, c->stream, a, w0, (const uint64_t *)wrec, (const uint32_t *)hlist, rows, best, counters)
+        switch (rw / 4u) {
+        case 1: EXP_LAUNCH(1); break;
+        case 2: EXP_LAUNCH(2); break;
+        case 3: EXP_LAUNCH(3); break;
+        default: EXP_LAUNCH(4); break;
         }
-        if (nhits == 0) continue;
-        // counts in scan order, one atomicMin per acceptable hit (the host does not wait for it: the next scan follows on the stream)
-        // (launches of at most 2^30 hits.  In an experiment of round 4 ONE launch of this kernel over 3.7 G hits gave wrong results
-        //  where the same hits in launches of 2^30 were right -- profiles/r04_seed_scan_experiments.txt; the cause was not found:
-        //  plain grids of up to 2^32 - 256 threads execute correctly, tools/ubench/biggrid.hip.  Kept as the tested shape.)
-        const uint32_t *rows = (const uint32_t *)c->s_rows.p;
-        uint64_t *best = (uint64_t *)c->s_best.p;
-        for (uint64_t h0 = 0; h0 < nhits; h0 += 1ull << 30) {
-            const uint64_t hn = std::min<uint64_t>(1ull << 30, nhits - h0);
-            const dim3 hg((uint32_t)((hn + 255) / 256));
-            const uint64_t *h = (const uint64_t *)c->s_hits.p + h0;
-            switch (rw / 4u) {
-            case 1: hipLaunchKernelGGL(k_seed_hamming_min<1>, hg, dim3(256), 0, c->stream, a, h, hn, rows, best); break;
-            case 2: hipLaunchKernelGGL(k_seed_hamming_min<2>, hg, dim3(256), 0, c->stream, a, h, hn, rows, best); break;
-            case 3: hipLaunchKernelGGL(k_seed_hamming_min<3>, hg, dim3(256), 0, c->stream, a, h, hn, rows, best); break;
-            default: hipLaunchKernelGGL(k_seed_hamming_min<4>, hg, dim3(256), 0, c->stream, a, h, hn, rows, best); break;
-            }
-        }
+#undef EXP_LAUNCH
         HIP_TRY(c, hipGetLastError());
-        c->ctr.candidates[pass] += nhits;
-        }
-        c->ctr.searched[pass] += a.n;
     }
     // the keys that a hit has lowered become the reads' results
     hipLaunchKernelGGL(k_seed_best_store, dim3((uint32_t)((a.n + 255) / 256)), dim3(256), 0, c->stream, a, (const uint64_t *)c->s_best.p);
     HIP_TRY(c, hipGetLastError());
+    unsigned long long nh[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(nh, counters, sizeof nh, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->ctr.candidates[0] += nh[0];
+    c->ctr.candidates[1] += nh[1];
+    for (int pass = first_strand; pass <= last_strand; pass++) c->ctr.searched[pass] += a.n;
     return PGRC_OK;
 }
 
@@ -570,31 +713,29 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
     const uint32_t L = c->prm.read_len;
     const char mode = c->prm.mode;
     SeedArgs a;
+    memset(&a, 0, sizeof a);
     a.L = L;
     a.mode = (uint32_t)mode;
     a.P = (mode == 'e') ? 1u : L / c->prm.seed_len;   // targetMismatches + 1 (ReadsMatchers.cpp:236)
     a.m = (mode == 'e') ? L : c->prm.seed_len;
     a.cstride = (mode == 'i') ? a.P : 1u;
     if (a.P == 0 || a.P > 15) { c->err = "modes d/i: 1..15 seed parts supported"; return PGRC_E_PARAM; }
-    a.pg = nullptr;
     a.G = c->G;
     a.stride = c->stride;
     a.nwr = (L + 15) / 16;
-    a.nmask = nullptr;
     a.kmax = c->prm.max_mismatches;
     a.kmin = c->prm.min_mismatches;
-    a.tbase = 0;
     if (c->n == 0) return PGRC_OK;
     int e;
     if (last_strand >= 1) {
         if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) return e;
         c->have_rc = true;
     }
-    // limits of the 64-bit hit record (read 28 bits | position in the segment 32 bits | part 4 bits); the knobs force
-    // small batches / segments so that tests cover the loops on small inputs
-    uint64_t batch = std::min<uint64_t>((1ull << 28) - 1, (1ull << 30) / a.P), seg = (1ull << 32) - 65536;   // (at most 2^30 (read, part) entries per batch: the sizes the tests and the C3 runs cover)
-    if (const char *k = getenv("PGRC_SEED_READ_BATCH")) batch = std::max<uint64_t>(1, strtoull(k, nullptr, 10));
-    if (const char *k = getenv("PGRC_SEED_SEGMENT")) seg = std::max<uint64_t>(4096, strtoull(k, nullptr, 10));
+    // a batch holds at most 2^30 entries (SX_FLAG); a launch of the scan 2^29 window starts (6 GB of scratch).  The knobs force
+    // small batches / launches so that tests cover the loops on small inputs
+    uint64_t batch = (1ull << 30) / a.P, seg = 1ull << 29;
+    if (const char *k = getenv("PGRC_SEED_READ_BATCH")) batch = std::max<uint64_t>(1, std::min<uint64_t>(batch, strtoull(k, nullptr, 10)));
+    if (const char *k = getenv("PGRC_SEED_SEGMENT")) seg = std::max<uint64_t>(4096, std::min<uint64_t>(seg, strtoull(k, nullptr, 10)));
     const uint32_t *d_nidx = (const uint32_t *)c->nread_idx.p;
     for (uint64_t r0 = 0; r0 < c->n; r0 += batch) {
         const uint64_t r1 = std::min(c->n, r0 + batch);

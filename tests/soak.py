@@ -63,10 +63,11 @@ def main():
         redo_any = "1" if rng.random() < 0.2 else ""
         from_end = "0" if rng.random() < 0.3 else ""
         spec = str(rng.choice(["", "", "", "0", "1", "3"]))
+        heavy = str(rng.choice(["", "", "1", "4", "4096"]))   # modes d / i / e: entries of a window above which the persistent grid takes it
         for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish), ("PGRC_SEED_SEGMENT", seg), ("PGRC_SEED_READ_BATCH", batch),
                          ("PGRC_MATCH_STAGE", stage), ("PGRC_EARLY_STOP", early), ("PGRC_SCREEN", screen), ("PGRC_DUAL", dual),
                          ("PGRC_HEAD_PAIR", pairk), ("PGRC_NREAD_INLINE", inline), ("PGRC_REDO_ANY", redo_any), ("PGRC_MATCH_FROM_END", from_end),
-                         ("PGRC_SPEC_LIMIT", spec)):
+                         ("PGRC_SPEC_LIMIT", spec), ("PGRC_SEED_HEAVY", heavy)):
             if val:
                 os.environ[key] = val
             else:
@@ -75,7 +76,7 @@ def main():
                       n_nset=nn if packed else None)
         what = dict(mode=mode, L=L, seed_len=seed_len, M=M, kmin=kmin, G=G, n=n, nn=nn, rev=rev, seed=seed, shards=shards,
                     packed=packed, variant=variant, finish=finish, seg=seg, batch=batch, stage=stage, early=early, screen=screen, dual=dual,
-                    pairk=pairk, inline=inline, redo_any=redo_any, from_end=from_end, spec=spec)
+                    pairk=pairk, inline=inline, redo_any=redo_any, from_end=from_end, spec=spec, heavy=heavy)
         for k in ("pos", "rc", "mism", "hist"):
             if not np.array_equal(np.asarray(g[k]), np.asarray(o[k])):
                 print("READS MISMATCH", what, k, flush=True)
