@@ -554,6 +554,33 @@ def test_seedindex_hits_reduced_by_atomic_minimum(monkeypatch, mode, heavy):
         assert_same_results(gpu_match(mode, pg, reads, seed_len, kmax, 1), o3, f"kmin = 1, mode {mode}")
 
 
+@pytest.mark.parametrize("mode,L,seed_len", [("d", 100, 38), ("d", 150, 38), ("i", 150, 38), ("i", 100, 25), ("e", 100, 100), ("e", 150, 150)])
+def test_seedindex_reverse_palindromes(mode, L, seed_len):
+    """One scan of the forward text serves both strands (canonical keys, seedidx.hip): a window that equals its own reverse
+    complement has equal keys and is a hit of BOTH strands for the parts that equal it.  Stretches S + rc(S) planted in the text
+    (every window centred on the junction is such a window), reads taken across the junctions in both orientations: results and
+    candidate counts as the reference's two scans give them."""
+    pg, reads = make_inputs(200_000, 4000, L, seed=5150 + L + seed_len)
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    k = 0
+    for st in range(10_000, 190_000, 9_000):
+        half = rng.choice(acgt, size=2 * L)
+        pg[st:st + 2 * L] = half
+        pg[st + 2 * L:st + 4 * L] = revcomp(half)
+        for d in (-L // 2, -L // 2 + 1, -L // 2 - 3, -19, -seed_len // 2 - L // 2 + L // 2):
+            p = st + 2 * L + d - (L // 2 if d == -19 else 0)
+            reads[k] = pg[p:p + L]; k += 1
+            reads[k] = revcomp(pg[p:p + L]); k += 1
+    kmax = 0 if mode == "e" else L // seed_len - 1
+    o = orc.oracle_match(mode, pg, reads, seed_len, kmax, 0)
+    g = gpu_match(mode, pg, reads, seed_len, kmax, 0)
+    assert_same_results(g, o, f"reverse palindromes, mode {mode} L={L}")
+    assert g["ctx"].counters()["candidates"] == o["candidates"], (g["ctx"].counters()["candidates"], o["candidates"])
+    if orc.have_ref():
+        assert_same_results(g, orc.ref_match(mode, pg, reads, seed_len, kmax, 0), "vs real reference")
+
+
 @pytest.mark.parametrize("mode", ["d", "i", "e"])
 def test_seedindex_hit_floods_on_low_complexity_text(mode):
     """A poly-A tract and reads taken from it: every window of the tract hits every part of those reads (~1.4 M hits
