@@ -702,7 +702,20 @@ static int cyc_tab_ready = 0;
 static void cyc_init(void) {
     if (cyc_tab_ready) return;
     for (int t = 0; t < 2; t++)
-        for (int c = 0; c < 256; c++) cyc_tab[t][c] = (uint32_t)(mix64(0xC0FFEEull * (t + 1) + (uint64_t)c * 0x9E3779B97F4A7C15ull) >> 16);
+        for (int c = 0; c < 256; c++) {
+            uint32_t x = (uint32_t)(mix64(0xC0FFEEull * (t + 1) + (uint64_t)c * 0x9E3779B97F4A7C15ull) >> 16);
+            cyc_tab[t][c] = x;
+        }
+    /* A C G T N: the words of the HIP path (seedidx.hip, cyc_t0 / cyc_t1; there table(complement) = bit reversal of table(symbol),
+     * which makes the key of a reverse complement a bijection of the key).  Beyond the canonical collisions there are table-dependent
+     * ones on periodic runs (the XOR over the rotations of one residue class mod 1, 2 or 4 depends on sub-parities of the word): with
+     * the same words both sides have the same ones, and the work counter `candidates` can be compared exactly. */
+    {
+        static const uint32_t w0[5] = {0x9E3779B9u, 0x7F4A7C15u, 0xA83E52FEu, 0x9D9EEC79u, 0x10824108u};
+        static const uint32_t w1[5] = {0xBF58476Du, 0x1CE4E5B9u, 0x9DA72738u, 0xB6E21AFDu, 0x2545A2A4u};
+        static const char sym[5] = {'A', 'C', 'G', 'T', 'N'};
+        for (int k = 0; k < 5; k++) { cyc_tab[0][(uint8_t)sym[k]] = w0[k]; cyc_tab[1][(uint8_t)sym[k]] = w1[k]; }
+    }
     cyc_tab_ready = 1;
 }
 static uint32_t rotl32(uint32_t x, uint32_t r) { r &= 31; return r ? (x << r) | (x >> (32 - r)) : x; }
@@ -777,6 +790,9 @@ int pgrc_or_match_seedindex(char mode, const char *pg, uint64_t pg_len, const ch
             text = rcpg;
         }
         if (pg_len < span) continue;
+        /* res->candidates[pass]: the (window, pattern) pairs with equal keys whose alignment lies inside the text -- the pairs the
+         * reference looks at, whatever the read's state lets it do with them (a work counter: the HIP path reports the same) */
+        uint64_t cands = 0;
         /* one rolling hash per residue class mod stride (ConstantLength...HashMatcher.h:105-137) */
         uint64_t *roll = (uint64_t *)malloc(sizeof(uint64_t) * stride);
         for (uint32_t r = 0; r < stride; r++)
@@ -796,6 +812,7 @@ int pgrc_or_match_seedindex(char mode, const char *pg, uint64_t pg_len, const ch
                 uint32_t part = pidx % P;
                 const char *rd = reads + ri * read_len;
                 if (mode == 'e') { /* ReadsMatchers.cpp:203-224: a key hit must pass compareReadWithPattern == 0 */
+                    cands++;
                     int eq = 1;
                     for (uint32_t k = 0; k < m && eq; k++) eq = rd[k] == text[t + k];
                     if (!eq) continue;
@@ -808,8 +825,9 @@ int pgrc_or_match_seedindex(char mode, const char *pg, uint64_t pg_len, const ch
                     continue;
                 }
                 /* ReadsMatchers.cpp:301-330 (d) / :368-397 (i) */
-                if (res->mism[ri] <= kmin) continue;
                 uint64_t shift = (mode == 'i') ? part : (uint64_t)part * m;
+                if (shift <= t && t - shift + read_len <= pg_len) cands++;
+                if (res->mism[ri] <= kmin) continue;
                 if (shift > t) continue;
                 uint64_t p = t - shift;
                 if (p + read_len > pg_len) continue;
@@ -831,6 +849,7 @@ int pgrc_or_match_seedindex(char mode, const char *pg, uint64_t pg_len, const ch
             }
         }
         free(roll);
+        res->candidates[pass] = cands;
     }
     if (mode == 'e') { /* DefaultReadsExactMatcher::transferMatchingResults :126-133 */
         res->hist[0] = res->matched;

@@ -37,20 +37,23 @@
 
 #define SX_EMPTY 0xFFFFFFFFFFFFFFFFull
 
-// two fixed 32-bit tables over the symbol values A0 C1 G2 T3 N4
+// two fixed 32-bit tables over the symbol values A0 C1 G2 T3 N4, with table(complement of v) = BIT REVERSAL of table(v) (N: a word
+// that is its own reversal).  Bit reversal turns rotl into rotr, so the key of the REVERSE COMPLEMENT of a sequence s[0 .. m) --
+// XOR_k rotl(table(comp(s[k])), k), the cyclic polynomial of the reversed, complemented sequence -- is a fixed bijection of the
+// key of s itself, half by half:   key_rc = rotl(bit_reverse(key), m - 1)   (key_rc32 below).  Two sequences collide under the one
+// iff they collide under the other -- all collisions, the canonical ones of the header and the table-dependent ones on periodic runs
+// (32 equal symbols, period-2 and period-4 runs: the XOR over the rotations of one residue class depends on sub-parities of the
+// word) alike --, which is what lets ONE scan of the forward text find exactly the candidates of the reference's two (SeedArgs).
 __device__ __forceinline__ uint32_t cyc_t0(uint32_t v) {
-    return v == 0 ? 0x9E3779B9u : v == 1 ? 0x7F4A7C15u : v == 2 ? 0xF39CC060u : v == 3 ? 0x5CEDC834u : 0x1082276Bu;
+    return v == 0 ? 0x9E3779B9u : v == 1 ? 0x7F4A7C15u : v == 2 ? 0xA83E52FEu : v == 3 ? 0x9D9EEC79u : 0x10824108u;
 }
 __device__ __forceinline__ uint32_t cyc_t1(uint32_t v) {
-    return v == 0 ? 0xBF58476Du : v == 1 ? 0x1CE4E5B9u : v == 2 ? 0x94D049BBu : v == 3 ? 0x133111EBu : 0x2545F491u;
+    return v == 0 ? 0xBF58476Du : v == 1 ? 0x1CE4E5B9u : v == 2 ? 0x9DA72738u : v == 3 ? 0xB6E21AFDu : 0x2545A2A4u;
 }
 __device__ __forceinline__ uint32_t rotl1(uint32_t x) { return (x << 1) | (x >> 31); }
-__device__ __forceinline__ uint32_t rotr1(uint32_t x) { return (x >> 1) | (x << 31); }
 __device__ __forceinline__ uint32_t rotlk(uint32_t x, uint32_t k) { k &= 31u; return k ? (x << k) | (x >> (32u - k)) : x; }
-// the same tables over the COMPLEMENT of a symbol (N is its own): key of the reverse complement of s[0 .. m) =
-// XOR_k rotl(table(comp(s[k])), k) -- the cyclic polynomial of the reversed, complemented sequence
-__device__ __forceinline__ uint32_t cyc_c0(uint32_t v) { return cyc_t0(v < 4u ? 3u - v : 4u); }
-__device__ __forceinline__ uint32_t cyc_c1(uint32_t v) { return cyc_t1(v < 4u ? 3u - v : 4u); }
+// one half of the key of the reverse complement from the same half of the key (m symbols)
+__device__ __forceinline__ uint32_t key_rc32(uint32_t h, uint32_t m) { return rotlk(__brev(h), m - 1u); }
 __device__ __forceinline__ uint64_t mix64d(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -87,15 +90,14 @@ struct SeedArgs {
     uint32_t fshift;           // 64 - fbits: the filter takes the TOP bits of the mixed key, the table its low bits
     // Both strands in ONE scan of the forward text.  A part is indexed under its CANONICAL key: the smaller of the key of the
     // part and the key of its reverse complement, with a flag saying which.  A window of the forward text has both keys as well
-    // (each rolls in O(1)), probes once with the smaller one and carries the same flag: equal flags = the window equals the part,
-    // a hit of the forward strand at its start t; different flags = it equals the part's reverse complement, i.e. the part occurs
-    // in the RC text at window start rc_top - t, rc_top = G - 1 - (m - 1) * cstride (the window's last symbol is the RC window's
-    // first).  "Equals" is the equivalence of the header: the rotation classes of the forward and of the reverse-complement
-    // polynomial are the same sets of positions and complementing is a bijection of the symbols, so two sequences collide under
-    // one iff they collide under the other, and u ~ v iff rc(u) ~ rc(v): the candidates of either strand are exactly the
-    // reference's.  A window whose two keys are equal (it is equivalent to its own reverse complement) is a hit of BOTH strands for
-    // the parts with equal keys -- flag 0 -- and of neither for the others under that key (which only a chance collision of all 64
-    // bits puts there).  Each strand has the window starts [0, nwin_all); with cstride > 1 the extent the reference gives a window
+    // (the second follows from the first: key_rc32), probes once with the smaller one and carries the same flag: equal flags = the
+    // window's key equals the part's, a hit of the forward strand at its start t; different flags = it equals the key of the part's
+    // reverse complement, i.e. the part's key equals that of the RC text's window that starts at rc_top - t, rc_top = G - 1 -
+    // (m - 1) * cstride (the window's last symbol is the RC window's first): a hit of the RC strand.  The key of the reverse
+    // complement is a bijection of the key, so these are exactly the pairs the reference's two scans find with this table --
+    // every collision of the rolling hash included.  A window whose two keys are equal is a hit of BOTH strands for the parts
+    // under that key, which have equal keys themselves -- flag 0 (a part with flag 1 there has a larger own key: no candidate of
+    // either strand).  Each strand has the window starts [0, nwin_all); with cstride > 1 the extent the reference gives a window
     // (m * cstride) is cstride - 1 more than it covers, so the scan walks the starts [0, rc_top] and each strand takes its own range.
     uint32_t want;             // bit 0: hits of the forward strand wanted, bit 1: of the RC strand
     uint64_t nwin_all, rc_top;
@@ -140,15 +142,13 @@ __global__ void __launch_bounds__(256) k_seed_insert(const SeedArgs a) {
     const uint32_t j = (uint32_t)(e % a.P);
     if (a.nflag && a.nflag[i]) return; // byte-path reads are inserted by k_seed_insert_ascii
     const uint32_t off = part_offset(a, j);
-    uint32_t h0 = 0, h1 = 0, g0 = 0, g1 = 0;
+    uint32_t h0 = 0, h1 = 0;
     for (uint32_t k = 0; k < a.m; k++) {
         const uint32_t c = read_code(a, i, off + k * a.cstride);
         h0 = rotl1(h0) ^ cyc_t0(c);
         h1 = rotl1(h1) ^ cyc_t1(c);
-        g0 ^= rotlk(cyc_c0(c), k);
-        g1 ^= rotlk(cyc_c1(c), k);
     }
-    table_insert(a, key_fix(h0, h1), key_fix(g0, g1), (uint32_t)e);
+    table_insert(a, key_fix(h0, h1), key_fix(key_rc32(h0, a.m), key_rc32(h1, a.m)), (uint32_t)e);
 }
 
 __global__ void __launch_bounds__(256) k_seed_insert_ascii(const SeedArgs a) {
@@ -159,15 +159,13 @@ __global__ void __launch_bounds__(256) k_seed_insert_ascii(const SeedArgs a) {
     const uint64_t i = a.nidx[t] - a.ibase;
     const uint8_t *row = a.nascii + t * a.L;
     const uint32_t off = part_offset(a, j);
-    uint32_t h0 = 0, h1 = 0, g0 = 0, g1 = 0;
+    uint32_t h0 = 0, h1 = 0;
     for (uint32_t k = 0; k < a.m; k++) {
         const uint32_t c = ascii_val(row[off + k * a.cstride]);
         h0 = rotl1(h0) ^ cyc_t0(c);
         h1 = rotl1(h1) ^ cyc_t1(c);
-        g0 ^= rotlk(cyc_c0(c), k);
-        g1 ^= rotlk(cyc_c1(c), k);
     }
-    table_insert(a, key_fix(h0, h1), key_fix(g0, g1), (uint32_t)(i * a.P + j));
+    table_insert(a, key_fix(h0, h1), key_fix(key_rc32(h0, a.m), key_rc32(h1, a.m)), (uint32_t)(i * a.P + j));
 }
 
 __global__ void __launch_bounds__(256) k_seed_place(const SeedArgs a, uint64_t nent) {
@@ -328,22 +326,20 @@ k_seed_probe(const SeedArgs a, uint64_t wbase, uint64_t nwin, uint64_t pg_words_
     const uint32_t so = g * cs * SCAN_R + phase;          // this thread's first start, relative to b0
     const uint32_t x0 = (uint32_t)(b0 + so - (w0 << 4));  // its tile-relative symbol index
     auto sym = [&](uint32_t x) -> uint32_t { return (tile[x >> 4] >> (2u * (x & 15u))) & 3u; };
-    uint32_t h0 = 0, h1 = 0, g0 = 0, g1 = 0;              // key of the window, key of its reverse complement
+    uint32_t h0 = 0, h1 = 0;                              // key of the window (the key of its reverse complement follows from it)
     if (worker)
         for (uint32_t k = 0; k < m; k++) {
             const uint32_t c = sym(x0 + k * cs);
             h0 = rotl1(h0) ^ cyc_t0(c);
             h1 = rotl1(h1) ^ cyc_t1(c);
-            g0 ^= rotlk(cyc_t0(3u - c), k);
-            g1 ^= rotlk(cyc_t1(3u - c), k);
         }
-    const uint32_t mr = m & 31u, mr1 = (m - 1u) & 31u;
+    const uint32_t mr = m & 31u;
     uint64_t keyv[SCAN_R], kv[SCAN_R];
     uint32_t slotv[SCAN_R], fw[SCAN_R], fbit[SCAN_R];      // (slots: the table has at most 2^31, seedidx_batch)
     uint32_t wflag = 0, pal = 0;                          // per start: the RC key is the canonical one; both keys are equal
 #pragma unroll
     for (int b = 0; b < SCAN_R; b++) {
-        const uint64_t kf = key_fix(h0, h1), kr = key_fix(g0, g1);
+        const uint64_t kf = key_fix(h0, h1), kr = key_fix(key_rc32(h0, m), key_rc32(h1, m));
         keyv[b] = kr < kf ? kr : kf;
         wflag |= kr < kf ? 1u << b : 0u;
         pal |= kr == kf ? 1u << b : 0u;
@@ -357,8 +353,6 @@ k_seed_probe(const SeedArgs a, uint64_t wbase, uint64_t nwin, uint64_t pg_words_
             const uint32_t o0 = cyc_t0(co), o1 = cyc_t1(co);
             h0 = rotl1(h0) ^ ((o0 << mr) | (mr ? o0 >> (32u - mr) : 0u)) ^ cyc_t0(cn);
             h1 = rotl1(h1) ^ ((o1 << mr) | (mr ? o1 >> (32u - mr) : 0u)) ^ cyc_t1(cn);
-            g0 = rotr1(g0 ^ cyc_t0(3u - co)) ^ rotlk(cyc_t0(3u - cn), mr1);     // the RC key drops its symbol 0, takes symbol m - 1
-            g1 = rotr1(g1 ^ cyc_t1(3u - co)) ^ rotlk(cyc_t1(3u - cn), mr1);
         }
     }
     // the filter first: a window whose bit is clear equals no indexed key -- one 4-byte gather in a bitmap of a thirty-second

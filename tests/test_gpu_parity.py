@@ -521,6 +521,8 @@ def test_seedindex_modes_parity(mode, L, seed_len, M, shortcut, G, n, n_with_n):
     o = orc.oracle_match(mode, pg, reads, seed_len, kmax, kmin)
     g = gpu_match(mode, pg, reads, seed_len, kmax, kmin)
     assert_same_results(g, o, f"mode {mode} L={L} seed={seed_len} M={M} shortcut={shortcut}")
+    # ONE scan of the forward text finds the (window, part) pairs with equal keys of both strands: as many as the oracle's two scans
+    assert g["ctx"].counters()["candidates"] == o["candidates"], (g["ctx"].counters()["candidates"], o["candidates"])
     if orc.have_ref():
         r = orc.ref_match(mode, pg, reads, seed_len, kmax, kmin, n_nset=(n if n_with_n else 0))
         assert_same_results(g, r, "vs real reference")
@@ -558,8 +560,9 @@ def test_seedindex_hits_reduced_by_atomic_minimum(monkeypatch, mode, heavy):
 def test_seedindex_reverse_palindromes(mode, L, seed_len):
     """One scan of the forward text serves both strands (canonical keys, seedidx.hip): a window that equals its own reverse
     complement has equal keys and is a hit of BOTH strands for the parts that equal it.  Stretches S + rc(S) planted in the text
-    (every window centred on the junction is such a window), reads taken across the junctions in both orientations: results and
-    candidate counts as the reference's two scans give them."""
+    (every window centred on the junction is such a window), reads taken across the junctions in both orientations: results as
+    the reference's two scans give them, and the same number of (window, part) pairs with equal keys per strand as the oracle's
+    two scans find (its tables hold the HIP path's words for A C G T N: table-dependent collisions on tandem tracts included)."""
     pg, reads = make_inputs(200_000, 4000, L, seed=5150 + L + seed_len)
     rng = np.random.default_rng(11)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -601,6 +604,7 @@ def test_seedindex_hit_floods_on_low_complexity_text(mode):
     o = orc.oracle_match(mode, pg, reads, seed_len, kmax, 0)
     g = gpu_match(mode, pg, reads, seed_len, kmax, 0)
     assert_same_results(g, o, f"hit flood, mode {mode}")
+    assert g["ctx"].counters()["candidates"] == o["candidates"]
     assert g["ctx"].counters()["candidates"][0] > 3 * 3000 * (L // seed_len) + 4096     # the guess was exceeded
     if orc.have_ref():
         assert_same_results(g, orc.ref_match(mode, pg, reads, seed_len, kmax, 0), "hit flood vs real reference")

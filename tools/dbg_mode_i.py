@@ -11,7 +11,7 @@ for mode in sys.argv[3:]:
     t = time.time(); o = orc.oracle_match(mode, pg, reads, 38, 3, 0); to = time.time() - t
     g = gpu_match(mode, pg, reads, 38, 3, 0)
     bad = np.flatnonzero((g["pos"] != o["pos"]) | (g["rc"] != o["rc"]) | (g["mism"] != o["mism"]))
-    print(mode, "G", G, "n", n, "oracle s %.1f" % to, "matched", g["matched"], o["matched"], "bad", bad.size, flush=True)
+    print(mode, "G", G, "n", n, "oracle s %.1f" % to, "matched", g["matched"], o["matched"], "bad", bad.size, "candidates gpu", g["ctx"].counters()["candidates"], "oracle", o["candidates"], flush=True)
     for i in bad[:8]:
         print("  read", i, "gpu", g["pos"][i], g["rc"][i], g["mism"][i], "oracle", o["pos"][i], o["rc"][i], o["mism"][i])
     if bad.size:
