@@ -233,7 +233,6 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
         (void)hipEventDestroy(c->side_ev[0]);
         (void)hipEventDestroy(c->side_ev[1]);
     }
-    if (c->os_mid_ev) (void)hipEventDestroy(c->os_mid_ev);
     if (c->build_stream) {
         (void)hipStreamDestroy(c->build_stream);
         (void)hipEventDestroy(c->build_ev[0]);
@@ -742,15 +741,7 @@ static int pgrc_build_both_indexes(pgrc_match_ctx *c, bool *two_streams, F mark)
         // nothing extra only as whole 64-byte runs (groups of 1 and 2: index pair 16.2 -> 24.9 ms; groups of 4: 17.0)
         c->pair_gm = (hp && hp[0] >= '1' && hp[0] <= '4') ? (1u << (hp[0] - '1')) - 1u : 3u;
     }
-    // PGRC_BUILD_STAGGER=1 (experiment): the second build starts when the first reaches its finish kernel -- the finish (a latency-bound
-    // mix) beside the other strand's hashing passes instead of finish beside finish
-    const char *stg = getenv("PGRC_BUILD_STAGGER");
-    const bool stagger = two && stg && stg[0] == '1';
-    if (stagger && !c->os_mid_ev && hipEventCreateWithFlags(&c->os_mid_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->os_mid_ev = nullptr; }
-    c->os_mid_record = stagger && c->os_mid_ev;
-    if ((e = pgrc_copmem_build_index(c, 0))) { c->pair_build = false; c->os_mid_record = false; return e; }
-    if (c->os_mid_record) HIP_TRY(c, hipStreamWaitEvent(c->build_stream, c->os_mid_ev, 0));
-    c->os_mid_record = false;
+    if ((e = pgrc_copmem_build_index(c, 0))) { c->pair_build = false; return e; }
     if (!two) mark(); // 2
     swap_index_sets(c);
     if (two) c->stream = c->build_stream;

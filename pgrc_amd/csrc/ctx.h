@@ -115,8 +115,6 @@ struct pgrc_match_ctx {
     bool screen_broken = false;         // no room for the second set: the passes run as the reference orders them
     hipStream_t build_stream = nullptr; // the RC index is built beside the forward one (screened schedule)
     hipEvent_t build_ev[2]{};
-    hipEvent_t os_mid_ev = nullptr;     // experiment PGRC_BUILD_STAGGER: recorded by the sweep front end before its finish kernel (idxsweep.hip)
-    bool os_mid_record = false;
 
     // pipelined hand-over (stream.hip): both indexes built ahead of the run; blocks of reads matched as they arrive
     bool idx_prepared = false;          // pgrc_match_prepare_index built (or is building) both strands' indexes of the current text

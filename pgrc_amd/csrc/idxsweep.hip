@@ -575,6 +575,5 @@ int pgrc_os_build_index(pgrc_match_ctx *c, int strand, uint32_t hbits) {
         else e = os_passes<1024, 8, 1, uint8_t>(c, strand, pl, b);
     }
     if (e) return e;
-    if (c->os_mid_record && c->os_mid_ev) HIP_TRY(c, hipEventRecord(c->os_mid_ev, c->stream));     // (PGRC_BUILD_STAGGER: the other strand's build starts here)
     return pgrc_ps_finish_packed(c, b.recB, b.pstart, b.slow, np, pl.cb, pl.rec_sh, b.recA);
 }
