@@ -2,7 +2,9 @@
 """One-off randomized soak at medium sizes (not part of the suite): texts of 5-80 Mbp and 0.2-2 M reads, so that the
 index build runs with realistic partition and tile counts (every PGRC_INDEX_SORT / PGRC_INDEX_FINISH variant), the match
 kernel with many waves in flight, and the sharded matcher with shards of real size.  HIP path vs oracle (mode c; the
-index itself is compared for a third of the cases).  usage: python tests/soak_medium.py [seconds] [seed]"""
+index itself is compared for a third of the cases); a quarter of the cases take mode d / i / e instead (texts up to 30 Mbp:
+the oracle's scan is serial), results AND the number of (window, part) pairs with equal keys per strand against the oracle's.
+usage: python tests/soak_medium.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -49,6 +51,36 @@ def main():
                 os.environ[key] = val
             else:
                 os.environ.pop(key, None)
+        if rng.random() < 0.25:                          # modes d / i / e (seedidx.hip)
+            mode = str(rng.choice(["d", "i", "e"]))
+            Gs, ns = min(G, 30_000_000), min(n, 1_000_000)
+            sl = L if mode == "e" else int(rng.choice([38, 38, 25, 45]))
+            if mode != "e" and L // sl < 1:
+                sl = L
+            km = 0 if mode == "e" else max(L // sl - 1, 0)
+            kn = km if (mode != "e" and rng.random() < 0.15) else 0
+            heavy = str(rng.choice(["", "", "1", "4096"]))
+            seg = str(int(rng.integers(1 << 20, 1 << 24))) if rng.random() < 0.3 else ""
+            for key, val in (("PGRC_SEED_HEAVY", heavy), ("PGRC_SEED_SEGMENT", seg)):
+                if val:
+                    os.environ[key] = val
+                else:
+                    os.environ.pop(key, None)
+            what = dict(mode=mode, L=L, seed_len=sl, kmax=km, kmin=kn, G=Gs, n=ns, nn=nn, seed=seed, shards=shards, heavy=heavy, seg=seg)
+            pg, reads = pg[:Gs], reads[:ns]
+            o = orc.oracle_match(mode, pg, reads, sl, km, kn)
+            g = gpu_match(mode, pg, reads, sl, km, kn, True, devices=[0] * shards if shards else None)
+            for k in ("pos", "rc", "mism", "hist"):
+                if not np.array_equal(np.asarray(g[k]), np.asarray(o[k])):
+                    print("MISMATCH", what, k, int((np.asarray(g[k]) != np.asarray(o[k])).sum()), flush=True)
+                    sys.exit(1)
+            if not shards and g["ctx"].counters()["candidates"] != o["candidates"]:
+                print("CANDIDATES MISMATCH", what, g["ctx"].counters()["candidates"], o["candidates"], flush=True)
+                sys.exit(1)
+            del g
+            cases += 1
+            print(f"{cases} ok ({time.time() - t0:.0f} s) {what}", flush=True)
+            continue
         what = dict(L=L, seed_len=seed_len, kmax=kmax, kmin=kmin, G=G, n=n, nn=nn, seed=seed, shards=shards, variant=variant, finish=finish, early=early, stage=stage, screen=screen, dual=dual, pairk=pairk, inline=inline, from_end=from_end)
         o = orc.oracle_match("c", pg, reads, seed_len, kmax, kmin, True, 16)
         g = gpu_match("c", pg, reads, seed_len, kmax, kmin, True, devices=[0] * shards if shards else None)
