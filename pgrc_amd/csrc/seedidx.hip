@@ -190,9 +190,9 @@ k_seed_nmask(const uint8_t *__restrict__ nascii, uint64_t nn, uint32_t L, uint32
     nmask[x] = (uint16_t)m;
 }
 
-__device__ __forceinline__ uint32_t hamming_vs_text_n(const SeedArgs &a, const uint32_t *__restrict__ text, uint64_t i, uint64_t trow, uint64_t p) {
+__device__ __forceinline__ uint32_t hamming_vs_text_n(const SeedArgs &a, const uint32_t *text, uint64_t text_w0, uint64_t i, uint64_t trow, uint64_t p) {
     uint32_t mm = 0;
-    const uint32_t *src = text + (p >> 4);
+    const uint32_t *src = text + ((p >> 4) - text_w0);
     const uint32_t b = ((uint32_t)p & 15u) * 2u;
     uint32_t lo = src[0];
     for (uint32_t w = 0; w < a.nwr; w++) {
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(ROWS_TPB) k_seed_rows(const SeedArgs a, uint32
 }
 
 template <int RW4>   // rw / 4
-__device__ __forceinline__ uint32_t hamming_row_vs_text(const SeedArgs &a, const uint32_t *__restrict__ text, const uint32_t *__restrict__ rows, uint64_t i, uint64_t p) {
+__device__ __forceinline__ uint32_t hamming_row_vs_text(const SeedArgs &a, const uint32_t *text, uint64_t text_w0, const uint32_t *__restrict__ rows, uint64_t i, uint64_t p) {
     const uint4 *row = (const uint4 *)(rows + i * (uint64_t)(RW4 * 4));
     uint32_t r[RW4 * 4];
 #pragma unroll
@@ -273,7 +273,7 @@ __device__ __forceinline__ uint32_t hamming_row_vs_text(const SeedArgs &a, const
         const uint4 v = row[q];
         r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
     }
-    const uint32_t *src = text + (p >> 4);
+    const uint32_t *src = text + ((p >> 4) - text_w0);      // (text: a stretch of the packed text staged in LDS, first word text_w0)
     const uint32_t b = ((uint32_t)p & 15u) * 2u;
     uint32_t mm = 0, lo = src[0];
 #pragma unroll
@@ -404,11 +404,24 @@ k_seed_probe(const SeedArgs a, uint64_t wbase, uint64_t nwin, uint64_t pg_words_
     for (uint32_t x = threadIdx.x; x < per_block && b0 + x < nwin; x += SCAN_TPB) wrec[b0 + x - wbase] = wst[x];
 }
 
+// The words of a strand's text that the alignments of the windows [t_lo, t_hi] of that strand can touch: an alignment starts at most L
+// symbols below its window (the part's offset in the read) and reads L symbols + one word of slack.
+__device__ __forceinline__ void seed_tile_span(uint64_t t_lo, uint64_t t_hi, uint32_t L, uint64_t *w0, uint32_t *nwords) {
+    const uint64_t lo = t_lo > L ? t_lo - L : 0ull;
+    *w0 = lo >> 4;
+    *nwords = (uint32_t)(((t_hi + L + 32u) >> 4) + 1u - *w0);
+}
+__device__ __forceinline__ void seed_tile_load(uint32_t *tile, const uint32_t *__restrict__ text, uint64_t w0, uint32_t nwords, uint64_t words_alloc, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t w = tid; w < nwords; w += nthreads) tile[w] = (w0 + w < words_alloc) ? text[w0 + w] : 0u;
+}
+
 // One hit: entry word `ew` of a window of the forward text at start tf (wflag: the window's RC key is the canonical one; pal: its
-// two keys are equal; rep: the second turn of such a window, for the other strand).
+// two keys are equal; rep: the second turn of such a window, for the other strand).  tile_fw / tile_rc: the stretch of the forward / the
+// RC text that every alignment of the caller's windows lies in, in LDS, from word w0_fw / w0_rc on (seed_tile_span).
 template <int RW4>
 __device__ __forceinline__ void seed_hit(const SeedArgs &a, uint32_t ew, uint32_t wflag, uint32_t pal, uint32_t rep, uint64_t tf,
-                                         const uint32_t *__restrict__ rows, uint64_t *__restrict__ best, uint32_t &cnt0, uint32_t &cnt1) {
+                                         const uint32_t *__restrict__ rows, uint64_t *__restrict__ best, uint32_t &cnt0, uint32_t &cnt1,
+                                         const uint32_t *tile_fw, uint64_t w0_fw, const uint32_t *tile_rc, uint64_t w0_rc) {
     const uint32_t e = ew & ~SX_FLAG, ef = ew >> 31;
     if (pal && ef) return;                                // (not a candidate: SeedArgs)
     const uint64_t i = e / a.P;
@@ -420,10 +433,13 @@ __device__ __forceinline__ void seed_hit(const SeedArgs &a, uint32_t ew, uint32_
     if (!((a.want >> strand) & 1u) || t >= a.nwin_all || shift > t || t - shift + a.L > a.G) return;
     if (strand) cnt1++; else cnt0++;
     const uint64_t p = t - shift;
-    const uint32_t *text = strand ? a.pg_rc : a.pg;
+    // the text of the strand around the window: staged in LDS by the caller (a hit's eleven text words were eleven gathers of a
+    // kernel whose vector-memory instructions, not its bytes, are the limit)
+    const uint32_t *text = strand ? tile_rc : tile_fw;
+    const uint64_t text_w0 = strand ? w0_rc : w0_fw;
     uint32_t mm;
-    if (a.nflag && a.nflag[i]) mm = hamming_vs_text_n(a, text, i, lower_bound_u32(a.nidx, a.nn, (uint32_t)(i + a.ibase)), p);   // a read with N
-    else mm = hamming_row_vs_text<RW4>(a, text, rows, i, p);
+    if (a.nflag && a.nflag[i]) mm = hamming_vs_text_n(a, text, text_w0, i, lower_bound_u32(a.nidx, a.nn, (uint32_t)(i + a.ibase)), p);   // a read with N
+    else mm = hamming_row_vs_text<RW4>(a, text, text_w0, rows, i, p);
     if (a.mode == 'e' ? mm != 0u : mm > a.kmax) return;   // ReadsMatchers.cpp:315-319 / :214: no limit a read can have lets it in
     const uint64_t key = ((uint64_t)(mm <= a.kmin ? 0u : mm) << 56) | ((uint64_t)strand << 55) | (t << 15) | ((uint64_t)(15u - j) << 11) | mm;
     if (best[i] <= key) return;                           // (a plain load: the key only ever falls; random 64-bit atomics run at a sixth of the rate of loads)
@@ -433,22 +449,35 @@ __device__ __forceinline__ void seed_hit(const SeedArgs &a, uint32_t ew, uint32_
 #define EXP_TPB 256
 #define EXP_R 8
 #define EXP_WIN (EXP_TPB * EXP_R)
+#define EXP_TILE_WORDS ((EXP_WIN + 2 * 256 + 64) / 16 + 4)   // words of a text around EXP_WIN windows (reads of at most 255 symbols)
+#define HV_TILE_WORDS ((2 * 256 + 64) / 16 + 4)               // ... around one window
 #define EXP_HEAVY 32u                    // entries of a window above which it goes to k_seed_heavy
 template <int RW4>
 __global__ void __launch_bounds__(EXP_TPB)
 k_seed_expand(const SeedArgs a, uint64_t wbase, uint64_t nwin, const uint64_t *__restrict__ wrec, const uint32_t *__restrict__ rows,
-              uint64_t *__restrict__ best, unsigned long long *__restrict__ counters, uint32_t *__restrict__ hlist, uint32_t heavy_thr) {
+              uint64_t *__restrict__ best, unsigned long long *__restrict__ counters, uint32_t *__restrict__ hlist, uint32_t heavy_thr, uint64_t pg_words_alloc) {
     // the windows [wbase, nwin) that k_seed_probe described; counters[0 / 1]: hits of the forward / the RC strand
     __shared__ uint32_t f_pre[EXP_WIN + 1];               // entries of a found window (twice that for a window with equal keys; at most 2 * 4096), then their exclusive prefix sums
     __shared__ uint32_t f_off[EXP_WIN];                   // its first entry
     __shared__ uint16_t f_meta[EXP_WIN];                  // window start - the block's first (11 bits) | bit 14: the RC key is the canonical one | bit 15: equal keys
     __shared__ uint32_t scan_tmp[EXP_TPB / 64];
     __shared__ uint16_t h_win[EXP_WIN];                   // the block's heavy windows (below), as offsets from its first window
+    __shared__ uint32_t t_fw[EXP_TILE_WORDS], t_rc[EXP_TILE_WORDS];   // the two texts around the block's windows
     __shared__ uint32_t nfound, nheavy, hbase, hitcnt[2];
     if (threadIdx.x == 0) { nfound = 0; nheavy = 0; hitcnt[0] = 0; hitcnt[1] = 0; }
     __syncthreads();
     const uint64_t b0 = wbase + (uint64_t)blockIdx.x * EXP_WIN;
     const uint32_t lane = threadIdx.x & 63u;
+    // forward windows [b0, b0 + EXP_WIN) are the RC strand's windows [rc_top - (b0 + EXP_WIN - 1), rc_top - b0]
+    uint64_t w0_fw, w0_rc;
+    {
+        uint32_t nw;
+        const uint64_t b1 = b0 + EXP_WIN - 1u;
+        seed_tile_span(b0, b1, a.L, &w0_fw, &nw);
+        seed_tile_load(t_fw, a.pg, w0_fw, nw, pg_words_alloc, threadIdx.x, EXP_TPB);
+        seed_tile_span(a.rc_top > b1 ? a.rc_top - b1 : 0ull, a.rc_top >= b0 ? a.rc_top - b0 : 0ull, a.L, &w0_rc, &nw);
+        if (a.want & 2u) seed_tile_load(t_rc, a.pg_rc, w0_rc, nw, pg_words_alloc, threadIdx.x, EXP_TPB);
+    }
     uint64_t rv[EXP_R];
 #pragma unroll
     for (int q = 0; q < EXP_R; q++) {                                     // (coalesced; all loads first)
@@ -529,7 +558,7 @@ k_seed_expand(const SeedArgs a, uint64_t wbase, uint64_t nwin, const uint64_t *_
             const uint32_t half = (f_pre[flo + 1] - f_pre[flo]) >> 1;
             if (k >= half) { k -= half; rep = 1; }
         }
-        seed_hit<RW4>(a, a.ent[f_off[flo] + k], (meta >> 14) & 1u, meta >> 15, rep, b0 + (meta & 0x3FFFu), rows, best, cnt0, cnt1);
+        seed_hit<RW4>(a, a.ent[f_off[flo] + k], (meta >> 14) & 1u, meta >> 15, rep, b0 + (meta & 0x3FFFu), rows, best, cnt0, cnt1, t_fw, w0_fw, t_rc, w0_rc);
     }
     if (cnt0) atomicAdd(&hitcnt[0], cnt0);
     if (cnt1) atomicAdd(&hitcnt[1], cnt1);
@@ -542,8 +571,9 @@ k_seed_expand(const SeedArgs a, uint64_t wbase, uint64_t nwin, const uint64_t *_
 template <int RW4>
 __global__ void __launch_bounds__(EXP_TPB)
 k_seed_heavy(const SeedArgs a, uint64_t wbase, const uint64_t *__restrict__ wrec, const uint32_t *__restrict__ hlist, const uint32_t *__restrict__ rows,
-             uint64_t *__restrict__ best, unsigned long long *__restrict__ counters) {
+             uint64_t *__restrict__ best, unsigned long long *__restrict__ counters, uint64_t pg_words_alloc) {
     __shared__ uint32_t hitcnt[2];
+    __shared__ uint32_t t_fw[EXP_TPB / 64][HV_TILE_WORDS], t_rc[EXP_TPB / 64][HV_TILE_WORDS];   // per wave: the two texts around its window
     if (threadIdx.x == 0) { hitcnt[0] = 0; hitcnt[1] = 0; }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -558,8 +588,19 @@ k_seed_heavy(const SeedArgs a, uint64_t wbase, const uint64_t *__restrict__ wrec
         const uint64_t r = wrec[w];
         const uint32_t off = (uint32_t)(r & WREC_OFF_MASK), pal = (uint32_t)(r >> 63), wflag = (uint32_t)(r >> 62) & 1u;
         const uint32_t cnt = (uint32_t)((r >> WREC_CNT_SH) & WREC_CNT_MASK);
+        const uint64_t tf = wbase + w, trc = a.rc_top >= tf ? a.rc_top - tf : 0ull;
+        const uint32_t wv = threadIdx.x >> 6;
+        uint64_t w0_fw, w0_rc;
+        uint32_t nw;
+        __builtin_amdgcn_wave_barrier();                  // (the lanes are done with the previous window's tiles)
+        seed_tile_span(tf, tf, a.L, &w0_fw, &nw);
+        seed_tile_load(t_fw[wv], a.pg, w0_fw, nw, pg_words_alloc, lane, 64u);
+        seed_tile_span(trc, trc, a.L, &w0_rc, &nw);
+        if (a.want & 2u) seed_tile_load(t_rc[wv], a.pg_rc, w0_rc, nw, pg_words_alloc, lane, 64u);
+        __threadfence_block();                            // the wave's LDS writes before its lanes' reads
+        __builtin_amdgcn_wave_barrier();
         for (uint32_t rep = 0; rep <= pal; rep++)
-            for (uint32_t k = lane; k < cnt; k += 64u) seed_hit<RW4>(a, a.ent[off + k], wflag, pal, rep, wbase + w, rows, best, cnt0, cnt1);
+            for (uint32_t k = lane; k < cnt; k += 64u) seed_hit<RW4>(a, a.ent[off + k], wflag, pal, rep, tf, rows, best, cnt0, cnt1, t_fw[wv], w0_fw, t_rc[wv], w0_rc);
     }
     if (cnt0) atomicAdd(&hitcnt[0], cnt0);
     if (cnt1) atomicAdd(&hitcnt[1], cnt1);
@@ -680,8 +721,8 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
         const dim3 hgrid((uint32_t)c->num_cus * 8u);
         const uint32_t heavy_thr = getenv("PGRC_SEED_HEAVY") ? (uint32_t)std::min(4096, std::max(1, atoi(getenv("PGRC_SEED_HEAVY")))) : EXP_HEAVY;
 #define EXP_LAUNCH(R)                                                                                                                                       \
-        hipLaunchKernelGGL((k_seed_expand<R>), egrid, dim3(EXP_TPB), 0, c->stream, a, w0, nwin, (const uint64_t *)wrec, rows, best, counters, hlist, heavy_thr); \
-        hipLaunchKernelGGL((k_seed_heavy<R>), hgrid, dim3(EXP_TPB), 0, c->stream, a, w0, (const uint64_t *)wrec, (const uint32_t *)hlist, rows, best, counters)
+        hipLaunchKernelGGL((k_seed_expand<R>), egrid, dim3(EXP_TPB), 0, c->stream, a, w0, nwin, (const uint64_t *)wrec, rows, best, counters, hlist, heavy_thr, pgw); \
+        hipLaunchKernelGGL((k_seed_heavy<R>), hgrid, dim3(EXP_TPB), 0, c->stream, a, w0, (const uint64_t *)wrec, (const uint32_t *)hlist, rows, best, counters, pgw)
         switch (rw / 4u) {
         case 1: EXP_LAUNCH(1); break;
         case 2: EXP_LAUNCH(2); break;
