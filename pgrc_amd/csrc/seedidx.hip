@@ -544,21 +544,29 @@ k_seed_expand(const SeedArgs a, uint64_t wbase, uint64_t nwin, const uint64_t *_
     __syncthreads();
     // the hits: pair o of the block = entry (o - prefix[f]) of the window f that holds it
     uint32_t cnt0 = 0, cnt1 = 0;
-    for (uint32_t o = threadIdx.x; o < total; o += EXP_TPB) {
+    // (one pair ahead: the entry word of the NEXT pair is on its way while this one's read, text and key are worked on)
+    auto locate = [&](uint32_t o, uint32_t *meta, uint32_t *rep) -> uint32_t {
         uint32_t flo = 0, fhi = nf;                       // f_pre[flo] <= o < f_pre[fhi]
         while (fhi - flo > 1u) {
             const uint32_t mid = (flo + fhi) >> 1;
             if (f_pre[mid] <= o) flo = mid;
             else fhi = mid;
         }
-        const uint32_t meta = f_meta[flo];
+        *meta = f_meta[flo];
         uint32_t k = o - f_pre[flo];
-        uint32_t rep = 0;                                 // a window with equal keys: its entries once more, for the other strand
-        if (meta >> 15) {
+        *rep = 0;                                         // a window with equal keys: its entries once more, for the other strand
+        if (*meta >> 15) {
             const uint32_t half = (f_pre[flo + 1] - f_pre[flo]) >> 1;
-            if (k >= half) { k -= half; rep = 1; }
+            if (k >= half) { k -= half; *rep = 1; }
         }
-        seed_hit<RW4>(a, a.ent[f_off[flo] + k], (meta >> 14) & 1u, meta >> 15, rep, b0 + (meta & 0x3FFFu), rows, best, cnt0, cnt1, t_fw, w0_fw, t_rc, w0_rc);
+        return a.ent[f_off[flo] + k];
+    };
+    uint32_t n_meta = 0, n_rep = 0, n_ew = 0;
+    if (threadIdx.x < total) n_ew = locate(threadIdx.x, &n_meta, &n_rep);
+    for (uint32_t o = threadIdx.x; o < total; o += EXP_TPB) {
+        const uint32_t meta = n_meta, rep = n_rep, ew = n_ew;
+        if (o + EXP_TPB < total) n_ew = locate(o + EXP_TPB, &n_meta, &n_rep);
+        seed_hit<RW4>(a, ew, (meta >> 14) & 1u, meta >> 15, rep, b0 + (meta & 0x3FFFu), rows, best, cnt0, cnt1, t_fw, w0_fw, t_rc, w0_rc);
     }
     if (cnt0) atomicAdd(&hitcnt[0], cnt0);
     if (cnt1) atomicAdd(&hitcnt[1], cnt1);
@@ -599,8 +607,14 @@ k_seed_heavy(const SeedArgs a, uint64_t wbase, const uint64_t *__restrict__ wrec
         if (a.want & 2u) seed_tile_load(t_rc[wv], a.pg_rc, w0_rc, nw, pg_words_alloc, lane, 64u);
         __threadfence_block();                            // the wave's LDS writes before its lanes' reads
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t rep = 0; rep <= pal; rep++)
-            for (uint32_t k = lane; k < cnt; k += 64u) seed_hit<RW4>(a, a.ent[off + k], wflag, pal, rep, tf, rows, best, cnt0, cnt1, t_fw[wv], w0_fw, t_rc[wv], w0_rc);
+        for (uint32_t rep = 0; rep <= pal; rep++) {
+            uint32_t n_ew = lane < cnt ? a.ent[off + lane] : 0u;           // (one entry ahead)
+            for (uint32_t k = lane; k < cnt; k += 64u) {
+                const uint32_t ew = n_ew;
+                if (k + 64u < cnt) n_ew = a.ent[off + k + 64u];
+                seed_hit<RW4>(a, ew, wflag, pal, rep, tf, rows, best, cnt0, cnt1, t_fw[wv], w0_fw, t_rc[wv], w0_rc);
+            }
+        }
     }
     if (cnt0) atomicAdd(&hitcnt[0], cnt0);
     if (cnt1) atomicAdd(&hitcnt[1], cnt1);
