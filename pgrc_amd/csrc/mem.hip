@@ -873,16 +873,14 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
         rocprim::double_buffer<uint64_t> sk((uint64_t *)m->d_skey[0].p, (uint64_t *)m->d_skey[1].p);
         rocprim::double_buffer<uint64_t> si((uint64_t *)m->d_sidx[0].p, (uint64_t *)m->d_sidx[1].p);
         hipLaunchKernelGGL(k_mem_flags, dim3(g), dim3(256), 0, c->stream, a, ek, ep, (uint64_t)nev, (uint8_t *)m->d_oflag.p, sk.current(), si.current(), d_nstale);
-        int qb = 1, db = 1;
-        while ((1ull << qb) < N2) qb++;
+        int db = 1;
         while ((1ull << db) < N2 + m->N) db++;
-        size_t t1 = 0, t2 = 0;
-        MEM_TRY(m, rocprim::radix_sort_pairs(nullptr, t1, sk, si, (size_t)nev, 0, qb, c->stream));
+        size_t t2 = 0;
         MEM_TRY(m, rocprim::radix_sort_pairs(nullptr, t2, sk, si, (size_t)nev, 0, db, c->stream));
         MEM_TRY(m, rocprim::inclusive_scan(nullptr, t3, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)nev, rocprim::plus<uint32_t>(), c->stream));
-        if ((e = pgrc_buf_ensure(c, m->d_tmp, std::max(std::max(t1, t2), std::max(t3, tbytes)) + 16))) { m->err = c->err; return e; }
-        // stable sorts: by window first, then by diagonal => (diagonal, window)
-        MEM_TRY(m, rocprim::radix_sort_pairs(m->d_tmp.p, t1, sk, si, (size_t)nev, 0, qb, c->stream));
+        if ((e = pgrc_buf_ensure(c, m->d_tmp, std::max(t2, std::max(t3, tbytes)) + 16))) { m->err = c->err; return e; }
+        // (diagonal, window) order: the events ARE in window order (step 2), so one stable sort by diagonal does it (until round 4 a
+        // sort by window came first: a third of the sorting time of an event-rich call, for nothing)
         hipLaunchKernelGGL(k_mem_diag, dim3(g), dim3(256), 0, c->stream, a, ek, ep, (const uint64_t *)si.current(), (uint64_t)nev, sk.current());
         MEM_TRY(m, rocprim::radix_sort_pairs(m->d_tmp.p, t2, sk, si, (size_t)nev, 0, db, c->stream));
         const uint64_t *sidx = si.current(), *skey = sk.current();
