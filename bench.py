@@ -37,6 +37,12 @@ WORKLOADS = {
     # C3 at PgRC's shipped mismatch limit (-M 3: k <= L / 3 = 50, pgrc-params.h:138-146)
     "C3-M3": (100_000_000, 150, 1_875_000_000, 38, 3, "c", False),
     "tiny-N": (1_000_000, 150, 18_750_000, 38, 50, "c", False),
+    # rows a5-a7: the reference's other matchers at the C3 size (ReadsMatchers.cpp:715-740: mode d / i with seed 38, the exact
+    # matcher when the seed is the whole read); seedidx.hip.  M = 3 as tools/modes_c3.py has it (k <= 3 = parts - 1)
+    "C3-d": (100_000_000, 150, 1_875_000_000, 38, 50, "d", False),
+    "C3-i": (100_000_000, 150, 1_875_000_000, 38, 50, "i", False),
+    "C3-e": (100_000_000, 150, 1_875_000_000, 150, 50, "e", False),
+    "tiny-d": (1_000_000, 150, 18_750_000, 38, 50, "d", False),
     # short reads (few seeds per read): where the dual kernel's schedule stops paying (tools/ab_match.py, PGRC_DUAL=0 / 1)
     "S75": (10_000_000, 75, 125_000_000, 38, 25, "c", False),
     "S50": (10_000_000, 50, 125_000_000, 38, 25, "c", False),
@@ -185,6 +191,12 @@ def main():
         total_reads = n_total * args.steps
         value = total_reads / dt
         step_sorted = sorted(step_ms)
+        if mode != "c":
+            print(json.dumps(seed_mode_line(args, ctx, ctr, value, dt, step_sorted, world, n_per, n_total, L, G, seed_len, kmax, mode, matched)), flush=True)
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         # ---- roofline of the dominant kernel: the forward-pass match kernel (k_copmem_match)
         # algorithmic bytes: per searched read its packed words and
         # the 10-B result; per executed seed probe one 8-B bucket range; per verified candidate a 4-B position
@@ -306,6 +318,41 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def seed_mode_line(args, ctx, ctr, value, dt, step_sorted, world, n_per, n_total, L, G, seed_len, kmax, mode, matched):
+    """The bench line of the workloads in modes d / i / e (rows a5-a7, seedidx.hip).  Algorithmic bytes counted SURVEY-8d style: per
+    window start and strand one 8-byte table key; per (window, part) pair with equal keys the entry (4 B), the read's and the
+    window's L symbols at 2 bits and the read's 8-byte key; per read its packed words and its three result fields.  What the path runs
+    into is the same as in mode c: random line requests (one per window probe, about three per hit), not bytes."""
+    import zlib
+    P = 1 if mode == "e" else L // seed_len
+    nw = (L + 15) // 16
+    nwin = G - (L if mode == "e" else seed_len * (P if mode == "i" else 1)) + 1
+    runs = args.steps + args.warmup
+    hits = (ctr["candidates"][0] + ctr["candidates"][1]) // max(runs, 1)                 # (the counters add up over the runs)
+    alg = 2 * nwin * 8 + hits * (4 + 2 * ((L + 3) // 4) + 8) + n_per * (4 * nw + 10)
+    ms = dt / args.steps * 1e3
+    pos, rc, mism, _, _ = ctx.get_results()
+    digest = "%08x-%08x-%08x" % (zlib.crc32(pos.data), zlib.crc32(rc.data), zlib.crc32(mism.data))
+    req = 2 * nwin + 3 * hits + n_per * P
+    return {"metric": "reads matched/sec (150 bp) at 1/2/4/8 MI355X; achieved HBM GB/s", "value": value, "unit": "reads/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_per_step_min_median_max": [step_sorted[0], step_sorted[len(step_sorted) // 2], step_sorted[-1]],
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {n_per} x {L} bp SE reads per GPU vs Pg of {G} bp, mode {mode} (parts of {seed_len} symbols, k<={kmax}), both strands",
+                       "symbols": "2-bit packed, 16 per u32 word (integer xor/popcount work, no floating point)",
+                       "reads_per_gpu": n_per, "read_len": L, "pg_len": G, "seed_len": seed_len, "max_mismatches": kmax, "matched_fraction": matched / n_per,
+                       "parallelism": f"reads sharded x{world}, Pg replicated"},
+            "roofline": {"bound": "hbm", "binding_limit": "random line requests: one per window start of the forward text (both strands in one scan), about three per hit",
+                         "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_seed_probe + k_seed_expand + k_seed_heavy (seedidx.hip)", "kernel_ms": ctr["ms_total"], "algorithmic_bytes": alg,
+                         "windows": nwin, "hits_per_step": hits, "random_requests_estimate": req, "gather_rate_G_per_s": req / (ms * 1e-3) / 1e9,
+                         "gather_ceiling_G_per_s": GATHER_CEILING_GPS},
+            "counters": {"searched": ctr["searched"], "candidates": ctr["candidates"]},
+            "results_digest": digest,
+            "cpu_baseline": {"value": None, "unit": "reads/s", "cores": 0, "kind": "reference",
+                             "sample": "not measured here: the reference's matchers of these modes scan the text serially (tests/test_gpu_fullsize.py and tools/dbg_mode_i.py "
+                                       "compare results and candidate counts with the oracle / the reference at sizes they finish)"}}
 
 
 def index_roofline(ctr, cp, G, n_strands):
