@@ -351,7 +351,7 @@ def seed_mode_line(args, ctx, ctr, value, dt, step_sorted, world, n_per, n_total
             "counters": {"searched": ctr["searched"], "candidates": ctr["candidates"]},
             "results_digest": digest,
             "cpu_baseline": {"value": None, "unit": "reads/s", "cores": 0, "kind": "reference",
-                             "sample": "not measured here: the reference's matchers of these modes scan the text serially (tests/test_gpu_fullsize.py and tools/dbg_mode_i.py "
+                             "sample": "not measured here: the reference's matchers of these modes scan the text serially (tests/test_gpu_fullsize.py and tools/modes_vs_oracle.py "
                                        "compare results and candidate counts with the oracle / the reference at sizes they finish)"}}
 
 

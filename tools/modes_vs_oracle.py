@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""debug: modes d / i at a middle size against the oracle (canonical-key scan)"""
+"""Modes d / i / e at a middle size (L = 150, seed 38, k <= 3) against the oracle: results and the number of (window, part) pairs with
+equal keys per strand -- the one scan of the forward text must find exactly the candidates of the oracle's two scans.
+usage: python tools/modes_vs_oracle.py <pg length> <reads> <mode> [<mode> ...]   (e.g. 30000000 2000000 d i e: ~1 min of oracle per mode)"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
