@@ -585,6 +585,21 @@ def test_seedindex_reverse_palindromes(mode, L, seed_len):
 
 
 @pytest.mark.parametrize("mode", ["d", "i", "e"])
+def test_seedindex_candidates_at_ten_megabases(mode):
+    """The one scan of the forward text against the oracle's two scans at a size where the synthetic Pg has thousands of planted
+    repeats and tandem tracts (10 Mbp, 600 k reads of 150 bp): the results, and the number of (window, part) pairs with equal keys
+    per strand to the last one -- the table-dependent collisions of the rolling hash on periodic runs included (table(complement) =
+    bit reversal of table(symbol), seedidx.hip; with two arbitrary tables a few hundred pairs per 10^8 differed)."""
+    L = 150
+    pg, reads = make_inputs(10_000_000, 600_000, L, seed=777)
+    seed_len, kmax = (L, 0) if mode == "e" else (38, 3)
+    o = orc.oracle_match(mode, pg, reads, seed_len, kmax, 0)
+    g = gpu_match(mode, pg, reads, seed_len, kmax, 0)
+    assert_same_results(g, o, f"10 Mbp, mode {mode}")
+    assert g["ctx"].counters()["candidates"] == o["candidates"], (g["ctx"].counters()["candidates"], o["candidates"])
+
+
+@pytest.mark.parametrize("mode", ["d", "i", "e"])
 def test_seedindex_hit_floods_on_low_complexity_text(mode):
     """A poly-A tract and reads taken from it: every window of the tract hits every part of those reads (~1.4 M hits
     from 8 kbp of text), which overflows the scan kernel's block-local hit buffer and the first guess of the hit
