@@ -54,10 +54,12 @@ def main():
     reads = synth.reads_host(g, pg, rs, 0, ns)
     use_ref = orc.have_ref() if a.checker == "auto" else a.checker == "reference"
     t = time.perf_counter()
+    if mode != "c":
+        use_ref = use_ref and a.checker == "reference"      # (modes d / i / e: the oracle's serial scan by default -- it also counts the candidates)
     if use_ref:
-        r = orc.ref_match("c", pg, reads, seed_len, kmax, 0, True, 0, 1, a.threads)
+        r = orc.ref_match(mode, pg, reads, seed_len, kmax, 0, True, 0, 1, a.threads)
     else:
-        r = orc.oracle_match("c", pg, reads, seed_len, kmax, 0, True, a.threads)
+        r = orc.oracle_match(mode, pg, reads, seed_len, kmax, 0, True, a.threads)
     cpu_s = time.perf_counter() - t
     out = {
         "workload": a.workload, "pg_len": G, "read_len": L, "sample_reads": ns, "gpu_reads": n_gpu,
@@ -68,11 +70,15 @@ def main():
         "n_pos_diff": int((pos[:ns] != r["pos"]).sum()), "n_mism_diff": int((mism[:ns] != r["mism"]).sum()),
         "matched_in_sample": int((r["mism"] != 255).sum()), "gpu_s": gpu_s, "cpu_s": cpu_s,
     }
+    if mode != "c" and not use_ref:
+        out["candidates_gpu"] = ctx.counters()["candidates"]
+        out["candidates_checker"] = [int(v) for v in r["candidates"]]
+        out["candidates_equal"] = out["candidates_gpu"] == out["candidates_checker"]
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))
-    sys.exit(0 if out["pos_equal"] and out["rc_equal"] and out["mism_equal"] else 1)
+    sys.exit(0 if out["pos_equal"] and out["rc_equal"] and out["mism_equal"] and out.get("candidates_equal", True) else 1)
 
 
 if __name__ == "__main__":
