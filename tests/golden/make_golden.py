@@ -4,6 +4,8 @@
 generator parameters (inputs are re-derived from include/pgrc_synth.h) + the reference's outputs.
 
     python tests/golden/make_golden.py        # needs /root/reference (run `make -C oracle ref` first)
+    python tests/golden/make_golden.py --only-missing     # keeps the fixtures that exist (a zip file carries its writing time:
+                                                          # regenerated data would be equal, the bytes of the files not)
 """
 import hashlib
 import json
@@ -45,6 +47,20 @@ CASES = [
     ("i_L100_s38_M3", "i", 100, 38, 3, 200000, 10000, 0, True, 121, False),
     ("i_L150_s38_M50", "i", 150, 38, 50, 200000, 8000, 0, True, 122, False),
     ("i_L250_s45_M50", "i", 250, 45, 50, 200000, 5000, 0, True, 123, False),
+    # round 5: the cells of SURVEY 8(c)'s grid (L x mode x M x seed) that were still empty
+    ("e_L250", "d", 250, 250, 50, 200000, 5000, 0, True, 124, False),
+    ("C_L150_s38_M50_shortcut", "C", 150, 38, 50, 200000, 8000, 0, True, 125, False),
+    ("C_L250_s38_M50_shortcut", "C", 250, 38, 50, 200000, 5000, 0, True, 126, False),
+    ("D_L150_s38_M50_shortcut", "D", 150, 38, 50, 200000, 8000, 0, True, 127, False),
+    ("D_L250_s45_M50_shortcut", "D", 250, 45, 50, 200000, 5000, 0, True, 128, False),
+    ("c_L250_s38_M3", "c", 250, 38, 3, 200000, 5000, 0, True, 129, False),
+    ("c_L250_s250_M50_exactish", "c", 250, 250, 50, 200000, 5000, 0, True, 130, False),
+    ("d_L150_s38_M3", "d", 150, 38, 3, 200000, 8000, 0, True, 131, False),
+    ("i_L150_s38_M3", "i", 150, 38, 3, 200000, 8000, 0, True, 132, False),
+    ("d_L250_s45_M3", "d", 250, 45, 3, 200000, 5000, 0, True, 133, False),
+    ("i_L250_s45_M3", "i", 250, 45, 3, 200000, 5000, 0, True, 134, False),
+    ("I_L150_s38_M50_shortcut", "I", 150, 38, 50, 200000, 8000, 0, True, 135, False),
+    ("c_L150_s38_M50_nreads", "c", 150, 38, 50, 200000, 8000, 600, True, 136, False),
 ]
 
 
@@ -80,8 +96,14 @@ def derive(mode, L, seed_len, M):
 def main():
     assert orc.have_ref(), "build oracle/_ref first (make -C oracle ref)"
     manifest = {}
+    only_missing = "--only-missing" in sys.argv
+    if only_missing:
+        with open(os.path.join(HERE, "manifest.json")) as f:
+            manifest = json.load(f)
     for c in CASES:
         name, mode, L, seed_len, M, G, n, n_with_n, rev, gseed, paired = c
+        if only_missing and name in manifest and os.path.exists(os.path.join(HERE, name + ".npz")):
+            continue
         pg, reads = case_inputs(c)
         kind, sl, kmax, kmin = derive(mode, L, seed_len, M)
         if kind == "c":
@@ -97,6 +119,10 @@ def main():
                           "inputs_sha256": hashlib.sha256(pg.tobytes() + reads.tobytes()).hexdigest(),
                           "matched": r["matched"]}
         print(name, r["matched"], "/", n)
+    if only_missing:
+        with open(os.path.join(HERE, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     # copMEM index dumps (CopMEMMatcher.cpp:140-231, serial build) for three tiny texts
     for name, G, seed_len, gseed in (("idx_s38", 100000, 38, 201), ("idx_s45", 100000, 45, 202), ("idx_s150", 120000, 150, 203)):
         pg, _ = make_inputs(G, 1, 150, seed=gseed)
