@@ -285,10 +285,25 @@ typedef struct {
  * reference's own falses count and did the read again in the reference's order (tests and bench.py draw their parity
  * samples from these reads).  n bytes; all zero when the last run did not take the dual kernel. */
 int pgrc_match_get_redo_flags(pgrc_match_ctx *ctx, uint8_t *flags);
-/* Measurement only (tools/ubench_partjoin.py, pgrc_amd/csrc/ubench.hip): n probes of a table of 2^hash_bits 16-byte heads,
- * once as random gathers and once partitioned by the top bucket bits and joined against heads staged in LDS.
- * ms[0..3] = record generation, gather, partitioning, join; sums[0..1] = the two ways' checksums (must agree). */
-int pgrc_match_ubench_partjoin(uint64_t n_probes, uint32_t hash_bits, float ms[4], uint64_t sums[2]);
+/* ---- run-time options.  A context reads the environment ONCE, in pgrc_match_create / pgrc_match_create_multi /
+ *      pgrc_mem_create -- never at a launch.  None of the variables changes a result; unset = the library's choice.
+ *   schedule of a two-strand run of mode c:
+ *     PGRC_DUAL=0|1          never / whenever it applies: one query per read over both strands (the dual kernel)
+ *     PGRC_SCREEN=0|1        never / whenever it applies: the screened schedule (exact-match screen, forward pass, RC pass)
+ *     PGRC_EARLY_STOP=0      every read probes all its seeds, as the reference does (and the two passes in turn)
+ *     PGRC_BUILD_STREAMS=1   the two index builds of such a run on one stream instead of two
+ *     PGRC_HEAD_PAIR=0|1..4  no pair table (a head table per strand) / groups of 1, 2, 4, 8 buckets (default 3 = groups of 4)
+ *     PGRC_NREAD_INLINE=0    every read with an N takes the byte-path kernel (default: the dual kernel takes those with <= 4 N)
+ *     PGRC_MATCH_STAGE=0     the per-strand match kernel without staged refills
+ *   index build:  PGRC_INDEX_SORT=sweep|own (front end), PGRC_INDEX_FINISH=general (the general finish kernel for every
+ *                 partition), PGRC_INDEX_CFG=n (variant / block shape of the passes: A/B runs)
+ *   modes d/i/e:  PGRC_SEED_FILTER=0|1, PGRC_SEED_HEAVY=n, PGRC_SEED_READ_BATCH=n, PGRC_SEED_SEGMENT=n, PGRC_SEED_BUILD=n
+ *   hand-over:    PGRC_UPLOAD_CHUNK_MB=n (staging chunk of append_reads_*), PGRC_STREAM_TIMING (milestones on stderr)
+ *   tests:        PGRC_FORCE_POS64=1, PGRC_TEST_NO_SECOND_INDEX, PGRC_MEM_EVENT_CAP=n, PGRC_ALLGATHER=rccl|copy
+ *   process-wide, read once per process: PGRC_DEVICE_POOL_GB (above), PGRC_DEBUG_ALLOC (log every device allocation)
+ * pgrc_match_reload_options reads the environment again for a LIVE context (tests and A/B tools that change a variable
+ * between two runs of one context). */
+int pgrc_match_reload_options(pgrc_match_ctx *ctx);
 /* enable per-kernel HIP-event timing + work counters for subsequent runs */
 int pgrc_match_set_profiling(pgrc_match_ctx *ctx, int enabled);
 int pgrc_match_get_counters(pgrc_match_ctx *ctx, pgrc_match_counters *out);

@@ -126,7 +126,6 @@ _PROTOS = [
     ("pgrc_match_extract_mismatches", C.c_int, [_P, _P, _P, _P, _P]),
     ("pgrc_match_get_redo_flags", C.c_int, [_P, _P]),
     ("pgrc_match_trim_device_memory", C.c_uint64, []),
-    ("pgrc_match_ubench_partjoin", C.c_int, [C.c_uint64, C.c_uint32, C.POINTER(C.c_float * 4), C.POINTER(C.c_uint64 * 2)]),
     ("pgrc_match_prepare_index", C.c_int, [_P, C.c_int32]),
     ("pgrc_match_stream_begin", C.c_int, [_P, _P, _P, _P]),
     ("pgrc_match_stream_end", C.c_int, [_P, _P, C.POINTER(C.c_uint64)]),
@@ -137,6 +136,7 @@ _PROTOS = [
     ("pgrc_match_copmem_params", C.c_int, [C.c_uint32, C.c_uint64, C.POINTER(CopmemParams)]),
     ("pgrc_match_export_index", C.c_int, [_P, C.c_int, _P, _P, C.POINTER(C.c_uint64)]),
     ("pgrc_match_export_pg", C.c_int, [_P, C.c_int, _P]),
+    ("pgrc_match_reload_options", C.c_int, [_P]),
     ("pgrc_match_set_profiling", C.c_int, [_P, C.c_int]),
     ("pgrc_match_get_counters", C.c_int, [_P, C.POINTER(Counters)]),
     ("pgrc_synth_pg_host", None, [C.POINTER(SynthPg), _P]),

@@ -63,7 +63,8 @@ int pgrc_buf_ensure(pgrc_match_ctx *c, DevBuf &b, size_t bytes) {
         return pgrc_hip_code(e);
     }
     b.bytes = bytes;
-    if (getenv("PGRC_DEBUG_ALLOC")) fprintf(stderr, "pgrc alloc ctx %p buf %p: %zu bytes at %p\n", (void *)c, (void *)&b, bytes, b.p);
+    static const bool debug_alloc = getenv("PGRC_DEBUG_ALLOC") != nullptr;     // (process-wide, read once)
+    if (debug_alloc) fprintf(stderr, "pgrc alloc ctx %p buf %p: %zu bytes at %p\n", (void *)c, (void *)&b, bytes, b.p);
     return PGRC_OK;
 }
 
@@ -110,6 +111,36 @@ extern "C" uint64_t pgrc_match_trim_device_memory(void) {
 }
 
 static thread_local std::string g_create_err; // reported by pgrc_match_last_error(NULL)
+
+// The environment, read once per context (ctx.h, PgrcOptions; include/pgrc_match.h lists the variables)
+PgrcOptions pgrc_options_from_env() {
+    PgrcOptions o;
+    auto flag = [](const char *name) -> int { const char *v = getenv(name); return (v && (v[0] == '0' || v[0] == '1')) ? v[0] - '0' : -1; };
+    auto num = [](const char *name) -> long long { const char *v = getenv(name); return (v && v[0]) ? atoll(v) : -1; };
+    o.dual = flag("PGRC_DUAL");
+    o.screen = flag("PGRC_SCREEN");
+    o.early_stop = flag("PGRC_EARLY_STOP") != 0;
+    o.builds_in_turn = flag("PGRC_BUILD_STREAMS") == 1;
+    if (const char *hp = getenv("PGRC_HEAD_PAIR")) o.head_pair = hp[0] == '0' ? 0u : (hp[0] >= '1' && hp[0] <= '4') ? 1u << (hp[0] - '1') : 4u;
+    if (const char *is = getenv("PGRC_INDEX_SORT")) o.index_front = !strcmp(is, "own") ? 1 : 0;
+    if (const char *fi = getenv("PGRC_INDEX_FINISH")) o.index_finish_general = !strcmp(fi, "general");
+    o.index_cfg = (int)num("PGRC_INDEX_CFG");
+    o.match_stage = flag("PGRC_MATCH_STAGE") != 0;
+    o.nread_inline = flag("PGRC_NREAD_INLINE") != 0;
+    o.force_pos64 = flag("PGRC_FORCE_POS64") == 1;
+    o.test_no_second_index = getenv("PGRC_TEST_NO_SECOND_INDEX") != nullptr;
+    o.stream_timing = getenv("PGRC_STREAM_TIMING") != nullptr;
+    if (num("PGRC_UPLOAD_CHUNK_MB") > 0) o.upload_chunk_mb = (uint64_t)std::min<long long>(4096, num("PGRC_UPLOAD_CHUNK_MB"));
+    o.seed_filter = flag("PGRC_SEED_FILTER");
+    if (num("PGRC_SEED_HEAVY") > 0) o.seed_heavy = (uint32_t)std::min<long long>(4096, num("PGRC_SEED_HEAVY"));
+    if (num("PGRC_SEED_READ_BATCH") > 0) o.seed_read_batch = (uint64_t)num("PGRC_SEED_READ_BATCH");
+    if (num("PGRC_SEED_SEGMENT") > 0) o.seed_segment = (uint64_t)num("PGRC_SEED_SEGMENT");
+    o.seed_build = (int)num("PGRC_SEED_BUILD");
+    if (num("PGRC_MEM_EVENT_CAP") > 0) o.mem_event_cap = (uint64_t)num("PGRC_MEM_EVENT_CAP");
+    if (const char *ag = getenv("PGRC_ALLGATHER")) o.allgather = !strcmp(ag, "rccl") ? 1 : !strcmp(ag, "copy") ? 2 : 0;
+    o.dual_variant = (int)num("PGRC_DUAL_VARIANT");
+    return o;
+}
 
 static int isqrt_floor(int v) {
     int r = 0;
@@ -193,6 +224,7 @@ int pgrc_match_create(const pgrc_match_params *p, pgrc_match_ctx **out) {
     (void)hipGetLastError(); // start from a clean sticky-error state
     pgrc_match_ctx *c = new pgrc_match_ctx();
     c->prm = *p;
+    c->opt = pgrc_options_from_env();
     c->device = dev;
     c->nw = (p->read_len + 15) / 16;
     {
@@ -267,6 +299,14 @@ int pgrc_match_set_profiling(pgrc_match_ctx *c, int enabled) {
         c->have_events = true;
     }
     c->profiling = enabled != 0;
+    return PGRC_OK;
+}
+
+int pgrc_match_reload_options(pgrc_match_ctx *c) {
+    if (!c) return PGRC_E_PARAM;
+    c->opt = pgrc_options_from_env();
+    if (c->multi)
+        for (const PgrcShardView &sv : pgrc_multi_shards(c)) sv.ctx->opt = c->opt;
     return PGRC_OK;
 }
 
@@ -444,8 +484,7 @@ int pgrc_match_begin_reads(pgrc_match_ctx *c, uint64_t n) {
 // ACGT packing (4 symbols per byte), 5 = its ACGNT packing (3 symbols per byte).  Staged through a bounded device
 // buffer and converted to the word-major 2-bit layout there; reads holding an N are flagged, and their ASCII rows
 // (made on the device for the packed formats) are kept for the side list of end_reads.
-static bool up_timing_on() { static const bool on = getenv("PGRC_STREAM_TIMING") != nullptr; return on; }
-#define UP_MARK(c, what) do { if (up_timing_on() && (c)->st_on) fprintf(stderr, "pgrc stream: %8.2f ms    append: %s\n", (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - (c)->st_t0) * 1e3, what); } while (0)
+#define UP_MARK(c, what) do { if ((c)->opt.stream_timing && (c)->st_on) fprintf(stderr, "pgrc stream: %8.2f ms    append: %s\n", (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - (c)->st_t0) * 1e3, what); } while (0)
 static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, int32_t symbols) {
     if (!c->up_open || c->up_next + count > c->n) { c->err = "append_reads: outside begin/end or too many rows"; return PGRC_E_STATE; }
     PGRC_ON_DEVICE(c);
@@ -459,7 +498,7 @@ static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, i
     // (a streamed run matches chunk by chunk, and every launch of the persistent match kernel pays ~4 ms of ramp and drain:
     //  C3 through the boundary 0.29 / 0.23 / 0.22 / 0.20 s with chunks of 128 / 256 / 512 / 1024 MiB, profiles/r03_boundary_c3.json)
     uint64_t chunk_mib = c->st_on ? 1024 : 256;
-    if (const char *v = getenv("PGRC_UPLOAD_CHUNK_MB")) chunk_mib = std::max<uint64_t>(1, std::min<uint64_t>(4096, (uint64_t)atoll(v)));   // (experiments)
+    if (c->opt.upload_chunk_mb) chunk_mib = c->opt.upload_chunk_mb;   // (experiments)
     const uint64_t CHR = std::max<uint64_t>(1024, ((chunk_mib << 20) / rb) & ~1023ull);
     for (int k = 0; k < 2; k++)
         if ((e = pgrc_buf_ensure(c, c->up_stage[k], (size_t)std::min(CHR, std::max<uint64_t>(count, 1)) * rb))) return e;
@@ -672,10 +711,8 @@ extern "C" {
 // PGRC_SCREEN=0 or the second set of index buffers does not fit.
 static bool screen_wanted(const pgrc_match_ctx *c, int first, int last) {
     if (c->prm.mode != 'c' || first != 0 || last != 1 || c->prm.min_mismatches != 0 || !c->n || c->screen_broken) return false;
-    const char *v = getenv("PGRC_SCREEN");     // 0: never, 1: whenever it applies; unset: where it pays
-    if (v && (v[0] == '0' || v[0] == '1')) return v[0] == '1';
-    const char *es = getenv("PGRC_EARLY_STOP");
-    if (es && es[0] == '0') return false;       // (the screen's proofs of absence ARE the early-stop rule)
+    if (c->opt.screen >= 0) return c->opt.screen == 1;     // PGRC_SCREEN: 0 never, 1 whenever it applies; unset: where it pays
+    if (!c->opt.early_stop) return false;       // (the screen's proofs of absence ARE the early-stop rule)
     // The screen is one more sweep over all reads (~5 probes each) and saves a read that matches the other strand exactly
     // the forward query it would lose: with fewer than ~48 seeds per read (L = 100: 37) the two about cancel
     // (profiles/r02_screen_ab.txt: C2 +2.6 %, C3 -12 %).
@@ -686,12 +723,9 @@ static bool screen_wanted(const pgrc_match_ctx *c, int first, int last) {
 // ... and, when they apply, rather ONE query per read over both strands (copmem.hip, "The dual kernel"); PGRC_DUAL=0: never
 static bool dual_wanted(const pgrc_match_ctx *c, int first, int last) {
     if (c->prm.mode != 'c' || first != 0 || last != 1 || c->prm.min_mismatches != 0 || !c->n || c->screen_broken) return false;
-    const char *v = getenv("PGRC_DUAL");
-    if (v && v[0] == '0') return false;
-    const char *es = getenv("PGRC_EARLY_STOP");
-    const char *sc = getenv("PGRC_SCREEN");
-    if ((es && es[0] == '0') || (sc && (sc[0] == '0' || sc[0] == '1'))) return false;   // the older schedules were asked for
-    if (v && v[0] == '1') return true;
+    if (c->opt.dual == 0) return false;
+    if (!c->opt.early_stop || c->opt.screen >= 0) return false;   // the older schedules were asked for
+    if (c->opt.dual == 1) return true;
     // Round 2 kept short reads (fewer than 48 seeds) on the two passes: the dual kernel cost C2 (100 bp, 37 seeds) +19 % then.
     // With the pair table and nothing launched behind it, it wins at every length measured (round 4, one context each,
     // profiles/r04_c2_dual_ab.txt): C2 16.3 -> 12.5 ms, 75 bp 13.4 -> 11.0, 50 bp 9.9 -> 8.6, 1 M x 150 bp 7.2 -> 4.6.
@@ -711,8 +745,7 @@ static int pgrc_build_both_indexes(pgrc_match_ctx *c, bool *two_streams, F mark)
     if ((e = pgrc_launch_revcomp(c, (const uint32_t *)c->pg2[0].p, (uint32_t *)c->pg2[1].p, c->G))) return e;
     c->have_rc = true;
     mark(); // 1
-    const char *bs = getenv("PGRC_BUILD_STREAMS");
-    bool two = !(bs && bs[0] == '1');
+    bool two = !c->opt.builds_in_turn;
     if (two && !c->build_stream) {
         hipError_t he = hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking);
         for (int k = 0; k < 2 && he == hipSuccess; k++) he = hipEventCreateWithFlags(&c->build_ev[k], hipEventDisableTiming);
@@ -727,8 +760,7 @@ static int pgrc_build_both_indexes(pgrc_match_ctx *c, bool *two_streams, F mark)
     // kernel's two gathers of a seed then hit one 64-byte line and one translation.  PGRC_HEAD_PAIR=0: a table per strand
     // (A/B runs); no room for the pair table: the same.
     {
-        const char *hp = getenv("PGRC_HEAD_PAIR");
-        bool pair = !(hp && hp[0] == '0');
+        bool pair = c->opt.head_pair != 0;
         if (pair) {
             const int pe = pgrc_buf_ensure(c, c->d_headpair, (size_t)c->cp.hash_size * 4 * sizeof(uint64_t));
             if (pe == PGRC_E_ALLOC) { (void)hipGetLastError(); pair = false; }
@@ -739,14 +771,14 @@ static int pgrc_build_both_indexes(pgrc_match_ctx *c, bool *two_streams, F mark)
         // (profiles/r04_head_interleave_ab.txt): both gathers of a seed cost one request as long as they share a 128-BYTE line
         // (groups of 1, 2, 4: dual kernel 79.5 -> 64.7 ms; groups of 8 = 256 bytes: 79.6), and the builds' head stores cost
         // nothing extra only as whole 64-byte runs (groups of 1 and 2: index pair 16.2 -> 24.9 ms; groups of 4: 17.0)
-        c->pair_gm = (hp && hp[0] >= '1' && hp[0] <= '4') ? (1u << (hp[0] - '1')) - 1u : 3u;
+        c->pair_gm = pair ? c->opt.head_pair - 1u : 3u;
     }
     if ((e = pgrc_copmem_build_index(c, 0))) { c->pair_build = false; return e; }
     if (!two) mark(); // 2
     swap_index_sets(c);
     if (two) c->stream = c->build_stream;
     // (PGRC_TEST_NO_SECOND_INDEX: tests take the out-of-memory road without exhausting the device)
-    e = getenv("PGRC_TEST_NO_SECOND_INDEX") ? PGRC_E_ALLOC : pgrc_copmem_build_index(c, 1);
+    e = c->opt.test_no_second_index ? PGRC_E_ALLOC : pgrc_copmem_build_index(c, 1);
     c->pair_build = false;
     c->stream = main_stream;
     if (two) {
@@ -763,6 +795,7 @@ static int pgrc_build_both_indexes(pgrc_match_ctx *c, bool *two_streams, F mark)
 bool pgrc_dual_applies(const pgrc_match_ctx *c) {
     pgrc_match_ctx probe;                     // (dual_wanted looks at n only to rule out an empty set)
     probe.prm = c->prm;
+    probe.opt = c->opt;
     probe.cp = c->cp;
     probe.n = 1;
     probe.screen_broken = c->screen_broken;
@@ -869,14 +902,11 @@ static int run_passes(pgrc_match_ctx *c, int first, int last) {
             if (dual) {
                 // the reads with N: those with at most 4 N's are the dual kernel's own (its N-aware hash and verification);
                 // the others go the byte path on the side stream, a read's forward query and then its RC query in one lane,
-                // behind the dual kernel.  (PGRC_NREAD_BESIDE=1 launches that kernel first, as a small persistent grid: it
-                //  still only starts when the dual kernel's persistent blocks leave -- profiles/r04_nread_ab.txt)
-                const char *nb = getenv("PGRC_NREAD_BESIDE");
-                const bool beside = nb && nb[0] == '1';
-                if (beside && (e = pgrc_copmem_match_nreads(c, 0, 1, true, true))) return e;
+                // behind the dual kernel.  (Launched first, as a small persistent grid, that kernel still only starts when the
+                //  dual kernel's persistent blocks leave -- profiles/r04_nread_beside_ab.txt)
                 if ((e = pgrc_copmem_match_dual(c))) return e;             // one query per read over both strands
                 mark(); // 4
-                if (!beside && (e = pgrc_copmem_match_nreads(c, 0, 1, false, true))) return e;
+                if ((e = pgrc_copmem_match_nreads(c, 0, 1, true))) return e;
                 if ((e = pgrc_copmem_join_nreads(c))) return e;
                 mark(); // 5: what the reads with N took beyond the dual kernel
                 mark(); // 6

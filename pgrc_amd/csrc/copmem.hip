@@ -27,123 +27,18 @@
 #include <cstring>
 #include <type_traits>
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-
 #include "ctx.h"
 #include "devutil.h"
 #include "headfmt.h"
+#include "matchdev.h"
+#include "dualkern.h"
 
 // ----------------------------------------------------------------------------- index build
 
-#define IDX_TPB 256
-#define IDX_TILE_WORDS (IDX_TPB + 16) // 256 positions * k1(<=16) symbols / 16 + K/16 + slack
-
-// Sort-based build, no atomics (the earlier build cascaded every sampled position through its bucket head with
-// random 64-bit atomicMin -- three sweeps at ~18 G atomics/s, 44 ms per strand at C3; rocPRIM's radix sort moves the
-// same 375 M records at 32 G/s, tools/ubench/sortrate.hip):
-//   1. k_copmem_index_gen   : sampled position t -> (bucket, entry), written in ascending position order (streaming)
-//   2. rocprim radix sort   : STABLE sort of the pairs by bucket => every bucket's entries are contiguous and in
-//                             ascending position order, i.e. exactly the order the reference's serial build appends them
-//   3. k_copmem_index_heads : one streaming pass over the sorted runs writes the 16-byte bucket heads; the sorted
-//                             entry array itself serves as ent[] (entry j >= 1 of a bucket whose run starts at i is
-//                             ent[i + j]; entries beyond the 13th are simply never addressed = the bucket cap)
-// The result is the reference's SERIAL index bit for bit, whatever the execution order.
-
-// One block walks tiles of IDX_TPB consecutive sampled positions; the tile's text words are loaded once,
-// coalesced, into LDS; every thread hashes its K-symbol window from LDS.
-__global__ void __launch_bounds__(IDX_TPB)
-k_copmem_index_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, uint64_t npos, uint32_t k1, uint32_t K,
-                   uint32_t mask, uint32_t *__restrict__ keys, uint64_t *__restrict__ vals) {
-    __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
-    __shared__ uint32_t tile[IDX_TILE_WORDS + 8];
-    hash_lut_init(lut);
-    const uint64_t ntiles = (npos + IDX_TPB - 1) / IDX_TPB;
-    for (uint64_t tIdx = blockIdx.x; tIdx < ntiles; tIdx += gridDim.x) {
-        const uint64_t t0 = tIdx * IDX_TPB;
-        const uint64_t t = t0 + threadIdx.x;
-        const uint64_t p0 = t0 * k1;
-        const uint64_t w0 = p0 >> 4;
-        const uint32_t need = (uint32_t)((((p0 & 15) + (uint64_t)(IDX_TPB - 1) * k1 + K + 15) >> 4) + 5);
-        __syncthreads();
-        for (uint32_t w = threadIdx.x; w < need; w += IDX_TPB) tile[w] = (w0 + w < pg_words_alloc) ? pg[w0 + w] : 0u;
-        __syncthreads();
-        if (t < npos) {
-            const uint64_t p = t * k1;
-            const uint32_t q = (uint32_t)((p >> 4) - w0);
-            const uint32_t sh = ((uint32_t)p & 15u) * 2u;
-            const uint32_t a0 = tile[q], a1 = tile[q + 1], a2 = tile[q + 2], a3 = tile[q + 3], a4 = tile[q + 4];
-            uint32_t fp;
-            const uint32_t h = copmem_hash32_fp(funnel_r(a0, a1, sh), funnel_r(a1, a2, sh), funnel_r(a2, a3, sh),
-                                                funnel_r(a3, a4, sh), K, lut, &fp) & mask;
-            keys[t] = h;
-            vals[t] = (p << PGRC_FP_BITS) | fp;
-        }
-    }
-}
-
-// sorted (bucket, entry) records -> bucket heads, written ONCE and in whole lines.  A block takes HEADS_REC consecutive
-// records and owns the buckets after the previous block's last bucket up to its own last bucket (the last block: up to
-// the end of the table); it stages them in LDS -- empty heads for buckets without a run, the head of every run that
-// starts in the block -- and streams the tile out, so no memset of the table and no partial-line scatter is needed.
-// A bucket range larger than the tile (sparse or degenerate text) is walked in tile-sized chunks.
-#define HEADS_TPB 256
-#define HEADS_RPT 4
-#define HEADS_REC (HEADS_TPB * HEADS_RPT)
-#define HEADS_CAP 2048u
-__global__ void __launch_bounds__(HEADS_TPB)
-k_copmem_index_heads(const uint32_t *__restrict__ sk, const uint64_t *__restrict__ se, uint64_t n, uint64_t hs,
-                     ulonglong2 *__restrict__ head, uint32_t hsh) {
-    __shared__ ulonglong2 tile[HEADS_CAP];
-    __shared__ uint32_t skey[HEADS_REC + 16];        // keys i0-1 .. i1+12 (0xFFFFFFFF beyond the end: never a bucket)
-    const uint64_t i0 = (uint64_t)blockIdx.x * HEADS_REC;
-    const uint64_t i1 = min(n, i0 + HEADS_REC);
-    // all loads of the block are issued up front: keys into LDS, this thread's 4 consecutive entries (+1) in registers
-    for (uint32_t x = threadIdx.x; x < HEADS_REC + 14; x += HEADS_TPB) {
-        const uint64_t i = i0 + x;                   // skey[x] = sk[i - 1]
-        skey[x] = (i >= 1 && i - 1 < n) ? sk[i - 1] : 0xFFFFFFFFu;
-    }
-    const uint64_t f = i0 + (uint64_t)threadIdx.x * HEADS_RPT;
-    uint64_t ev[HEADS_RPT + 1];
-#pragma unroll
-    for (int k = 0; k <= HEADS_RPT; k++) ev[k] = (f + k < n) ? se[f + k] : 0ull;
-    __syncthreads();
-    const uint64_t lo = i0 ? (uint64_t)skey[0] + 1 : 0;                       // first owned bucket
-    const uint64_t hi = (i1 == n) ? hs : (uint64_t)skey[i1 - i0] + 1;         // one past the last owned bucket
-    bool st[HEADS_RPT];
-    uint32_t bk[HEADS_RPT];
-    ulonglong2 hv[HEADS_RPT];
-#pragma unroll
-    for (int k = 0; k < HEADS_RPT; k++) {
-        const uint32_t x = threadIdx.x * HEADS_RPT + k + 1;                   // skey index of record f + k
-        const uint32_t b = skey[x];
-        st[k] = (f + k < i1) && (f + k == 0 || skey[x - 1] != b);             // first record of its bucket
-        bk[k] = b;
-        hv[k] = make_ulonglong2(ev[k], HEAD_EMPTY);
-        if (st[k]) {
-            uint32_t cnt = 1;
-            while (cnt < PGRC_BUCKET_CAP && skey[x + cnt] == b) cnt++;       // x + cnt <= HEADS_REC + 13
-            if (cnt == 2) hv[k].y = ev[k + 1];
-            else if (cnt > 2) {
-                hv[k].x |= HEAD_OVF;
-                hv[k].y = (f + k + 1) | ((uint64_t)cnt << 56);               // entries 1.. at ent[(i + 1) + j - 1]
-            }
-        }
-    }
-    for (uint64_t base = lo; base < hi; base += HEADS_CAP) {
-        const uint32_t m = (uint32_t)min((uint64_t)HEADS_CAP, hi - base);
-        for (uint32_t x = threadIdx.x; x < m; x += HEADS_TPB) tile[x] = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < HEADS_RPT; k++)
-            if (st[k] && bk[k] >= base && bk[k] - base < m) tile[bk[k] - base] = hv[k];
-        __syncthreads();
-        for (uint32_t x = threadIdx.x; x < m; x += HEADS_TPB) head[head_slot(base + x, hsh)] = tile[x];
-        __syncthreads();
-    }
-}
-
-#define IDX_MAX_BLOCKS 4096u
+// The build itself lives in idxsweep.hip (the default front end: two scatter passes that hash the text themselves) and
+// idxsort.hip (the partition finish; the stable front end "own").  History: round 1 generated (bucket, entry) records and
+// sorted them with the library's radix sort (16.3 ms per strand at C3), round 2 kept the library for the two top passes
+// only; both forms left the product in round 5 -- no library kernel is on the path.
 
 // a text shorter than K: every head of this strand's table is empty
 __global__ void __launch_bounds__(256) k_heads_empty(ulonglong2 *__restrict__ head, uint64_t hs, uint32_t hsh) {
@@ -156,8 +51,6 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     const uint64_t hs = c->cp.hash_size;
     c->npos = (c->G >= K) ? (c->G - K) / k1 + 1 : 0;
     const uint64_t npos = c->npos;
-    // (the match kernel addresses ent[] with 32-bit indices unless it runs its 64-bit-position variant, which a text
-    //  with 2^32 or more sampled positions always does)
     int e;
     if (c->pair_build) {             // both strands' heads in one table of 32-byte slots (ctx.h)
         if ((e = pgrc_buf_ensure(c, c->d_headpair, hs * 4 * sizeof(uint64_t)))) return e;
@@ -179,50 +72,22 @@ int pgrc_copmem_build_index(pgrc_match_ctx *c, int strand) {
     }
     int hbits = 0;
     while ((1ull << hbits) < hs) hbits++;
-    // How the records get grouped by bucket (all four give the serial reference index, byte for byte):
-    //   "sweep" (default): two hand-written one-sweep scatter passes over the TOP bucket bits that hash the text
-    //             themselves and shrink the records to 8 bytes (idxsweep.hip), then one block per partition of 8192
-    //             buckets finishes counting, cap, order and heads in LDS (idxsort.hip); no library call;
-    //   "hybrid" (round 2's default): record generation + the library's radix sort over the top bucket bits (two 8-bit
-    //             passes), then the same finish;
-    //   "own":    the same finish behind hand-written scatter passes that hash the text themselves (no library call);
-    //   "rocprim": round 1's path -- full library sort, streaming head kernel (also taken for 2^32 or more samples).
-    const char *sel = getenv("PGRC_INDEX_SORT");
-    const bool want_lib = sel && !strcmp(sel, "rocprim"), want_own = sel && !strcmp(sel, "own");
-    const bool want_sweep = !sel || !sel[0] || !strcmp(sel, "sweep");
-    if (want_sweep && pgrc_os_applicable(c, (uint32_t)hbits)) return pgrc_os_build_index(c, strand, (uint32_t)hbits);
-    const bool partition = !want_lib && pgrc_ps_applicable(c, (uint32_t)hbits);
+    // How the records get grouped by bucket (both give the serial reference index, byte for byte):
+    //   "sweep" (default): two hand-written scatter passes over the TOP bucket bits that hash the text themselves and
+    //             shrink the records to 8 bytes (idxsweep.hip), then one block per partition finishes counting, cap, order
+    //             and heads in LDS (idxsort.hip);
+    //   "own":    the same finish behind STABLE scatter passes of (u32 bucket, u64 entry) records (idxsort.hip): what
+    //             texts with more than 2^30 sampled positions take (the 8-byte records of "sweep" have no room for them).
+    // The match kernels address ent[] with 32-bit indices unless they run their 64-bit-position variant; both front ends
+    // stop at 2^32 samples (a text of k1 * 2^32 > 17 G symbols).
+    if (c->opt.index_front == 0 && pgrc_os_applicable(c, (uint32_t)hbits)) return pgrc_os_build_index(c, strand, (uint32_t)hbits);
+    if (!pgrc_ps_applicable(c, (uint32_t)hbits)) {
+        c->err = "index build: texts with 2^32 or more sampled positions are not supported";
+        return PGRC_E_PARAM;
+    }
     const uint32_t cb = pgrc_ps_partition_bits((uint32_t)hbits);
-    if (partition && want_own) {
-        if ((e = pgrc_ps_scatter_front(c, strand, (uint32_t)hbits, cb))) return e;
-        return pgrc_ps_finish(c, (const uint32_t *)c->d_skey[1].p, (const uint64_t *)c->d_sval[1].p, (uint32_t)hbits, cb, (uint64_t *)c->d_sval[0].p);
-    }
-    // scratch lives in the context (grow-only): no hipMalloc / hipFree (= device synchronisation) per build
-    for (int k = 0; k < 2; k++) {
-        if ((e = pgrc_buf_ensure(c, c->d_skey[k], (npos + 16) * sizeof(uint32_t)))) return e;
-        if ((e = pgrc_buf_ensure(c, c->d_sval[k], (npos + 16) * sizeof(uint64_t)))) return e;
-    }
-    rocprim::double_buffer<uint32_t> keys((uint32_t *)c->d_skey[0].p, (uint32_t *)c->d_skey[1].p);
-    rocprim::double_buffer<uint64_t> vals((uint64_t *)c->d_sval[0].p, (uint64_t *)c->d_sval[1].p);
-    size_t tbytes = 0;
-    const unsigned bit0 = partition ? cb : 0u;
-    hipError_t he = rocprim::radix_sort_pairs(nullptr, tbytes, keys, vals, (size_t)npos, bit0, hbits, c->stream);
-    if (he != hipSuccess) { c->err = "rocprim size query failed"; return PGRC_E_DEVICE; }
-    if ((e = pgrc_buf_ensure(c, c->d_sorttmp, tbytes + 16))) return e;
-
-    const uint64_t ntiles = (npos + IDX_TPB - 1) / IDX_TPB;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ntiles, 1), IDX_MAX_BLOCKS);
-    hipLaunchKernelGGL(k_copmem_index_gen, dim3(grid), dim3(IDX_TPB), 0, c->stream, (const uint32_t *)c->pg2[strand].p,
-                       c->pg_words + PGRC_PG_PAD_WORDS, npos, k1, K, (uint32_t)(hs - 1), keys.current(), vals.current());
-    HIP_TRY(c, hipGetLastError());
-    he = rocprim::radix_sort_pairs(c->d_sorttmp.p, tbytes, keys, vals, (size_t)npos, bit0, hbits, c->stream);
-    if (he != hipSuccess) { c->err = std::string("index sort: ") + hipGetErrorString(he); return PGRC_E_DEVICE; }
-    if (partition) return pgrc_ps_finish(c, keys.current(), vals.current(), (uint32_t)hbits, cb, vals.alternate());
-    hipLaunchKernelGGL(k_copmem_index_heads, dim3((uint32_t)((npos + HEADS_REC - 1) / HEADS_REC)), dim3(HEADS_TPB), 0, c->stream,
-                       (const uint32_t *)keys.current(), (const uint64_t *)vals.current(), npos, hs, c->head_ptr, c->head_sh);
-    HIP_TRY(c, hipGetLastError());
-    c->ent_ptr = vals.current();
-    return PGRC_OK;
+    if ((e = pgrc_ps_scatter_front(c, strand, (uint32_t)hbits, cb))) return e;
+    return pgrc_ps_finish(c, (const uint32_t *)c->d_skey[1].p, (const uint64_t *)c->d_sval[1].p, (uint32_t)hbits, cb, (uint64_t *)c->d_sval[0].p);
 }
 
 // ---- canonical export for tests: the reference's (cumm, sampledPositions) from heads + ent ----
@@ -258,11 +123,10 @@ int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_po
     HIP_TRY(c, hipMemsetAsync(cnt.p, 0, (hs + 2) * sizeof(uint32_t), c->stream));
     const uint32_t sgrid = (uint32_t)((hs + 255) / 256 < 65536u * 8u ? (hs + 255) / 256 : 65536u * 8u);
     hipLaunchKernelGGL(k_export_counts, dim3(sgrid), dim3(256), 0, c->stream, (const ulonglong2 *)c->head_ptr, c->head_sh, hs, (uint32_t *)cnt.p);
-    size_t tb = 0;
-    hipError_t he = rocprim::exclusive_scan(nullptr, tb, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)(hs + 2), rocprim::plus<uint32_t>(), c->stream);
-    if (he == hipSuccess && (e = pgrc_buf_ensure(c, temp, tb))) { cleanup(); return e; }
-    if (he == hipSuccess)
-        he = rocprim::exclusive_scan(temp.p, tb, (uint32_t *)cnt.p, (uint32_t *)cumm.p, 0u, (size_t)(hs + 2), rocprim::plus<uint32_t>(), c->stream);
+    // cumm = exclusive scan of the counts (the build's own scan kernels; in place in `cnt`, then copied)
+    if ((e = pgrc_buf_ensure(c, temp, (pgrc_ps_scan_blocks(hs + 2) + 2) * sizeof(uint32_t)))) { cleanup(); return e; }
+    if ((e = pgrc_ps_scan_u32(c, (uint32_t *)cnt.p, hs + 2, (uint32_t *)temp.p))) { cleanup(); return e; }
+    hipError_t he = hipMemcpyAsync(cumm.p, cnt.p, (hs + 2) * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream);
     uint32_t total = 0;
     if (he == hipSuccess) he = hipMemcpyAsync(&total, (uint32_t *)cumm.p + hs, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
@@ -309,16 +173,6 @@ struct MatchArgs {
     uint8_t *scr_flag;
 };
 
-#define MATCH_TPB 256
-
-// Per-read state of the reference's sequential query (CopMEMMatcher.cpp:483-566).
-template <typename pos_t>
-struct ReadState {
-    uint32_t limit, falses, cur;
-    pos_t best; // all ones = none (text positions stay below 2^32 - 256, resp. 2^40 - 256: api.hip alloc_pg)
-    bool done;
-};
-
 // The query as a per-lane state machine.  A plain loop over seeds makes a whole wave wait out up to
 // three dependent memory latencies per seed (bucket head -> bucket entry -> text window) whenever ANY
 // of its 64 reads needs them.  Here every lane advances its own read by one memory access per
@@ -332,75 +186,6 @@ struct ReadState {
 //     accepted with m > 0 mismatches -- or lying in a repeat -- meets the same alignments again at every
 //     later seed sampled there; their head/tail counts cannot change, only the limit they are judged
 //     against does, so the text window is fetched once.
-#define SM_MAX_SEEDS 240
-#ifndef VC_BITS
-#define VC_BITS 2           // verify-cache slots per read = 1 << VC_BITS (direct mapped)
-#endif
-#define VC_SLOTS (1 << VC_BITS)
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-struct __attribute__((packed, aligned(4))) U32x4A4 { u32x4 v; }; // 16-B load that only needs 4-B alignment
-struct __attribute__((packed, aligned(8))) U64x2A8 { unsigned long long x, y; }; // 16-B load, 8-B aligned
-// KQ = K/4 when known at compile time (7 for the default seed 38), 0 = run-time loop.
-template <int KQ>
-__device__ __forceinline__ uint32_t hash_fp_window(const uint32_t w0, const uint32_t w1, const uint32_t w2, const uint32_t w3,
-                                                   uint32_t K, const uint32_t *lut, uint32_t *fp_out) {
-    if (KQ == 0) return copmem_hash32_fp(w0, w1, w2, w3, K, lut, fp_out);
-    const uint32_t w[4] = {w0, w1, w2, w3};
-    uint32_t h = 4u * KQ, fp = 0, fb = 0;
-#pragma unroll
-    for (int j = 0; j < KQ; j++) {
-        const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;   // static register, static shift
-        const uint32_t x = (j < 3) ? lut[b & 63u] : lut[64u + (b & 15u)];
-        h = (h ^ (x + (uint32_t)j)) * 171717u;
-        const uint32_t width = (j < 3) ? 2u : 4u;
-        if (fb + width <= PGRC_FP_BITS) {
-            fp |= ((j < 3) ? (b >> 6) : (b >> 4)) << fb;
-            fb += width;
-        }
-    }
-    *fp_out = fp;
-    return h;
-}
-
-// The same for a window of a read that holds N's (npw: up to four read positions, one per byte, 0xFF = none; s = the
-// window's first read position).  The packed read carries code 0 = 'A' (0x41) where the read has an N, the reference
-// hashes the byte 'N' (0x4E): every N that falls on a hashed byte of step j adds 0x0D to that byte of the step's word --
-// no carry leaves the byte, so the patched word is exactly the reference's.  The fingerprint keeps the packed codes: a
-// difference it counts at an N position is a real mismatch (an N equals nothing), one it misses only weakens the lower
-// bound, which stays a lower bound.
-template <int KQ>
-__device__ __forceinline__ uint32_t hash_fp_window_n(const uint32_t w0, const uint32_t w1, const uint32_t w2, const uint32_t w3,
-                                                     uint32_t K, const uint32_t *lut, uint32_t *fp_out, uint32_t npw, uint32_t s) {
-    uint32_t qj[4], inc[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t q = ((npw >> (8 * i)) & 0xFFu) - s;          // (none = 0xFF: 255 - s >= K, since s + K <= L <= 255)
-        const uint32_t j = q >> 2, b = q & 3u;
-        const bool hashed = q < K && b < (j < 3u ? 3u : 2u);
-        qj[i] = hashed ? j : 0xFFFFFFFFu;
-        inc[i] = 0x0Du << (8u * b);
-    }
-    const uint32_t w[4] = {w0, w1, w2, w3};
-    const uint32_t kq = KQ ? (uint32_t)KQ : (K >> 2);
-    uint32_t h = 4u * kq, fp = 0, fb = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < (KQ ? (uint32_t)KQ : 14u); j++) {
-        if (!KQ && j >= kq) break;
-        const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        uint32_t x = (j < 3) ? lut[b & 63u] : lut[64u + (b & 15u)];
-#pragma unroll
-        for (int i = 0; i < 4; i++) x += (qj[i] == j) ? inc[i] : 0u;
-        h = (h ^ (x + j)) * 171717u;
-        const uint32_t width = (j < 3) ? 2u : 4u;
-        if (fb + width <= PGRC_FP_BITS) {
-            fp |= ((j < 3) ? (b >> 6) : (b >> 4)) << fb;
-            fb += width;
-        }
-    }
-    *fp_out = fp;
-    return h;
-}
-
 #ifndef PROBE_AHEAD
 #define PROBE_AHEAD 1       // probing lanes fetch the next seed's bucket head together with their own
 #endif
@@ -409,13 +194,6 @@ __device__ __forceinline__ uint32_t hash_fp_window_n(const uint32_t w0, const ui
 #else
 #define MATCH_OCCUPANCY_ATTR
 #endif
-#ifndef MATCH_STAGE
-#define MATCH_STAGE 32      // reads a wave stages in LDS per burst of full-line loads (k_copmem_match_sm, STAGE)
-#endif
-#ifndef MATCH_CHUNK
-#define MATCH_CHUNK 1024u // reads a wave reserves per visit to the global work counter (256 / 512 / 1024: step +0 / -0.2 / -0.4 %)
-#endif
-
 // reads a wave reserves per visit to the global work counter: 1024 for a whole read set (256 / 512 / 1024: step +0 / -0.2 /
 // -0.4 % at C3), less for a short launch -- a block of a streamed run: 7 M reads over ~5000 resident waves are 1.35 chunks of
 // 1024 per wave, i.e. half the waves do two chunks while the others wait (10 ms per block instead of 6)
@@ -425,7 +203,6 @@ __device__ __forceinline__ uint32_t hash_fp_window_n(const uint32_t w0, const ui
 static uint32_t pgrc_match_chunk(const pgrc_match_ctx *c, uint64_t n) {
     const uint64_t waves = (uint64_t)c->num_cus * 20u;           // (about what is resident)
     uint32_t chunk = MATCH_CHUNK;
-    if (const char *mc = getenv("PGRC_MATCH_CHUNK")) chunk = std::max(64, std::min(1 << 16, atoi(mc))) & ~63u;   // (experiments)
     while (chunk > 64u && n / chunk < waves * 8u) chunk >>= 1;
     return chunk;
 }
@@ -1024,457 +801,45 @@ __global__ void __launch_bounds__(NREAD_TPB) k_copmem_match_n(const NReadArgs a)
 }
 
 // ----------------------------------------------------------------------------- one query over both strands
+// (the kernel: dualkern.h)
 
-// The dual kernel: a two-pass run (min_mismatches == 0) as ONE query per read over both strands' indexes.  A read
-// window hashes to the same bucket number in both tables, so every seed probes the forward and the RC head together
-// (two gathers in flight); the forward bucket's entries are judged first, then the RC bucket's.  Each strand is a
-// query of its own whose limit is additionally capped by what the other strand has found -- forward by the RC count (a
-// forward alignment only matters if it is at least as good), RC by the forward count - 1 (it must be strictly better) --
-// and each stops by the early-stop rule against its capped limit.  Why the result is the reference's (all forward
-// seeds, then all RC seeds): a query under ANY sequence of limits that never falls below the smallest count m_min among
-// its candidates accepts the FIRST candidate with m_min and nothing after it, which is the reference's final
-// alignment; the caps never fall below the counts that still matter.  All of it presupposes that no run would have cut
-// a bucket by the falses budget: U bounds the falses of any run over the candidates seen so far (1 for a candidate
-// whose head count -- or already its fingerprint -- exceeds the starting limit or whose tail is clean, else 2); U > budget when a bucket is
-// opened -> the lane does that read again in the reference's order, right here (F_SEQ: the real forward query with its
-// falses count and bucket truncation, then the real RC query from its result) -- hidden behind the other lanes.
-// oracle/pgrc_oracle.c restates the scheme (pgrc_or_match_copmem_dual); tests/test_early_stop_rule.py expects it to
-// equal the reference's two passes on every input.
-struct DualArgs {
-    const uint32_t *pg[2];        // packed text, forward and reverse complement
-    uint64_t G;
-    const uint32_t *reads;
-    uint64_t n, stride;
-    const uint8_t *nflag;         // reads with N: 1 = the byte path of the ordinary passes, 3 = taken here, its N positions in npos
-    const uint32_t *npos;         // (ctx.h nread_npos; nullptr: every flagged read goes the byte path)
-    const ulonglong2 *head[2];    // head of bucket h of strand x at head[x][head_slot(h, hsh)] (headfmt.h); the pair table: the two
-    uint32_t hsh;                 // heads of a bucket number share a line (one line request and one translation for both gathers)
-    const uint64_t *ent[2];
-    uint64_t *pos;
-    uint8_t *rc;
-    uint8_t *mism;
-    unsigned long long *counters; // [0] searched [1] candidates [2] heads probed [3] entry fetches [4] verifies [5] redo [6] seeds probed
-    unsigned long long *work;
-    uint8_t *redo_flag;           // per read: 2 = done again in the reference's order (F_SEQ); introspection only
-    uint32_t L, K, k1, k2, mask, kmax;
-    uint32_t spec;                // 0, or the small limit + 1 every read first tries (speculative first attempt)
-    uint32_t redo_above;          // a bucket of more entries than this, opened while U > budget, sends the read back (4; 0 = round 3's rule: any bucket)
-    uint32_t from_end;            // 1: chunks of reads are handed out from the end of the read set
-    uint32_t chunk;               // reads a wave reserves per visit to the work counter (pgrc_match_chunk)
-};
-
-template <int NW, int KQ, bool POS64>
-#ifndef DUAL_WAVES_PER_EU
-#define DUAL_WAVES_PER_EU 5      // (experiments: tools/variants.sh)
+#ifdef PGRC_AB_DUAL
+int pgrc_copmem_match_dual_r04(pgrc_match_ctx *c);    // tools/variants/dual_r04.hip: round 4's kernel, for in-context A/B runs
 #endif
-__global__ void __launch_bounds__(MATCH_TPB) __attribute__((amdgpu_waves_per_eu(NW <= 10 ? DUAL_WAVES_PER_EU : 4)))   // (97 registers without the hint: 4 waves)
-k_copmem_match_dual(const DualArgs a) {
-    typedef typename std::conditional<POS64, uint64_t, uint32_t>::type pos_t;
-    constexpr pos_t POS_NONE = (pos_t)~(pos_t)0;
-    constexpr uint32_t EPOCH_BITS = POS64 ? 12u : 15u;   // one bit less than the single-strand kernel: the strand is part of the tag
-    constexpr int SW = MATCH_STAGE;
-    __shared__ uint32_t lut[PGRC_HASH_LUT_WORDS];
-    __shared__ uint32_t fpm_tab[SM_MAX_SEEDS];
-    __shared__ uint2 vcache[VC_SLOTS][MATCH_TPB];
-    __shared__ uint32_t rd_lds[NW][MATCH_TPB];
-    __shared__ uint32_t stg[MATCH_TPB / 64][NW][SW];
-    __shared__ uint8_t stg_c[MATCH_TPB / 64][SW], stg_f[MATCH_TPB / 64][SW];
-    __shared__ uint32_t stg_n[MATCH_TPB / 64][SW];
-    __shared__ ulonglong2 hdR_lds[MATCH_TPB];    // the RC head of a lane's current seed, waiting for the forward bucket to finish
-    const uint32_t wv = threadIdx.x >> 6;
-    uint32_t wbeg = 0, wend = 0, wnext = 0;
-    hash_lut_init(lut);
-    const int H = ((int)a.L / 8) * 8;
-    const uint32_t nseeds = (a.L - a.K) / a.k2 + 1;
-    for (uint32_t t = threadIdx.x; t < nseeds && t < SM_MAX_SEEDS; t += blockDim.x)
-        fpm_tab[t] = fp_head_mask(a.K, t * a.k2, (uint32_t)H);
-#pragma unroll
-    for (int k = 0; k < VC_SLOTS; k++) vcache[k][threadIdx.x] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-    __syncthreads();
+#ifndef DUAL_WAVES
+#define DUAL_WAVES 6             // waves per SIMD the dual kernel is built for at read lengths up to 160 (NW <= 10)
+#endif
 
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t n_search = 0, n_cand = 0, n_probe = 0, n_ent = 0, n_ver = 0, n_redo = 0, n_seed = 0;
-    uint32_t sh[NW];
-#pragma unroll
-    for (int k = 0; k < NW; k++) sh[k] = 0u;
-    const uint32_t budget = (a.L + 1u - a.K) / a.k2;
-    const uint32_t sbits = 2u * a.k2;
-    const uint32_t rper = (a.K + a.k1 * a.k2 - 1u) / (a.k1 * a.k2) * a.k1;
-
-    enum { M_PROBE = 0, M_ENTRY = 1, M_VERIFY = 2, M_NEED = 3, M_ADV = 4, M_DEAD = 5 };
-    // F_SEQ: the falses bound ran out: the lane does this read again in the reference's order, right here (forward query
-    // with its real falses count and bucket truncation, then -- F_SEQ1 -- the RC query from the forward result)
-    // F_SPEC (round 4): the read's first attempt, with both strands' limits cut to a.spec - 1 (see the launcher)
-    enum { F_ACT0 = 1, F_ACT1 = 2, F_FOUND0 = 4, F_FOUND1 = 8, F_DIRTY0 = 16, F_DIRTY1 = 32, F_REDO = 64, F_FWDEXACT = 128,
-           F_SEQ = 256, F_SEQ1 = 512, F_SPEC = 1024 };
-    uint32_t mode = M_NEED;
-    uint32_t idx = 0, cin = 0, epoch = 0;
-    uint32_t npw = 0xFFFFFFFFu;   // the read's N positions, one per byte (0xFF = none): a read with 1-4 N's (hash_fp_window_n)
-    uint32_t cnext = 0, cend = 0;
-    uint32_t si = 0, rq = 0;
-    // per strand (0 forward, 1 RC): own limit (-1 once an exact alignment is accepted), best count and position,
-    // bound on the falses of any run, clean rounds
-    int lim0 = 0, lim1 = 0, L0 = 0;
-    uint32_t cur0 = 0, cur1 = 0, U0 = 0, U1 = 0, rcl0 = 0, rcl1 = 0, fl = 0;
-    pos_t best0 = POS_NONE, best1 = POS_NONE;
-    uint32_t x = 0;               // the strand whose bucket is being gone through
-    pos_t lo = 0;
-    uint32_t nb = 0, j = 0, fp_read = 0;
-    pos_t cand_p = 0;
-    uint64_t pend_e = 0;
-    bool has_pend = false;
-    constexpr int PWN = ((NW + 1 + 3) / 4) * 4;
-
-    // the limit a candidate of strand s is judged against: its own, capped by what the other strand has found
-    auto eff = [&](uint32_t s) -> int {
-        if (fl & F_SEQ) return s == 0u ? lim0 : lim1;                // the reference's order: no coupling
-        if (s == 0u) return (fl & F_FOUND1) ? min(lim0, (int)cur1) : lim0;
-        return (fl & F_FOUND0) ? min(lim1, (int)cur0 - 1) : lim1;
-    };
-
-    for (;;) {
-        // ---- refill (as in k_copmem_match_sm, staged)
-        const unsigned long long need = __ballot(mode == M_NEED);
-        if (need) {
-            if (cnext == cend) {
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(a.work, (unsigned long long)a.chunk);
-                base = __shfl(base, 0, 64);
-                const uint32_t lo_ = (uint32_t)min((uint64_t)base, a.n), hi_ = (uint32_t)min((uint64_t)base + a.chunk, a.n);
-                // a.from_end: the chunks are handed out from the END of the read set (each still walked upwards): PgRC's sum set
-                // ends with the N set, whose reads rarely match exactly and probe five times the buckets of an average read --
-                // taken last they are what the last waves still work on when the others have run dry
-                cnext = __builtin_amdgcn_readfirstlane(a.from_end ? (uint32_t)a.n - hi_ : lo_);
-                cend = __builtin_amdgcn_readfirstlane(a.from_end ? (uint32_t)a.n - lo_ : hi_);
-            }
-            if (wnext == wend && cnext != cend) {
-                const uint32_t nst = min((uint32_t)SW, cend - cnext);
-                wbeg = wnext = cnext;
-                wend = cnext = __builtin_amdgcn_readfirstlane(cnext + nst);
-                if (lane < nst) {
-#pragma unroll
-                    for (int k = 0; k < NW; k++) stg[wv][k][lane] = a.reads[(uint64_t)k * a.stride + wbeg + lane];
-                    stg_c[wv][lane] = a.mism[wbeg + lane];
-                    stg_f[wv][lane] = a.nflag ? a.nflag[wbeg + lane] : (uint8_t)0;
-                    stg_n[wv][lane] = a.npos ? a.npos[wbeg + lane] : 0xFFFFFFFFu;
-                }
-                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            const uint32_t avail = wend - wnext;
-            if (avail == 0) {
-                if (mode == M_NEED) mode = M_DEAD;
-            } else {
-                const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                const uint32_t take = min((uint32_t)__popcll(need), avail);
-                bool started = false;
-                if (mode == M_NEED && rank < take) {
-                    const uint32_t sj = wnext - wbeg + rank;
-                    idx = wbeg + sj;
-                    cin = stg_c[wv][sj];
-                    const uint32_t nfl = stg_f[wv][sj];
-                    if ((nfl == 0u || (nfl == 3u && a.npos)) && cin != 0u) {   // ReadsMatchers.cpp:430 with min_mismatches == 0
-                        npw = nfl ? stg_n[wv][sj] : 0xFFFFFFFFu;
-#pragma unroll
-                        for (int k = 0; k < NW; k++) rd_lds[k][threadIdx.x] = sh[k] = stg[wv][k][sj];
-                        L0 = (cin < a.kmax) ? (int)cin - 1 : (int)a.kmax;   // :488-489
-                        const bool spec = a.spec && L0 >= (int)a.spec;       // first with the small limit a.spec - 1
-                        lim0 = lim1 = spec ? (int)a.spec - 1 : L0;
-                        cur0 = cur1 = cin;
-                        best0 = best1 = POS_NONE;
-                        U0 = U1 = 0;
-                        rcl0 = rcl1 = 0;
-                        fl = F_ACT0 | F_ACT1 | (spec ? (uint32_t)F_SPEC : 0u);
-                        si = 0;
-                        rq = 0;
-                        has_pend = false;
-                        epoch = (epoch + 1u) & ((1u << EPOCH_BITS) - 1u);
-                        if (epoch == 0) {
-#pragma unroll
-                            for (int k = 0; k < VC_SLOTS; k++) vcache[k][threadIdx.x] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-                            epoch = 1;
-                        }
-                        started = true;
-                        mode = M_PROBE;
-                    }
-                }
-                wnext = __builtin_amdgcn_readfirstlane(wnext + take);
-                n_search += (uint32_t)__popcll(__ballot(started));
-            }
-        }
-        if (!__any(mode != M_DEAD)) break;
-
-        const uint32_t m0 = mode;
-        // ---- this iteration's loads
-        ulonglong2 hdF = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
-        uint64_t v = 0;
-        bool counted_ent = false;
-        uint32_t ncand_it = 0, nprobe_it = 0;
-        bool n_redo_it = false;
-        if (m0 == M_PROBE) {
-            uint32_t h;
-            if (__any(npw != 0xFFFFFFFFu))                           // (wave-uniform: only waves that hold a read with N's take the patched hash)
-                h = hash_fp_window_n<KQ>(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u, NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read,
-                                         npw, si * a.k2) & a.mask;
-            else
-                h = hash_fp_window<KQ>(sh[0], NW > 1 ? sh[1 % NW] : 0u, NW > 2 ? sh[2 % NW] : 0u,
-                                       NW > 3 ? sh[3 % NW] : 0u, a.K, lut, &fp_read) & a.mask;
-            ulonglong2 hr = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
-            if (fl & F_ACT0) hdF = a.head[0][head_slot(h, a.hsh)];
-            if (fl & F_ACT1) hr = a.head[1][head_slot(h, a.hsh)];
-            hdR_lds[threadIdx.x] = hr;
-            nprobe_it = ((fl & F_ACT0) ? 1u : 0u) + ((fl & F_ACT1) ? 1u : 0u);
-        } else if (m0 == M_ENTRY) {
-            if (has_pend) {
-                v = pend_e;
-                has_pend = false;
-            } else {
-                const U64x2A8 q = *reinterpret_cast<const U64x2A8 *>((x ? a.ent[1] : a.ent[0]) + lo + j - 1);
-                v = q.x;
-                pend_e = q.y;
-                has_pend = j + 1 < nb;
-                counted_ent = true;
-            }
-        }
-        // ---- consume
-        uint32_t next = m0;
-        bool bdone = false;           // the current strand's bucket is finished
-        // a verified alignment of the current strand (head count mh, tail count mt)
-        auto judge = [&](uint32_t mh, uint32_t mt, pos_t p) {
-            const int m = (int)(mh + mt);
-            if (fl & F_SEQ) {                                        // the real count of CopMEMMatcher.cpp:536-551
-                const int lm = eff(x);
-                const uint32_t u = ((int)mh > lm) ? 1u : (m > lm) ? 2u : 0u;
-                if (x == 0u) U0 += u; else U1 += u;
-            } else {
-                // what any run can count for this candidate: 1 if the head alone exceeds every limit a run can have, or if
-                // the tail is clean (then it is a head reject or an acceptance), else 2 (a tail reject is counted twice)
-                const uint32_t u = ((int)mh > L0 || mt == 0u) ? 1u : 2u;
-                if (x == 0u) U0 += u; else U1 += u;
-            }
-            if (m > eff(x)) return;
-            if (x == 0u) { cur0 = (uint32_t)m; best0 = p; lim0 = m - 1; fl |= F_FOUND0; }
-            else { cur1 = (uint32_t)m; best1 = p; lim1 = m - 1; fl |= F_FOUND1; }
-            if (m == 0) {                                            // m <= min_mismatches: this strand's query returns
-                fl &= ~(x == 0u ? (uint32_t)F_ACT0 : (uint32_t)F_ACT1);
-                if (x == 0u) fl |= F_FWDEXACT;                       // ... and the RC pass would skip the read
-            }
-        };
-        // what follows an examined entry
-        auto after_entry = [&]() {
-            if (fl & F_FWDEXACT) next = M_NEED;
-            else if (!(fl & (x == 0u ? (uint32_t)F_ACT0 : (uint32_t)F_ACT1))) bdone = true;   // an exact RC alignment: that query is over
-            else if (j < nb) next = M_ENTRY;
-            else bdone = true;
-        };
-        auto take_entry = [&](const uint64_t e) {
-            const uint32_t s = si * a.k2;
-            const uint64_t sp = e >> PGRC_FP_BITS;
-            if ((uint64_t)s <= sp && sp - s + a.L <= a.G) {          // :517-520
-                ncand_it++;
-                const pos_t p = (pos_t)(sp - s);
-                const uint32_t xr = ((uint32_t)e ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
-                const int fpc = __popc((xr | (xr >> 1)) & fpm_tab[si]);   // a lower bound of the head count
-                if (fpc > eff(x)) {
-                    const uint32_t u = ((fl & F_SEQ) || fpc > L0) ? 1u : 2u;   // (sequential: a certain head reject)
-                    if (x == 0u) U0 += u; else U1 += u;
-                } else {
-                    const uint2 cv = vcache[((uint32_t)p * 0x9E3779B1u + x) >> (32 - VC_BITS)][threadIdx.x];
-                    const bool hit = POS64 ? (cv.x == (uint32_t)p && (cv.y >> 20) == epoch && ((cv.y >> 19) & 1u) == x &&
-                                              ((cv.y >> 11) & 0xFFu) == (uint32_t)((uint64_t)p >> 32))
-                                           : (cv.x == (uint32_t)p && (cv.y >> 17) == epoch && ((cv.y >> 16) & 1u) == x);
-                    if (hit) judge(cv.y & 0xFFu, (cv.y >> 8) & (POS64 ? 0x7u : 0xFFu), p);
-                    else {
-                        cand_p = p;
-                        next = M_VERIFY;
-                        return;
-                    }
-                }
-            }
-            after_entry();
-        };
-        // open the bucket of strand x for the current seed
-        auto open_bucket = [&](const ulonglong2 hx) {
-            const uint32_t cnt = head_count(hx);
-            if (!cnt) {
-                bdone = true;
-                return;
-            }
-            // some run could have cut THIS bucket to its first 4 entries by now (:510-514 -- all the budget ever does; a bucket
-            // of at most 4 is the same bucket whatever the falses count): not decidable this way -> the read again, in the
-            // reference's order
-            if (!(fl & F_SEQ) && (x == 0u ? U0 : U1) > budget && cnt > a.redo_above) {
-                fl |= F_REDO;
-                next = M_NEED;
-                return;
-            }
-            nb = cnt;
-            if ((fl & F_SEQ) && (x == 0u ? U0 : U1) > budget) nb = min(nb, PGRC_TRUNC_BUCKET);   // :510-514
-            if (rq < a.k1 && (cnt >= PGRC_BUCKET_CAP || nb < cnt)) fl |= (x == 0u ? (uint32_t)F_DIRTY0 : (uint32_t)F_DIRTY1);
-            has_pend = cnt == 2 && nb > 1;
-            pend_e = hx.y;
-            lo = (pos_t)(hx.y & W1_BASE_MASK);
-            j = 1;
-            take_entry(hx.x & ENT_MASK);
-        };
-        if (m0 == M_VERIFY) {
-            uint32_t pw[PWN];
-            const uint32_t *src = (x ? a.pg[1] : a.pg[0]) + (cand_p >> 4);   // the text is padded: PWN words are always in bounds
-#pragma unroll
-            for (int k = 0; k < PWN; k += 4) {
-                const u32x4 q = reinterpret_cast<const U32x4A4 *>(src + k)->v;
-                pw[k] = q.x; pw[k + 1] = q.y; pw[k + 2] = q.z; pw[k + 3] = q.w;
-            }
-            const uint32_t b = ((uint32_t)cand_p & 15u) * 2u;
-            uint32_t mh = 0, mt = 0;
-            if (__any(npw != 0xFFFFFFFFu)) {                         // (wave-uniform) an N of the read equals no text symbol
-#pragma unroll
-                for (int k = 0; k < NW; k++) {
-                    const uint32_t xr = funnel_r(pw[k], pw[k + 1], b) ^ rd_lds[k][threadIdx.x];
-                    uint32_t d = (xr | (xr >> 1)) & 0x55555555u;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const uint32_t q = (npw >> (8 * i)) & 0xFFu;
-                        d |= ((q >> 4) == (uint32_t)k) ? 1u << (2u * (q & 15u)) : 0u;   // (none = 0xFF: symbol 255 lies beyond every read)
-                    }
-                    mh += (uint32_t)__popc(d & sym_mask(k, 0, H));
-                    mt += (uint32_t)__popc(d & sym_mask(k, H, (int)a.L));
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < NW; k++) {
-                    const uint32_t tw = funnel_r(pw[k], pw[k + 1], b);
-                    const uint32_t rw = rd_lds[k][threadIdx.x];
-                    mh += mism2(tw, rw, sym_mask(k, 0, H));
-                    mt += mism2(tw, rw, sym_mask(k, H, (int)a.L));
-                }
-            }
-            vcache[((uint32_t)cand_p * 0x9E3779B1u + x) >> (32 - VC_BITS)][threadIdx.x] =
-                make_uint2((uint32_t)cand_p, POS64 ? (mh | (mt << 8) | ((uint32_t)((uint64_t)cand_p >> 32) << 11) | (x << 19) | (epoch << 20))
-                                                   : (mh | (mt << 8) | (x << 16) | (epoch << 17)));
-            judge(mh, mt, cand_p);
-            after_entry();
-        } else if (m0 == M_ENTRY) {
-            j++;
-            take_entry(v);
-        } else if (m0 == M_PROBE) {
-            x = (fl & F_ACT0) ? 0u : 1u;
-            open_bucket(x == 0u ? hdF : hdR_lds[threadIdx.x]);
-        }
-        // the forward bucket is done: the RC head of the same seed waits in LDS
-        if (bdone && x == 0u && (fl & F_ACT1)) {
-            bdone = false;
-            x = 1u;
-            open_bucket(hdR_lds[threadIdx.x]);
-        }
-        if (bdone) next = M_ADV;
-        if (next == M_ADV) {                                         // to the next seed
-            si++;
-            has_pend = false;
-            if (rq == a.k1 - 1u) {                                   // a round is behind this read
-                rcl0 += (fl & F_DIRTY0) ? 0u : 1u;
-                rcl1 += (fl & F_DIRTY1) ? 0u : 1u;
-                fl &= ~(uint32_t)(F_DIRTY0 | F_DIRTY1);
-            }
-            rq = (rq + 1u == rper) ? 0u : rq + 1u;
-#pragma unroll
-            for (int k = 0; k < NW - 1; k++) sh[k] = funnel_r(sh[k], sh[k + 1], sbits);
-            sh[NW - 1] >>= sbits;
-            if ((fl & F_ACT0) && (int)rcl0 > eff(0u)) fl &= ~(uint32_t)F_ACT0;   // nothing acceptable is left on that strand
-            if ((fl & F_ACT1) && (int)rcl1 > eff(1u)) fl &= ~(uint32_t)F_ACT1;
-            next = (si < nseeds && (fl & (F_ACT0 | F_ACT1))) ? M_PROBE : M_NEED;
-        }
-        // ---- the reference's order for a read whose falses bound ran out: restart it as a forward query, then an RC query
-        if (next == M_NEED && m0 <= M_VERIFY && (((fl & F_REDO) != 0u) || ((fl & (F_SEQ | F_SEQ1 | F_FWDEXACT)) == F_SEQ))) {
-            const bool second = (fl & F_SEQ) != 0u;                  // the forward query just ended: now the RC query
-            const uint32_t c1 = (second && (fl & F_FOUND0)) ? cur0 : cin;   // what the RC query has to beat (:488-489)
-            if (!second) {
-                lim0 = L0; cur0 = cin; best0 = POS_NONE; U0 = 0; rcl0 = 0;
-                fl = F_SEQ | F_ACT0;
-                n_redo_it = true;
-                a.redo_flag[idx] = 2;
-            } else {
-                lim1 = (c1 < a.kmax) ? (int)c1 - 1 : (int)a.kmax; cur1 = c1; best1 = POS_NONE; U1 = 0; rcl1 = 0;
-                fl = (fl & (F_FOUND0 | F_SEQ)) | F_SEQ1 | F_ACT1;
-            }
-            si = 0;
-            rq = 0;
-            has_pend = false;
-#pragma unroll
-            for (int kk = 0; kk < NW; kk++) sh[kk] = rd_lds[kk][threadIdx.x];
-            next = M_PROBE;
-        }
-        // ---- the first attempt with the small limit found nothing on either strand: the read again with its real limit
-        // (what the verify cache holds stays valid: counts do not depend on the limit)
-        if (next == M_NEED && m0 <= M_VERIFY && (fl & (F_SPEC | F_FOUND0 | F_FOUND1 | F_SEQ)) == F_SPEC) {
-            lim0 = lim1 = L0;
-            cur0 = cur1 = cin;
-            best0 = best1 = POS_NONE;
-            U0 = U1 = 0;
-            rcl0 = rcl1 = 0;
-            fl = F_ACT0 | F_ACT1;
-            si = 0;
-            rq = 0;
-            has_pend = false;
-#pragma unroll
-            for (int kk = 0; kk < NW; kk++) sh[kk] = rd_lds[kk][threadIdx.x];
-            next = M_PROBE;
-        }
-        {
-            const uint32_t seeds_it = (uint32_t)__popcll(__ballot(nprobe_it >= 1));
-            n_seed += seeds_it;
-            n_probe += seeds_it + (uint32_t)__popcll(__ballot(nprobe_it >= 2));
-        }
-        n_ent += (uint32_t)__popcll(__ballot(counted_ent));
-        n_ver += (uint32_t)__popcll(__ballot(m0 == M_VERIFY));
-        n_cand += (uint32_t)__popcll(__ballot(ncand_it >= 1)) + (uint32_t)__popcll(__ballot(ncand_it >= 2));
-        const bool fin = next == M_NEED && m0 <= M_VERIFY;
-        if (fin) {
-            // the read is finished: forward wins ties, RC must be strictly better (ReadsMatchers.cpp:437-447, both passes)
-            if ((fl & F_FOUND1) && !((fl & F_FOUND0) && cur0 <= cur1)) {
-                a.pos[idx] = a.G - ((uint64_t)best1 + a.L);
-                a.rc[idx] = 1;
-                a.mism[idx] = (uint8_t)cur1;
-            } else if (fl & F_FOUND0) {
-                a.pos[idx] = (uint64_t)best0;
-                a.rc[idx] = 0;
-                a.mism[idx] = (uint8_t)cur0;
-            }
-        }
-        n_redo += (uint32_t)__popcll(__ballot(n_redo_it));
-        mode = next;
-    }
-    if (a.counters && lane == 0) {
-        atomicAdd(&a.counters[0], (unsigned long long)n_search);
-        atomicAdd(&a.counters[1], (unsigned long long)n_cand);
-        atomicAdd(&a.counters[2], (unsigned long long)n_probe);
-        atomicAdd(&a.counters[3], (unsigned long long)n_ent);
-        atomicAdd(&a.counters[4], (unsigned long long)n_ver);
-        atomicAdd(&a.counters[5], (unsigned long long)n_redo);
-        atomicAdd(&a.counters[6], (unsigned long long)n_seed);
+template <int NW, int WAVES>
+static void launch_dual_w(pgrc_match_ctx *c, const DualArgs &a) {
+    const uint64_t want = (a.n + MATCH_TPB - 1) / MATCH_TPB;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)c->num_cus * 8u);
+    const bool pos64 = c->G + 256 >= (1ull << 32) || c->opt.force_pos64;
+    const bool k28 = a.K == 28;
+    if (pos64) {
+        if (k28) hipLaunchKernelGGL((k_copmem_match_dual<NW, 7, true, WAVES>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_copmem_match_dual<NW, 0, true, WAVES>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+    } else {
+        if (k28) hipLaunchKernelGGL((k_copmem_match_dual<NW, 7, false, WAVES>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_copmem_match_dual<NW, 0, false, WAVES>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
     }
 }
 
 template <int NW>
 static void launch_dual(pgrc_match_ctx *c, const DualArgs &a) {
-    const uint64_t want = (a.n + MATCH_TPB - 1) / MATCH_TPB;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)c->num_cus * 8u);
-    const char *f64 = getenv("PGRC_FORCE_POS64");
-    const bool pos64 = c->G + 256 >= (1ull << 32) || (f64 && f64[0] == '1');
-    const bool k28 = a.K == 28;
-    const char *xl = getenv("PGRC_EXTRA_LDS");    // experiment knob: extra dynamic LDS per block lowers the occupancy
-    const uint32_t dyn_lds = xl ? (uint32_t)atoi(xl) : 0u;
-    if (pos64) {
-        if (k28) hipLaunchKernelGGL((k_copmem_match_dual<NW, 7, true>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
-        else hipLaunchKernelGGL((k_copmem_match_dual<NW, 0, true>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
-    } else {
-        if (k28) hipLaunchKernelGGL((k_copmem_match_dual<NW, 7, false>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
-        else hipLaunchKernelGGL((k_copmem_match_dual<NW, 0, false>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a);
-    }
+#ifdef PGRC_AB_DUAL
+    // A/B builds carry the same kernel at five waves per SIMD too (PGRC_DUAL_VARIANT=5) -- for 100 / 150 bp reads only
+    if (c->opt.dual_variant == 5 && (NW == 7 || NW == 10)) { launch_dual_w<(NW == 7 || NW == 10) ? NW : 10, 5>(c, a); return; }
+#endif
+    launch_dual_w<NW, (NW <= 10 ? DUAL_WAVES : 4)>(c, a);
 }
 
 // The dual kernel over all reads without N: the ACTIVE index set must describe the RC strand, the alternate set the
 // forward strand (api.hip builds them in that order).  The reads with N follow in two ordinary passes (phase 4).
 int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
+#ifdef PGRC_AB_DUAL
+    if (c->opt.dual_variant == 4) return pgrc_copmem_match_dual_r04(c);
+#endif
     const uint64_t lo = std::min<uint64_t>(c->range_lo, c->n), rn = std::min<uint64_t>(c->n - lo, c->range_n);   // (a block of a streamed run, or everything)
     if (rn == 0) return PGRC_OK;
     if (c->index_strand != 1 || c->alt_index_strand != 0 || !c->ent_ptr || !c->alt_ent_ptr || !c->d_scr_pos.p || c->head_sh != c->alt_head_sh) {
@@ -1489,10 +854,8 @@ int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     a.n = rn;
     a.stride = c->stride;
     a.nflag = (c->n_nreads || c->up_open) ? (const uint8_t *)c->nread_flag.p + lo : nullptr;   // (during an upload the side list is not final yet: the flags are)
-    {
-        const char *ni = getenv("PGRC_NREAD_INLINE");              // 0: every read with an N goes the byte path (A/B runs, tests)
-        a.npos = (a.nflag && !(ni && ni[0] == '0') && c->nread_npos.p) ? (const uint32_t *)c->nread_npos.p + lo : nullptr;
-    }
+    // PGRC_NREAD_INLINE=0: every read with an N goes the byte path (A/B runs, tests)
+    a.npos = (a.nflag && c->opt.nread_inline && c->nread_npos.p) ? (const uint32_t *)c->nread_npos.p + lo : nullptr;
     a.head[0] = (const ulonglong2 *)c->alt_head_ptr;
     a.head[1] = (const ulonglong2 *)c->head_ptr;
     a.hsh = c->head_sh;
@@ -1511,31 +874,6 @@ int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     a.k2 = (uint32_t)c->cp.k2;
     a.mask = c->cp.hash_size - 1;
     a.kmax = c->prm.max_mismatches;
-    {
-        const char *ra = getenv("PGRC_REDO_ANY");                   // 1: round 3's rule (A/B runs)
-        a.redo_above = (ra && ra[0] == '1') ? 0u : PGRC_TRUNC_BUCKET;
-        // Speculative first attempt (round 4).  With a large limit (PgRC's -M 3: k <= 50 at 150 bp) the fingerprints reject
-        // nothing until a read has found its alignment, so every false candidate of its first seeds costs a text window:
-        // 14 verified windows per read at C3 against 3 at k <= 3.  A read therefore first runs its query with both strands'
-        // limits cut to a.spec - 1 (3): whatever that finds is the reference's result (the query is the same dual query with a
-        // smaller kmax, hence the reference's with that kmax; an alignment with m <= 3 mismatches found there is the first one
-        // with the smallest count on the winning strand under ANY larger limit too -- U keeps bounding the falses of the run
-        // with the REAL limit, so a bucket some run could have cut still sends the read back); a read that finds nothing
-        // starts again with its real limit (the tenth of C3's reads with more than 3 mismatches).  MEASURED, AND OFF BY DEFAULT:
-        // at C3 with k <= 50 the dual kernel takes 98.3 ms without it and 101.1 / 110.5 / 107.2 / 104.4 / 100.7 ms with a first
-        // attempt at 0 / 1 / 2 / 3 / 5 (profiles/r04_spec_limit_ab.txt): the second query of the reads that find nothing costs
-        // more than the windows the others save.  PGRC_SPEC_LIMIT = the small limit switches it on (tests).
-        const char *sl = getenv("PGRC_SPEC_LIMIT");
-        const int slv = sl ? atoi(sl) : -1;
-        a.spec = slv < 0 ? 0u : (uint32_t)slv + 1u;
-        // (Round 4, measured and removed: "two seeds per iteration" -- probing lanes also fetched their NEXT seed's two heads and,
-        //  when the current seed needed nothing beyond its heads (four of five do), took the next one in the same iteration;
-        //  heads that could not be used were dropped.  C3: 71.6 -> 74.8 ms, -M 3: 103.4 -> 114.0, C3-N: 74.3 -> 78.1
-        //  (profiles/r04_dual_ahead_ab.txt; that binary also spilled 9 registers, which cost the switched-off leg 5 ms against
-        //  66 ms without the code).  More requests per lane do not help: what the kernel responds to is resident waves.)
-        const char *fe = getenv("PGRC_MATCH_FROM_END");             // 0: chunks from the start of the read set (A/B runs)
-        a.from_end = (fe && fe[0] == '0') ? 0u : 1u;
-    }
     switch (c->nw) {
 #define CASE_NW(N) case N: launch_dual<N>(c, a); break;
         CASE_NW(2) CASE_NW(3) CASE_NW(4) CASE_NW(5) CASE_NW(6) CASE_NW(7) CASE_NW(8) CASE_NW(9)
@@ -1554,14 +892,11 @@ static void launch_match(pgrc_match_ctx *c, const MatchArgs &a) {
     // persistent grid: what the chip can hold (8 blocks of 4 waves per CU is the register/LDS limit at most)
     const uint64_t want = (a.n + MATCH_TPB - 1) / MATCH_TPB;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)c->num_cus * 8u);
-    const char *xl = getenv("PGRC_EXTRA_LDS");    // experiment knob: extra dynamic LDS per block lowers the occupancy
-    const uint32_t dyn_lds = xl ? (uint32_t)atoi(xl) : 0u;
-    const char *f64 = getenv("PGRC_FORCE_POS64"); // test knob: run the 64-bit-position kernel on a small text
-    const bool pos64 = c->G + 256 >= (1ull << 32) || (f64 && f64[0] == '1');
+    const uint32_t dyn_lds = 0u;
+    const bool pos64 = c->G + 256 >= (1ull << 32) || c->opt.force_pos64;   // (PGRC_FORCE_POS64: the 64-bit-position kernel on a small text)
     const bool k28 = a.K == 28;                   // the default seed: compile-time hash loop
     // PGRC_MATCH_STAGE=0: every refilling lane loads its own read (A/B knob; staged is 1.8 % faster on C3, same context)
-    const char *sg = getenv("PGRC_MATCH_STAGE");
-    const bool staged = !(sg && sg[0] == '0');
+    const bool staged = c->opt.match_stage;
 #define PGRC_LAUNCH_MATCH(KQ_, P64_)                                                                                              \
     do {                                                                                                                          \
         if (staged) hipLaunchKernelGGL((k_copmem_match_sm<NW, KQ_, P64_, MATCH_STAGE>), dim3(grid), dim3(MATCH_TPB), dyn_lds, c->stream, a); \
@@ -1579,16 +914,11 @@ static void launch_match(pgrc_match_ctx *c, const MatchArgs &a) {
 
 // The reads with N through the strands first .. last (k_copmem_match_n), on the side stream: it starts when what the main
 // stream holds so far is done (the indexes; a streamed run: when c->n_after says so) and the caller joins it later
-// (pgrc_copmem_join_nreads).  Every strand asked for must be one of the two index sets of the context.  beside_dual: a
-// persistent grid of a few waves per CU, launched BEFORE the dual kernel so that it holds its slots from the start (its
-// lanes are chains of dependent accesses: beside the dual kernel they cost that kernel a wave slot per SIMD for a while,
-// behind it 19 ms at C3 with nothing else to run).
-int pgrc_copmem_match_nreads(pgrc_match_ctx *c, int first, int last, bool beside_dual, bool only_many) {
+// (pgrc_copmem_join_nreads).  Every strand asked for must be one of the two index sets of the context.  (Launched BEFORE the
+// dual kernel as a small persistent grid it still only starts when that kernel's blocks leave: profiles/r04_nread_beside_ab.txt.)
+int pgrc_copmem_match_nreads(pgrc_match_ctx *c, int first, int last, bool only_many) {
     if (!c->n_nreads) return PGRC_OK;
-    {
-        const char *ni = getenv("PGRC_NREAD_INLINE");
-        if (ni && ni[0] == '0') only_many = false;
-    }
+    if (!c->opt.nread_inline) only_many = false;
     if (only_many && !c->n_many) return PGRC_OK;                        // (the dual kernel takes every read with at most 4 N's)
     NReadArgs a;
     a.skip_flag = only_many ? (const uint8_t *)c->nread_flag.p : nullptr;
@@ -1615,10 +945,7 @@ int pgrc_copmem_match_nreads(pgrc_match_ctx *c, int first, int last, bool beside
     a.mask = c->cp.hash_size - 1;
     a.kmax = c->prm.max_mismatches;
     a.kmin = c->prm.min_mismatches;
-    {
-        const char *es = getenv("PGRC_EARLY_STOP");
-        a.early = (es && es[0] == '0') ? 0u : 1u;
-    }
+    a.early = c->opt.early_stop ? 1u : 0u;
     a.first = (uint32_t)first;
     a.last = (uint32_t)last;
     if (!c->side_stream) {   // stream and both events, or nothing
@@ -1644,12 +971,7 @@ int pgrc_copmem_match_nreads(pgrc_match_ctx *c, int first, int last, bool beside
         HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->side_ev[0], 0));
     }
     const uint64_t tiles = (c->n_nreads + NREAD_TPB - 1) / NREAD_TPB;
-    uint32_t per_cu = 64u;                                              // alone or beside an ordinary pass: whatever fits
-    if (beside_dual) {
-        const char *ng = getenv("PGRC_NREAD_BLOCKS");                   // blocks of two waves per CU beside the dual kernel
-        per_cu = ng && atoi(ng) > 0 ? (uint32_t)atoi(ng) : 2u;
-    }
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, (uint64_t)c->num_cus * per_cu);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, (uint64_t)c->num_cus * 64u);   // whatever fits
     const uint32_t lds = 2u * ((uint32_t)c->nw + 1u) * NREAD_TPB * (uint32_t)sizeof(uint32_t);
     hipLaunchKernelGGL(k_copmem_match_n, dim3(grid), dim3(NREAD_TPB), lds, c->side_stream, a);
     HIP_TRY(c, hipGetLastError());
@@ -1699,17 +1021,14 @@ int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase) {
     a.strand = (uint32_t)strand;
     a.k1 = (uint32_t)c->cp.k1;
     a.chunk = pgrc_match_chunk(c, rn);
-    {
-        const char *es = getenv("PGRC_EARLY_STOP");       // 0: every read probes all its seeds (A/B runs, tests)
-        a.early = (es && es[0] == '0') ? 0u : 1u;
-    }
+    a.early = c->opt.early_stop ? 1u : 0u;               // PGRC_EARLY_STOP=0: every read probes all its seeds (A/B runs, tests)
     // The reads with N (a percent or two, one lane each, latency-bound) start first on a side stream and run beside the
     // main kernel, whose persistent blocks simply take the remaining slots; the two kernels write disjoint reads.
     // (the screen only flags reads; reads with N are never flagged.  The N kernel walks the side list, whose indexes
     //  count from read 0: it runs on whole-set launches only, never on a block of a streamed run)
     const bool with_n = c->n_nreads && phase != 1 && !c->range_skip_n && lo == 0 && rn == c->n;
     if (with_n) {
-        const int ne = pgrc_copmem_match_nreads(c, strand, strand, false, false);
+        const int ne = pgrc_copmem_match_nreads(c, strand, strand, false);
         if (ne) return ne;
     }
     if (phase != 4)                  // (phase 4: the dual kernel has done every read without N)

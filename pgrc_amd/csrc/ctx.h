@@ -36,7 +36,39 @@ struct DevBuf {
 
 struct pgrc_multi;   // multi.hip
 
+// Run-time options of a context.  The environment is read ONCE, when the context is created (pgrc_options_from_env,
+// api.hip) -- never at a launch -- so a production matcher does not change schedule because somebody's environment
+// changes under it; pgrc_match_reload_options(ctx) reads it again (tests and A/B tools that toggle a knob of a live
+// context).  include/pgrc_match.h documents every variable.  None of them changes a result.
+struct PgrcOptions {
+    int dual = -1;                  // PGRC_DUAL        -1 the library's choice, 0 never, 1 whenever the dual kernel applies
+    int screen = -1;                // PGRC_SCREEN      -1 not asked for, 0 never, 1 whenever the screened schedule applies
+    bool early_stop = true;         // PGRC_EARLY_STOP=0: every read probes all its seeds, as the reference does
+    bool builds_in_turn = false;    // PGRC_BUILD_STREAMS=1: the two index builds of a two-strand run on one stream
+    uint32_t head_pair = 4;         // PGRC_HEAD_PAIR   0: a head table per strand; 1..4: pair table with groups of 1, 2, 4, 8 buckets
+    int index_front = 0;            // PGRC_INDEX_SORT  0 "sweep" (idxsweep.hip), 1 "own" (idxsort.hip's stable scatter passes)
+    bool index_finish_general = false;   // PGRC_INDEX_FINISH=general: the general finish kernel for every partition
+    int index_cfg = -1;             // PGRC_INDEX_CFG   block shape / variant of the build's passes (A/B runs; -1 = default)
+    bool match_stage = true;        // PGRC_MATCH_STAGE=0: refilling lanes load their own read (k_copmem_match_sm)
+    bool nread_inline = true;       // PGRC_NREAD_INLINE=0: every read with an N takes the byte path
+    bool force_pos64 = false;       // PGRC_FORCE_POS64=1: the 64-bit-position kernels on a small text (tests)
+    bool test_no_second_index = false;   // PGRC_TEST_NO_SECOND_INDEX: the second index set "does not fit" (tests)
+    bool stream_timing = false;     // PGRC_STREAM_TIMING: milestones of a streamed run on stderr
+    uint64_t upload_chunk_mb = 0;   // PGRC_UPLOAD_CHUNK_MB: staging chunk of append_reads_* (0 = 256, or 1024 for a streamed run)
+    int seed_filter = -1;           // PGRC_SEED_FILTER  modes d/i/e: -1 where it pays, 0 never, 1 always
+    uint32_t seed_heavy = 0;        // PGRC_SEED_HEAVY   modes d/i/e: entries of a window above which the persistent grid expands it (0 = default)
+    uint64_t seed_read_batch = 0;   // PGRC_SEED_READ_BATCH / PGRC_SEED_SEGMENT: reads per batch / window starts per launch (tests; 0 = default)
+    uint64_t seed_segment = 0;
+    int seed_build = -1;            // PGRC_SEED_BUILD   modes d/i/e: how the table is built (A/B runs; -1 = default)
+    uint64_t mem_event_cap = 0;     // PGRC_MEM_EVENT_CAP: first guess of the Pg-vs-Pg matcher's event buffer (tests; 0 = default)
+    int allgather = 0;              // PGRC_ALLGATHER    multi-device contexts: 0 by device list, 1 "rccl", 2 "copy" (tests)
+    int dual_variant = -1;          // PGRC_DUAL_VARIANT which build of the dual kernel runs (A/B builds only; -1 = default)
+};
+PgrcOptions pgrc_options_from_env();
+
 struct pgrc_match_ctx {
+    PgrcOptions opt;                    // read from the environment by pgrc_match_create (see above)
+
     // several devices behind this object (pgrc_match_create_multi): it is then only the front, the work happens in
     // one child context per device
     pgrc_multi *multi = nullptr;
@@ -262,9 +294,16 @@ int pgrc_prepare_both_indexes(pgrc_match_ctx *c);
 bool pgrc_dual_applies(const pgrc_match_ctx *c);
 int pgrc_copmem_match_phase(pgrc_match_ctx *c, int strand, int phase);
 int pgrc_copmem_match_dual(pgrc_match_ctx *c);
-int pgrc_copmem_match_nreads(pgrc_match_ctx *c, int first, int last, bool beside_dual, bool only_many);
+int pgrc_copmem_match_nreads(pgrc_match_ctx *c, int first, int last, bool only_many);
 int pgrc_copmem_join_nreads(pgrc_match_ctx *c);
 int pgrc_copmem_export_index(pgrc_match_ctx *c, uint32_t *h_cumm, uint32_t *h_positions, uint64_t *count);
+
+// radix.hip: stable LSD radix sort of 64-bit records by the bit field [bit_lo, bit_hi) (hand-written; d_b / k_b / v_b: scratch of n
+// records; `scratch` grows as needed; *sorted: wherever the last pass put them); the pairs form carries a 64-bit value per key
+int pgrc_radix_sort_u64(pgrc_match_ctx *c, uint64_t *d_a, uint64_t *d_b, uint64_t n, uint32_t bit_lo, uint32_t bit_hi, DevBuf &scratch,
+                        uint64_t **sorted);
+int pgrc_radix_sort_pairs_u64(pgrc_match_ctx *c, uint64_t *k_a, uint64_t *k_b, uint64_t *v_a, uint64_t *v_b, uint64_t n, uint32_t bit_lo, uint32_t bit_hi,
+                              DevBuf &scratch, uint64_t **ksorted, uint64_t **vsorted);
 
 // seedidx.hip (modes d / i / e)
 int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand);

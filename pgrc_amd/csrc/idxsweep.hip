@@ -40,8 +40,18 @@ struct OsPlan {
     uint32_t tbits, rec_sh;               // bits of t; rec_sh = tbits + 22 = where the bucket bits start in a record
     uint32_t k1, K, mask;
     uint64_t n, ntiles1, ntiles2_max;     // sampled positions, tiles of pass 1, upper bound of the tiles of pass 2
-    uint32_t dbg;                         // experiments (PGRC_OS_DBG): 1 = blocks exit at once, 2 = no global stores, 4 = no record loads
+    uint32_t xcd;                         // 1: tile t of a pass goes to the block that shares an XCD (and its L2) with the blocks of tiles t - 1, t + 1
 };
+
+// Which tile block b of nb takes.  The dispatcher hands consecutive blocks to the 8 XCDs in turn (b % 8 labels the blocks that
+// share an XCD and its L2: cdna_hip_programming.md T1); the tiles of a scatter pass write runs that are NEIGHBOURS in every
+// digit's bin, so two tiles in a row leave every line between their runs half written.  With the remap those halves meet in
+// one L2 (a speed choice only: any placement gives the same bytes).
+__device__ __forceinline__ uint32_t os_tile_of_block(uint32_t b, uint32_t nb, uint32_t xcd) {
+    if (!xcd) return b;
+    const uint32_t x = b & 7u, q = nb >> 3, r = nb & 7u;
+    return x * q + min(x, r) + (b >> 3);
+}
 
 __device__ __forceinline__ uint32_t os_block_scan(uint32_t v, uint32_t *smem, uint32_t *total) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
@@ -139,7 +149,7 @@ k_os_count_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, const O
     hash_lut_init(lut);
     const uint32_t D1 = 1u << pl.b1, m1 = D1 - 1u;
     for (uint32_t d = threadIdx.x; d < D1; d += TPB) h1[d] = 0;
-    const uint64_t tile = blockIdx.x, t0 = tile * TILE;
+    const uint64_t tile = os_tile_of_block(blockIdx.x, gridDim.x, pl.xcd), t0 = tile * TILE;
     const uint64_t w0 = os_stage_text(pg, pg_words_alloc, t0, TILE, pl.k1, pl.K, txt);
     __syncthreads();
 #pragma unroll
@@ -250,10 +260,10 @@ struct OsTileLds {
 // ranks E records per thread by digit (LDS atomics: any order inside a digit), stages the records digit by digit in LDS
 // and streams the runs out.  s.gbase[] must be loaded by the caller (before or after: a barrier follows the ranking).
 // dig[i] = OS_MAXD for a record that does not exist.
-template <int TPB, int E, typename AUX, bool HAS_AUX>
-__device__ __forceinline__ void os_scatter_tile(OsTileLds &s, uint64_t *recS, AUX *auxS, AUX *digS, const uint64_t (&rec)[E], const AUX (&aux)[E],
+template <int TPB, int E, typename AUX, typename DIG, bool HAS_AUX>
+__device__ __forceinline__ void os_scatter_tile(OsTileLds &s, uint64_t *recS, AUX *auxS, DIG *digS, const uint64_t (&rec)[E], const AUX (&aux)[E],
                                                 const uint32_t (&dig)[E], uint32_t nvalid, uint32_t D, uint64_t *__restrict__ rec_out,
-                                                AUX *__restrict__ aux_out, uint32_t dbg) {
+                                                AUX *__restrict__ aux_out) {
     uint32_t rank[E];
 #pragma unroll
     for (int i = 0; i < E; i++) rank[i] = dig[i] < OS_MAXD ? atomicAdd(&s.cnt[dig[i]], 1u) : 0u;
@@ -280,11 +290,10 @@ __device__ __forceinline__ void os_scatter_tile(OsTileLds &s, uint64_t *recS, AU
             const uint32_t slot = s.dstart[dig[i]] + rank[i];
             recS[slot] = rec[i];
             if (HAS_AUX) auxS[slot] = aux[i];
-            digS[slot] = (AUX)dig[i];
+            digS[slot] = (DIG)dig[i];
         }
     }
     __syncthreads();
-    if (dbg & 2u) return;
     for (uint32_t j = threadIdx.x; j < nvalid; j += TPB) {
         const uint64_t dest = (uint64_t)(s.gbase[digS[j]] + j);      // (mod 2^32 arithmetic: the sum is the true index < 2^32)
         rec_out[dest] = recS[j];
@@ -294,7 +303,7 @@ __device__ __forceinline__ void os_scatter_tile(OsTileLds &s, uint64_t *recS, AU
 
 // ---------------------------------------------------------------- pass 1: text -> records in bins of bucket bits [cb, cb+b1)
 
-template <int KQ, int TPB, int E, int MINB, typename AUX>
+template <int KQ, int TPB, int E, int MINB, typename AUX, typename DIG>
 __global__ void __launch_bounds__(TPB, (MINB * TPB) / 256)      // (HIP: threads per block, WAVES PER SIMD)
 k_os_scatter_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, const OsPlan pl, const uint32_t *__restrict__ off1,
                  uint64_t *__restrict__ rec_out, AUX *__restrict__ aux_out) {
@@ -304,13 +313,12 @@ k_os_scatter_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, const
     __shared__ OsTileLds s;
     // dynamic LDS: recS[TILE] u64 | auxS[TILE] | digS[TILE]; the text words of the tile alias recS (dead once hashed)
     uint64_t *recS = reinterpret_cast<uint64_t *>(dyn);
-    AUX *auxS = reinterpret_cast<AUX *>(recS + TILE);
-    AUX *digS = auxS + TILE;
+    DIG *digS = reinterpret_cast<DIG *>(recS + TILE);           // (the wider type first: alignment)
+    AUX *auxS = reinterpret_cast<AUX *>(digS + TILE);
     uint32_t *txt = dyn;
-    if (pl.dbg & 1u) return;
     hash_lut_init(lut);
     const uint32_t D1 = 1u << pl.b1, m1 = D1 - 1u, cbmask = (1u << pl.cb) - 1u;
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = os_tile_of_block(blockIdx.x, gridDim.x, pl.xcd);
     for (uint32_t d = threadIdx.x; d < D1; d += TPB) {
         s.cnt[d] = 0;
         s.gbase[d] = off1[(uint64_t)d * pl.ntiles1 + tile];
@@ -325,8 +333,7 @@ k_os_scatter_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, const
     for (int i = 0; i < E; i++) {
         const uint64_t t = t0 + (uint64_t)i * TPB + threadIdx.x;
         uint32_t h = 0, fp = 0;
-        if (t < pl.n && !(pl.dbg & 4u)) os_hash_at<KQ>(txt, w0, t * pl.k1, pl.K, lut, &h, &fp);
-        if (pl.dbg & 4u) h = (uint32_t)t * 2654435761u;
+        if (t < pl.n) os_hash_at<KQ>(txt, w0, t * pl.k1, pl.K, lut, &h, &fp);
         h &= pl.mask;
         rec[i] = ((uint64_t)(h & cbmask) << pl.rec_sh) | (t << PGRC_FP_BITS) | fp;
         aux[i] = (AUX)(h >> (pl.cb + pl.b1));
@@ -334,7 +341,7 @@ k_os_scatter_gen(const uint32_t *__restrict__ pg, uint64_t pg_words_alloc, const
     }
     __syncthreads();                                             // the text words are dead: recS may be written
     const uint32_t nvalid = (uint32_t)min((uint64_t)TILE, pl.n - t0);
-    os_scatter_tile<TPB, E, AUX, true>(s, recS, auxS, digS, rec, aux, dig, nvalid, D1, rec_out, aux_out, pl.dbg);
+    os_scatter_tile<TPB, E, AUX, DIG, true>(s, recS, auxS, digS, rec, aux, dig, nvalid, D1, rec_out, aux_out);
 }
 
 // ---------------------------------------------------------------- pass 2: bins -> partitions of bucket bits [cb, hbits)
@@ -348,8 +355,7 @@ k_os_scatter_bins(const uint64_t *__restrict__ rec_in, const AUX *__restrict__ a
     __shared__ OsTileLds s;
     uint64_t *recS = reinterpret_cast<uint64_t *>(dyn);
     AUX *digS = reinterpret_cast<AUX *>(recS + TILE);
-    if (pl.dbg & 1u) return;
-    const uint32_t D2 = 1u << pl.b2, tile = blockIdx.x;
+    const uint32_t D2 = 1u << pl.b2, tile = os_tile_of_block(blockIdx.x, gridDim.x, pl.xcd);
     const OsBinTile bt = desc[tile];
     if (bt.bin == 0xFFFFFFFFu) return;
     for (uint32_t d = threadIdx.x; d < D2; d += TPB) {
@@ -366,96 +372,30 @@ k_os_scatter_bins(const uint64_t *__restrict__ rec_in, const AUX *__restrict__ a
     for (int i = 0; i < E; i++) {
         const uint32_t j = (uint32_t)i * TPB + threadIdx.x;
         const bool ok = j < bt.nvalid;
-        rec[i] = (ok && !(pl.dbg & 4u)) ? rec_in[(uint64_t)bt.r0 + j] : 0ull;
-        dig[i] = ok ? ((pl.dbg & 4u) ? (j * 2654435761u >> 7) & (D2 - 1u) : (uint32_t)aux_in[(uint64_t)bt.r0 + j]) : OS_MAXD;
+        rec[i] = ok ? rec_in[(uint64_t)bt.r0 + j] : 0ull;
+        dig[i] = ok ? (uint32_t)aux_in[(uint64_t)bt.r0 + j] : OS_MAXD;
     }
     __syncthreads();
-    os_scatter_tile<TPB, E, AUX, false>(s, recS, (AUX *)nullptr, digS, rec, aux, dig, bt.nvalid, D2, rec_out, (AUX *)nullptr, pl.dbg);
-}
-
-// The same pass as a persistent kernel: one block per CU walks tiles blockIdx.x, + gridDim.x, ... and loads the NEXT
-// tile's records, digits and offsets into registers before it works on the current one (the LDS-staged block leaves room
-// for only one block of 16 waves per CU, so nothing else hides the load burst).
-template <int TPB, int E, typename AUX>
-__global__ void __launch_bounds__(TPB)
-k_os_scatter_bins_p(const uint64_t *__restrict__ rec_in, const AUX *__restrict__ aux_in, const OsPlan pl, const OsBinTile *__restrict__ desc,
-                    const uint32_t *__restrict__ off2, uint64_t *__restrict__ rec_out, uint32_t *__restrict__ pstart) {
-    constexpr uint32_t TILE = TPB * E;
-    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];   // (64-bit records are staged in it: 8-byte LDS accesses must be aligned)
-    __shared__ OsTileLds s;
-    uint64_t *recS = reinterpret_cast<uint64_t *>(dyn);
-    AUX *digS = reinterpret_cast<AUX *>(recS + TILE);
-    if (pl.dbg & 1u) return;
-    const uint32_t D2 = 1u << pl.b2;
-    const uint32_t ntiles = (uint32_t)pl.ntiles2_max;
-    uint32_t tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    OsBinTile bt = desc[tile], nbt = bt;
-    uint64_t rec[E], nrec[E];
-    AUX dg[E], ndg[E];
-    uint32_t g = 0, ng = 0;                                      // this thread's digit: where the tile's run starts
-    // unconditional loads, clamped to the tile's last record (the arrays have spare entries behind the last record)
-    auto load = [&](const OsBinTile &t, uint32_t tl, uint64_t *r, AUX *d, uint32_t *gg) {
-        if (threadIdx.x < D2) *gg = off2[(uint64_t)threadIdx.x * pl.ntiles2_max + tl];
-        const uint32_t last = t.nvalid ? t.nvalid - 1u : 0u;
-#pragma unroll
-        for (int i = 0; i < E; i++) {
-            const uint64_t x = (uint64_t)t.r0 + min((uint32_t)i * TPB + threadIdx.x, last);
-            r[i] = rec_in[x];
-            d[i] = aux_in[x];
-        }
-    };
-    if (bt.bin == 0xFFFFFFFFu) return;
-    load(bt, tile, rec, dg, &g);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): inside the loop only the prefetch is in flight
-    for (;;) {
-        const uint32_t tn = tile + gridDim.x;
-        bool more = tn < ntiles;
-        if (more) {
-            nbt = desc[tn];
-            more = nbt.bin != 0xFFFFFFFFu;
-            if (more) load(nbt, tn, nrec, ndg, &ng);
-        }
-        for (uint32_t d = threadIdx.x; d < OS_MAXD; d += TPB) s.cnt[d] = 0;
-        if (threadIdx.x < D2) {
-            s.gbase[threadIdx.x] = g;
-            // the first tile of a bin: its offsets are, per d_hi, the records of (d_hi, smaller d_lo) = the start of partition (d_hi, d_lo)
-            if (bt.first) pstart[(threadIdx.x << pl.b1) | bt.bin] = g;
-        }
-        uint32_t dig[E];
-        AUX aux[E] = {};
-#pragma unroll
-        for (int i = 0; i < E; i++) dig[i] = (uint32_t)i * TPB + threadIdx.x < bt.nvalid ? (uint32_t)dg[i] : OS_MAXD;
-        __syncthreads();
-        os_scatter_tile<TPB, E, AUX, false>(s, recS, (AUX *)nullptr, digS, rec, aux, dig, bt.nvalid, D2, rec_out, (AUX *)nullptr, pl.dbg);
-        if (!more) break;
-        __syncthreads();                                         // (the staging arrays and counters are reused)
-        tile = tn;
-        bt = nbt;
-        g = ng;
-#pragma unroll
-        for (int i = 0; i < E; i++) {
-            rec[i] = nrec[i];
-            dg[i] = ndg[i];
-        }
-    }
+    os_scatter_tile<TPB, E, AUX, AUX, false>(s, recS, (AUX *)nullptr, digS, rec, aux, dig, bt.nvalid, D2, rec_out, (AUX *)nullptr);
 }
 
 // ---------------------------------------------------------------- driver
 
-static bool os_plan(const pgrc_match_ctx *c, uint32_t hbits, OsPlan *pl) {
+// cb_target: bucket bits the finish takes per partition (13: round 3's 8192-bucket partitions; 12: round 5's 4096-bucket
+// partitions, three finish blocks per CU).  The two passes cover the rest: at most 9 bits each.
+static bool os_plan(const pgrc_match_ctx *c, uint32_t hbits, uint32_t cb_target, OsPlan *pl) {
     const uint64_t n = c->npos;
     if (!n || n >= 0xFFFFF000ull || hbits < 16 || hbits > 31 || c->cp.k1 > 16 || c->cp.K > 56 || c->cp.K < 4) return false;
     uint32_t tbits = 1;
     while ((1ull << tbits) < n) tbits++;
     if (tbits + PGRC_FP_BITS + 8u > 64u) return false;
-    const uint32_t cb = std::min<uint32_t>(OS_CB_MAX, 64u - PGRC_FP_BITS - tbits);
-    if (cb < 12u || hbits < cb + 2u) return false;             // (the finish kernel works in rounds of 4096 buckets)
+    uint32_t cb = std::min<uint32_t>(cb_target, 64u - PGRC_FP_BITS - tbits);
+    if (hbits > cb + 18u) cb = hbits - 18u;                    // two passes of at most 9 bits
+    if (cb < 12u || cb > OS_CB_MAX || cb > 64u - PGRC_FP_BITS - tbits || hbits < cb + 2u) return false;
     const uint32_t top = hbits - cb;
-    if (top > 18u) return false;                               // two passes of at most 9 bits
     pl->hbits = hbits;
     pl->cb = cb;
-    pl->b1 = top / 2;
+    pl->b1 = (top + 1u) / 2u;                                  // (the wider digit first: the digit that travels with the records is b2)
     pl->b2 = top - pl->b1;
     pl->tbits = tbits;
     pl->rec_sh = tbits + PGRC_FP_BITS;
@@ -464,14 +404,18 @@ static bool os_plan(const pgrc_match_ctx *c, uint32_t hbits, OsPlan *pl) {
     pl->mask = (uint32_t)(c->cp.hash_size - 1);
     pl->n = n;
     pl->ntiles1 = pl->ntiles2_max = 0;
-    const char *dbg = getenv("PGRC_OS_DBG");
-    pl->dbg = dbg ? (uint32_t)atoi(dbg) : 0u;
+    pl->xcd = 0;
     return true;
 }
 
+// PGRC_INDEX_CFG (A/B runs), a bit set: 1 = XCD-aware tile order in the passes, 2 = partitions of 8192 buckets (round 3's
+// finish: one block of 1024 threads per CU) instead of 4096
+static uint32_t os_cfg_bits(const pgrc_match_ctx *c, uint32_t dflt) { return c->opt.index_cfg >= 0 ? (uint32_t)c->opt.index_cfg : dflt; }
+#define OS_CFG_DEFAULT 0u
+
 bool pgrc_os_applicable(const pgrc_match_ctx *c, uint32_t hbits) {
     OsPlan pl;
-    return os_plan(c, hbits, &pl);
+    return os_plan(c, hbits, (os_cfg_bits(c, OS_CFG_DEFAULT) & 2u) ? 13u : 12u, &pl);
 }
 
 template <typename F>
@@ -487,18 +431,19 @@ struct OsBufs {
     void *aux;
 };
 
-// everything between the text and the finish, in one block shape: TPB threads x E records, MINB blocks per CU
-template <int TPB, int E, int MINB, typename AUX, bool PERSIST2 = false>
+// everything between the text and the finish, in one block shape: TPB threads x E records, MINB blocks per CU; AUX = type of the
+// pass-2 digit that travels with a pass-1 record, DIG = type of a staged pass-1 digit
+template <int TPB, int E, int MINB, typename AUX, typename DIG>
 static int os_passes(pgrc_match_ctx *c, int strand, const OsPlan &pl, const OsBufs &b) {
     constexpr uint32_t TILE = TPB * E;
     const uint32_t *pg = (const uint32_t *)c->pg2[strand].p;
     const uint64_t pgw = c->pg_words + PGRC_PG_PAD_WORDS;
     const uint32_t D1 = 1u << pl.b1, D2 = 1u << pl.b2;
     const size_t txt_bytes = (size_t)os_txt_words(TILE, pl.k1, pl.K) * sizeof(uint32_t);
-    const size_t lds1 = std::max<size_t>((size_t)TILE * (8 + 2 * sizeof(AUX)), txt_bytes), lds2 = (size_t)TILE * (8 + sizeof(AUX));
+    const size_t lds1 = std::max<size_t>((size_t)TILE * (8 + sizeof(AUX) + sizeof(DIG)), txt_bytes), lds2 = (size_t)TILE * (8 + sizeof(AUX));
     const bool k7 = pl.K == 28;
-    hipError_t he = k7 ? os_allow_lds(k_os_scatter_gen<7, TPB, E, MINB, AUX>, lds1) : os_allow_lds(k_os_scatter_gen<0, TPB, E, MINB, AUX>, lds1);
-    if (he == hipSuccess) he = PERSIST2 ? os_allow_lds(k_os_scatter_bins_p<TPB, E, AUX>, lds2) : os_allow_lds(k_os_scatter_bins<TPB, E, MINB, AUX>, lds2);
+    hipError_t he = k7 ? os_allow_lds(k_os_scatter_gen<7, TPB, E, MINB, AUX, DIG>, lds1) : os_allow_lds(k_os_scatter_gen<0, TPB, E, MINB, AUX, DIG>, lds1);
+    if (he == hipSuccess) he = os_allow_lds(k_os_scatter_bins<TPB, E, MINB, AUX>, lds2);
     if (he == hipSuccess) he = k7 ? os_allow_lds(k_os_count_gen<7, TPB, E>, txt_bytes) : os_allow_lds(k_os_count_gen<0, TPB, E>, txt_bytes);
     if (he != hipSuccess) { c->err = std::string("index build: ") + hipGetErrorString(he); return pgrc_hip_code(he); }
     const dim3 g1((uint32_t)pl.ntiles1), g2((uint32_t)pl.ntiles2_max), blk(TPB);
@@ -508,42 +453,35 @@ static int os_passes(pgrc_match_ctx *c, int strand, const OsPlan &pl, const OsBu
     else hipLaunchKernelGGL((k_os_count_gen<0, TPB, E>), g1, blk, txt_bytes, c->stream, pg, pgw, pl, b.cnt1);
     if ((e = pgrc_ps_scan_u32(c, b.cnt1, (uint64_t)D1 * pl.ntiles1, b.bsum))) return e;
     hipLaunchKernelGGL(k_os_prepare, dim3(1), dim3(1024), 0, c->stream, pl, (const uint32_t *)b.cnt1, b.tile_start, b.pstart, TILE);
-    if (k7) hipLaunchKernelGGL((k_os_scatter_gen<7, TPB, E, MINB, AUX>), g1, blk, lds1, c->stream, pg, pgw, pl, (const uint32_t *)b.cnt1, b.recA, (AUX *)b.aux);
-    else hipLaunchKernelGGL((k_os_scatter_gen<0, TPB, E, MINB, AUX>), g1, blk, lds1, c->stream, pg, pgw, pl, (const uint32_t *)b.cnt1, b.recA, (AUX *)b.aux);
+    if (k7) hipLaunchKernelGGL((k_os_scatter_gen<7, TPB, E, MINB, AUX, DIG>), g1, blk, lds1, c->stream, pg, pgw, pl, (const uint32_t *)b.cnt1, b.recA, (AUX *)b.aux);
+    else hipLaunchKernelGGL((k_os_scatter_gen<0, TPB, E, MINB, AUX, DIG>), g1, blk, lds1, c->stream, pg, pgw, pl, (const uint32_t *)b.cnt1, b.recA, (AUX *)b.aux);
     // pass 2
     hipLaunchKernelGGL(k_os_tiles, dim3((uint32_t)((pl.ntiles2_max + 255) / 256)), dim3(256), 0, c->stream, pl, (const uint32_t *)b.cnt1, (const uint32_t *)b.tile_start, TILE, b.desc);
     hipLaunchKernelGGL((k_os_count_bins<512, AUX>), g2, dim3(512), 0, c->stream, (const AUX *)b.aux, (const OsBinTile *)b.desc, pl, b.cnt2);
     if ((e = pgrc_ps_scan_u32(c, b.cnt2, (uint64_t)D2 * pl.ntiles2_max, b.bsum))) return e;
-    if (PERSIST2)
-        hipLaunchKernelGGL((k_os_scatter_bins_p<TPB, E, AUX>), dim3((uint32_t)std::min<uint64_t>(pl.ntiles2_max, (uint64_t)c->num_cus)), blk, lds2, c->stream,
-                           (const uint64_t *)b.recA, (const AUX *)b.aux, pl, (const OsBinTile *)b.desc, (const uint32_t *)b.cnt2, b.recB, b.pstart);
-    else
-        hipLaunchKernelGGL((k_os_scatter_bins<TPB, E, MINB, AUX>), g2, blk, lds2, c->stream, (const uint64_t *)b.recA, (const AUX *)b.aux, pl,
-                           (const OsBinTile *)b.desc, (const uint32_t *)b.cnt2, b.recB, b.pstart);
+    hipLaunchKernelGGL((k_os_scatter_bins<TPB, E, MINB, AUX>), g2, blk, lds2, c->stream, (const uint64_t *)b.recA, (const AUX *)b.aux, pl,
+                       (const OsBinTile *)b.desc, (const uint32_t *)b.cnt2, b.recB, b.pstart);
     HIP_TRY(c, hipGetLastError());
     return PGRC_OK;
 }
 
 int pgrc_os_build_index(pgrc_match_ctx *c, int strand, uint32_t hbits) {
     OsPlan pl;
-    if (!os_plan(c, hbits, &pl)) { c->err = "index build (sweep): not applicable"; return PGRC_E_PARAM; }
-    // Block shape of the passes (PGRC_OS_CFG = index into the table below: A/B runs).  Default 1: 1024 threads x 6 records,
-    // 61 KB of LDS and 64 registers: two blocks per CU, one hashing while the other stores.  C3, per strand (profiles/
-    // r03_os_cfgs.txt): pass 1 / pass 2 = 3.0 / 1.8 ms (shape 0: 1024 x 8, one block per CU), 1.8 / 1.75 (1), 2.2 / 2.1 (2: 512 x 8,
-    // three per CU), 3.3 / 2.75 (3: 512 x 16), 3.0 / 2.4 (4: shape 0 with a persistent, prefetching pass 2).
-    struct Shape { uint32_t tpb, e; };
-    static const Shape shapes[] = {{1024, 8}, {1024, 6}, {512, 8}, {512, 16}, {1024, 8}};
-    const char *cfgs = getenv("PGRC_OS_CFG");
-    uint32_t cfg = cfgs ? (uint32_t)atoi(cfgs) : 1u;
-    if (cfg >= sizeof shapes / sizeof shapes[0]) cfg = 1;
-    const bool aux16 = pl.b2 > 8;
-    if (aux16) cfg = 0;                                        // (9-bit digits: 16-bit digit arrays: the 8-record shape, one block per CU)
-    const uint64_t n = pl.n, tile = (uint64_t)shapes[cfg].tpb * shapes[cfg].e;
+    const uint32_t cfg = os_cfg_bits(c, OS_CFG_DEFAULT);
+    if (!os_plan(c, hbits, (cfg & 2u) ? 13u : 12u, &pl)) { c->err = "index build (sweep): not applicable"; return PGRC_E_PARAM; }
+    pl.xcd = cfg & 1u;
+    // Block shape of the passes: 1024 threads x 6 records, 61-68 KB of LDS and 64 registers: two blocks per CU, one hashing while
+    // the other stores.  Measured at C3 in round 3, per strand (profiles/r03_os_cfgs.txt): pass 1 / pass 2 = 3.0 / 1.8 ms with 1024
+    // x 8 (one block per CU), 1.8 / 1.75 with 1024 x 6, 2.2 / 2.1 with 512 x 8 (three per CU), 3.3 / 2.75 with 512 x 16, 3.0 / 2.4
+    // with a persistent, prefetching pass 2.  Nine-bit digits in BOTH passes (tables of 2^30 buckets and more: 16-bit digit
+    // arrays) take the 8-record shape, one block per CU.
+    const bool aux16 = pl.b2 > 8, dig16 = pl.b1 > 8;
+    const uint64_t n = pl.n, tile = aux16 ? 8192u : 6144u;
     const uint32_t D1 = 1u << pl.b1, D2 = 1u << pl.b2, np = 1u << (pl.hbits - pl.cb);
     pl.ntiles1 = (n + tile - 1) / tile;
     pl.ntiles2_max = pl.ntiles1 + D1;
     int e;
-    // buffers (grow-only, shared with the other front ends): d_sval[0] = pass-1 records, later ent[]; d_sval[1] = pass-2
+    // buffers (grow-only, shared with the other front end): d_sval[0] = pass-1 records, later ent[]; d_sval[1] = pass-2
     // records; d_skey[0] = the pass-2 digit of every pass-1 record; d_sorttmp = count matrices, tables, flags
     if ((e = pgrc_buf_ensure(c, c->d_sval[0], (n + 16) * sizeof(uint64_t))) || (e = pgrc_buf_ensure(c, c->d_sval[1], (n + 16) * sizeof(uint64_t))) ||
         (e = pgrc_buf_ensure(c, c->d_skey[0], (n + 16) * sizeof(uint32_t))))
@@ -565,15 +503,9 @@ int pgrc_os_build_index(pgrc_match_ctx *c, int strand, uint32_t hbits) {
     b.recB = (uint64_t *)c->d_sval[1].p;
     b.aux = c->d_skey[0].p;
     HIP_TRY(c, hipMemsetAsync(b.slow, 0, flag_words * sizeof(uint32_t), c->stream));
-    switch (cfg) {
-    case 1: e = os_passes<1024, 6, 2, uint8_t>(c, strand, pl, b); break;
-    case 2: e = os_passes<512, 8, 3, uint8_t>(c, strand, pl, b); break;
-    case 3: e = os_passes<512, 16, 1, uint8_t>(c, strand, pl, b); break;
-    case 4: e = os_passes<1024, 8, 1, uint8_t, true>(c, strand, pl, b); break;
-    default:
-        if (aux16) e = os_passes<1024, 8, 1, uint16_t>(c, strand, pl, b);
-        else e = os_passes<1024, 8, 1, uint8_t>(c, strand, pl, b);
-    }
+    if (aux16) e = os_passes<1024, 8, 1, uint16_t, uint16_t>(c, strand, pl, b);
+    else if (dig16) e = os_passes<1024, 6, 2, uint8_t, uint16_t>(c, strand, pl, b);
+    else e = os_passes<1024, 6, 2, uint8_t, uint8_t>(c, strand, pl, b);
     if (e) return e;
     return pgrc_ps_finish_packed(c, b.recB, b.pstart, b.slow, np, pl.cb, pl.rec_sh, b.recA);
 }

@@ -34,9 +34,7 @@
 #include <thread>
 #include <vector>
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
+#include "scanops.h"
 
 #include "ctx.h"
 #include "devutil.h"
@@ -50,7 +48,7 @@ struct pgrc_mem_ctx {
     const char *src = nullptr;        // borrowed host text
     uint64_t N = 0;
     bool have_src = false;
-    DevBuf d_dest, d_nmap, d_stage, d_flag, d_cursor, d_evk[2], d_evv[2], d_tmp, d_orun, d_oflag;
+    DevBuf d_dest, d_nmap, d_stage, d_flag, d_cursor, d_evk[2], d_evv[2], d_tmp, d_scan, d_orun, d_oflag;
     DevBuf d_skey[2], d_sidx[2], d_first, d_runid, d_rstart, d_rend;   // events by (diagonal, window): sort ping-pong, runs
     DevBuf d_rdend, d_outc, d_ebstart, d_ebin, d_ebout, d_ebinc, d_small, d_match;   // the replay: per run, per event, per event block
     hipEvent_t ev[5]{};               // phase timing (created on first use)
@@ -473,10 +471,10 @@ k_mem_replay(const MemReplayArgs r) {
 }
 
 struct MemLastValid {          // scan operator: the rightmost recorded match
-    __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return b != MR_NONE ? b : a; }
+    __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return b != MR_NONE ? b : a; }
 };
 struct MemIsAccept {
-    __host__ __device__ uint32_t operator()(uint8_t oc) const { return oc == MO_ACCEPT ? 1u : 0u; }
+    __device__ uint32_t operator()(uint8_t oc) const { return oc == MO_ACCEPT ? 1u : 0u; }
 };
 
 // smallest event index with outcome MO_STALE (everything before it is final)
@@ -694,7 +692,7 @@ void pgrc_mem_destroy(pgrc_mem_ctx *m) {
         (void)hipDeviceSynchronize();          // (its buffers go to the pool of device buffers: nothing may still be running)
     }
     DevBuf *bufs[] = {&m->d_dest, &m->d_nmap, &m->d_stage, &m->d_flag, &m->d_cursor, &m->d_evk[0], &m->d_evk[1], &m->d_evv[0],
-                      &m->d_evv[1], &m->d_tmp, &m->d_orun, &m->d_oflag, &m->d_skey[0], &m->d_skey[1], &m->d_sidx[0],
+                      &m->d_evv[1], &m->d_tmp, &m->d_scan, &m->d_orun, &m->d_oflag, &m->d_skey[0], &m->d_skey[1], &m->d_sidx[0],
                       &m->d_sidx[1], &m->d_first, &m->d_runid, &m->d_rstart, &m->d_rend, &m->d_rdend, &m->d_outc, &m->d_ebstart,
                       &m->d_ebin, &m->d_ebout, &m->d_ebinc, &m->d_small, &m->d_match};
     for (DevBuf *b : bufs) pgrc_buf_free(*b);
@@ -819,8 +817,7 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     // ---- 1. events
     if ((e = pgrc_buf_ensure(c, m->d_cursor, 8))) { m->err = c->err; return e; }
     uint64_t cap = std::max<uint64_t>(nprobes / 64 + 65536, m->d_evk[0].bytes / 8);
-    if (const char *ev_cap = getenv("PGRC_MEM_EVENT_CAP"))   // test knob: start tiny to exercise the regrow-and-rerun path
-        cap = std::max<uint64_t>(1, (uint64_t)atoll(ev_cap));
+    if (c->opt.mem_event_cap) cap = c->opt.mem_event_cap;   // (PGRC_MEM_EVENT_CAP, test knob: start tiny to exercise the regrow-and-rerun path)
     unsigned long long nev = 0;
     (void)hipEventRecord(ev[0], c->stream);
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -848,14 +845,12 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     // ---- 2. the order in which the reference meets them: by window, then by bucket order
     int tb = 1;
     while ((1ull << tb) < nprobes) tb++;
-    rocprim::double_buffer<uint64_t> keys((uint64_t *)m->d_evk[0].p, (uint64_t *)m->d_evk[1].p);
-    rocprim::double_buffer<uint64_t> vals((uint64_t *)m->d_evv[0].p, (uint64_t *)m->d_evv[1].p);
-    size_t tbytes = 0;
-    MEM_TRY(m, rocprim::radix_sort_pairs(nullptr, tbytes, keys, vals, (size_t)nev, 0, 4 + tb, c->stream));
-    if ((e = pgrc_buf_ensure(c, m->d_tmp, tbytes + 16))) { m->err = c->err; return e; }
-    MEM_TRY(m, rocprim::radix_sort_pairs(m->d_tmp.p, tbytes, keys, vals, (size_t)nev, 0, 4 + tb, c->stream));
+    // (a stable LSD sort of (key, value) pairs: radix.hip, hand-written; the library's pair sort until round 5)
+    uint64_t *ksorted = nullptr, *vsorted = nullptr;
+    if ((e = pgrc_radix_sort_pairs_u64(c, (uint64_t *)m->d_evk[0].p, (uint64_t *)m->d_evk[1].p, (uint64_t *)m->d_evv[0].p, (uint64_t *)m->d_evv[1].p, nev, 0,
+                                       4 + tb, m->d_tmp, &ksorted, &vsorted))) { m->err = c->err; return e; }
     (void)hipEventRecord(ev[2], c->stream);
-    const uint64_t *ek = (const uint64_t *)keys.current(), *ep = (const uint64_t *)vals.current();
+    const uint64_t *ek = ksorted, *ep = vsorted;
 
     // ---- 3. side contexts; extents per run of connected events on a diagonal
     if ((e = pgrc_buf_ensure(c, m->d_orun, cap * 4)) || (e = pgrc_buf_ensure(c, m->d_oflag, cap)) || (e = pgrc_buf_ensure(c, m->d_first, cap * 4)) ||
@@ -868,24 +863,22 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     uint64_t *d_range = (uint64_t *)m->d_small.p + 2;
     MEM_TRY(m, hipMemsetAsync(m->d_small.p, 0, 64, c->stream));
     const uint32_t g = (uint32_t)((nev + 255) / 256);
-    size_t t3 = 0;
+    // scratch of the scans below (scanops.h): block folds of nev values
+    if ((e = pgrc_buf_ensure(c, m->d_scan, sco_scratch_words(nev) * sizeof(uint32_t)))) { m->err = c->err; return e; }
+    uint32_t *d_bsum = (uint32_t *)m->d_scan.p;
     {
-        rocprim::double_buffer<uint64_t> sk((uint64_t *)m->d_skey[0].p, (uint64_t *)m->d_skey[1].p);
-        rocprim::double_buffer<uint64_t> si((uint64_t *)m->d_sidx[0].p, (uint64_t *)m->d_sidx[1].p);
-        hipLaunchKernelGGL(k_mem_flags, dim3(g), dim3(256), 0, c->stream, a, ek, ep, (uint64_t)nev, (uint8_t *)m->d_oflag.p, sk.current(), si.current(), d_nstale);
+        uint64_t *sk0 = (uint64_t *)m->d_skey[0].p, *si0 = (uint64_t *)m->d_sidx[0].p;
+        hipLaunchKernelGGL(k_mem_flags, dim3(g), dim3(256), 0, c->stream, a, ek, ep, (uint64_t)nev, (uint8_t *)m->d_oflag.p, sk0, si0, d_nstale);
         int db = 1;
         while ((1ull << db) < N2 + m->N) db++;
-        size_t t2 = 0;
-        MEM_TRY(m, rocprim::radix_sort_pairs(nullptr, t2, sk, si, (size_t)nev, 0, db, c->stream));
-        MEM_TRY(m, rocprim::inclusive_scan(nullptr, t3, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)nev, rocprim::plus<uint32_t>(), c->stream));
-        if ((e = pgrc_buf_ensure(c, m->d_tmp, std::max(t2, std::max(t3, tbytes)) + 16))) { m->err = c->err; return e; }
         // (diagonal, window) order: the events ARE in window order (step 2), so one stable sort by diagonal does it (until round 4 a
         // sort by window came first: a third of the sorting time of an event-rich call, for nothing)
-        hipLaunchKernelGGL(k_mem_diag, dim3(g), dim3(256), 0, c->stream, a, ek, ep, (const uint64_t *)si.current(), (uint64_t)nev, sk.current());
-        MEM_TRY(m, rocprim::radix_sort_pairs(m->d_tmp.p, t2, sk, si, (size_t)nev, 0, db, c->stream));
-        const uint64_t *sidx = si.current(), *skey = sk.current();
+        hipLaunchKernelGGL(k_mem_diag, dim3(g), dim3(256), 0, c->stream, a, ek, ep, (const uint64_t *)si0, (uint64_t)nev, sk0);
+        uint64_t *sks = nullptr, *sis = nullptr;
+        if ((e = pgrc_radix_sort_pairs_u64(c, sk0, (uint64_t *)m->d_skey[1].p, si0, (uint64_t *)m->d_sidx[1].p, nev, 0, (uint32_t)db, m->d_tmp, &sks, &sis))) { m->err = c->err; return e; }
+        const uint64_t *sidx = sis, *skey = sks;
         hipLaunchKernelGGL(k_mem_connect, dim3(g), dim3(256), 0, c->stream, a, ek, ep, sidx, skey, (uint64_t)nev, (uint32_t *)m->d_first.p);
-        MEM_TRY(m, rocprim::inclusive_scan(m->d_tmp.p, t3, (uint32_t *)m->d_first.p, (uint32_t *)m->d_runid.p, (size_t)nev, rocprim::plus<uint32_t>(), c->stream));
+        MEM_TRY(m, (sco_scan<true>(c->stream, (const uint32_t *)m->d_first.p, (uint32_t *)m->d_runid.p, (uint64_t)nev, ScoIdentity(), ScoPlus(), 0u, d_bsum)));
         hipLaunchKernelGGL(k_mem_run_ends, dim3(g), dim3(256), 0, c->stream, a, ek, ep, sidx, (const uint32_t *)m->d_first.p,
                            (const uint32_t *)m->d_runid.p, (uint64_t)nev, (uint64_t *)m->d_rstart.p, (uint64_t *)m->d_rend.p, (uint64_t *)m->d_rdend.p);
         hipLaunchKernelGGL(k_mem_apply, dim3(g), dim3(256), 0, c->stream, sidx, (const uint32_t *)m->d_runid.p, (uint64_t)nev,
@@ -905,7 +898,7 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     }
     uint32_t *d_lead = (uint32_t *)m->d_first.p, *d_lid = (uint32_t *)m->d_runid.p;      // (free again: the runs are numbered)
     hipLaunchKernelGGL(k_mem_lead, dim3(g), dim3(256), 0, c->stream, ek, (uint64_t)nev, nmain, d_lead);
-    MEM_TRY(m, rocprim::inclusive_scan(m->d_tmp.p, t3, d_lead, d_lid, (size_t)nev, rocprim::plus<uint32_t>(), c->stream));
+    MEM_TRY(m, (sco_scan<true>(c->stream, (const uint32_t *)d_lead, d_lid, (uint64_t)nev, ScoIdentity(), ScoPlus(), 0u, d_bsum)));
     uint32_t neb = 0, nstale = 0;
     MEM_TRY(m, hipMemcpyAsync(&neb, d_lid + (nev - 1), 4, hipMemcpyDeviceToHost, c->stream));
     MEM_TRY(m, hipMemcpyAsync(&nstale, d_nstale, 4, hipMemcpyDeviceToHost, c->stream));
@@ -914,9 +907,6 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     if ((e = pgrc_buf_ensure(c, m->d_ebstart, ((size_t)neb + 1) * 4)) || (e = pgrc_buf_ensure(c, m->d_ebin, (size_t)neb * 4)) ||
         (e = pgrc_buf_ensure(c, m->d_ebout, (size_t)neb * 4)) || (e = pgrc_buf_ensure(c, m->d_ebinc, (size_t)neb * 4))) { m->err = c->err; return e; }
     hipLaunchKernelGGL(k_mem_eb_start, dim3(g), dim3(256), 0, c->stream, (const uint32_t *)d_lead, (const uint32_t *)d_lid, (uint64_t)nev, (uint32_t *)m->d_ebstart.p);
-    size_t t4 = 0;
-    MEM_TRY(m, rocprim::exclusive_scan(nullptr, t4, (uint32_t *)nullptr, (uint32_t *)nullptr, MR_NONE, (size_t)neb, MemLastValid(), c->stream));
-    if (t4 + 16 > m->d_tmp.bytes && (e = pgrc_buf_ensure(c, m->d_tmp, t4 + 16))) { m->err = c->err; return e; }
     MemReplayArgs ra;
     ra.ek = ek;
     ra.orun = (const uint32_t *)m->d_orun.p;
@@ -941,7 +931,7 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     auto settle = [&]() -> int {
         for (;;) {
             uint32_t changed = 0;
-            MEM_TRY(m, rocprim::exclusive_scan(m->d_tmp.p, t4, (uint32_t *)m->d_ebout.p, (uint32_t *)m->d_ebinc.p, MR_NONE, (size_t)neb, MemLastValid(), c->stream));
+            MEM_TRY(m, (sco_scan<false>(c->stream, (const uint32_t *)m->d_ebout.p, (uint32_t *)m->d_ebinc.p, (uint64_t)neb, ScoIdentity(), MemLastValid(), MR_NONE, d_bsum)));
             MEM_TRY(m, hipMemsetAsync(d_changed, 0, 4, c->stream));
             hipLaunchKernelGGL(k_mem_replay, dim3(gb), dim3(64 * MEM_RP_WAVES), 0, c->stream, ra);
             MEM_TRY(m, hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
@@ -986,11 +976,7 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     // ---- 5. the matches, in discovery order
     const auto th0 = std::chrono::steady_clock::now();
     uint32_t *d_slot = (uint32_t *)m->d_first.p;                                       // (the block leaders are not needed any more)
-    auto acc_in = rocprim::make_transform_iterator((const uint8_t *)m->d_outc.p, MemIsAccept());
-    size_t t5 = 0;
-    MEM_TRY(m, rocprim::inclusive_scan(nullptr, t5, acc_in, d_slot, (size_t)nev, rocprim::plus<uint32_t>(), c->stream));
-    if (t5 + 16 > m->d_tmp.bytes && (e = pgrc_buf_ensure(c, m->d_tmp, t5 + 16))) { m->err = c->err; return e; }
-    MEM_TRY(m, rocprim::inclusive_scan(m->d_tmp.p, t5, acc_in, d_slot, (size_t)nev, rocprim::plus<uint32_t>(), c->stream));
+    MEM_TRY(m, (sco_scan<true>(c->stream, (const uint8_t *)m->d_outc.p, d_slot, (uint64_t)nev, MemIsAccept(), ScoPlus(), 0u, d_bsum)));
     uint32_t nmatch = 0;
     MEM_TRY(m, hipMemcpyAsync(&nmatch, d_slot + (nev - 1), 4, hipMemcpyDeviceToHost, c->stream));
     MEM_TRY(m, hipStreamSynchronize(c->stream));

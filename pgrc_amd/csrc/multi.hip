@@ -140,6 +140,7 @@ int pgrc_match_create_multi(const pgrc_match_params *p, int32_t n_devices, const
     pgrc_multi *m = new pgrc_multi();
     f->multi = m;
     f->prm = *p;
+    f->opt = pgrc_options_from_env();
     f->device = devices[0];
     f->nw = (p->read_len + 15) / 16;
     int e = PGRC_OK;
@@ -194,8 +195,8 @@ static int allgather_text(pgrc_match_ctx *f, uint64_t sw) {
     pgrc_multi *m = f->multi;
     const size_t k = m->child.size();
     m->ms_allgather = 0;
-    const char *eng = getenv("PGRC_ALLGATHER");     // "rccl" / "copy": force an engine (tests); default by device list
-    const bool force_rccl = eng && !strcmp(eng, "rccl"), force_copy = eng && !strcmp(eng, "copy");
+    // PGRC_ALLGATHER = "rccl" / "copy": force an engine (tests); default by device list
+    const bool force_rccl = f->opt.allgather == 1, force_copy = f->opt.allgather == 2;
     if (k == 1 && !force_rccl) return PGRC_OK;
     const bool use_rccl = force_rccl || (m->distinct && !force_copy);
     const auto t0 = std::chrono::steady_clock::now();

@@ -1,8 +1,9 @@
 // radix.hip -- a stable LSD radix sort of 64-bit records by a bit field, hand-written for gfx950 (no library call).
 //
-// Who sorts with it (round 4): the position order of the Pg-order export (export.hip: records = position << 32 | read,
-// ReadsMatchers.cpp:563-574).  (The hits of modes d / i / e were sorted with it for part of round 4; they are reduced without
-// any sort now, seedidx.hip.  The events of the Pg-vs-Pg matcher, mem.hip, still take the library's pair sort.)
+// Who sorts with it: the position order of the Pg-order export (export.hip: records = position << 32 | read,
+// ReadsMatchers.cpp:563-574) and, since round 5, the events of the Pg-vs-Pg matcher (mem.hip: 64-bit keys that carry a 64-bit
+// value each -- the PAIRS form of the scatter kernel stages both and moves 40 bytes per record and pass).  (The hits of modes
+// d / i / e were sorted with it for part of round 4; they are reduced without any sort now, seedidx.hip.)
 //
 // One pass over `dbits` <= 8 key bits, tiles of RX_TILE consecutive records:
 //   k_rx_hist     every tile counts its records per digit (LDS atomics)        -> cnt[digit][tile]
@@ -74,10 +75,12 @@ __device__ __forceinline__ uint32_t rx_block_scan(uint32_t v, uint32_t *smem, ui
 
 // Records arrive as RX_E groups per wave; group i of wave w holds the tile's records w * 512 + i * 64 + lane, so "earlier
 // wave, then earlier group, then lower lane" is the input order -- and the order equal digits leave in.
+template <bool PAIRS>
 __global__ void __launch_bounds__(RX_TPB)
-k_rx_scatter(const uint64_t *__restrict__ in, uint64_t n, uint32_t shift, uint32_t dbits, uint64_t ntiles,
-             const uint32_t *__restrict__ base, uint64_t *__restrict__ out) {
+k_rx_scatter(const uint64_t *__restrict__ in, const uint64_t *__restrict__ vin, uint64_t n, uint32_t shift, uint32_t dbits, uint64_t ntiles,
+             const uint32_t *__restrict__ base, uint64_t *__restrict__ out, uint64_t *__restrict__ vout) {
     __shared__ RxLds s;
+    extern __shared__ __attribute__((aligned(16))) uint64_t valS[];      // PAIRS: the values, staged beside their keys (64 KB)
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t D = 1u << dbits, dmask = D - 1u;
     const uint64_t tile = blockIdx.x;
@@ -88,6 +91,14 @@ k_rx_scatter(const uint64_t *__restrict__ in, uint64_t n, uint32_t shift, uint32
     for (int i = 0; i < RX_E; i++) {
         const uint32_t x = wv * RX_WSPAN + (uint32_t)i * 64u + lane;
         rec[i] = x < nvalid ? in[t0 + x] : 0ull;
+    }
+    uint64_t val[PAIRS ? RX_E : 1];
+    if (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < RX_E; i++) {
+            const uint32_t x = wv * RX_WSPAN + (uint32_t)i * 64u + lane;
+            val[PAIRS ? i : 0] = x < nvalid ? vin[t0 + x] : 0ull;
+        }
     }
     for (uint32_t x = threadIdx.x; x < RX_NW * RX_MAXD; x += RX_TPB) (&s.hist[0][0])[x] = (uint16_t)0;
     for (uint32_t d = threadIdx.x; d < D; d += RX_TPB) s.gbase[d] = base[(uint64_t)d * ntiles + tile];
@@ -133,32 +144,39 @@ k_rx_scatter(const uint64_t *__restrict__ in, uint64_t n, uint32_t shift, uint32
         const bool valid = wv * RX_WSPAN + (uint32_t)i * 64u + lane < nvalid;
         if (valid) {
             const uint32_t d = (uint32_t)(rec[i] >> shift) & dmask;
-            s.recS[s.dstart[d] + s.hist[wv][d] + rank[i]] = rec[i];
+            const uint32_t slot = s.dstart[d] + s.hist[wv][d] + rank[i];
+            s.recS[slot] = rec[i];
+            if (PAIRS) valS[slot] = val[PAIRS ? i : 0];
         }
     }
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < nvalid; j += RX_TPB) {
         const uint64_t r = s.recS[j];
         const uint32_t d = (uint32_t)(r >> shift) & dmask;
-        out[(uint64_t)s.gbase[d] + (j - s.dstart[d])] = r;
+        const uint64_t dest = (uint64_t)s.gbase[d] + (j - s.dstart[d]);
+        out[dest] = r;
+        if (PAIRS) vout[dest] = valS[j];
     }
 }
 
 // Sorts d_a[0 .. n) by the bits [bit_lo, bit_hi) of every record, stable; d_b: n records of scratch; `scratch` grows as
-// needed (count matrix).  *sorted = d_a or d_b, wherever the last pass put the records.  All on c->stream, no
-// synchronisation.
-int pgrc_radix_sort_u64(pgrc_match_ctx *c, uint64_t *d_a, uint64_t *d_b, uint64_t n, uint32_t bit_lo, uint32_t bit_hi, DevBuf &scratch,
-                        uint64_t **sorted) {
+// needed (count matrix).  *sorted = d_a or d_b, wherever the last pass put the records.  With v_a / v_b (both or neither): every
+// record carries a 64-bit value that moves with it; *vsorted = where the values ended up.  All on c->stream, no synchronisation.
+static int rx_sort(pgrc_match_ctx *c, uint64_t *d_a, uint64_t *d_b, uint64_t *v_a, uint64_t *v_b, uint64_t n, uint32_t bit_lo, uint32_t bit_hi,
+                   DevBuf &scratch, uint64_t **sorted, uint64_t **vsorted) {
     *sorted = d_a;
+    if (vsorted) *vsorted = v_a;
     if (n < 2 || bit_hi <= bit_lo) return PGRC_OK;
     if (n >= 0xFFFFF000ull) { c->err = "radix sort: too many records"; return PGRC_E_PARAM; }
+    const bool pairs = v_a != nullptr;
     const uint64_t ntiles = (n + RX_TILE - 1) / RX_TILE;
     const uint64_t ncnt = (uint64_t)RX_MAXD * ntiles;
     int e;
     if ((e = pgrc_buf_ensure(c, scratch, (ncnt + pgrc_ps_scan_blocks(ncnt) + 2) * sizeof(uint32_t) + 256))) return e;
+    if (pairs) HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_rx_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RX_TILE * sizeof(uint64_t))));
     uint32_t *cnt = (uint32_t *)scratch.p, *bsum = cnt + ncnt;
     const uint32_t bits = bit_hi - bit_lo, passes = (bits + 7) / 8;
-    uint64_t *src = d_a, *dst = d_b;
+    uint64_t *src = d_a, *dst = d_b, *vsrc = v_a, *vdst = v_b;
     uint32_t shift = bit_lo;
     for (uint32_t p = 0; p < passes; p++) {
         // digits as even as the field allows (31 bits: 8 8 8 7)
@@ -167,12 +185,28 @@ int pgrc_radix_sort_u64(pgrc_match_ctx *c, uint64_t *d_a, uint64_t *d_b, uint64_
         hipLaunchKernelGGL(k_rx_hist, dim3((uint32_t)ntiles), dim3(RX_TPB), 0, c->stream, (const uint64_t *)src, n, shift, D - 1u, ntiles, cnt);
         HIP_TRY(c, hipGetLastError());
         if ((e = pgrc_ps_scan_u32(c, cnt, (uint64_t)D * ntiles, bsum))) return e;
-        hipLaunchKernelGGL(k_rx_scatter, dim3((uint32_t)ntiles), dim3(RX_TPB), 0, c->stream, (const uint64_t *)src, n, shift, dbits, ntiles,
-                           (const uint32_t *)cnt, dst);
+        if (pairs)
+            hipLaunchKernelGGL(k_rx_scatter<true>, dim3((uint32_t)ntiles), dim3(RX_TPB), RX_TILE * sizeof(uint64_t), c->stream, (const uint64_t *)src, (const uint64_t *)vsrc, n,
+                               shift, dbits, ntiles, (const uint32_t *)cnt, dst, vdst);
+        else
+            hipLaunchKernelGGL(k_rx_scatter<false>, dim3((uint32_t)ntiles), dim3(RX_TPB), 0, c->stream, (const uint64_t *)src, (const uint64_t *)nullptr, n, shift, dbits,
+                               ntiles, (const uint32_t *)cnt, dst, (uint64_t *)nullptr);
         HIP_TRY(c, hipGetLastError());
         std::swap(src, dst);
+        std::swap(vsrc, vdst);
         shift += dbits;
     }
     *sorted = src;
+    if (vsorted) *vsorted = vsrc;
     return PGRC_OK;
+}
+
+int pgrc_radix_sort_u64(pgrc_match_ctx *c, uint64_t *d_a, uint64_t *d_b, uint64_t n, uint32_t bit_lo, uint32_t bit_hi, DevBuf &scratch,
+                        uint64_t **sorted) {
+    return rx_sort(c, d_a, d_b, nullptr, nullptr, n, bit_lo, bit_hi, scratch, sorted, nullptr);
+}
+
+int pgrc_radix_sort_pairs_u64(pgrc_match_ctx *c, uint64_t *k_a, uint64_t *k_b, uint64_t *v_a, uint64_t *v_b, uint64_t n, uint32_t bit_lo, uint32_t bit_hi,
+                              DevBuf &scratch, uint64_t **ksorted, uint64_t **vsorted) {
+    return rx_sort(c, k_a, k_b, v_a, v_b, n, bit_lo, bit_hi, scratch, ksorted, vsorted);
 }

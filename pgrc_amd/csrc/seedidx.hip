@@ -666,7 +666,7 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
     // 0.16 s -- and costs a dependent round trip where many do (modes d / i with four parts per read: 0.42 -> 0.43 s): used
     // when there is at most one key per eight text positions (PGRC_SEED_FILTER=0 / 1: never / always, tests and A/B runs)
     bool use_filter = nent * 8 <= c->G;
-    if (const char *v = getenv("PGRC_SEED_FILTER")) use_filter = v[0] != '0';
+    if (c->opt.seed_filter >= 0) use_filter = c->opt.seed_filter != 0;
     a.filter = nullptr;
     a.fshift = 0;
     if (use_filter) {
@@ -733,7 +733,7 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
         else hipLaunchKernelGGL(k_seed_probe<false>, pgrid, dim3(SCAN_TPB), 0, c->stream, a, w0, nwin, pgw, wrec);
         HIP_TRY(c, hipMemsetAsync(counters + 2, 0, 2 * sizeof(unsigned long long), c->stream));       // heavy windows listed / taken
         const dim3 hgrid((uint32_t)c->num_cus * 8u);
-        const uint32_t heavy_thr = getenv("PGRC_SEED_HEAVY") ? (uint32_t)std::min(4096, std::max(1, atoi(getenv("PGRC_SEED_HEAVY")))) : EXP_HEAVY;
+        const uint32_t heavy_thr = c->opt.seed_heavy ? c->opt.seed_heavy : EXP_HEAVY;
 #define EXP_LAUNCH(R)                                                                                                                                       \
         hipLaunchKernelGGL((k_seed_expand<R>), egrid, dim3(EXP_TPB), 0, c->stream, a, w0, nwin, (const uint64_t *)wrec, rows, best, counters, hlist, heavy_thr, pgw); \
         hipLaunchKernelGGL((k_seed_heavy<R>), hgrid, dim3(EXP_TPB), 0, c->stream, a, w0, (const uint64_t *)wrec, (const uint32_t *)hlist, rows, best, counters, pgw)
@@ -783,8 +783,8 @@ int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand) {
     // a batch holds at most 2^30 entries (SX_FLAG); a launch of the scan 2^29 window starts (6 GB of scratch).  The knobs force
     // small batches / launches so that tests cover the loops on small inputs
     uint64_t batch = (1ull << 30) / a.P, seg = 1ull << 29;
-    if (const char *k = getenv("PGRC_SEED_READ_BATCH")) batch = std::max<uint64_t>(1, std::min<uint64_t>(batch, strtoull(k, nullptr, 10)));
-    if (const char *k = getenv("PGRC_SEED_SEGMENT")) seg = std::max<uint64_t>(4096, std::min<uint64_t>(seg, strtoull(k, nullptr, 10)));
+    if (c->opt.seed_read_batch) batch = std::max<uint64_t>(1, std::min<uint64_t>(batch, c->opt.seed_read_batch));
+    if (c->opt.seed_segment) seg = std::max<uint64_t>(4096, std::min<uint64_t>(seg, c->opt.seed_segment));
     const uint32_t *d_nidx = (const uint32_t *)c->nread_idx.p;
     for (uint64_t r0 = 0; r0 < c->n; r0 += batch) {
         const uint64_t r1 = std::min(c->n, r0 + batch);

@@ -26,9 +26,8 @@
 #include "ctx.h"
 
 // PGRC_STREAM_TIMING=1: host-clock milestones of a streamed run on stderr
-static bool timing_on() { static const bool on = getenv("PGRC_STREAM_TIMING") != nullptr; return on; }
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-#define ST_MARK(c, what) do { if (timing_on()) fprintf(stderr, "pgrc stream: %8.2f ms  %s\n", (now_s() - (c)->st_t0) * 1e3, what); } while (0)
+#define ST_MARK(c, what) do { if ((c)->opt.stream_timing) fprintf(stderr, "pgrc stream: %8.2f ms  %s\n", (now_s() - (c)->st_t0) * 1e3, what); } while (0)
 
 extern "C" int pgrc_match_prepare_index(pgrc_match_ctx *c, int32_t both_strands) {
     if (!c) return PGRC_E_PARAM;
@@ -63,7 +62,7 @@ static void stream_worker(pgrc_match_ctx *c) {
             if (he == hipSuccess) he = hipMemcpyAsync(c->st_mism + b.lo, (const uint8_t *)c->d_mism.p + b.lo, b.cnt, hipMemcpyDeviceToHost, down);
             if (he == hipSuccess) he = hipStreamSynchronize(down);
         }
-        if (timing_on()) fprintf(stderr, "pgrc stream: %8.2f ms  results of block [%llu, +%llu) on the host\n", (now_s() - c->st_t0) * 1e3, (unsigned long long)b.lo, (unsigned long long)b.cnt);
+        if (c->opt.stream_timing) fprintf(stderr, "pgrc stream: %8.2f ms  results of block [%llu, +%llu) on the host\n", (now_s() - c->st_t0) * 1e3, (unsigned long long)b.lo, (unsigned long long)b.cnt);
         if (b.done) (void)hipEventDestroy(b.done);
         if (he != hipSuccess) {
             std::lock_guard<std::mutex> g(c->st_mu);
@@ -147,7 +146,7 @@ extern "C" int pgrc_match_stream_begin(pgrc_match_ctx *c, uint64_t *pos, uint8_t
 // rows [lo, lo + cnt) are unpacked (queued on the upload stream): match them on the main stream, hand them to the worker
 int pgrc_stream_block_arrived(pgrc_match_ctx *c, uint64_t lo, uint64_t cnt, bool may_hold_n, int turn) {
     if (!c->st_on || !cnt) return PGRC_OK;
-    if (timing_on()) fprintf(stderr, "pgrc stream: %8.2f ms  block [%llu, +%llu) copied and queued for unpacking\n", (now_s() - c->st_t0) * 1e3, (unsigned long long)lo, (unsigned long long)cnt);
+    if (c->opt.stream_timing) fprintf(stderr, "pgrc stream: %8.2f ms  block [%llu, +%llu) copied and queued for unpacking\n", (now_s() - c->st_t0) * 1e3, (unsigned long long)lo, (unsigned long long)cnt);
     HIP_TRY(c, hipEventRecord(c->up_ev[turn], c->up_stream[turn]));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->up_ev[turn], 0));
     // the kernels' read cursors start at zero for every launch
@@ -192,11 +191,11 @@ extern "C" int pgrc_match_stream_end(pgrc_match_ctx *c, uint64_t hist[256], uint
     // blocks' kernels skip the reads with N, so the two write disjoint reads); the main stream joins it at its tail
     if (c->n_nreads) {
         c->n_after = c->st_ready;
-        e = pgrc_copmem_match_nreads(c, 0, 1, false, c->st_dual);   // (the blocks' dual kernel took the reads with at most 4 N's)               // (one launch: a read's forward query, then its RC query)
+        e = pgrc_copmem_match_nreads(c, 0, 1, c->st_dual);   // one launch: a read's forward query, then its RC query (the blocks' dual kernel took the reads with at most 4 N)
         if (!e) e = pgrc_copmem_join_nreads(c);
         c->n_after = nullptr;
     }
-    if (timing_on()) { (void)hipStreamSynchronize(c->stream); ST_MARK(c, "all blocks matched, reads with N done"); }
+    if (c->opt.stream_timing) { (void)hipStreamSynchronize(c->stream); ST_MARK(c, "all blocks matched, reads with N done"); }
     if (!e) e = pgrc_launch_hist(c);                                 // synchronises the main stream: every block is done
     ST_MARK(c, "histogram done");
     if (!e && c->n_nreads) {

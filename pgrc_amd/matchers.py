@@ -311,6 +311,11 @@ class MatchContext:
         self._ck(lib.pgrc_match_export_pg(self._h, strand, w.ctypes.data_as(C.c_void_p)))
         return w
 
+    def reload_options(self):
+        """The library reads its PGRC_* run-time options from the environment ONCE, when a context is created; tests and A/B
+        tools that change one for a live context ask it to read them again (pgrc_match_reload_options)."""
+        self._ck(lib.pgrc_match_reload_options(self._h))
+
     def set_profiling(self, on: bool = True):
         self._ck(lib.pgrc_match_set_profiling(self._h, 1 if on else 0))
 

@@ -47,7 +47,8 @@ def main():
         o = orc.oracle_match(mode, pg, reads, seed_len, kmax, kmin, rev)
         shards = int(rng.integers(2, 6)) if rng.random() < 0.3 else 0
         packed = bool(rng.random() < 0.5)
-        variant = str(rng.choice(["", "", "own", "rocprim"]))
+        variant = str(rng.choice(["", "", "own"]))
+        icfg = str(rng.choice(["", "", "1", "2", "3"]))     # round 5: XCD-aware tile order (1), partitions of 8192 buckets (2)
         finish = "general" if rng.random() < 0.3 else ""
         # modes d / i / e: small text segments and read batches now and then (the loops a >= 4 Gi text / >= 2^28 reads take)
         seg = str(int(rng.integers(4096, 40000))) if mode != "c" and rng.random() < 0.4 else ""
@@ -56,18 +57,13 @@ def main():
         early = "0" if rng.random() < 0.25 else ""       # ... probing every seed of every read (no early stop)
         dual = str(rng.choice(["", "1", "1", "0"]))         # one query per read over both strands: forced / where it pays / never
         screen = str(rng.choice(["", "", "0", "1"]))       # "" = the dual kernel where it applies       # ... the two passes in the reference's order (no exact-match screen)
-        # round 4: the pair table by group size (0 = a table per strand), reads with few N's inside the dual kernel or not, the redo
-        # rule, chunks from the end or the start, the speculative first attempt
+        # round 4: the pair table by group size (0 = a table per strand), reads with few N's inside the dual kernel or not
         pairk = str(rng.choice(["", "", "0", "1", "2", "3", "4"]))
         inline = "0" if rng.random() < 0.3 else ""
-        redo_any = "1" if rng.random() < 0.2 else ""
-        from_end = "0" if rng.random() < 0.3 else ""
-        spec = str(rng.choice(["", "", "", "0", "1", "3"]))
         heavy = str(rng.choice(["", "", "1", "4", "4096"]))   # modes d / i / e: entries of a window above which the persistent grid takes it
-        for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish), ("PGRC_SEED_SEGMENT", seg), ("PGRC_SEED_READ_BATCH", batch),
+        for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_CFG", icfg), ("PGRC_INDEX_FINISH", finish), ("PGRC_SEED_SEGMENT", seg), ("PGRC_SEED_READ_BATCH", batch),
                          ("PGRC_MATCH_STAGE", stage), ("PGRC_EARLY_STOP", early), ("PGRC_SCREEN", screen), ("PGRC_DUAL", dual),
-                         ("PGRC_HEAD_PAIR", pairk), ("PGRC_NREAD_INLINE", inline), ("PGRC_REDO_ANY", redo_any), ("PGRC_MATCH_FROM_END", from_end),
-                         ("PGRC_SPEC_LIMIT", spec), ("PGRC_SEED_HEAVY", heavy)):
+                         ("PGRC_HEAD_PAIR", pairk), ("PGRC_NREAD_INLINE", inline), ("PGRC_SEED_HEAVY", heavy)):
             if val:
                 os.environ[key] = val
             else:
@@ -76,7 +72,7 @@ def main():
                       n_nset=nn if packed else None)
         what = dict(mode=mode, L=L, seed_len=seed_len, M=M, kmin=kmin, G=G, n=n, nn=nn, rev=rev, seed=seed, shards=shards,
                     packed=packed, variant=variant, finish=finish, seg=seg, batch=batch, stage=stage, early=early, screen=screen, dual=dual,
-                    pairk=pairk, inline=inline, redo_any=redo_any, from_end=from_end, spec=spec, heavy=heavy)
+                    pairk=pairk, inline=inline, icfg=icfg, heavy=heavy)
         for k in ("pos", "rc", "mism", "hist"):
             if not np.array_equal(np.asarray(g[k]), np.asarray(o[k])):
                 print("READS MISMATCH", what, k, flush=True)

@@ -36,7 +36,8 @@ def main():
         pg, reads = make_inputs(G, n, L, seed=seed, n_with_n=nn, pool_div=int(rng.choice([8, 64])), tandem_every=int(rng.choice([0, 2, 64])),
                                 paired=bool(rng.random() < 0.3))
         shards = int(rng.integers(2, 5)) if rng.random() < 0.3 else 0
-        variant = str(rng.choice(["", "", "own", "rocprim"]))
+        variant = str(rng.choice(["", "", "own"]))
+        icfg = str(rng.choice(["", "", "1", "2", "3"]))     # round 5: XCD-aware tile order (1), partitions of 8192 buckets (2)
         finish = "general" if rng.random() < 0.25 else ""
         early = "0" if rng.random() < 0.2 else ""        # the match kernel probing every seed of every read
         stage = "0" if rng.random() < 0.2 else ""        # ... and without staged refills
@@ -44,9 +45,8 @@ def main():
         screen = str(rng.choice(["", "", "0", "1"]))       # "" = the dual kernel where it applies       # ... and the two passes in the reference's order (no exact-match screen)
         pairk = str(rng.choice(["", "", "0", "1", "3", "4"]))       # round 4: the pair table by group size (0 = a table per strand)
         inline = "0" if rng.random() < 0.3 else ""
-        from_end = "0" if rng.random() < 0.3 else ""
-        for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_FINISH", finish), ("PGRC_EARLY_STOP", early), ("PGRC_MATCH_STAGE", stage), ("PGRC_SCREEN", screen), ("PGRC_DUAL", dual),
-                         ("PGRC_HEAD_PAIR", pairk), ("PGRC_NREAD_INLINE", inline), ("PGRC_MATCH_FROM_END", from_end)):
+        for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_CFG", icfg), ("PGRC_INDEX_FINISH", finish), ("PGRC_EARLY_STOP", early), ("PGRC_MATCH_STAGE", stage), ("PGRC_SCREEN", screen), ("PGRC_DUAL", dual),
+                         ("PGRC_HEAD_PAIR", pairk), ("PGRC_NREAD_INLINE", inline)):
             if val:
                 os.environ[key] = val
             else:
@@ -81,7 +81,7 @@ def main():
             cases += 1
             print(f"{cases} ok ({time.time() - t0:.0f} s) {what}", flush=True)
             continue
-        what = dict(L=L, seed_len=seed_len, kmax=kmax, kmin=kmin, G=G, n=n, nn=nn, seed=seed, shards=shards, variant=variant, finish=finish, early=early, stage=stage, screen=screen, dual=dual, pairk=pairk, inline=inline, from_end=from_end)
+        what = dict(L=L, seed_len=seed_len, kmax=kmax, kmin=kmin, G=G, n=n, nn=nn, seed=seed, shards=shards, variant=variant, finish=finish, early=early, stage=stage, screen=screen, dual=dual, pairk=pairk, inline=inline, icfg=icfg)
         o = orc.oracle_match("c", pg, reads, seed_len, kmax, kmin, True, 16)
         g = gpu_match("c", pg, reads, seed_len, kmax, kmin, True, devices=[0] * shards if shards else None)
         for k in ("pos", "rc", "mism", "hist"):

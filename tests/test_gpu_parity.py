@@ -65,16 +65,19 @@ def test_index_bucket_cap_on_low_complexity_text():
     assert np.array_equal(c, cumm) and np.array_equal(p, positions)
 
 
-@pytest.mark.parametrize("variant", ["sweep", "sweep+general", "hybrid", "own", "rocprim", "hybrid+general", "own+general"])
+@pytest.mark.parametrize("variant", ["sweep", "sweep+general", "sweep/1", "sweep/2", "sweep/3", "sweep/2+general", "own", "own+general"])
 def test_index_build_variants(monkeypatch, variant):
-    """The four ways the records get grouped by bucket (copmem.hip: the one-sweep scatter passes of idxsweep.hip, the
-    default; library sort of the top bits + in-LDS finish; round 2's scatter passes + the same finish; round 1's full
-    library sort) and both finish kernels give the
-    serial reference index -- on a uniform text with realistic partition sizes, and on repeats / low-complexity tracts
-    whose buckets overflow the 13-entry cap and whose partitions overflow the fast kernel."""
+    """The ways the records get grouped by bucket (copmem.hip: the scatter passes of idxsweep.hip that hash the text
+    themselves, the default -- with partitions of 4096 buckets and, PGRC_INDEX_CFG bit 2, of 8192; bit 1: XCD-aware tile
+    order --; the stable scatter passes of idxsort.hip) and both finish kernels give the serial reference index -- on a
+    uniform text with realistic partition sizes, and on repeats / low-complexity tracts whose buckets overflow the 13-entry
+    cap and whose partitions overflow the fast kernel."""
     from pgrc_amd import MatchContext
     sort, _, fin = variant.partition("+")
+    sort, _, cfg = sort.partition("/")
     monkeypatch.setenv("PGRC_INDEX_SORT", sort)
+    if cfg:
+        monkeypatch.setenv("PGRC_INDEX_CFG", cfg)
     if fin:
         monkeypatch.setenv("PGRC_INDEX_FINISH", fin)
     rng = np.random.default_rng(11)
@@ -290,20 +293,6 @@ def test_dual_kernel_takes_reads_with_few_ns(monkeypatch, L, kmax, inline):
         assert_same_results(g, r, "vs real reference")
 
 
-@pytest.mark.parametrize("small", ["0", "3"])
-def test_dual_kernel_speculative_first_attempt(monkeypatch, small):
-    """PGRC_SPEC_LIMIT (off by default: measured, no gain): every read first runs its query with both limits cut to the small
-    value and only starts again with the real limit (k <= 50: PgRC's -M 3) if that finds nothing.  Same results."""
-    monkeypatch.setenv("PGRC_DUAL", "1")
-    monkeypatch.setenv("PGRC_SPEC_LIMIT", small)
-    for L, n_with_n in ((150, 200), (100, 0)):
-        pg, reads = make_inputs(300_000, 5000, L, seed=70 + L, n_with_n=n_with_n, pool_div=32)
-        o = orc.oracle_match("c", pg, reads, 38, L // 3, 0)
-        g = gpu_match("c", pg, reads, 38, L // 3, 0)
-        assert_same_results(g, o, f"first attempt at {small}, L={L}")
-        assert g["ctx"].counters()["screened"] == 2
-
-
 def test_reference_packed_reads_entry_point():
     pg, reads = make_inputs(150000, 3000, 150, seed=8)
     o = orc.oracle_match("c", pg, reads, 38, 3, 0)
@@ -441,6 +430,7 @@ def test_two_index_schedules_fall_back_when_the_second_index_does_not_fit(monkey
     for run in range(2):
         if run == 1:
             monkeypatch.delenv("PGRC_TEST_NO_SECOND_INDEX")      # the context remembers
+            ctx.reload_options()                                  # (the environment is only read when asked: the knob is really gone)
         ctx.init_results()
         ctx.run(True)
         pos, rc, mism, hist, matched = ctx.get_results()

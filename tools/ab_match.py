@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""In-process A/B of match-kernel tuning knobs (env vars read at every launch) on one device, interleaved rounds
+"""In-process A/B of run-time options (PGRC_* variables, re-read by the context before every run: MatchContext.reload_options) on one device, interleaved rounds
 (cdna_hip_programming.md rule 24: never rank builds across processes/devices).
 usage: tools/ab_match.py [--workload C3] [--rounds 4] VAR=val,VAR=val  VAR=val ...   (each arg = one variant)"""
 import argparse, json, os, sys, statistics
@@ -40,6 +40,7 @@ def main():
         for i, v in enumerate(variants):
             for k in keys: os.environ.pop(k, None)
             os.environ.update(v)
+            ctx.reload_options()
             ctx.init_results(); ctx.run(True)
             c = ctx.counters()
             _, _, _, hist, matched = ctx.get_results(arrays=False)

@@ -1,4 +1,5 @@
-// ubench.hip -- measurement only (tools/ubench_partjoin.py): can PARTITIONED probing beat random probing of the bucket heads?
+// partjoin.hip -- measurement only (tools/ubench_partjoin.py; built by `make -C pgrc_amd/csrc partjoin` into
+// tools/ubench/libpgrc_partjoin.so = the product objects + this file; NOT part of libpgrc_match.so): can PARTITIONED probing beat random probing of the bucket heads?
 //
 // VERDICT r03 item 7.  The match kernels gather one bucket head per probed seed at the chip's random-request rate.  The
 // alternative: write the probes out as records (bucket, probe id), partition them by the top 16 bucket bits with the
