@@ -63,7 +63,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("PGRC_BENCH_WORKLOAD", "C3"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline's main leg (0 = all of the box's hardware threads: BASELINE.md section 3, `-t $(nproc)`)")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the boundary leg (host buffers -> host results through the C ABI, PCIe included; never `value`)")
     ap.add_argument("--no-cpu-t1", action="store_true", help="skip the -t 1 leg of the CPU baseline (two more serial index builds)")
     ap.add_argument("--cpu-sample-reads", type=int, default=3_000_000)
     ap.add_argument("--parity-sample-reads", type=int, default=100_000,
@@ -152,12 +153,17 @@ def main():
         del d_pg
     elif d_pg is not None:
         ctx.set_pg_packed_device(d_pg.data_ptr(), G)
+        ctx._pg_ptr, ctx._pg_keep = d_pg.data_ptr(), d_pg
+
+    ag_ms = []                        # per step: the all-gather (this rank's clock, the stream drained on both sides)
 
     def step():
         if world > 1:
             # the ONE data-path collective: all-gather of the packed text (RCCL over xGMI; pgrc_amd/dist.py)
+            ta = time.perf_counter()
             d_full = pdist.all_gather_packed_pg(d_slice, world)
             torch.cuda.current_stream().synchronize()
+            ag_ms.append((time.perf_counter() - ta) * 1e3)
             ctx.set_pg_packed_device(d_full.data_ptr(), G)
         ctx.init_results()
         ctx.run(True)
@@ -170,6 +176,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    del ag_ms[:]
     step_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -186,6 +193,16 @@ def main():
     _, _, _, hist, matched = ctx.get_results(arrays=False)
     ctr = ctx.counters()
     cp = copmem_params(seed_len, G)
+    # N > 1: what every rank spent where (the driver's SCALE record is one number per N: this makes it readable) -- the last
+    # step's device phases, the all-gather per step (mean), the rank's own clock over its K steps
+    per_rank = None
+    if world > 1:
+        mine = {"rank": rank, "reads": n_per, "ms_per_step": sum(step_ms) / max(len(step_ms), 1), "allgather_ms": sum(ag_ms) / max(len(ag_ms), 1),
+                "index_ms": ctr["ms_index"][0] + ctr["ms_index"][1], "match_ms": ctr["ms_screen"] + ctr["ms_match"][0] + ctr["ms_match"][1],
+                "other_ms": ctr["ms_other"], "total_device_ms": ctr["ms_total"], "matched": int(matched)}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
 
     if rank == 0:
         total_reads = n_total * args.steps
@@ -232,10 +249,10 @@ def main():
         # this process, so the value comes from the committed separate `rocprofv3 --pmc` passes of this very command
         # (tools/pmc_groups.sh + tools/pmc_traffic.py -> profiles/); null for workloads that were not profiled.
         traffic, traffic_src, index_traffic = None, None, None
-        tp = os.path.join(ROOT, "profiles", f"r04_{args.workload.lower()}_traffic.json")
-        for older in (f"r03_{args.workload.lower()}_traffic.json", f"r02_{args.workload.lower()}_traffic.json", f"r01_final_{args.workload.lower()}_traffic.json"):
-            if not os.path.exists(tp):
-                tp = os.path.join(ROOT, "profiles", older)
+        for rnd in ("r05", "r04", "r03", "r02", "r01_final"):
+            tp = os.path.join(ROOT, "profiles", f"{rnd}_{args.workload.lower()}_traffic.json")
+            if os.path.exists(tp):
+                break
         if world == 1 and os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
@@ -243,9 +260,15 @@ def main():
                 # "two passes": fwd, rc; "screened": screen, fwd, rc; "dual": dual kernel, fwd, rc (the two redo passes)
                 if tj.get("schedule", "two passes") != schedule:
                     raise KeyError("profile taken under another schedule")
-                traffic = tj["dispatches"][0 if schedule == "dual" else dom + (1 if schedule == "screened" else 0)]["hbm_bytes"]
+                dsp = tj["dispatches"][0 if schedule == "dual" else dom + (1 if schedule == "screened" else 0)]
+                # HBM bytes: every read request of the L2 is a 128-BYTE line that FETCH_SIZE tallies at 64 (calibrated in round 5
+                # on random gathers: profiles/r05_ubench_gather_pmc.txt) -- profiles of earlier rounds stored the raw FETCH_SIZE
+                traffic = dsp["hbm_bytes"] if "unit_note" in tj else 2.0 * dsp["fetch_bytes"] + dsp["write_bytes"]
                 traffic_src = os.path.relpath(tp, ROOT)
-                index_traffic = tj.get("index_per_strand", {}).get("hbm_bytes")
+                ips = tj.get("index_per_strand", {})
+                index_traffic = ips.get("hbm_bytes")
+                if index_traffic and "unit_note" not in tj:
+                    index_traffic = None                      # (an older round's build: not this one's bytes)
             except Exception:
                 traffic = None
         out = {
@@ -278,6 +301,8 @@ def main():
                                        traffic_note="HBM bytes of both strands' builds from the same committed PMC passes as `traffic`"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_unit": "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE: a TCC_EA0_RDREQ is a 128-byte line on gfx950, for random 16-byte gathers as for streams (profiles/r05_ubench_gather_pmc.txt)",
+                         "traffic_GBps": (traffic / (ms * 1e-3) / 1e9 if traffic and ms > 0 else None),
                          "kernel": kname, "schedule": schedule,
                          "kernel_ms": ms, "algorithmic_bytes": alg_bytes,
                          # every launch of the match kernel in a step (the screened schedule has three: screen, forward
@@ -301,6 +326,8 @@ def main():
                           "index_note": ("both index builds run at once on two streams: index_fwd is the pair, index_rc ~ 0"
                                          if ctr["screened"] and ctr["ms_index"][1] < 0.1 * ctr["ms_index"][0] else None)},
             "dist_backend": args.dist_backend if world > 1 else None,
+            "allgather_ms": (sum(ag_ms) / max(len(ag_ms), 1) if world > 1 else None),       # rank 0's mean per step (inside the timed region)
+            "ranks": per_rank,
             "counters": {k: ctr[k] for k in ("searched", "candidates", "probes", "entry_fetches", "verifies", "index_entries", "dual", "redo_reads", "dual_seed_probes")},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -309,50 +336,201 @@ def main():
             except Exception as e:  # the GPU measurement must not be lost to a host-side problem
                 out["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(e)}
 
-        if world == 1 and args.parity_sample_reads > 0:
+        if args.parity_sample_reads > 0:          # (at N > 1: rank 0's shard -- its own reads, the gathered text it matched them against)
             try:
                 out["parity_sample"] = parity_sample(args, ctx, g, rs, n_per, L, G, seed_len, kmax)
+                if world > 1:
+                    out["parity_sample"]["shard"] = f"rank 0 of {world}: reads [{first_read}, {first_read + n_per}) of the set"
             except Exception as e:
                 out["parity_sample"] = {"diff": None, "error": repr(e)}
+        if world == 1 and not args.no_boundary and args.workload in ("C3", "C3-N"):
+            try:
+                out["boundary"] = boundary_leg(n_per, L, G, kmax)
+            except Exception as e:
+                out["boundary"] = {"reads_per_s": None, "error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def boundary_leg(n, L, G, kmax):
+    """What a PgRC process pays at the drop-in boundary (never `value`): the encoder's call site hands over a finished pseudogenome
+    as ASCII and the LQ + N sum set in the reference's two packings, all in HOST memory, and wants the three result vectors back
+    in host memory (pgrc-encoder.cpp:342-374 -> mapReadsIntoPg -> matchConstantLengthReads, matching/ReadsMatchers.cpp:162-172,
+    :421-451).  Timed from context creation to the arrays on the host, through pgrc_match_set_pg_ascii / _prepare_index /
+    _stream_begin / _append_reads_packed / _stream_end (the pipelined hand-over, pgrc_amd/csrc/stream.hip) and, for comparison,
+    with the steps in turn; PCIe included.  One throw-away job first (first allocations, code object load).  Outside the timed
+    loop, like cpu_baseline."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import boundary_c3
+    from pgrc_amd import MatchContext
+    t0 = time.perf_counter()
+    pg, lq_rows, n_rows, n_lq, n_n = boundary_c3.make_host_inputs(n, L, G, 0.02)
+    prep_s = time.perf_counter() - t0
+    sets = [(lq_rows, n_lq, 4), (n_rows, n_n, 5)]
+    res = (np.full(n, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64), np.zeros(n, dtype=np.uint8), np.full(n, 255, dtype=np.uint8))
+    for r_ in res:
+        r_ += 0
+    up_bytes = int(pg.nbytes + lq_rows.nbytes + n_rows.nbytes)
+    down_bytes = n * 10
+    # the link itself: pinned 1 GiB copies each way (what tools/ubench/pcie.hip measures)
+    pin = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
+    dev = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    link = {}
+    for name, (src, dst) in (("h2d", (pin, dev)), ("d2h", (dev, pin))):
+        dst.copy_(src, non_blocking=True); torch.cuda.synchronize()
+        t = time.perf_counter(); dst.copy_(src, non_blocking=True); torch.cuda.synchronize()
+        link[name] = (1 << 30) / (time.perf_counter() - t) / 1e9
+    del pin, dev
+    warm = MatchContext(L, 38, kmax, 0, "c"); warm.set_pg_ascii(pg); warm.set_reads_packed_sets(sets); warm.init_results(); warm.run(True)
+    warm.get_results(out=res)
+    ref = tuple(a.copy() for a in res)
+    del warm
+    legs = {}
+    for leg in ("pipelined", "in_turn"):
+        best = None
+        for rep_ in range(2):
+            t = time.perf_counter()
+            ctx = MatchContext(L, 38, kmax, 0, "c"); ctx.set_pg_ascii(pg)
+            if leg == "pipelined":
+                ctx.prepare_index(True)
+                pos, rc, mism, hist, matched = ctx.match_streamed(sets, out=res)
+            else:
+                ctx.set_reads_packed_sets(sets); ctx.init_results(); ctx.run(True)
+                pos, rc, mism, hist, matched = ctx.get_results(out=res)
+            dt = time.perf_counter() - t
+            same = bool(np.array_equal(pos, ref[0]) and np.array_equal(rc, ref[1]) and np.array_equal(mism, ref[2]))
+            del ctx
+            if best is None or dt < best[0]:
+                best = (dt, same, int(matched))
+        legs[leg] = {"s": best[0], "reads_per_s": n / best[0], "same_results": best[1]}
+    pl = legs["pipelined"]
+    link_bound_s = up_bytes / (link["h2d"] * 1e9) + down_bytes / (link["d2h"] * 1e9)
+    return {"what": "C3-N through the C ABI from HOST buffers (ASCII text, the reference's packed LQ + N rows) to the three result vectors on the host; PCIe included; best of two jobs after a throw-away one",
+            "reads_per_s": pl["reads_per_s"], "s": pl["s"], "same_results_as_in_turn": pl["same_results"] and legs["in_turn"]["same_results"],
+            "in_turn": legs["in_turn"], "up_bytes": up_bytes, "down_bytes": down_bytes,
+            "up_GBps": up_bytes / pl["s"] / 1e9, "down_GBps": down_bytes / pl["s"] / 1e9,
+            "link_GBps": link, "link_bound_s": link_bound_s, "link_bound_reads_per_s": n / link_bound_s,
+            "frac_of_link_bound": link_bound_s / pl["s"], "prep_s": prep_s}
+
+
 def seed_mode_line(args, ctx, ctr, value, dt, step_sorted, world, n_per, n_total, L, G, seed_len, kmax, mode, matched):
-    """The bench line of the workloads in modes d / i / e (rows a5-a7, seedidx.hip).  Algorithmic bytes counted SURVEY-8d style: per
-    window start and strand one 8-byte table key; per (window, part) pair with equal keys the entry (4 B), the read's and the
-    window's L symbols at 2 bits and the read's 8-byte key; per read its packed words and its three result fields.  What the path runs
-    into is the same as in mode c: random line requests (one per window probe, about three per hit), not bytes."""
+    """The bench line of the workloads in modes d / i / e (rows a5-a7, seedidx.hip).  Algorithmic bytes counted SURVEY-8d style (ONE
+    formula, the one tools/modes_c3.py prints): per window start and strand one 8-byte table key; per (window, part) pair with equal
+    keys -- a hit -- the entry (4 B), the read's and the window's L symbols at 2 bits and the read's 8-byte key; per read its packed
+    words and its three result fields.  `hits` are those of the LAST run (pgrc_match_run clears the counters when it starts).  What
+    the path runs into is the same as in mode c: random line requests (one per window probe, about three per hit), not bytes."""
     import zlib
+    import numpy as np
     P = 1 if mode == "e" else L // seed_len
     nw = (L + 15) // 16
     nwin = G - (L if mode == "e" else seed_len * (P if mode == "i" else 1)) + 1
-    runs = args.steps + args.warmup
-    hits = (ctr["candidates"][0] + ctr["candidates"][1]) // max(runs, 1)                 # (the counters add up over the runs)
+    hits = ctr["candidates"][0] + ctr["candidates"][1]
     alg = 2 * nwin * 8 + hits * (4 + 2 * ((L + 3) // 4) + 8) + n_per * (4 * nw + 10)
     ms = dt / args.steps * 1e3
     pos, rc, mism, _, _ = ctx.get_results()
     digest = "%08x-%08x-%08x" % (zlib.crc32(pos.data), zlib.crc32(rc.data), zlib.crc32(mism.data))
     req = 2 * nwin + 3 * hits + n_per * P
-    return {"metric": "reads matched/sec (150 bp) at 1/2/4/8 MI355X; achieved HBM GB/s", "value": value, "unit": "reads/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_per_step_min_median_max": [step_sorted[0], step_sorted[len(step_sorted) // 2], step_sorted[-1]],
-            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {n_per} x {L} bp SE reads per GPU vs Pg of {G} bp, mode {mode} (parts of {seed_len} symbols, k<={kmax}), both strands",
-                       "symbols": "2-bit packed, 16 per u32 word (integer xor/popcount work, no floating point)",
-                       "reads_per_gpu": n_per, "read_len": L, "pg_len": G, "seed_len": seed_len, "max_mismatches": kmax, "matched_fraction": matched / n_per,
-                       "parallelism": f"reads sharded x{world}, Pg replicated"},
-            "roofline": {"bound": "hbm", "binding_limit": "random line requests: one per window start of the forward text (both strands in one scan), about three per hit",
-                         "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_seed_probe + k_seed_expand + k_seed_heavy (seedidx.hip)", "kernel_ms": ctr["ms_total"], "algorithmic_bytes": alg,
-                         "windows": nwin, "hits_per_step": hits, "random_requests_estimate": req, "gather_rate_G_per_s": req / (ms * 1e-3) / 1e9,
-                         "gather_ceiling_G_per_s": GATHER_CEILING_GPS},
-            "counters": {"searched": ctr["searched"], "candidates": ctr["candidates"]},
-            "results_digest": digest,
-            "cpu_baseline": {"value": None, "unit": "reads/s", "cores": 0, "kind": "reference",
-                             "sample": "not measured here: the reference's matchers of these modes scan the text serially (tests/test_gpu_fullsize.py and tools/modes_vs_oracle.py "
-                                       "compare results and candidate counts with the oracle / the reference at sizes they finish)"}}
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", f"r05_{args.workload.lower()}_traffic.json")
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get("hbm_bytes_per_step")
+        except Exception:
+            traffic = None
+    out = {"metric": "reads matched/sec (150 bp) at 1/2/4/8 MI355X; achieved HBM GB/s", "value": value, "unit": "reads/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_per_step_min_median_max": [step_sorted[0], step_sorted[len(step_sorted) // 2], step_sorted[-1]],
+           "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+           "config": {"workload": f"{args.workload}: {n_per} x {L} bp SE reads per GPU vs Pg of {G} bp, mode {mode} (parts of {seed_len} symbols, k<={kmax}), both strands",
+                      "symbols": "2-bit packed, 16 per u32 word (integer xor/popcount work, no floating point)",
+                      "reads_per_gpu": n_per, "read_len": L, "pg_len": G, "seed_len": seed_len, "max_mismatches": kmax, "matched_fraction": matched / n_per,
+                      "parallelism": f"reads sharded x{world}, Pg replicated"},
+           "roofline": {"bound": "hbm", "binding_limit": "random line requests: one per window start of the forward text (both strands in one scan), about three per hit",
+                        "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                        "traffic_source": (os.path.relpath(tp, ROOT) if traffic else None),
+                        "kernel": "k_seed_probe + k_seed_expand + k_seed_heavy (seedidx.hip)", "kernel_ms": ctr["ms_total"], "kernel_ms_note": "device time of the whole run (HIP events), host waits between batches included",
+                        "algorithmic_bytes": alg, "algorithmic_bytes_formula": "2 strands x windows x 8 + hits x (4 + 2 x ceil(L/4) + 8) + reads x (4 x words + 10)",
+                        "windows": nwin, "hits_per_step": hits,
+                        "random_requests_ESTIMATE": req, "gather_rate_G_per_s_ESTIMATE": req / (ms * 1e-3) / 1e9, "estimate_note": "2 per window start + 3 per hit + 1 per (read, part): a model, not a counter",
+                        "gather_ceiling_G_per_s": GATHER_CEILING_GPS},
+           "counters": {"searched": ctr["searched"], "candidates": ctr["candidates"]},
+           "results_digest": digest}
+    if world == 1 and args.parity_sample_reads > 0:
+        try:
+            out["parity_sample"] = seed_parity_sample(args, ctx, n_per, L, G, seed_len, kmax, mode)
+        except Exception as e:
+            out["parity_sample"] = {"diff": None, "error": repr(e)}
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = seed_cpu_baseline(n_per, L, G, seed_len, kmax, mode)
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 0, "kind": "reference", "sample": "failed: " + repr(e)}
+    return out
+
+
+def seed_parity_sample(args, ctx, n_per, L, G, seed_len, kmax, mode):
+    """Bit-parity inside the bench line of modes d / i / e: the first reads of the workload matched ALONE against the whole text on the
+    GPU (a second context over the same device buffers: in these modes the candidates depend on which reads are indexed together) and by
+    the oracle's serial scan of the whole text (tests/oracle.py: the reference's DefaultReadsApproxMatcher /
+    InterleavedReadsApproxMatcher / DefaultReadsExactMatcher::executeMatching, matching/ReadsMatchers.cpp:198-230, :297-409, restated;
+    about 80 s on one core at the C3 text) -- results AND the number of hits per strand."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as orc
+    from pgrc_amd import MatchContext
+    ns = min(args.parity_sample_reads, 20_000, n_per)
+    nw, stride = (L + 15) // 16, (n_per + 63) & ~63
+    idx = np.arange(ns, dtype=np.int64)
+    reads = reads_from_hbm(ctx._keep_reads, idx, nw, stride, L)
+    pg = host_text(ctx, G)
+    cx = MatchContext(L, seed_len, kmax, 0, mode)
+    cx.set_pg_packed_device(ctx._pg_ptr, G)
+    cx.set_reads_device(ctx._keep_reads.data_ptr(), ns, stride, keep=ctx._keep_reads)
+    cx.init_results()
+    cx.run(True)
+    pos, rc, mism, _, _ = cx.get_results()
+    cand = cx.counters()["candidates"]
+    del cx
+    t = time.perf_counter()
+    o = orc.oracle_match(mode, pg, reads, seed_len, kmax, 0, True, 1)
+    secs = time.perf_counter() - t
+    d_pos, d_rc, d_mism = int((pos != o["pos"]).sum()), int((rc != o["rc"]).sum()), int((mism != o["mism"]).sum())
+    d_cand = int(int(cand[0]) != int(o["candidates"][0])) + int(int(cand[1]) != int(o["candidates"][1]))
+    return {"reads": ns, "drawn": f"the first {ns} reads of the workload, matched alone against the whole {G}-bp text", "checker": "oracle port (serial scan of the whole text)",
+            "diff": d_pos + d_rc + d_mism + d_cand, "diff_pos": d_pos, "diff_rc": d_rc, "diff_mism": d_mism,
+            "hits_gpu": [int(v) for v in cand], "hits_checker": [int(v) for v in o["candidates"]],
+            "matched_in_sample": int((o["mism"] != 255).sum()), "checker_s": secs}
+
+
+def seed_cpu_baseline(n_per, L, G, seed_len, kmax, mode, scale=50):
+    """The reference's matcher of this mode on the host, one thread (the code is serial: ConstantLengthPatternsOnTextHashMatcher +
+    ReadsMatchers.cpp:198-230, :297-409).  Its scan of the whole text would take minutes, so the leg is a SCALED-DOWN INSTANCE of the
+    same workload at the same read density: a text of G / 50 symbols from the same generator and n / 50 reads drawn from it.  The rate
+    is that instance's, not an extrapolation; the real instance's hash table is 50 times larger (more cache misses per probe), so the
+    reference is slower than this on the full job."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as orc
+    from pgrc_amd import synth
+    Gs, ns = G // scale, n_per // scale
+    g = synth.pg_params(Gs, seed=12345)
+    pg = synth.pg_host(g)
+    rs = synth.reads_params(ns, L, seed=12345)
+    reads = synth.reads_host(g, pg, rs, 0, ns)
+    kind = "reference" if orc.have_ref() else "port"
+    t = time.perf_counter()
+    if kind == "reference":
+        r = orc.ref_match(mode, pg, reads, seed_len, kmax, 0, True, 0, 1, 1)
+    else:
+        r = orc.oracle_match(mode, pg, reads, seed_len, kmax, 0, True, 1)
+    secs = time.perf_counter() - t
+    return {"value": ns / secs, "unit": "reads/s", "cores": 1, "nproc": os.cpu_count(), "kind": kind, "extrapolated": False,
+            "sample": f"a 1/{scale} instance of the workload at the same read density: {ns} x {L} bp reads against a {Gs}-bp text of the same generator, both strands, "
+                      f"one thread (the reference's matcher of mode {mode} is serial): {secs:.1f} s; the full instance's table is {scale} x larger, so its rate is lower",
+            "matched_in_sample": int((r["mism"] != 255).sum())}
 
 
 def index_roofline(ctr, cp, G, n_strands):
@@ -382,12 +560,15 @@ def cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax):
     """The CPU path timed on this box's host cores, on a bounded sample: the WHOLE pseudogenome (so index size and
     cache behaviour are the real ones) and the first `cpu_sample_reads` reads of the same read set.  Whole-job
     rate for the full read set is extrapolated from two runs (fixed cost a = 2 index builds + RC sweeps, slope b
-    per read):  value = N / (a + b*N).  kind "reference" = the real PgRC code (oracle/_ref); "port" = oracle/."""
+    per read):  value = N / (a + b*N).  kind "reference" = the real PgRC code (oracle/_ref); "port" = oracle/.
+    Three legs, as BASELINE.md section 3 asks: `-t $(nproc)` (the main value: BASELINE.json configs[1] says "CPU -t all"),
+    `-t 16` (what rounds 1-4 reported) and `-t 1` (serial index build, one thread in the per-read loop: the parity target)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle as orc
     from pgrc_amd import synth
-    threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+    nproc = os.cpu_count() or 1
+    threads = nproc if args.cpu_threads <= 0 else max(1, min(args.cpu_threads, nproc))
     t_prep = time.perf_counter()
     pg = host_text(ctx, G)
     ns = min(args.cpu_sample_reads, n_per)
@@ -395,26 +576,26 @@ def cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax):
         ns = min(ns, int(ctx._host_rows[1]))       # (the sample stays inside the LQ set: the N set is the end of the sum set)
     reads = synth.reads_host(g, pg, rs, 0, ns)
     prep_s = time.perf_counter() - t_prep
-    n_small = max(1000, ns // 100)
-    if orc.have_ref():
-        kind = "reference"
+    kind = "reference" if orc.have_ref() else "port"
 
-        def run(n):
-            t = time.perf_counter()
-            r = orc.ref_match("c", pg, reads[:n], seed_len, kmax, 0, True, 0, threads, threads)
-            return time.perf_counter() - t, r
-    else:
-        kind = "port"
+    def run(n, thr):
+        t = time.perf_counter()
+        if kind == "reference":
+            r = orc.ref_match("c", pg, reads[:n], seed_len, kmax, 0, True, 0, thr, thr)     # (index threads = loop threads = -t)
+        else:
+            r = orc.oracle_match("c", pg, reads[:n], seed_len, kmax, 0, True, thr)
+        return time.perf_counter() - t, r
 
-        def run(n):
-            t = time.perf_counter()
-            r = orc.oracle_match("c", pg, reads[:n], seed_len, kmax, 0, True, threads)
-            return time.perf_counter() - t, r
-    t_small, _ = run(n_small)
-    t_big, r = run(ns)
-    b = max((t_big - t_small) / (ns - n_small), 1e-12)
-    a = max(t_small - b * n_small, 0.0)
-    value = n_per / (a + b * n_per)
+    def leg(thr, n_small, n_big):
+        """two runs -> fixed seconds a, seconds per read b, the rate extrapolated to the workload's read count"""
+        t_small, _ = run(n_small, thr)
+        t_big, r = run(n_big, thr)
+        b = max((t_big - t_small) / (n_big - n_small), 1e-12)
+        a = max(t_small - b * n_small, 0.0)
+        return {"value": n_per / (a + b * n_per), "unit": "reads/s", "cores": thr, "extrapolated": True, "fixed_s": a, "per_read_us": b * 1e6,
+                "sample": f"n={n_small}: {t_small:.2f}s, n={n_big}: {t_big:.2f}s"}, r
+
+    main, r = leg(threads, max(1000, ns // 100), ns)
     # The sample is also compared with the GPU result on the same reads.  NOTE: timed at `threads` > 1 the
     # reference builds its copMEM index with its racy multithreaded code (CopMEMMatcher.cpp:238-254, :284-305;
     # which of a crowded bucket's entries survive the 13-entry cap varies from run to run), so a small number
@@ -422,17 +603,15 @@ def cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax):
     # (tests/fullscale_parity.py, tests/).
     pos, rc, mism, _, _ = ctx.get_results()
     diff = int((mism[:ns] != r["mism"]).sum())
-    # the same path at -t 1 (BASELINE.md section 3 asks for both): serial index build, one thread in the per-read loop, on a
-    # smaller sample of the same reads (two runs again: the fixed cost is two serial index builds over the whole text)
+    t16 = None
+    if threads != min(16, nproc) and nproc >= 16:
+        t16, _ = leg(16, max(1000, ns // 100), ns)
+    # the same path at -t 1: serial index build, one thread in the per-read loop, on a smaller sample of the same reads
+    # (two runs again: the fixed cost is two serial index builds over the whole text)
     t1 = None
-    if not args.no_cpu_t1 and kind == "reference":
-        n1s, n1b = 1000, min(50_000, ns)
-        run1 = lambda n: (lambda t0: (orc.ref_match("c", pg, reads[:n], seed_len, kmax, 0, True, 0, 1, 1), time.perf_counter() - t0)[1])(time.perf_counter())
-        ts, tb = run1(n1s), run1(n1b)
-        b1 = max((tb - ts) / (n1b - n1s), 1e-12)
-        a1 = max(ts - b1 * n1s, 0.0)
-        t1 = {"value": n_per / (a1 + b1 * n_per), "unit": "reads/s", "cores": 1, "extrapolated": True, "fixed_s": a1, "per_read_us": b1 * 1e6,
-              "sample": f"n={n1s}: {ts:.2f}s, n={n1b}: {tb:.2f}s (PgHelpers::numberOfThreads = 1, one OpenMP thread)"}
+    if not args.no_cpu_t1 and kind == "reference" and threads != 1:
+        t1, _ = leg(1, 1000, min(50_000, ns))
+        t1["sample"] += " (PgHelpers::numberOfThreads = 1, one OpenMP thread)"
     cpu_model = None
     try:
         for ln in open("/proc/cpuinfo"):
@@ -441,11 +620,11 @@ def cpu_baseline(args, ctx, g, rs, n_per, L, G, seed_len, kmax):
                 break
     except OSError:
         pass
-    return {"value": value, "unit": "reads/s", "cores": threads, "nproc": os.cpu_count(), "cpu_model": cpu_model, "t1": t1, "kind": kind, "extrapolated": True,
+    return {"value": main["value"], "unit": "reads/s", "cores": threads, "nproc": nproc, "cpu_model": cpu_model, "t16": t16, "t1": t1, "kind": kind, "extrapolated": True,
             "sample": f"EXTRAPOLATED from a bounded sample: whole {G}-bp Pg, first {ns} reads of the workload, both strands incl. index builds; two runs "
-                      f"(n={n_small}: {t_small:.2f}s, n={ns}: {t_big:.2f}s) => fixed {a:.2f}s + {b * 1e6:.3f}us/read, "
-                      f"extrapolated to {n_per} reads; sample-only rate {ns / t_big:.0f} reads/s",
-            "fixed_s": a, "per_read_us": b * 1e6, "prep_s": prep_s,
+                      f"({main['sample']}) => fixed {main['fixed_s']:.2f}s + {main['per_read_us']:.3f}us/read, "
+                      f"extrapolated to {n_per} reads",
+            "fixed_s": main["fixed_s"], "per_read_us": main["per_read_us"], "prep_s": prep_s,
             "sample_reads_with_other_mismatch_count_than_gpu": diff,
             "note": "reference timed as shipped at -t %d (racy multithreaded index build); bit-parity is pinned against "
                     "its serial index build elsewhere" % threads}

@@ -203,10 +203,9 @@ typedef struct {
  * original indexes, RC flags of SeparatedPseudoGenome::getReadsList(); it must carry no mismatches): in front of a new
  * entry go all old entries at SMALLER positions, an old entry at the same position follows it (:1004-1019). */
 typedef struct {
-    const uint32_t *order;        /* n_matched read indexes; NULL (round 4): the library makes the order on the device --
-                                   * ascending match position, reads matched at one position in ascending read index (a
-                                   * stable radix sort of (position, read) records; text below 2^32 symbols); n_matched is
-                                   * then ignored */
+    const uint32_t *order;        /* n_matched read indexes.  NULL is only accepted with n_matched == 0 (no matched read) or with
+                                   * order_on_device set: anything else is PGRC_E_PARAM (a forgotten order must not silently
+                                   * become another tie order) */
     uint64_t n_matched;
     const uint32_t *read_org_idx; /* original index of every READ (IndexesMapping::getReadOriginalIndex), NULL = identity */
     const uint8_t *list_off;      /* the old list: list_count offset deltas */
@@ -215,6 +214,9 @@ typedef struct {
     uint64_t list_count;
     int32_t rev_compl_pair_file;  /* mismatch lists in the original read's orientation iff rc != (orgIdx odd) (:553) */
     int32_t byte_per_read_length; /* PgHelpers::bytePerReadLengthMode */
+    int32_t order_on_device;      /* != 0: the library makes the order on the device -- ascending match position, reads matched at
+                                   * one position in ascending read index (a stable radix sort of (position, read) records; text
+                                   * below 2^32 symbols) -- and ignores order / n_matched */
 } pgrc_export_pg_order_args;
 int pgrc_match_export_pg_order(pgrc_match_ctx *ctx, const pgrc_export_pg_order_args *args, pgrc_export_streams *out);
 /* exportMatchesInOriginalOrder for a caller-made entry list (pgrc_match_export_original_order makes the list itself):
@@ -296,7 +298,7 @@ int pgrc_match_get_redo_flags(pgrc_match_ctx *ctx, uint8_t *flags);
  *     PGRC_NREAD_INLINE=0    every read with an N takes the byte-path kernel (default: the dual kernel takes those with <= 4 N)
  *     PGRC_MATCH_STAGE=0     the per-strand match kernel without staged refills
  *   index build:  PGRC_INDEX_SORT=sweep|own (front end), PGRC_INDEX_FINISH=general (the general finish kernel for every
- *                 partition), PGRC_INDEX_CFG=n (variant / block shape of the passes: A/B runs)
+ *                 partition), PGRC_INDEX_CFG=0 (the passes without the XCD-aware tile order: A/B runs)
  *   modes d/i/e:  PGRC_SEED_FILTER=0|1, PGRC_SEED_HEAVY=n, PGRC_SEED_READ_BATCH=n, PGRC_SEED_SEGMENT=n, PGRC_SEED_BUILD=n
  *   hand-over:    PGRC_UPLOAD_CHUNK_MB=n (staging chunk of append_reads_*), PGRC_STREAM_TIMING (milestones on stderr)
  *   tests:        PGRC_FORCE_POS64=1, PGRC_TEST_NO_SECOND_INDEX, PGRC_MEM_EVENT_CAP=n, PGRC_ALLGATHER=rccl|copy
@@ -307,6 +309,11 @@ int pgrc_match_reload_options(pgrc_match_ctx *ctx);
 /* enable per-kernel HIP-event timing + work counters for subsequent runs */
 int pgrc_match_set_profiling(pgrc_match_ctx *ctx, int enabled);
 int pgrc_match_get_counters(pgrc_match_ctx *ctx, pgrc_match_counters *out);
+/* the same for a caller that may have been built against another version of this header: pgrc_match_counters only ever grows at
+ * its END, and this writes exactly out_size bytes -- the first out_size bytes of the current struct, zeros beyond what the
+ * library knows -- so `pgrc_match_get_counters_sized(ctx, &c, sizeof c)` never writes past the caller's struct (pgrc_match_get_counters
+ * writes the library's sizeof) */
+int pgrc_match_get_counters_sized(pgrc_match_ctx *ctx, void *out, size_t out_size);
 
 /* ---- synthetic inputs (include/pgrc_synth.h) ---- */
 #include "pgrc_synth.h"

@@ -464,8 +464,9 @@ namespace PgTools {
         }
         ExtendedReadsListWithConstantAccessOption *rl = sPg->getReadsList();
         pgrc_export_pg_order_args a;
-        a.order = deviceSort ? nullptr : order.data();
-        a.n_matched = deviceSort ? matchedReadsCount : order.size();
+        a.order = deviceSort ? nullptr : order.data();          // (an empty vector's data() may be NULL: fine with n_matched == 0)
+        a.n_matched = deviceSort ? 0 : order.size();
+        a.order_on_device = deviceSort ? 1 : 0;
         a.read_org_idx = readOrg.data();
         a.list_off = rl->off.data();
         a.list_org_idx = rl->orgIdx.data();

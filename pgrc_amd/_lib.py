@@ -62,7 +62,7 @@ class ExportStreams(C.Structure):   # pgrc_export_streams
 class ExportPgOrderArgs(C.Structure):   # pgrc_export_pg_order_args
     _fields_ = [("order", C.c_void_p), ("n_matched", C.c_uint64), ("read_org_idx", C.c_void_p), ("list_off", C.c_void_p),
                 ("list_org_idx", C.c_void_p), ("list_rev_comp", C.c_void_p), ("list_count", C.c_uint64),
-                ("rev_compl_pair_file", C.c_int32), ("byte_per_read_length", C.c_int32)]
+                ("rev_compl_pair_file", C.c_int32), ("byte_per_read_length", C.c_int32), ("order_on_device", C.c_int32)]
 
 
 class ExportOriginalOrderArgs(C.Structure):   # pgrc_export_original_order_args
@@ -139,6 +139,7 @@ _PROTOS = [
     ("pgrc_match_reload_options", C.c_int, [_P]),
     ("pgrc_match_set_profiling", C.c_int, [_P, C.c_int]),
     ("pgrc_match_get_counters", C.c_int, [_P, C.POINTER(Counters)]),
+    ("pgrc_match_get_counters_sized", C.c_int, [_P, _P, C.c_size_t]),
     ("pgrc_synth_pg_host", None, [C.POINTER(SynthPg), _P]),
     ("pgrc_synth_reads_host", None, [C.POINTER(SynthPg), _P, C.POINTER(SynthReads), C.c_uint64, C.c_uint64, _P]),
     ("pgrc_synth_pg_device", C.c_int, [C.POINTER(SynthPg), _P, _P]),

@@ -68,7 +68,8 @@ int pgrc_buf_ensure(pgrc_match_ctx *c, DevBuf &b, size_t bytes) {
     return PGRC_OK;
 }
 
-void pgrc_buf_free(DevBuf &b) {
+// quiesced: the caller has waited for the device since the buffer was last used (pgrc_buf_free_all: one wait for a batch)
+static void buf_free(DevBuf &b, bool quiesced) {
     if (b.p) {
         int dev = -1;
         bool kept = false;
@@ -77,7 +78,7 @@ void pgrc_buf_free(DevBuf &b) {
             // used to give that guarantee by waiting for the device; so does this (large buffers are only given back on
             // destroy, on growth and on error paths -- never between the blocks of a streamed run, which keeps what it must free
             // until its end).
-            (void)hipDeviceSynchronize();
+            if (!quiesced) (void)hipDeviceSynchronize();
             std::lock_guard<std::mutex> g(g_pool_mu);
             if (g_pool_bytes + b.bytes <= pool_cap()) {
                 g_pool.push_back({b.p, b.bytes, dev});
@@ -89,6 +90,16 @@ void pgrc_buf_free(DevBuf &b) {
     }
     b.p = nullptr;
     b.bytes = 0;
+}
+
+void pgrc_buf_free(DevBuf &b) { buf_free(b, false); }
+
+// several buffers at once: ONE wait for the device (if any of them is large enough for the pool), not one per buffer
+void pgrc_buf_free_all(DevBuf *const *bufs, size_t count) {
+    bool any = false;
+    for (size_t k = 0; k < count; k++) any |= bufs[k]->p && bufs[k]->bytes >= POOL_MIN;
+    if (any) (void)hipDeviceSynchronize();
+    for (size_t k = 0; k < count; k++) buf_free(*bufs[k], true);
 }
 
 extern "C" uint64_t pgrc_match_trim_device_memory(void) {
@@ -274,7 +285,7 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
                       &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_head, &c->d_headpair, &c->d_skey[0], &c->d_skey[1], &c->d_sval[0], &c->d_sval[1], &c->d_sorttmp,
                       &c->alt_head, &c->alt_skey[0], &c->alt_skey[1], &c->alt_sval[0], &c->alt_sval[1], &c->alt_sorttmp, &c->d_scr_pos, &c->d_scr_flag,
                       &c->s_keys, &c->s_filter, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp, &c->s_nmask, &c->s_best, &c->s_rows};
-    for (DevBuf *b : bufs) pgrc_buf_free(*b);
+    pgrc_buf_free_all(bufs, sizeof bufs / sizeof bufs[0]);       // (the device is idle: waited for above)
     for (DevBuf &b : c->up_nchunks) pgrc_buf_free(b);
     if (c->have_events)
         for (auto &e : c->ev) (void)hipEventDestroy(e);
@@ -460,7 +471,8 @@ int pgrc_match_begin_reads(pgrc_match_ctx *c, uint64_t n) {
     int e = begin_reads(c, n, true);
     if (e) return e;
     if ((e = pgrc_buf_ensure(c, c->nread_flag, n))) return e;
-    if ((e = pgrc_buf_ensure(c, c->nread_npos, n * sizeof(uint32_t)))) return e;   // (only read where the flag says 3)
+    // (nread_npos, 4 bytes per read, only exists once a block that CAN hold an N arrives: ASCII rows or an ACGNT set -- an ACGT
+    //  set cannot, and at C3 the array is 400 MB that a memory-tight job would rather give its second index set)
     // (cleared on a stream of its own and waited for: the main stream may hold index builds started ahead of the run --
     //  pgrc_match_prepare_index --, which neither this nor the uploads that follow should queue behind)
     if (!c->up_stream[0]) {
@@ -529,6 +541,7 @@ static int append_rows(pgrc_match_ctx *c, const uint8_t *rows, uint64_t count, i
             rcode = pgrc_launch_unpack_reads_acgnt(c, (const uint8_t *)stage, first, cnt, L, (uint32_t *)c->reads_own.p, c->stride,
                                                    (uint8_t *)c->nread_flag.p, (uint32_t *)flag.p);
         // where the N's of the flagged reads are (flag 1 -> 3 for reads with at most 4 of them: the dual kernel's own)
+        if (rcode == PGRC_OK && symbols != 4) rcode = pgrc_buf_ensure(c, c->nread_npos, std::max<uint64_t>(c->n, 1) * sizeof(uint32_t));   // (first such block: allocated)
         if (rcode == PGRC_OK && symbols != 4)
             rcode = pgrc_launch_npos_rows(c, (const uint8_t *)stage, symbols, first, cnt, L, (uint8_t *)c->nread_flag.p, (uint32_t *)c->nread_npos.p);
         c->stream = main_stream;
@@ -1036,6 +1049,18 @@ int pgrc_match_get_counters(pgrc_match_ctx *c, pgrc_match_counters *out) {
     if (c->multi) return pgrc_multi_get_counters(c, out);
     *out = c->ctr;
     out->index_entries[0] = out->index_entries[1] = c->npos;
+    return PGRC_OK;
+}
+
+// the same for a caller built against an older (shorter) or newer (longer) pgrc_match_counters: the struct only ever grows at
+// its end, so the first min(size, sizeof) bytes are what that caller knows; what it has beyond is zeroed
+int pgrc_match_get_counters_sized(pgrc_match_ctx *c, void *out, size_t out_size) {
+    if (!c || !out) return PGRC_E_PARAM;
+    pgrc_match_counters full;
+    const int e = pgrc_match_get_counters(c, &full);
+    if (e) return e;
+    memset(out, 0, out_size);
+    memcpy(out, &full, std::min(out_size, sizeof full));
     return PGRC_OK;
 }
 

@@ -48,7 +48,7 @@ struct PgrcOptions {
     uint32_t head_pair = 4;         // PGRC_HEAD_PAIR   0: a head table per strand; 1..4: pair table with groups of 1, 2, 4, 8 buckets
     int index_front = 0;            // PGRC_INDEX_SORT  0 "sweep" (idxsweep.hip), 1 "own" (idxsort.hip's stable scatter passes)
     bool index_finish_general = false;   // PGRC_INDEX_FINISH=general: the general finish kernel for every partition
-    int index_cfg = -1;             // PGRC_INDEX_CFG   block shape / variant of the build's passes (A/B runs; -1 = default)
+    int index_cfg = -1;             // PGRC_INDEX_CFG=0  the passes of the index build without the XCD-aware tile order (A/B runs)
     bool match_stage = true;        // PGRC_MATCH_STAGE=0: refilling lanes load their own read (k_copmem_match_sm)
     bool nread_inline = true;       // PGRC_NREAD_INLINE=0: every read with an N takes the byte path
     bool force_pos64 = false;       // PGRC_FORCE_POS64=1: the 64-bit-position kernels on a small text (tests)
@@ -227,6 +227,7 @@ struct PgrcDeviceScope {
 
 int pgrc_buf_ensure(pgrc_match_ctx *c, DevBuf &b, size_t bytes);
 void pgrc_buf_free(DevBuf &b);
+void pgrc_buf_free_all(DevBuf *const *bufs, size_t count);   // one wait for the device for the whole batch
 
 // api.hip: (re)allocates and clears both strands' text buffers for a text of G symbols
 extern "C" int pgrc_pg_alloc(pgrc_match_ctx *c, uint64_t G);

@@ -402,7 +402,8 @@ namespace {
 struct Bufs {
     DevBuf order, rorg, loff, lorg, lrc, lpos, epos, eread, eorg, erc, emc, off, mbase, sym, roff, bs, flag;
     void release() {
-        for (DevBuf *b : {&order, &rorg, &loff, &lorg, &lrc, &lpos, &epos, &eread, &eorg, &erc, &emc, &off, &mbase, &sym, &roff, &bs, &flag}) pgrc_buf_free(*b);
+        DevBuf *all[] = {&order, &rorg, &loff, &lorg, &lrc, &lpos, &epos, &eread, &eorg, &erc, &emc, &off, &mbase, &sym, &roff, &bs, &flag};
+        pgrc_buf_free_all(all, sizeof all / sizeof all[0]);         // (one wait for the device, not one per pooled buffer)
     }
 };
 }
@@ -413,7 +414,7 @@ static int mismatch_streams_from_shards(pgrc_match_ctx *view, Bufs &b, uint64_t 
     const std::vector<PgrcShardView> sh = pgrc_multi_shards(f);
     const uint64_t n = view->n;
     DevBuf par, rev, cumAll, codesAll, offsAll;
-    auto done = [&](int e) { for (DevBuf *x : {&par, &rev, &cumAll, &codesAll, &offsAll}) pgrc_buf_free(*x); return e; };
+    auto done = [&](int e) { DevBuf *all[] = {&par, &rev, &cumAll, &codesAll, &offsAll}; pgrc_buf_free_all(all, 5); return e; };
     int e;
     if ((e = pgrc_buf_ensure(view, par, n ? n : 1)) || (e = pgrc_buf_ensure(view, rev, n ? n : 1)) || (e = pgrc_buf_ensure(view, cumAll, (n + 1) * sizeof(uint64_t))) ||
         (e = pgrc_buf_ensure(view, codesAll, total)) || (e = pgrc_buf_ensure(view, offsAll, total * sizeof(uint16_t))))
@@ -456,7 +457,8 @@ static int mismatch_streams_from_shards(pgrc_match_ctx *view, Bufs &b, uint64_t 
         }
         {
             PgrcDeviceScope cs(c->device);
-            for (DevBuf *x : {&d_rev, &d_cum, &d_codes, &d_offs}) pgrc_buf_free(*x);
+            DevBuf *all[] = {&d_rev, &d_cum, &d_codes, &d_offs};
+            pgrc_buf_free_all(all, 4);
         }
         if (se) return done(se);
         base += tot_s;
@@ -596,7 +598,7 @@ static int device_position_order(pgrc_match_ctx *c, Bufs &b, uint64_t *m_out) {
     const uint64_t n = c->n;
     if (c->G >= (1ull << 32)) { c->err = "export_pg_order: the device-made order needs a text below 2^32 symbols (pass order[])"; return PGRC_E_PARAM; }
     DevBuf flag, slot, ra, rb, scratch;
-    auto done = [&](int e) { for (DevBuf *x : {&flag, &slot, &ra, &rb, &scratch}) pgrc_buf_free(*x); return e; };
+    auto done = [&](int e) { DevBuf *all[] = {&flag, &slot, &ra, &rb, &scratch}; pgrc_buf_free_all(all, 5); return e; };
     int e;
     if ((e = pgrc_buf_ensure(c, flag, n)) || (e = pgrc_buf_ensure(c, slot, (n + 1) * sizeof(uint64_t)))) return done(e);
     if (n) hipLaunchKernelGGL(k_ord_flags, dim3(grid_for(n)), dim3(256), 0, c->stream, (const uint64_t *)c->d_pos.p, n, (uint8_t *)flag.p);
@@ -623,9 +625,9 @@ static int export_pg_order(pgrc_match_ctx *c, const pgrc_export_pg_order_args *x
     const uint64_t h = x->list_count;
     const uint32_t width = x->byte_per_read_length ? 1u : 2u;
     int e;
-    if (x->order) {
-        if ((e = upload(c, b.order, x->order, m * sizeof(uint32_t)))) return e;
-    } else if ((e = device_position_order(c, b, &m))) return e;
+    if (x->order_on_device) {
+        if ((e = device_position_order(c, b, &m))) return e;
+    } else if ((e = upload(c, b.order, x->order, m * sizeof(uint32_t)))) return e;    // (order == NULL: m == 0, checked by the caller)
     const uint64_t ne = m + h;
     if (x->read_org_idx && (e = upload(c, b.rorg, x->read_org_idx, c->n * sizeof(uint32_t)))) return e;
     if ((e = upload(c, b.loff, x->list_off, h)) || (e = upload(c, b.lorg, x->list_org_idx, h * sizeof(uint32_t)))) return e;
@@ -687,7 +689,8 @@ struct GatheredView {
     pgrc_match_ctx view;
     DevBuf pos, rc, mism;
     ~GatheredView() {
-        for (DevBuf *b : {&pos, &rc, &mism}) pgrc_buf_free(*b);
+        DevBuf *all[] = {&pos, &rc, &mism};
+        pgrc_buf_free_all(all, 3);
     }
     int build(pgrc_match_ctx *f) {
         const std::vector<PgrcShardView> sh = pgrc_multi_shards(f);
@@ -767,8 +770,11 @@ extern "C" int pgrc_match_export_pg_order(pgrc_match_ctx *c, const pgrc_export_p
     if (!c || !x || !out || (x->list_count && (!x->list_off || !x->list_org_idx))) return PGRC_E_PARAM;
     memset(out, 0, sizeof *out);
     if (!c->have_results || !c->have_pg || !c->have_reads) { c->err = "export: run first"; return PGRC_E_STATE; }
-    if (x->n_matched > c->n) { c->err = "export: more matched reads than reads"; return PGRC_E_PARAM; }
-    for (uint64_t j = 0; x->order && j < x->n_matched; j++)
+    if (!x->order_on_device) {
+        if (x->n_matched > c->n) { c->err = "export: more matched reads than reads"; return PGRC_E_PARAM; }
+        if (!x->order && x->n_matched) { c->err = "export_pg_order: order == NULL with n_matched > 0 (set order_on_device to let the library make the order)"; return PGRC_E_PARAM; }
+    }
+    for (uint64_t j = 0; !x->order_on_device && x->order && j < x->n_matched; j++)
         if (x->order[j] >= c->n) { c->err = "export_pg_order: read index out of range"; return PGRC_E_PARAM; }
     pgrc_match_ctx *w = c;
     int ge = view_for(c, &w);
@@ -811,7 +817,7 @@ static int export_original_order(pgrc_match_ctx *c, const pgrc_export_original_o
     const uint64_t total = x->reads_total_count;
     const uint32_t parts = x->pair_file_mode ? 2u : 1u, width = x->byte_per_read_length ? 1u : 2u;
     DevBuf owner, keep, rank, flag;
-    auto done = [&](int code) { pgrc_buf_free(owner); pgrc_buf_free(keep); pgrc_buf_free(rank); pgrc_buf_free(flag); return code; };
+    auto done = [&](int code) { DevBuf *all[] = {&owner, &keep, &rank, &flag}; pgrc_buf_free_all(all, 4); return code; };
     int e;
     if ((e = upload(c, b.rorg, x->read_org_idx, c->n * sizeof(uint32_t))) || (e = pgrc_buf_ensure(c, owner, std::max<uint64_t>(total, 1) * sizeof(uint32_t))) ||
         (e = pgrc_buf_ensure(c, keep, std::max<uint64_t>(total, 1))) || (e = pgrc_buf_ensure(c, rank, (total + 1) * sizeof(uint64_t))) ||

@@ -371,13 +371,17 @@ __device__ __forceinline__ void ps_unpack(const PsRecFmt f, uint64_t rec, uint32
 // scalar instructions per wave and partition -- every round walks all of a thread's records and 64-bit entry arithmetic was
 // redone at each use -- and the SIMDs were busy with them for more than half of its 5 ms; memory was not the limit (storing
 // nothing saves 0.6 ms, prefetching the next partition's records into registers nothing).  Hence: ONE round over the
-// partition's 2^cb buckets, bucket and rank of every record computed once, and a persistent grid.
-// Round 5: what the kernel waits for between its phases is latency (the record burst, the barriers, the head stores), and with
-// ONE block of 16 waves per CU nothing else runs meanwhile.  Partitions of 4096 buckets finished by blocks of 512 threads fit
-// THREE blocks per CU (52 KB of LDS each) -- if a thread gets by with 80 registers: a packed record stays ONE 64-bit word in
-// registers (its bucket is a shift away, its entry a multiplication: computed where they are used) instead of bucket + entry.
-template <int E, int PFF_TPB, int PFF_SUBBITS, int CAPI, bool PACKED, int WAVES>
-__global__ void __launch_bounds__(PFF_TPB) __attribute__((amdgpu_waves_per_eu(WAVES)))
+// partition's 2^cb buckets (the counters and a staging area for 6144 entries fit in 84 KB: the register count allows one
+// block per CU anyway), bucket and entry of every record computed once, and a persistent grid.
+// Round 5 (profiles/r05_index_variants.txt, r05_ubench_headwrite.txt): the kernel is at the ceiling of its WRITE PATTERN, not of
+// its instructions.  A strand's build owns one 64-byte half of every 128-byte line of the pair table; writing 8.6 GB that way
+// while 3 GB stream in takes 3.1-3.3 ms in a kernel that does nothing else (this one: 3.4).  Measured and not kept: partitions of
+// 4096 buckets finished by 512-thread blocks, three per CU (3.5 ms; and pass 1 pays 0.4 ms for its ninth digit bit); the same
+// with the records kept packed in registers (80 VGPRs: 3.5 ms; the 8192-bucket form of it: 4.1 ms); a kernel that keeps the
+// partition's heads as an IMAGE in LDS which the records write themselves into (half the instructions: 3.2 ms alone, but 80 KB
+// of LDS x 2 blocks leave no room for the other strand's kernels: the pair of builds got slower, 18.7 against 16.6 ms).
+template <int E, int PFF_TPB, int PFF_SUBBITS, int CAPI, bool PACKED>
+__global__ void __launch_bounds__(PFF_TPB)
 k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals, const uint32_t *__restrict__ pstart, uint32_t cb, uint32_t np,
                  uint64_t *__restrict__ ent, ulonglong2 *__restrict__ head, uint32_t hsh, uint32_t *__restrict__ slow_flag, const PsRecFmt fmt) {
     constexpr uint32_t PFF_SUB = 1u << PFF_SUBBITS, PFF_CAP = (uint32_t)CAPI, BPT = PFF_SUB / PFF_TPB;
@@ -398,26 +402,20 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
             if (threadIdx.x == 0) slow_flag[p] = 1;
             continue;
         }
-        // the partition's records in registers: record i of this thread is s + i * PFF_TPB + threadIdx.x, the first `mine` exist.
-        // PACKED: the 64-bit word as it is; else the entry (rec[]) and its bucket (kk[])
-        const uint32_t cnt = (uint32_t)(e - s);
-        const uint32_t mine = cnt > threadIdx.x ? (cnt - threadIdx.x + PFF_TPB - 1u) / PFF_TPB : 0u;
-        uint64_t rec[E];
-        uint32_t kk[PACKED ? 1 : E];
+        // the partition's records: bucket (all ones: no record) and entry, in registers
+        uint32_t k[E];
+        uint64_t v[E];
 #pragma unroll
         for (int i = 0; i < E; i++) {
             const uint64_t x = s + (uint64_t)i * PFF_TPB + threadIdx.x;
-            rec[i] = x < e ? vals[x] : 0ull;
-            if (!PACKED) kk[i] = x < e ? keys[x] & cbmask : 0u;
+            if (PACKED) {
+                ps_unpack(fmt, x < e ? vals[x] : 0ull, &k[i], &v[i]);
+            } else {
+                k[i] = x < e ? keys[x] & cbmask : 0u;
+                v[i] = x < e ? vals[x] : 0ull;
+            }
+            if (x >= e) k[i] = 0xFFFFFFFFu;
         }
-        auto bucket_of = [&](int i) -> uint32_t { return PACKED ? (uint32_t)(rec[i] >> fmt.sh) : kk[PACKED ? 0 : i]; };
-        auto entry_of = [&](int i) -> uint64_t {
-            if (!PACKED) return rec[i];
-            uint32_t k;
-            uint64_t v;
-            ps_unpack(fmt, rec[i], &k, &v);
-            return v;
-        };
         for (uint32_t b = threadIdx.x; b < PFF_SUB + PFF_SUB / 16; b += PFF_TPB) pk[b] = 0;
         if (threadIdx.x < 2) flags[threadIdx.x] = 0;
         if (threadIdx.x == 2) nbig = 0;
@@ -426,37 +424,34 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
         uint32_t ranks = 0, ranks_lo = 0;
 #pragma unroll
         for (int i = 0; i < E; i++) {
-            if ((uint32_t)i < mine) ranks |= min(atomicAdd(&pk[PFF_PAD(bucket_of(i))], 1u), 15u) << (4 * (i & 7));
+            if (k[i] != 0xFFFFFFFFu) ranks |= min(atomicAdd(&pk[PFF_PAD(k[i])], 1u), 15u) << (4 * (i & 7));
             if (E > 8 && i == 7) { ranks_lo = ranks; ranks = 0; }
         }
         __syncthreads();
         // 2. scan of the kept counts (low half) and of the entries that go to ent[] (high half): BPT consecutive buckets per thread
-        uint32_t total;
+        uint32_t total, xtotal;
         {
             const uint32_t b0 = threadIdx.x * BPT;
-            uint32_t sum = 0;
+            uint32_t c[BPT], sum = 0;
             bool ovf = false;
 #pragma unroll
             for (uint32_t q = 0; q < BPT; q++) {
-                const uint32_t cq = pk[PFF_PAD(b0 + q)];
-                ovf |= cq > PGRC_BUCKET_CAP;
-                const uint32_t kc = min(cq, PGRC_BUCKET_CAP);
+                c[q] = pk[PFF_PAD(b0 + q)];
+                ovf |= c[q] > PGRC_BUCKET_CAP;
+                const uint32_t kc = min(c[q], PGRC_BUCKET_CAP);
                 sum += kc | ((kc > 2u ? kc - 1u : 0u) << 16);
             }
             uint32_t both;
             uint32_t off = psc_block_scan(sum, scan_tmp, &both);
             total = both & 0xFFFFu;
+            xtotal = both >> 16;
 #pragma unroll
             for (uint32_t q = 0; q < BPT; q++) {
-                const uint32_t cq = pk[PFF_PAD(b0 + q)];                       // (read again rather than kept: registers)
-                const uint32_t kc = min(cq, PGRC_BUCKET_CAP), o = off & 0xFFFFu;
-                pk[PFF_PAD(b0 + q)] = (o & 0x1FFFu) | (min(cq, 14u) << 13) | ((off >> 16) << 17);
-                if (cq > PGRC_BUCKET_CAP && total <= PFF_CAP)               // an over-full bucket: its slots start as "no entry yet" (step 3)
+                const uint32_t kc = min(c[q], PGRC_BUCKET_CAP), o = off & 0xFFFFu;
+                pk[PFF_PAD(b0 + q)] = (o & 0x1FFFu) | (min(c[q], 14u) << 13) | ((off >> 16) << 17);
+                if (c[q] > PGRC_BUCKET_CAP && total <= PFF_CAP)               // an over-full bucket: its slots start as "no entry yet" (step 3)
                     for (uint32_t j = 0; j < PGRC_BUCKET_CAP; j++) entS[o + j] = ~0ull;
-                if (kc > 2u) {
-                    const uint32_t bi = atomicAdd(&nbig, 1u);
-                    if (bi < PFF_SUB) big[bi] = (uint16_t)(b0 + q);
-                }
+                if (kc > 2u) big[atomicAdd(&nbig, 1u)] = (uint16_t)(b0 + q);
                 off += kc | ((kc > 2u ? kc - 1u : 0u) << 16);
             }
             if (ovf) flags[0] = 1;
@@ -475,10 +470,10 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
         uint32_t live = 0;
 #pragma unroll
         for (int i = 0; i < E; i++) {
-            if ((uint32_t)i < mine) {
-                const uint32_t w = pk[PFF_PAD(bucket_of(i))];
+            if (k[i] != 0xFFFFFFFFu) {
+                const uint32_t w = pk[PFF_PAD(k[i])];
                 const uint32_t r = ((E > 8 && i < 8 ? ranks_lo : ranks) >> (4 * (i & 7))) & 15u;
-                if (PFF_KEPT(w) <= PGRC_BUCKET_CAP) entS[PFF_OFF(w) + r] = entry_of(i);
+                if (PFF_KEPT(w) <= PGRC_BUCKET_CAP) entS[PFF_OFF(w) + r] = v[i];
                 else live |= 1u << i;
             }
         }
@@ -486,33 +481,13 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
             __syncthreads();
 #pragma unroll 1
             for (uint32_t r = 0; r < PGRC_BUCKET_CAP; r++) {
-#pragma unroll 1
-                for (int i = 0; i < E; i++)
-                    if ((live >> i) & 1u) {
-                        uint64_t ri = rec[0];                 // (register arrays are not indexed dynamically: select record i)
-                        uint32_t ki = PACKED ? 0u : kk[0];
 #pragma unroll
-                        for (int q = 1; q < E; q++) { if (q == i) { ri = rec[q]; if (!PACKED) ki = kk[PACKED ? 0 : q]; } }
-                        uint32_t k;
-                        uint64_t v;
-                        if (PACKED) ps_unpack(fmt, ri, &k, &v);
-                        else { k = ki; v = ri; }
-                        atomicMin((unsigned long long *)&entS[PFF_OFF(pk[PFF_PAD(k)]) + r], (unsigned long long)v);
-                    }
+                for (int i = 0; i < E; i++)
+                    if ((live >> i) & 1u) atomicMin((unsigned long long *)&entS[PFF_OFF(pk[PFF_PAD(k[i])]) + r], (unsigned long long)v[i]);
                 __syncthreads();
-#pragma unroll 1
-                for (int i = 0; i < E; i++)
-                    if ((live >> i) & 1u) {
-                        uint64_t ri = rec[0];
-                        uint32_t ki = PACKED ? 0u : kk[0];
 #pragma unroll
-                        for (int q = 1; q < E; q++) { if (q == i) { ri = rec[q]; if (!PACKED) ki = kk[PACKED ? 0 : q]; } }
-                        uint32_t k;
-                        uint64_t v;
-                        if (PACKED) ps_unpack(fmt, ri, &k, &v);
-                        else { k = ki; v = ri; }
-                        if (entS[PFF_OFF(pk[PFF_PAD(k)]) + r] == v) live &= ~(1u << i);
-                    }
+                for (int i = 0; i < E; i++)
+                    if (((live >> i) & 1u) && entS[PFF_OFF(pk[PFF_PAD(k[i])]) + r] == v[i]) live &= ~(1u << i);
                 __syncthreads();
             }
         }
@@ -547,6 +522,7 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
             head[head_slot(((uint64_t)p << cb) + b, hsh)] = hd;
         }
         __syncthreads();                                      // (the next partition reuses counters and staging area)
+        (void)xtotal;
     }
 }
 
@@ -781,22 +757,21 @@ static int ps_launch_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uin
     } else {
         // registers per thread sized for the mean partition (uniform hash values); whatever is larger is flagged
         const uint64_t need = n / np + n / np / 4 + 512;
-        // Block shapes.  Partitions of 8192 buckets (cb = 13): 1024 threads x 8 records (16 for larger partitions: tables beyond
-        // 2^29 buckets), one block per CU -- measured at C3 in round 2 (index build per strand): 512 x 16: 15.1 ms, 256 x 32:
-        // 16.0, 1024 x 8: 13.5.  Partitions of 4096 buckets (cb <= 12, round 5; packed records only): 512 threads x 8 records,
-        // 52 KB of LDS and 80 registers: THREE blocks per CU that fill one another's waits (16 records: two blocks per CU).
-#define PFF_LAUNCH(E, TPB, SB, CAP, PK, WV, PERCU)                                                                             \
-        hipLaunchKernelGGL((k_ps_finish_fast<E, TPB, SB, CAP, PK, WV>), dim3(std::min<uint32_t>(np, (uint32_t)c->num_cus * PERCU)), \
-                           dim3(TPB), 0, c->stream, d_keys, d_vals, pst2, cb, np, d_ent, head, hsh, slow, fmt)
-        if (packed && cb <= 12u) {
-            if (need <= 4096) PFF_LAUNCH(8, 512, 12, 3328, true, 6, 3u);
-            else PFF_LAUNCH(16, 512, 12, 4095, true, 3, 2u);
-        } else if (packed) {
-            if (need <= 8192) PFF_LAUNCH(8, 1024, 13, 6144, true, 4, 1u);
-            else PFF_LAUNCH(16, 1024, 13, 8191, true, 4, 1u);
+        const uint32_t fgrid = std::min<uint32_t>(np, (uint32_t)c->num_cus);     // persistent: one block of 16 waves per CU
+        // block shape: 1024 threads x 8 records (16 for larger partitions: tables beyond 2^29 buckets), two 4096-bucket
+        // rounds.  Measured at C3 (index build per strand, tools/ab_finish_cfg.sh in the round-2 history): 512 x 16: 15.1 ms,
+        // 256 x 32: 16.0, 256 x 32 with 2048-bucket rounds: 16.8, 512 x 16 with 2048-bucket rounds: 16.4, 1024 x 8: 13.5.
+#define PFF_LAUNCH(E, TPB, SB, CAP, PK)                                                                                   \
+        hipLaunchKernelGGL((k_ps_finish_fast<E, TPB, SB, CAP, PK>), dim3(fgrid), dim3(TPB), 0, c->stream, d_keys, d_vals,  \
+                           pst2, cb, np, d_ent, head, hsh, slow, fmt)
+        // (one round of 2^cb <= 8192 buckets; staging area for 6144 entries -- the mean partition holds 0.7 * 8192 -- resp.
+        //  8191 where partitions are larger: tables beyond 2^29 buckets)
+        if (packed) {
+            if (need <= 8192) PFF_LAUNCH(8, 1024, 13, 6144, true);
+            else PFF_LAUNCH(16, 1024, 13, 8191, true);
         } else {
-            if (need <= 8192) PFF_LAUNCH(8, 1024, 13, 6144, false, 4, 1u);
-            else PFF_LAUNCH(16, 1024, 13, 8191, false, 4, 1u);
+            if (need <= 8192) PFF_LAUNCH(8, 1024, 13, 6144, false);
+            else PFF_LAUNCH(16, 1024, 13, 8191, false);
         }
 #undef PFF_LAUNCH
         hipLaunchKernelGGL(k_ps_slow_list, dim3((np + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)slow, np, todo, todo_count);

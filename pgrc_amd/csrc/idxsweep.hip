@@ -23,6 +23,12 @@
 // over 8-byte {flag, count} granules was built first and measured: its INC frontier advances by at most
 // `tiles looked at per step / granule load latency` ~ 15 tiles/us chip-wide, which capped a pass at ~3 ms at C3 whatever
 // the block shape -- profiles/r03_os_lookback_cfgs.txt.  Direct stores without LDS staging were 2-4x slower.)
+//
+// Round 5, measured and not kept (profiles/r05_index_variants.txt): pass 1 WITHOUT the counting pre-pass -- every bin a fixed
+// number of slots, a tile reserves the run of each of its digits with one returning global atomic, the exact road queued behind
+// it and skipped unless a bin ran over (device-side flag).  The reserving pass took 2.7 ms where counting (0.67) + scattering
+// (1.75) take 2.4: 256 dependent atomics per tile cost more than hashing the text a second time, and the records of a partition
+// then arrive in no order at all, which the general finish kernel of the flagged partitions pays for (0.16 -> 1.8 ms).
 #include <stdlib.h>
 #include <string.h>
 
@@ -381,21 +387,19 @@ k_os_scatter_bins(const uint64_t *__restrict__ rec_in, const AUX *__restrict__ a
 
 // ---------------------------------------------------------------- driver
 
-// cb_target: bucket bits the finish takes per partition (13: round 3's 8192-bucket partitions; 12: round 5's 4096-bucket
-// partitions, three finish blocks per CU).  The two passes cover the rest: at most 9 bits each.
-static bool os_plan(const pgrc_match_ctx *c, uint32_t hbits, uint32_t cb_target, OsPlan *pl) {
+static bool os_plan(const pgrc_match_ctx *c, uint32_t hbits, OsPlan *pl) {
     const uint64_t n = c->npos;
     if (!n || n >= 0xFFFFF000ull || hbits < 16 || hbits > 31 || c->cp.k1 > 16 || c->cp.K > 56 || c->cp.K < 4) return false;
     uint32_t tbits = 1;
     while ((1ull << tbits) < n) tbits++;
     if (tbits + PGRC_FP_BITS + 8u > 64u) return false;
-    uint32_t cb = std::min<uint32_t>(cb_target, 64u - PGRC_FP_BITS - tbits);
-    if (hbits > cb + 18u) cb = hbits - 18u;                    // two passes of at most 9 bits
-    if (cb < 12u || cb > OS_CB_MAX || cb > 64u - PGRC_FP_BITS - tbits || hbits < cb + 2u) return false;
+    const uint32_t cb = std::min<uint32_t>(OS_CB_MAX, 64u - PGRC_FP_BITS - tbits);
+    if (cb < 12u || hbits < cb + 2u) return false;             // (the finish kernel works in rounds of 4096 buckets)
     const uint32_t top = hbits - cb;
+    if (top > 18u) return false;                               // two passes of at most 9 bits
     pl->hbits = hbits;
     pl->cb = cb;
-    pl->b1 = (top + 1u) / 2u;                                  // (the wider digit first: the digit that travels with the records is b2)
+    pl->b1 = top / 2;
     pl->b2 = top - pl->b1;
     pl->tbits = tbits;
     pl->rec_sh = tbits + PGRC_FP_BITS;
@@ -404,18 +408,13 @@ static bool os_plan(const pgrc_match_ctx *c, uint32_t hbits, uint32_t cb_target,
     pl->mask = (uint32_t)(c->cp.hash_size - 1);
     pl->n = n;
     pl->ntiles1 = pl->ntiles2_max = 0;
-    pl->xcd = 0;
+    pl->xcd = 1;
     return true;
 }
 
-// PGRC_INDEX_CFG (A/B runs), a bit set: 1 = XCD-aware tile order in the passes, 2 = partitions of 8192 buckets (round 3's
-// finish: one block of 1024 threads per CU) instead of 4096
-static uint32_t os_cfg_bits(const pgrc_match_ctx *c, uint32_t dflt) { return c->opt.index_cfg >= 0 ? (uint32_t)c->opt.index_cfg : dflt; }
-#define OS_CFG_DEFAULT 0u
-
 bool pgrc_os_applicable(const pgrc_match_ctx *c, uint32_t hbits) {
     OsPlan pl;
-    return os_plan(c, hbits, (os_cfg_bits(c, OS_CFG_DEFAULT) & 2u) ? 13u : 12u, &pl);
+    return os_plan(c, hbits, &pl);
 }
 
 template <typename F>
@@ -467,15 +466,16 @@ static int os_passes(pgrc_match_ctx *c, int strand, const OsPlan &pl, const OsBu
 
 int pgrc_os_build_index(pgrc_match_ctx *c, int strand, uint32_t hbits) {
     OsPlan pl;
-    const uint32_t cfg = os_cfg_bits(c, OS_CFG_DEFAULT);
-    if (!os_plan(c, hbits, (cfg & 2u) ? 13u : 12u, &pl)) { c->err = "index build (sweep): not applicable"; return PGRC_E_PARAM; }
-    pl.xcd = cfg & 1u;
+    if (!os_plan(c, hbits, &pl)) { c->err = "index build (sweep): not applicable"; return PGRC_E_PARAM; }
+    // XCD-aware tile order in the passes (os_tile_of_block; round 5): at C3 pass 2 goes 1.83 -> 1.38 ms per strand, pass 1 1.81 ->
+    // 1.74, the pair of builds 18.5 -> 17.1 ms in one context (profiles/r05_index_variants.txt).  PGRC_INDEX_CFG=0: off (A/B runs).
+    pl.xcd = c->opt.index_cfg == 0 ? 0u : 1u;
     // Block shape of the passes: 1024 threads x 6 records, 61-68 KB of LDS and 64 registers: two blocks per CU, one hashing while
     // the other stores.  Measured at C3 in round 3, per strand (profiles/r03_os_cfgs.txt): pass 1 / pass 2 = 3.0 / 1.8 ms with 1024
     // x 8 (one block per CU), 1.8 / 1.75 with 1024 x 6, 2.2 / 2.1 with 512 x 8 (three per CU), 3.3 / 2.75 with 512 x 16, 3.0 / 2.4
     // with a persistent, prefetching pass 2.  Nine-bit digits in BOTH passes (tables of 2^30 buckets and more: 16-bit digit
     // arrays) take the 8-record shape, one block per CU.
-    const bool aux16 = pl.b2 > 8, dig16 = pl.b1 > 8;
+    const bool aux16 = pl.b2 > 8;
     const uint64_t n = pl.n, tile = aux16 ? 8192u : 6144u;
     const uint32_t D1 = 1u << pl.b1, D2 = 1u << pl.b2, np = 1u << (pl.hbits - pl.cb);
     pl.ntiles1 = (n + tile - 1) / tile;
@@ -504,7 +504,6 @@ int pgrc_os_build_index(pgrc_match_ctx *c, int strand, uint32_t hbits) {
     b.aux = c->d_skey[0].p;
     HIP_TRY(c, hipMemsetAsync(b.slow, 0, flag_words * sizeof(uint32_t), c->stream));
     if (aux16) e = os_passes<1024, 8, 1, uint16_t, uint16_t>(c, strand, pl, b);
-    else if (dig16) e = os_passes<1024, 6, 2, uint8_t, uint16_t>(c, strand, pl, b);
     else e = os_passes<1024, 6, 2, uint8_t, uint8_t>(c, strand, pl, b);
     if (e) return e;
     return pgrc_ps_finish_packed(c, b.recB, b.pstart, b.slow, np, pl.cb, pl.rec_sh, b.recA);

@@ -286,6 +286,7 @@ k_npos_rows(const uint8_t *__restrict__ rows, int symbols, uint64_t first, uint6
 int pgrc_launch_npos_rows(pgrc_match_ctx *c, const uint8_t *d_rows, int symbols, uint64_t first, uint64_t count, uint32_t L,
                           uint8_t *d_nflag, uint32_t *d_npos) {
     if (!count) return PGRC_OK;
+    if (L > 255 || !d_npos) { c->err = "npos_rows: a read position must fit one byte (read_len <= 255)"; return PGRC_E_PARAM; }
     const uint32_t rb = symbols == 0 ? L : (L + 2) / 3;
     const uint32_t grid = (uint32_t)((count + 255) / 256 < 65536 ? (count + 255) / 256 : 65536);
     hipLaunchKernelGGL(k_npos_rows, dim3(grid), dim3(256), 0, c->stream, d_rows, symbols, first, count, L, rb, d_nflag, d_npos);

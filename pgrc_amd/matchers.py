@@ -260,7 +260,9 @@ class MatchContext:
                 np.ascontiguousarray(list_org_idx, dtype=np.uint32)]
         a = _lib.ExportPgOrderArgs()
         if order is not None:
-            a.order, a.n_matched = keep[0].ctypes.data, keep[0].size
+            a.order, a.n_matched = (keep[0].ctypes.data if keep[0].size else None), keep[0].size
+        else:
+            a.order_on_device = 1
         a.list_off, a.list_org_idx, a.list_count = keep[1].ctypes.data, keep[2].ctypes.data, keep[1].size
         if list_rev_comp is not None:
             keep.append(np.ascontiguousarray(list_rev_comp, dtype=np.uint8))
@@ -327,7 +329,7 @@ class MatchContext:
 
     def counters(self) -> dict:
         c = Counters()
-        self._ck(lib.pgrc_match_get_counters(self._h, C.byref(c)))
+        self._ck(lib.pgrc_match_get_counters_sized(self._h, C.byref(c), C.sizeof(c)))
         return {"searched": list(c.searched), "candidates": list(c.candidates), "probes": list(c.probes),
                 "entry_fetches": list(c.entry_fetches), "verifies": list(c.verifies), "index_entries": list(c.index_entries), "ms_index": list(c.ms_index), "ms_match": list(c.ms_match),
                 "ms_other": c.ms_other, "ms_total": c.ms_total, "ms_allgather": c.ms_allgather,

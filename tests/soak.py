@@ -48,7 +48,7 @@ def main():
         shards = int(rng.integers(2, 6)) if rng.random() < 0.3 else 0
         packed = bool(rng.random() < 0.5)
         variant = str(rng.choice(["", "", "own"]))
-        icfg = str(rng.choice(["", "", "1", "2", "3"]))     # round 5: XCD-aware tile order (1), partitions of 8192 buckets (2)
+        icfg = str(rng.choice(["", "", "0"]))     # round 5: the passes without the XCD-aware tile order
         finish = "general" if rng.random() < 0.3 else ""
         # modes d / i / e: small text segments and read batches now and then (the loops a >= 4 Gi text / >= 2^28 reads take)
         seg = str(int(rng.integers(4096, 40000))) if mode != "c" and rng.random() < 0.4 else ""

@@ -37,7 +37,7 @@ def main():
                                 paired=bool(rng.random() < 0.3))
         shards = int(rng.integers(2, 5)) if rng.random() < 0.3 else 0
         variant = str(rng.choice(["", "", "own"]))
-        icfg = str(rng.choice(["", "", "1", "2", "3"]))     # round 5: XCD-aware tile order (1), partitions of 8192 buckets (2)
+        icfg = str(rng.choice(["", "", "0"]))     # round 5: the passes without the XCD-aware tile order
         finish = "general" if rng.random() < 0.25 else ""
         early = "0" if rng.random() < 0.2 else ""        # the match kernel probing every seed of every read
         stage = "0" if rng.random() < 0.2 else ""        # ... and without staged refills

@@ -178,3 +178,41 @@ def test_device_made_position_order(n, G, dups):
     got = many["ctx"].export_pg_order(None, case["list_off"], case["list_org"], case["list_rc"], case["read_org"], False, True)
     for k in xu.STREAMS:
         assert np.array_equal(got[k], want[k]), (n, G, k, "three shards")
+
+
+def test_order_null_is_only_accepted_without_matched_reads_or_with_the_flag():
+    """pgrc_export_pg_order_args.order == NULL: with n_matched > 0 and without order_on_device it is a caller's
+    mistake (PGRC_E_PARAM, not silently another tie order); with n_matched == 0 it means "no matched read" -- what
+    HipReadsMatcher hands over on its host-sort road when nothing matched (an empty vector's data() is NULL) -- and the export
+    is the old list alone; with order_on_device the library makes the order."""
+    from pgrc_amd import _lib, PgrcMatchError
+    case, pair = _case("se")
+    L = case["L"]
+    g = gpu_match("c", case["pg"], case["reads"], 38, L // 3, 0, n_nset=case["n_n"])
+    ctx = g["ctx"]
+    keep = [np.ascontiguousarray(case["list_off"], dtype=np.uint8), np.ascontiguousarray(case["list_org"], dtype=np.uint32)]
+
+    def call(n_matched, on_device):
+        a = _lib.ExportPgOrderArgs()
+        a.n_matched, a.order_on_device = n_matched, on_device
+        a.list_off, a.list_org_idx, a.list_count = keep[0].ctypes.data, keep[1].ctypes.data, keep[0].size
+        a.byte_per_read_length = 1
+        st = _lib.ExportStreams()
+        rc = _lib.lib.pgrc_match_export_pg_order(ctx._h, C.byref(a), C.byref(st))
+        n = int(st.n_entries)
+        _lib.lib.pgrc_match_free_export(C.byref(st))
+        return rc, n
+    rc, _ = call(5, 0)
+    assert rc == 1                                   # PGRC_E_PARAM
+    rc, n = call(0, 0)
+    assert rc == 0 and n == keep[0].size             # the old list alone
+    rc, n = call(0, 1)
+    assert rc == 0 and n == keep[0].size + int((g["mism"] != 255).sum())
+    # a run in which no read matches at all, on both roads
+    reads = np.full((64, L), ord("A"), dtype=np.uint8)
+    reads[:, ::2] = ord("C")
+    g0 = gpu_match("c", case["pg"], reads, 38, 0, 0)
+    if int((g0["mism"] != 255).sum()) == 0:
+        for order in (np.zeros(0, dtype=np.uint32), None):
+            got = g0["ctx"].export_pg_order(order, case["list_off"], case["list_org"], case["list_rc"], None, False, True)
+            assert got["org_idx"].size == keep[0].size

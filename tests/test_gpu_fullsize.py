@@ -170,6 +170,41 @@ def test_c3_full_size_properties_and_sample(c3world):
         del cx
 
 
+def test_c3_full_size_seed_modes_bit_parity(c3world):
+    """Rows a5-a7 bit for bit at the FULL C3 text (until round 5 only the builder-run script
+    tests/fullscale_parity.py did this): a sample of the workload's reads matched against the whole 1.875 Gbp Pg in modes d, i
+    and e -- positions, strands, counts AND the number of (window, part) pairs with equal keys per strand -- against the
+    oracle's serial scans of the whole text (DefaultReadsApproxMatcher / InterleavedReadsApproxMatcher /
+    DefaultReadsExactMatcher::executeMatching, matching/ReadsMatchers.cpp:198-230, :297-409).  The three scans (about 80 s
+    each on one core) run side by side in threads: the checker's C code releases the interpreter lock."""
+    from concurrent.futures import ThreadPoolExecutor
+    w = c3world
+    L, G, kmax = w.L, w.G, w.kmax
+    ns = 60_000
+    reads = w.reads_se[:ns]
+    nw, stride = (L + 15) // 16, (ns + 63) & ~63
+    d_rd = torch.empty(nw * stride, dtype=torch.int32, device="cuda")
+    synth.reads_device(w.g, w.d_pg.data_ptr(), w.rs_se, 0, ns, d_rd.data_ptr(), stride)
+    torch.cuda.synchronize()
+    legs = [("d", w.seed_len, kmax), ("i", w.seed_len, kmax), ("e", L, 0)]
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        futs = [pool.submit(orc.oracle_match, mode, w.pg, reads, sl, km, 0, True, 1) for mode, sl, km in legs]
+        got = []
+        for mode, sl, km in legs:                 # (the GPU legs while the scans run)
+            cx = MatchContext(L, sl, km, 0, mode)
+            cx.set_pg_packed_device(w.d_pg.data_ptr(), G)
+            cx.set_reads_device(d_rd.data_ptr(), ns, stride, keep=d_rd)
+            cx.init_results()
+            cx.run(True)
+            got.append(cx.get_results()[:3] + (cx.counters()["candidates"],))
+            del cx
+        want = [f.result() for f in futs]
+    for (mode, sl, km), (pos, rc, mism, cand), o in zip(legs, got, want):
+        assert np.array_equal(pos, o["pos"]) and np.array_equal(rc, o["rc"]) and np.array_equal(mism, o["mism"]), mode
+        assert [int(v) for v in cand] == [int(v) for v in o["candidates"]], (mode, cand, o["candidates"])
+        assert int((mism != 255).sum()) >= (0.55 if mode == "e" else 0.85) * ns, mode
+
+
 def test_c4_full_size_eight_shards(c3world):
     """configs[3]: 100 M x 150 bp PE, reads sharded 8 ways, the packed Pg assembled from 8 slices.  The 8 ranks' work
     runs back to back on this device: every rank's slice of the host text is packed by pgrc_match_pack_pg_slice into
