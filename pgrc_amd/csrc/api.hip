@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "ctx.h"
@@ -141,6 +142,9 @@ PgrcOptions pgrc_options_from_env() {
     o.force_pos64 = flag("PGRC_FORCE_POS64") == 1;
     o.test_no_second_index = getenv("PGRC_TEST_NO_SECOND_INDEX") != nullptr;
     o.stream_timing = getenv("PGRC_STREAM_TIMING") != nullptr;
+    o.host_pack = flag("PGRC_HOST_PACK") == 1;
+    if (num("PGRC_HOST_THREADS") > 0) o.host_threads = (uint32_t)std::min<long long>(256, num("PGRC_HOST_THREADS"));
+    if (num("PGRC_STREAM_GRID") > 0) o.stream_blocks_per_cu = (uint32_t)std::min<long long>(8, num("PGRC_STREAM_GRID"));
     if (num("PGRC_UPLOAD_CHUNK_MB") > 0) o.upload_chunk_mb = (uint64_t)std::min<long long>(4096, num("PGRC_UPLOAD_CHUNK_MB"));
     o.seed_filter = flag("PGRC_SEED_FILTER");
     if (num("PGRC_SEED_HEAVY") > 0) o.seed_heavy = (uint32_t)std::min<long long>(4096, num("PGRC_SEED_HEAVY"));
@@ -151,6 +155,76 @@ PgrcOptions pgrc_options_from_env() {
     if (const char *ag = getenv("PGRC_ALLGATHER")) o.allgather = !strcmp(ag, "rccl") ? 1 : !strcmp(ag, "copy") ? 2 : 0;
     o.dual_variant = (int)num("PGRC_DUAL_VARIANT");
     return o;
+}
+
+// ---- host-side packing of an ASCII text to 2 bits per symbol (A0 C1 G2 T3; symbol i at bits 2 (i mod 16) of word i / 16: ctx.h)
+// returns false when a symbol outside ACGT was met (the words are then garbage there)
+static bool pack_ascii_scalar(const uint8_t *src, uint64_t count, uint32_t *dst) {
+    bool ok = true;
+    for (uint64_t w = 0; w * 16 < count; w++) {
+        uint32_t word = 0;
+        const uint64_t m = std::min<uint64_t>(16, count - w * 16);
+        for (uint64_t k = 0; k < m; k++) {
+            const uint32_t ch = src[w * 16 + k];
+            uint32_t x = (ch >> 1) & 3u;
+            x ^= x >> 1;                                      // A0 C1 G2 T3
+            ok &= ch == (uint32_t)"ACGT"[x];
+            word |= x << (2 * k);
+        }
+        dst[w] = word;
+    }
+    return ok;
+}
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) static bool pack_ascii_avx2(const uint8_t *src, uint64_t count, uint32_t *dst) {
+    const __m256i three = _mm256_set1_epi8(3), one = _mm256_set1_epi8(1);
+    const __m256i lut = _mm256_setr_epi8('A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i w1 = _mm256_set1_epi16(0x0401), w2 = _mm256_set1_epi32(0x00100001);
+    const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    __m256i allok = _mm256_set1_epi8(-1);
+    uint64_t i = 0;
+    for (; i + 32 <= count; i += 32) {
+        const __m256i v = _mm256_loadu_si256((const __m256i *)(src + i));
+        const __m256i code = _mm256_xor_si256(_mm256_and_si256(_mm256_srli_epi16(v, 1), three), _mm256_and_si256(_mm256_srli_epi16(v, 2), one));
+        allok = _mm256_and_si256(allok, _mm256_cmpeq_epi8(_mm256_shuffle_epi8(lut, code), v));
+        const __m256i b4 = _mm256_madd_epi16(_mm256_maddubs_epi16(code, w1), w2);     // one packed byte in the low byte of every dword
+        const __m256i sh = _mm256_shuffle_epi8(b4, pick);
+        dst[i / 16] = (uint32_t)_mm256_extract_epi32(sh, 0);
+        dst[i / 16 + 1] = (uint32_t)_mm256_extract_epi32(sh, 4);
+    }
+    bool ok = _mm256_movemask_epi8(allok) == -1;
+    if (i < count) ok &= pack_ascii_scalar(src + i, count - i, dst + i / 16);
+    return ok;
+}
+#endif
+
+// `threads` host threads (0: up to 16 of the machine's), each a contiguous range of whole words
+bool pgrc_pack_ascii_host(const uint8_t *src, uint64_t count, uint32_t *dst, uint32_t threads) {
+    auto one = [](const uint8_t *s, uint64_t n, uint32_t *d) -> bool {
+#if defined(__x86_64__)
+        static const bool avx2 = __builtin_cpu_supports("avx2");
+        if (avx2) return pack_ascii_avx2(s, n, d);
+#endif
+        return pack_ascii_scalar(s, n, d);
+    };
+    uint32_t T = threads ? threads : std::min<uint32_t>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    const uint64_t words = (count + 15) / 16;
+    if (words < (1u << 16)) T = 1;
+    if (T == 1) return one(src, count, dst);
+    std::vector<std::thread> th;
+    std::vector<char> okv(T, 1);
+    const uint64_t per = (words + T - 1) / T;
+    for (uint32_t t = 0; t < T; t++) {
+        const uint64_t w0 = std::min(words, t * per), w1 = std::min(words, w0 + per);
+        if (w0 == w1) continue;
+        th.emplace_back([&, t, w0, w1]() { okv[t] = one(src + w0 * 16, std::min(count, w1 * 16) - w0 * 16, dst + w0) ? 1 : 0; });
+    }
+    for (std::thread &x : th) x.join();
+    bool ok = true;
+    for (char v : okv) ok &= v != 0;
+    return ok;
 }
 
 static int isqrt_floor(int v) {
@@ -284,7 +358,7 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
     DevBuf *bufs[] = {&c->pg2[0], &c->pg2[1], &c->reads_own, &c->nread_idx, &c->nread_ascii, &c->nread_flag, &c->nread_npos, &c->d_pos,
                       &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_head, &c->d_headpair, &c->d_skey[0], &c->d_skey[1], &c->d_sval[0], &c->d_sval[1], &c->d_sorttmp,
                       &c->alt_head, &c->alt_skey[0], &c->alt_skey[1], &c->alt_sval[0], &c->alt_sval[1], &c->alt_sorttmp, &c->d_scr_pos, &c->d_scr_flag,
-                      &c->s_keys, &c->s_filter, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp, &c->s_nmask, &c->s_best, &c->s_rows};
+                      &c->s_keys, &c->s_filter, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp, &c->s_sort, &c->s_nmask, &c->s_best, &c->s_rows};
     pgrc_buf_free_all(bufs, sizeof bufs / sizeof bufs[0]);       // (the device is idle: waited for above)
     for (DevBuf &b : c->up_nchunks) pgrc_buf_free(b);
     if (c->have_events)
@@ -361,6 +435,53 @@ int pgrc_match_pack_pg_slice(pgrc_match_ctx *c, const char *pg, uint64_t count, 
     if (!c || (!pg && count) || !d_words_out) return PGRC_E_PARAM;
     if (c->multi) return pgrc_multi_pack_pg_slice(c, pg, count, d_words_out);
     PGRC_ON_DEVICE(c);
+    // Round 5: the text is packed to 2 bits per symbol ON THE HOST (pgrc_pack_ascii_host below: a few threads, AVX2 where the CPU
+    // has it) and a quarter of the bytes cross the link -- 1.9 GB of ASCII took 35 ms of a C3-size job's 150 ms, and the link is that
+    // job's bound.  Chunk k is copied while chunk k + 1 is packed.  PGRC_HOST_PACK=0: the bytes go up as they are and
+    // a kernel packs them (rounds 1-4).
+    if (c->opt.host_pack && count >= (1ull << 22)) {
+        // T worker threads (started once per call) pack chunk k into pinned buffer k % 2, each its share of the chunk's words; this
+        // thread copies a chunk when all have packed it and frees its buffer when the copy is through -- the workers pack chunk
+        // k + 1 meanwhile.  The buffers are pinned (one pair per process: the copies are plain DMA, nothing is pinned on the fly).
+        const uint64_t CH = 32ull << 20;                     // symbols per chunk (a multiple of 16)
+        static std::mutex pin_mu;
+        static uint32_t *pin[2] = {nullptr, nullptr};
+        std::unique_lock<std::mutex> pin_lock(pin_mu);       // (one text at a time through the pair of buffers)
+        for (int k = 0; k < 2; k++)
+            if (!pin[k]) HIP_TRY(c, hipHostMalloc((void **)&pin[k], CH / 4, hipHostMallocDefault));
+        const uint32_t T = c->opt.host_threads ? c->opt.host_threads : std::min<uint32_t>(8u, std::max(1u, std::thread::hardware_concurrency()));
+        const uint64_t nchunks = (count + CH - 1) / CH;
+        std::vector<std::atomic<uint32_t>> packed(nchunks);
+        for (auto &x : packed) x.store(0);
+        std::atomic<uint64_t> copied{0};                     // chunks whose copy is through
+        std::atomic<bool> bad{false};
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < T; t++)
+            th.emplace_back([&, t]() {
+                for (uint64_t k = 0; k < nchunks; k++) {
+                    while (k >= 2 && copied.load(std::memory_order_acquire) < k - 1) std::this_thread::yield();     // buffer k % 2 is free
+                    const uint64_t off = k * CH, len = std::min(CH, count - off), words = (len + 15) / 16;
+                    const uint64_t per = (words + T - 1) / T, w0 = std::min(words, t * per), w1 = std::min(words, w0 + per);
+                    if (w1 > w0 && !pgrc_pack_ascii_host((const uint8_t *)pg + off + w0 * 16, std::min(len, w1 * 16) - w0 * 16, pin[k & 1] + w0, 1)) bad = true;
+                    packed[k].fetch_add(1, std::memory_order_release);
+                }
+            });
+        hipError_t he = hipSuccess;
+        for (uint64_t k = 0; k < nchunks; k++) {
+            while (packed[k].load(std::memory_order_acquire) < T) std::this_thread::yield();
+            const uint64_t off = k * CH, len = std::min(CH, count - off), words = (len + 15) / 16;
+            if (he == hipSuccess) he = hipMemcpyAsync((uint32_t *)d_words_out + off / 16, pin[k & 1], words * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+            copied.store(k + 1, std::memory_order_release);  // (also after an error: the workers must run out)
+        }
+        for (std::thread &x : th) x.join();
+        HIP_TRY(c, he);
+        if (bad) {
+            c->err = "pseudogenome contains a symbol outside ACGT";
+            return PGRC_E_SYMBOL;
+        }
+        return PGRC_OK;
+    }
     const uint64_t CH = 64ull << 20; // 64 Mi symbols per staging chunk (multiple of 16)
     DevBuf stage, flag;
     int e;

@@ -813,7 +813,12 @@ int pgrc_copmem_match_dual_r04(pgrc_match_ctx *c);    // tools/variants/dual_r04
 template <int NW, int WAVES>
 static void launch_dual_w(pgrc_match_ctx *c, const DualArgs &a) {
     const uint64_t want = (a.n + MATCH_TPB - 1) / MATCH_TPB;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)c->num_cus * 8u);
+    // A persistent grid: more blocks than fit (six per CU at 150 bp) simply queue.  On the blocks of a STREAMED run (stream.hip) the
+    // grid leaves a wave slot per SIMD free (five blocks per CU): the upload side's small kernels -- unpacking the next chunk, the
+    // rows of the reads with N -- otherwise wait for a whole launch of this kernel to end before they get a CU
+    // (PGRC_STREAM_GRID = blocks per CU; profiles/r05_boundary_stream_grid_ab.txt).
+    const uint32_t per_cu = (c->st_on && c->range_n != ~0ull) ? (c->opt.stream_blocks_per_cu ? c->opt.stream_blocks_per_cu : 8u) : 8u;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)c->num_cus * per_cu);
     const bool pos64 = c->G + 256 >= (1ull << 32) || c->opt.force_pos64;
     const bool k28 = a.K == 28;
     if (pos64) {

@@ -54,6 +54,9 @@ struct PgrcOptions {
     bool force_pos64 = false;       // PGRC_FORCE_POS64=1: the 64-bit-position kernels on a small text (tests)
     bool test_no_second_index = false;   // PGRC_TEST_NO_SECOND_INDEX: the second index set "does not fit" (tests)
     bool stream_timing = false;     // PGRC_STREAM_TIMING: milestones of a streamed run on stderr
+    bool host_pack = false;         // PGRC_HOST_PACK=1: an ASCII text is packed by host threads into pinned buffers (default: bytes go up, a kernel packs)
+    uint32_t host_threads = 0;      // PGRC_HOST_THREADS: host threads that pack the text (0 = up to 8)
+    uint32_t stream_blocks_per_cu = 0;   // PGRC_STREAM_GRID: blocks per CU of the dual kernel on the blocks of a streamed run (0 = default)
     uint64_t upload_chunk_mb = 0;   // PGRC_UPLOAD_CHUNK_MB: staging chunk of append_reads_* (0 = 256, or 1024 for a streamed run)
     int seed_filter = -1;           // PGRC_SEED_FILTER  modes d/i/e: -1 where it pays, 0 never, 1 always
     uint32_t seed_heavy = 0;        // PGRC_SEED_HEAVY   modes d/i/e: entries of a window above which the persistent grid expands it (0 = default)
@@ -65,6 +68,7 @@ struct PgrcOptions {
     int dual_variant = -1;          // PGRC_DUAL_VARIANT which build of the dual kernel runs (A/B builds only; -1 = default)
 };
 PgrcOptions pgrc_options_from_env();
+bool pgrc_pack_ascii_host(const uint8_t *src, uint64_t count, uint32_t *dst, uint32_t threads);   // api.hip: ASCII ACGT -> 2-bit words, false = a symbol outside ACGT
 
 struct pgrc_match_ctx {
     PgrcOptions opt;                    // read from the environment by pgrc_match_create (see above)
@@ -175,7 +179,7 @@ struct pgrc_match_ctx {
     double st_t0 = 0;
 
     // read-side seed index (modes d / i / e)
-    DevBuf s_keys, s_vals, s_tab, s_hits, s_tmp;
+    DevBuf s_keys, s_vals, s_tab, s_hits, s_tmp, s_sort;
     DevBuf s_filter;        // modes d/i/e: one bit per slice of the key space (seedidx.hip)
     DevBuf s_nmask;                             // N masks of the reads with N (modes d/i/e)
     DevBuf s_best, s_rows;                      // the atomic-minimum reduction: one key per read, the batch's reads row by row (seedidx.hip 3c)

@@ -383,7 +383,7 @@ __device__ __forceinline__ void ps_unpack(const PsRecFmt f, uint64_t rec, uint32
 template <int E, int PFF_TPB, int PFF_SUBBITS, int CAPI, bool PACKED>
 __global__ void __launch_bounds__(PFF_TPB)
 k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals, const uint32_t *__restrict__ pstart, uint32_t cb, uint32_t np,
-                 uint64_t *__restrict__ ent, ulonglong2 *__restrict__ head, uint32_t hsh, uint32_t *__restrict__ slow_flag, const PsRecFmt fmt) {
+                 uint64_t *__restrict__ ent, ulonglong2 *__restrict__ head, uint32_t hsh, uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count, const PsRecFmt fmt) {
     constexpr uint32_t PFF_SUB = 1u << PFF_SUBBITS, PFF_CAP = (uint32_t)CAPI, BPT = PFF_SUB / PFF_TPB;
     static_assert(CAPI <= 8191 && (E == 8 || E == 16) && PFF_SUBBITS <= 13, "staging slots are 13-bit; ranks are packed 8 per register");
     __shared__ uint32_t pk[PFF_SUB + PFF_SUB / 16];
@@ -399,7 +399,7 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
     for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
         const uint64_t s = pstart[p], e = pstart[p + 1];
         if (e - s > (uint64_t)E * PFF_TPB) {                  // more records than the registers hold: the general kernel's
-            if (threadIdx.x == 0) slow_flag[p] = 1;
+            if (threadIdx.x == 0) todo[atomicAdd(todo_count, 1u)] = p;      // (the list of the general kernel, any order)
             continue;
         }
         // the partition's records: bucket (all ones: no record) and entry, in registers
@@ -459,7 +459,7 @@ k_ps_finish_fast(const uint32_t *__restrict__ keys, const uint64_t *__restrict__
         }
         __syncthreads();
         if (flags[1]) {                                       // more entries than the staging area holds: the general kernel redoes the partition
-            if (threadIdx.x == 0) slow_flag[p] = 1;
+            if (threadIdx.x == 0) todo[atomicAdd(todo_count, 1u)] = p;
             __syncthreads();                                  // (flags[] is rewritten for the next partition)
             continue;
         }
@@ -677,12 +677,6 @@ k_ps_finish(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals
     }
 }
 
-// the partitions the fast kernel flagged, as a list (any order)
-__global__ void __launch_bounds__(256) k_ps_slow_list(const uint32_t *__restrict__ slow_flag, uint32_t np, uint32_t *__restrict__ list, uint32_t *__restrict__ count) {
-    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < np; p += gridDim.x * blockDim.x)
-        if (slow_flag[p]) list[atomicAdd(count, 1u)] = p;
-}
-
 // ---------------------------------------------------------------- drivers
 
 uint32_t pgrc_ps_partition_bits(uint32_t hbits) { return hbits > PS_CB + 16u ? hbits - 16u : PS_CB; }
@@ -744,6 +738,8 @@ static int ps_launch_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uin
     fmt.sh = packed_sh;
     fmt.k1 = (uint32_t)c->cp.k1;
     const bool packed = packed_sh != 0;
+    // the partitions the fast kernel cannot take go straight to the general kernel's list (round 5: no flags + compaction kernel in
+    // between -- a 256-block launch that, beside the other strand's build, waited 1.4 ms on average for its turn)
     uint32_t *todo = slow + np, *todo_count = todo + np;
     ulonglong2 *head = c->head_ptr;
     const uint32_t hsh = c->head_sh;
@@ -763,7 +759,7 @@ static int ps_launch_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uin
         // 256 x 32: 16.0, 256 x 32 with 2048-bucket rounds: 16.8, 512 x 16 with 2048-bucket rounds: 16.4, 1024 x 8: 13.5.
 #define PFF_LAUNCH(E, TPB, SB, CAP, PK)                                                                                   \
         hipLaunchKernelGGL((k_ps_finish_fast<E, TPB, SB, CAP, PK>), dim3(fgrid), dim3(TPB), 0, c->stream, d_keys, d_vals,  \
-                           pst2, cb, np, d_ent, head, hsh, slow, fmt)
+                           pst2, cb, np, d_ent, head, hsh, todo, todo_count, fmt)
         // (one round of 2^cb <= 8192 buckets; staging area for 6144 entries -- the mean partition holds 0.7 * 8192 -- resp.
         //  8191 where partitions are larger: tables beyond 2^29 buckets)
         if (packed) {
@@ -774,7 +770,6 @@ static int ps_launch_finish(pgrc_match_ctx *c, const uint32_t *d_keys, const uin
             else PFF_LAUNCH(16, 1024, 13, 8191, false);
         }
 #undef PFF_LAUNCH
-        hipLaunchKernelGGL(k_ps_slow_list, dim3((np + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)slow, np, todo, todo_count);
         if (packed) hipLaunchKernelGGL(k_ps_finish<true>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, hsh, (const uint32_t *)todo, (const uint32_t *)todo_count, np, fmt);
         else hipLaunchKernelGGL(k_ps_finish<false>, dim3(ggrid), dim3(PF_TPB), 0, c->stream, d_keys, d_vals, pst2, cb, d_ent, head, hsh, (const uint32_t *)todo, (const uint32_t *)todo_count, np, fmt);
     }
