@@ -54,7 +54,7 @@ struct PgrcOptions {
     bool force_pos64 = false;       // PGRC_FORCE_POS64=1: the 64-bit-position kernels on a small text (tests)
     bool test_no_second_index = false;   // PGRC_TEST_NO_SECOND_INDEX: the second index set "does not fit" (tests)
     bool stream_timing = false;     // PGRC_STREAM_TIMING: milestones of a streamed run on stderr
-    bool host_pack = false;         // PGRC_HOST_PACK=1: an ASCII text is packed by host threads into pinned buffers (default: bytes go up, a kernel packs)
+    bool host_pack = true;          // PGRC_HOST_PACK=0: an ASCII text goes up as bytes and a kernel packs it (rounds 1-4); default: host threads pack it into pinned buffers
     uint32_t host_threads = 0;      // PGRC_HOST_THREADS: host threads that pack the text (0 = up to 8)
     uint32_t stream_blocks_per_cu = 0;   // PGRC_STREAM_GRID: blocks per CU of the dual kernel on the blocks of a streamed run (0 = default)
     uint64_t upload_chunk_mb = 0;   // PGRC_UPLOAD_CHUNK_MB: staging chunk of append_reads_* (0 = 256, or 1024 for a streamed run)
@@ -177,6 +177,8 @@ struct pgrc_match_ctx {
     int st_err = 0;
     std::vector<std::pair<uint64_t, uint64_t>> st_nblocks;   // blocks holding reads with N: downloaded again at the end
     double st_t0 = 0;
+    hipEvent_t st_tbase = nullptr;                           // PGRC_STREAM_TIMING: device times of the blocks' match launches
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> st_tev;
 
     // read-side seed index (modes d / i / e)
     DevBuf s_keys, s_vals, s_tab, s_hits, s_tmp, s_sort;

@@ -14,9 +14,11 @@
 //             stored-position skip, limit = count-1), countSequenceMismatchesVsUnpacked SymbolsPackingFacility.cpp:344-374
 //
 // MI355X design (round 4, its fourth form; the measurements that led here: profiles/r04_seed_scan_experiments.txt).
-//   1. The read-part keys go into an open-addressing table in HBM whose slots own a contiguous RANGE of an entry array (counts by
-//      atomicAdd while inserting, one exclusive scan, one placement pass) -- no chains: what a text window matches is read as a
-//      stream, by any lane.
+//   1. The read-part keys go into an open-addressing table in HBM whose slots own a contiguous RANGE of an entry array -- no chains:
+//      what a text window matches is read as a stream, by any lane.  Round 5: the table is built by SORTING, not by claiming slots
+//      (section 1 below): the (key, entry) pairs are sorted by the key's table order (radix.hip), the sorted entry column IS the entry
+//      array, and the distinct keys take their slots by a prefix maximum -- no atomicCAS, no rank atomics, no scan over the table, and
+//      a slot is ONE 16-byte word {key, first entry | entries << 32}: a window's key test and its range are one gather.
 //   2. ONE scan of the forward text serves both strands (canonical keys, SeedArgs), in two kernels: k_seed_probe finds every
 //      window's range (one 8-byte word per window start); k_seed_expand shares the entries of the windows of its stretch among its
 //      lanes (prefix sums over the range lengths, a binary search per entry), and the windows with many entries -- repeats, tandem
@@ -34,6 +36,7 @@
 
 #include "ctx.h"
 #include "devutil.h"
+#include "scanops.h"
 
 #define SX_EMPTY 0xFFFFFFFFFFFFFFFFull
 
@@ -80,12 +83,13 @@ struct SeedArgs {
     uint32_t mode;             // 'd', 'i', 'e'
     uint32_t kmax, kmin;
     uint64_t ibase;            // first read of the batch (reads / result pointers are already offset; nidx holds set-wide indexes)
-    // the table: slot s holds a key and owns the entries ent[toff[s] .. toff[s + 1])
-    uint64_t *tkeys;
-    uint32_t *toff;            // while inserting: entries per slot; after the scan: first entry of the slot (tsize + 1 words)
+    // the table: slot s = {key in table order (seed_table_key), first entry | entries << 32} owns ent[first .. first + entries);
+    // a key's home slot is the low tbits bits of its mixed form; a lookup walks upwards from there (the table has SX_PAD slots behind
+    // its 2^tbits: no wrap) until it meets the key or an empty slot
+    ulonglong2 *tab;
     uint64_t tmask;
-    uint32_t *eslot, *erank;   // per entry (read, part): its slot (bit 31: the flag below) and its rank among the slot's entries
-    uint32_t *ent;             // entry index | flag << 31, grouped by slot
+    uint32_t tbits;
+    uint32_t *ent;             // entry index | flag << 31, grouped by key
     uint32_t *filter;          // one bit per 2^-fbits of the key space: set iff some indexed key falls there
     uint32_t fshift;           // 64 - fbits: the filter takes the TOP bits of the mixed key, the table its low bits
     // Both strands in ONE scan of the forward text.  A part is indexed under its CANONICAL key: the smaller of the key of the
@@ -113,9 +117,26 @@ __device__ __forceinline__ uint32_t read_code(const SeedArgs &a, uint64_t i, uin
 __device__ __forceinline__ uint32_t ascii_val(uint8_t ch) { return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u; }
 __device__ __forceinline__ uint32_t part_offset(const SeedArgs &a, uint32_t j) { return a.mode == 'i' ? j : j * a.m; }
 
-// ---- 1. the table: every (read, part) entry finds the slot of its canonical key and takes a rank there; the counts become
-// the slots' ranges; the entries go to their places
-__device__ __forceinline__ void table_insert(const SeedArgs &a, uint64_t kf, uint64_t kr, uint32_t e) {
+// ---- 1. the table, built by sorting (round 5; rounds 3-4 claimed slots with atomicCAS and ranks with atomicAdd: two returning
+// random atomics per entry, then a scan over the whole table and a placement pass: 63 of a C3 run's 185 ms in mode d).
+//   keys     every (read, part) entry -> the pair (table key of its canonical key, entry index | flag << 31), in entry order;
+//   sort     the pairs by the key, all 64 bits, stable (radix.hip): equal keys are adjacent, home slots ascend, and the sorted
+//            value column IS the entry array, grouped by key;
+//   place    the distinct keys d = 0, 1, ... in sorted order take the slots  final(d) = max(home(d), final(d - 1) + 1)
+//            = d + max_{j <= d} (home(j) - j):  a prefix MAXIMUM (scanops.h) -- exactly the table that inserting the keys in that
+//            order with linear probing would leave, so a lookup that walks upwards from the home slot until it meets the key or an
+//            empty slot finds every key: all slots between a key's home and its slot are taken by keys with homes no larger.
+// Nothing random is written: the slots are filled in ascending order.
+#define SX_PAD 65536ull                  // slots behind the 2^tbits home slots (a cluster at the very end of the table grows into them)
+
+// the key as the table holds it: the mixed key rotated so that its home slot (its low tbits bits) comes first -- ascending table
+// keys = ascending home slots; all ones is "empty" (the one key that would map there shares the neighbouring value: 2^-64)
+__device__ __forceinline__ uint64_t seed_table_key(uint64_t mixed, uint32_t tbits) {
+    const uint64_t k = (mixed << (64u - tbits)) | (mixed >> tbits);
+    return k == SX_EMPTY ? SX_EMPTY - 1 : k;
+}
+
+__device__ __forceinline__ void seed_pair(const SeedArgs &a, uint64_t kf, uint64_t kr, uint32_t e, uint64_t *__restrict__ keys, uint64_t *__restrict__ vals) {
     const uint64_t key = kr < kf ? kr : kf;                       // canonical (SeedArgs)
     const uint32_t flag = kr < kf ? SX_FLAG : 0u;
     const uint64_t mixed = mix64d(key);
@@ -123,24 +144,16 @@ __device__ __forceinline__ void table_insert(const SeedArgs &a, uint64_t kf, uin
         const uint64_t fb = mixed >> a.fshift;
         atomicOr(&a.filter[fb >> 5], 1u << (fb & 31u));
     }
-    uint64_t slot = mixed & a.tmask;
-    for (;;) {
-        const unsigned long long prev = atomicCAS((unsigned long long *)&a.tkeys[slot], (unsigned long long)SX_EMPTY, (unsigned long long)key);
-        if (prev == SX_EMPTY || prev == key) {
-            a.erank[e] = atomicAdd(&a.toff[slot], 1u);
-            a.eslot[e] = (uint32_t)slot | flag;
-            return;
-        }
-        slot = (slot + 1) & a.tmask;
-    }
+    keys[e] = seed_table_key(mixed, a.tbits);
+    vals[e] = (uint64_t)(e | flag);
 }
 
-__global__ void __launch_bounds__(256) k_seed_insert(const SeedArgs a) {
+__global__ void __launch_bounds__(256) k_seed_keys(const SeedArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict__ vals) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= a.n * a.P) return;
     const uint64_t i = e / a.P;
     const uint32_t j = (uint32_t)(e % a.P);
-    if (a.nflag && a.nflag[i]) return; // byte-path reads are inserted by k_seed_insert_ascii
+    if (a.nflag && a.nflag[i]) return; // the entries of the reads with N come from their ASCII rows (k_seed_keys_ascii)
     const uint32_t off = part_offset(a, j);
     uint32_t h0 = 0, h1 = 0;
     for (uint32_t k = 0; k < a.m; k++) {
@@ -148,10 +161,10 @@ __global__ void __launch_bounds__(256) k_seed_insert(const SeedArgs a) {
         h0 = rotl1(h0) ^ cyc_t0(c);
         h1 = rotl1(h1) ^ cyc_t1(c);
     }
-    table_insert(a, key_fix(h0, h1), key_fix(key_rc32(h0, a.m), key_rc32(h1, a.m)), (uint32_t)e);
+    seed_pair(a, key_fix(h0, h1), key_fix(key_rc32(h0, a.m), key_rc32(h1, a.m)), (uint32_t)e, keys, vals);
 }
 
-__global__ void __launch_bounds__(256) k_seed_insert_ascii(const SeedArgs a) {
+__global__ void __launch_bounds__(256) k_seed_keys_ascii(const SeedArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict__ vals) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= a.nn * a.P) return;
     const uint64_t t = x / a.P;
@@ -165,15 +178,51 @@ __global__ void __launch_bounds__(256) k_seed_insert_ascii(const SeedArgs a) {
         h0 = rotl1(h0) ^ cyc_t0(c);
         h1 = rotl1(h1) ^ cyc_t1(c);
     }
-    table_insert(a, key_fix(h0, h1), key_fix(key_rc32(h0, a.m), key_rc32(h1, a.m)), (uint32_t)(i * a.P + j));
+    seed_pair(a, key_fix(h0, h1), key_fix(key_rc32(h0, a.m), key_rc32(h1, a.m)), (uint32_t)(i * a.P + j), keys, vals);
 }
 
-__global__ void __launch_bounds__(256) k_seed_place(const SeedArgs a, uint64_t nent) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nent) return;
-    const uint32_t w = a.eslot[e];
-    a.ent[a.toff[w & ~SX_FLAG] + a.erank[e]] = (uint32_t)e | (w & SX_FLAG);
+// sorted pairs -> first[i] = 1 where a new key starts, ent[i] = the entry word
+__global__ void __launch_bounds__(256)
+k_seed_mark(const uint64_t *__restrict__ ks, const uint64_t *__restrict__ vs, uint64_t nent, uint32_t *__restrict__ first, uint32_t *__restrict__ ent) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nent; i += (uint64_t)gridDim.x * blockDim.x) {
+        first[i] = (i == 0 || ks[i] != ks[i - 1]) ? 1u : 0u;
+        ent[i] = (uint32_t)vs[i];
+    }
 }
+
+// dnum[i] = distinct keys up to and including i (inclusive scan of first[]): key d = dnum - 1 starts at dstart[d]; its home, as the
+// biased difference home - d that the prefix maximum runs over (hb[] zeroed by the caller beyond the last key: the maximum's identity)
+#define SX_BIAS (1u << 30)
+__global__ void __launch_bounds__(256)
+k_seed_compact(const uint64_t *__restrict__ ks, const uint32_t *__restrict__ first, const uint32_t *__restrict__ dnum, uint64_t nent, uint32_t tbits,
+               uint32_t *__restrict__ dstart, uint32_t *__restrict__ hb, uint32_t *__restrict__ nd_out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nent; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (first[i]) {
+            const uint32_t d = dnum[i] - 1u;
+            dstart[d] = (uint32_t)i;
+            hb[d] = (uint32_t)(ks[i] >> (64u - tbits)) - d + SX_BIAS;        // (home < 2^30, d < 2^30: no wrap)
+        }
+        if (i == nent - 1) {
+            dstart[dnum[i]] = (uint32_t)nent;                                // the end of the last key's range
+            *nd_out = dnum[i];
+        }
+    }
+}
+
+// key d goes to slot d + (prefix maximum of home - j over j <= d)
+__global__ void __launch_bounds__(256)
+k_seed_place(const uint64_t *__restrict__ ks, const uint32_t *__restrict__ dstart, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nd_p,
+             uint64_t tslots, ulonglong2 *__restrict__ tab, uint32_t *__restrict__ ovf) {
+    const uint32_t nd = *nd_p;
+    for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < nd; d += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t slot = d + (uint64_t)pm[d] - SX_BIAS;
+        if (slot >= tslots) { *ovf = 1u; continue; }
+        const uint32_t s0 = dstart[d], s1 = dstart[d + 1];
+        tab[slot] = make_ulonglong2(ks[s0], (uint64_t)s0 | ((uint64_t)(s1 - s0) << 32));
+    }
+}
+
+struct SeedMaxOp { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
 
 // ---- 3. the hits' Hamming counts and what the reference's rule leaves of them
 // reads with N: their packed words hold code 0 at the N positions; a 16-bit mask per word forces those symbols to count
@@ -334,16 +383,17 @@ k_seed_probe(const SeedArgs a, uint64_t wbase, uint64_t nwin, uint64_t pg_words_
             h1 = rotl1(h1) ^ cyc_t1(c);
         }
     const uint32_t mr = m & 31u;
-    uint64_t keyv[SCAN_R], kv[SCAN_R];
+    uint64_t keyv[SCAN_R];                                // the window's canonical key in table order (seed_table_key)
+    ulonglong2 kv[SCAN_R];                                // the slot looked at: {key, first entry | entries << 32}
     uint32_t slotv[SCAN_R], fw[SCAN_R], fbit[SCAN_R];      // (slots: the table has at most 2^31, seedidx_batch)
     uint32_t wflag = 0, pal = 0;                          // per start: the RC key is the canonical one; both keys are equal
 #pragma unroll
     for (int b = 0; b < SCAN_R; b++) {
         const uint64_t kf = key_fix(h0, h1), kr = key_fix(key_rc32(h0, m), key_rc32(h1, m));
-        keyv[b] = kr < kf ? kr : kf;
         wflag |= kr < kf ? 1u << b : 0u;
         pal |= kr == kf ? 1u << b : 0u;
-        const uint64_t mixed = mix64d(keyv[b]);
+        const uint64_t mixed = mix64d(kr < kf ? kr : kf);
+        keyv[b] = seed_table_key(mixed, a.tbits);
         slotv[b] = (uint32_t)(mixed & a.tmask);
         fbit[b] = FILTER ? (uint32_t)((mixed >> a.fshift) & 31u) : 0u;
         fw[b] = FILTER ? (uint32_t)(mixed >> a.fshift >> 5) : 0u;
@@ -364,35 +414,35 @@ k_seed_probe(const SeedArgs a, uint64_t wbase, uint64_t nwin, uint64_t pg_words_
         fw[b] = (worker && t < nwin) ? (FILTER ? a.filter[fw[b]] : 1u) : 0u;
     }
 #pragma unroll
-    for (int b = 0; b < SCAN_R; b++) kv[b] = ((fw[b] >> fbit[b]) & 1u) ? a.tkeys[slotv[b]] : SX_EMPTY;
+    for (int b = 0; b < SCAN_R; b++) kv[b] = ((fw[b] >> fbit[b]) & 1u) ? a.tab[slotv[b]] : make_ulonglong2(SX_EMPTY, 0ull);
     // collisions (the slot holds another key) are resolved together: every round issues the next-slot loads of all starts
     // still searching before any of them is looked at
     uint32_t srch = 0, fnd = 0;
 #pragma unroll
     for (int b = 0; b < SCAN_R; b++) {
-        if (kv[b] == keyv[b]) fnd |= 1u << b;
-        else if (kv[b] != SX_EMPTY) srch |= 1u << b;
+        if (kv[b].x == keyv[b]) fnd |= 1u << b;
+        else if (kv[b].x != SX_EMPTY && kv[b].x < keyv[b]) srch |= 1u << b;      // (keys ascend along a cluster: a larger one ends the search too)
     }
     while (__any(srch != 0)) {
 #pragma unroll
         for (int b = 0; b < SCAN_R; b++)
             if (srch & (1u << b)) {
-                slotv[b] = (uint32_t)((slotv[b] + 1ull) & a.tmask);
-                kv[b] = a.tkeys[slotv[b]];
+                slotv[b] = slotv[b] + 1u;                 // (no wrap: SX_PAD slots lie behind the last home slot, and one of them is empty)
+                kv[b] = a.tab[slotv[b]];
             }
 #pragma unroll
         for (int b = 0; b < SCAN_R; b++)
             if (srch & (1u << b)) {
-                if (kv[b] == SX_EMPTY) srch &= ~(1u << b);
-                else if (kv[b] == keyv[b]) { fnd |= 1u << b; srch &= ~(1u << b); }
+                if (kv[b].x == keyv[b]) { fnd |= 1u << b; srch &= ~(1u << b); }
+                else if (kv[b].x == SX_EMPTY || kv[b].x > keyv[b]) srch &= ~(1u << b);
             }
     }
-    // the ranges of the keys found (two adjacent words), one word per window start
+    // the range of a key found rides in its slot: one word per window start
     uint32_t lo[SCAN_R], hi[SCAN_R];
 #pragma unroll
     for (int b = 0; b < SCAN_R; b++) {
         lo[b] = hi[b] = 0;
-        if (fnd & (1u << b)) { lo[b] = a.toff[slotv[b]]; hi[b] = a.toff[slotv[b] + 1ull]; }
+        if (fnd & (1u << b)) { lo[b] = (uint32_t)kv[b].y; hi[b] = lo[b] + (uint32_t)(kv[b].y >> 32); }
     }
     // (through LDS: a thread's starts are cstride apart -- written directly, a wave's store would touch 64 lines 8 bytes at a time)
 #pragma unroll
@@ -637,11 +687,9 @@ __global__ void __launch_bounds__(256) k_seed_best_store(const SeedArgs a, const
 }
 
 
-__global__ void __launch_bounds__(256) k_seed_table_init(uint64_t *keys, uint32_t *counts, uint64_t n) {
-    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= n; s += (uint64_t)gridDim.x * blockDim.x) {
-        if (s < n) keys[s] = SX_EMPTY;
-        counts[s] = 0u;                                   // (n + 1 words: the scan leaves the number of entries in the last)
-    }
+__global__ void __launch_bounds__(256) k_seed_table_init(ulonglong2 *tab, uint64_t n) {
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (uint64_t)gridDim.x * blockDim.x)
+        tab[s] = make_ulonglong2(SX_EMPTY, 0ull);
 }
 
 
@@ -654,13 +702,16 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
     const uint32_t L = a.L;
     const uint64_t nent = a.n * a.P;
     uint64_t tsize = 1024;
-    while (tsize < 2 * nent) tsize <<= 1;   // (4 / 8 * nent: the exact matcher at C3 12 / 16 % faster, modes d / i unchanged; the filter below does better)
-    const uint64_t nbs = pgrc_ps_scan_blocks(tsize + 1) + 2;
+    uint32_t tbits = 10;
+    while (tsize < 2 * nent) { tsize <<= 1; tbits++; }   // (4 / 8 * nent: the exact matcher at C3 12 / 16 % faster, modes d / i unchanged; the filter below does better)
+    const uint64_t tslots = tsize + SX_PAD;
     int e;
-    if ((e = pgrc_buf_ensure(c, c->s_keys, tsize * sizeof(uint64_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->s_vals, (tsize + 1) * sizeof(uint32_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->s_tab, 3 * nent * sizeof(uint32_t)))) return e;          // slot, rank, place of every entry
-    if ((e = pgrc_buf_ensure(c, c->s_tmp, 64 + nbs * sizeof(uint32_t)))) return e;        // four counters, the scan's block sums
+    // the table; the (key, entry) pairs twice (the sort's ping-pong); per entry: first-of-its-key flag, running number of keys, the
+    // entry array; per distinct key (at most nent): start of its range, home - number (and its prefix maximum)
+    if ((e = pgrc_buf_ensure(c, c->s_keys, tslots * sizeof(ulonglong2)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->s_vals, 4 * nent * sizeof(uint64_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->s_tab, (6 * nent + 8) * sizeof(uint32_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->s_tmp, 128 + sco_scratch_words(nent) * sizeof(uint32_t)))) return e;        // counters, flags, the scans' block folds
     // the filter: 32 bits per indexed key (3 % of the windows of a random text pass it by chance), at most 2^36 bits.  It
     // pays when most windows of the text equal no key -- the exact matcher at C3: 100 M keys against 1.9 G windows, 0.20 ->
     // 0.16 s -- and costs a dependent round trip where many do (modes d / i with four parts per read: 0.42 -> 0.43 s): used
@@ -677,12 +728,12 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
         a.filter = (uint32_t *)c->s_filter.p;
         a.fshift = 64u - (uint32_t)fbits;
     }
-    a.tkeys = (uint64_t *)c->s_keys.p;
-    a.toff = (uint32_t *)c->s_vals.p;
+    a.tab = (ulonglong2 *)c->s_keys.p;
     a.tmask = tsize - 1;
-    a.eslot = (uint32_t *)c->s_tab.p;
-    a.erank = a.eslot + nent;
-    a.ent = a.erank + nent;
+    a.tbits = tbits;
+    uint64_t *kA = (uint64_t *)c->s_vals.p, *kB = kA + nent, *vA = kB + nent, *vB = vA + nent;
+    uint32_t *first = (uint32_t *)c->s_tab.p, *dnum = first + nent, *dstart = dnum + nent, *hb = dstart + nent + 1, *pm = hb + nent;
+    a.ent = pm + nent;
     if (a.nn) {
         if ((e = pgrc_buf_ensure(c, c->s_nmask, a.nn * a.nwr * sizeof(uint16_t)))) return e;
         a.nmask = (const uint16_t *)c->s_nmask.p;
@@ -690,15 +741,25 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
                            a.nwr, (uint16_t *)c->s_nmask.p);
     }
     unsigned long long *counters = (unsigned long long *)c->s_tmp.p;   // [0 / 1] hits of the forward / the RC strand
-    uint32_t *bsum = (uint32_t *)((char *)c->s_tmp.p + 64);
-    HIP_TRY(c, hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(k_seed_table_init, dim3(4096), dim3(256), 0, c->stream, a.tkeys, a.toff, tsize);
-    hipLaunchKernelGGL(k_seed_insert, dim3((uint32_t)((nent + 255) / 256)), dim3(256), 0, c->stream, a);
+    uint32_t *nd_dev = (uint32_t *)((char *)c->s_tmp.p + 64), *ovf_dev = nd_dev + 1;   // distinct keys; "the table ran over"
+    uint32_t *bsum = (uint32_t *)((char *)c->s_tmp.p + 128);
+    HIP_TRY(c, hipMemsetAsync(c->s_tmp.p, 0, 128, c->stream));
+    // 1. the table (section 1): pairs, sort, distinct keys, prefix maximum, placement
+    const uint32_t egrid = (uint32_t)std::min<uint64_t>((nent + 255) / 256, 65536ull * 4);
+    hipLaunchKernelGGL(k_seed_table_init, dim3(8192), dim3(256), 0, c->stream, a.tab, tslots);
+    hipLaunchKernelGGL(k_seed_keys, dim3((uint32_t)((nent + 255) / 256)), dim3(256), 0, c->stream, a, kA, vA);
     if (a.nn)
-        hipLaunchKernelGGL(k_seed_insert_ascii, dim3((uint32_t)((a.nn * a.P + 255) / 256)), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(k_seed_keys_ascii, dim3((uint32_t)((a.nn * a.P + 255) / 256)), dim3(256), 0, c->stream, a, kA, vA);
     HIP_TRY(c, hipGetLastError());
-    if ((e = pgrc_ps_scan_u32(c, a.toff, tsize + 1, bsum))) return e;
-    hipLaunchKernelGGL(k_seed_place, dim3((uint32_t)((nent + 255) / 256)), dim3(256), 0, c->stream, a, nent);
+    uint64_t *ks = nullptr, *vs = nullptr;
+    if ((e = pgrc_radix_sort_pairs_u64(c, kA, kB, vA, vB, nent, 0, 64, c->s_sort, &ks, &vs))) return e;
+    hipLaunchKernelGGL(k_seed_mark, dim3(egrid), dim3(256), 0, c->stream, (const uint64_t *)ks, (const uint64_t *)vs, nent, first, a.ent);
+    HIP_TRY(c, (sco_scan<true>(c->stream, (const uint32_t *)first, dnum, nent, ScoIdentity(), ScoPlus(), 0u, bsum)));
+    HIP_TRY(c, hipMemsetAsync(hb, 0, nent * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_seed_compact, dim3(egrid), dim3(256), 0, c->stream, (const uint64_t *)ks, (const uint32_t *)first, (const uint32_t *)dnum, nent, tbits, dstart, hb, nd_dev);
+    HIP_TRY(c, (sco_scan<true>(c->stream, (const uint32_t *)hb, pm, nent, ScoIdentity(), SeedMaxOp(), 0u, bsum)));
+    hipLaunchKernelGGL(k_seed_place, dim3(egrid), dim3(256), 0, c->stream, (const uint64_t *)ks, (const uint32_t *)dstart, (const uint32_t *)pm, (const uint32_t *)nd_dev, tslots, a.tab, ovf_dev);
+    HIP_TRY(c, hipGetLastError());
 
     // a read's hits become its result by the atomic minimum of section 3b: a start key per read, the batch's reads row by row
     const uint32_t rw = (a.nwr + 3u) & ~3u;                 // <= 16: reads have at most 255 symbols (pgrc_match_create)
@@ -750,8 +811,11 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
     hipLaunchKernelGGL(k_seed_best_store, dim3((uint32_t)((a.n + 255) / 256)), dim3(256), 0, c->stream, a, (const uint64_t *)c->s_best.p);
     HIP_TRY(c, hipGetLastError());
     unsigned long long nh[2] = {0, 0};
+    uint32_t tinfo[2] = {0, 0};
     HIP_TRY(c, hipMemcpyAsync(nh, counters, sizeof nh, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(tinfo, nd_dev, sizeof tinfo, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (tinfo[1]) { c->err = "modes d/i/e: a cluster of keys ran over the end of the table"; return PGRC_E_DEVICE; }
     c->ctr.candidates[0] += nh[0];
     c->ctr.candidates[1] += nh[1];
     for (int pass = first_strand; pass <= last_strand; pass++) c->ctr.searched[pass] += a.n;

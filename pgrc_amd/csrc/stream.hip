@@ -139,6 +139,10 @@ extern "C" int pgrc_match_stream_begin(pgrc_match_ctx *c, uint64_t *pos, uint8_t
     c->st_on = true;
     c->have_results = false;
     c->st_t0 = now_s();
+    if (c->opt.stream_timing) {
+        if (!c->st_tbase) HIP_TRY(c, hipEventCreate(&c->st_tbase));
+        HIP_TRY(c, hipEventRecord(c->st_tbase, c->stream));
+    }
     ST_MARK(c, "stream_begin done");
     return PGRC_OK;
 }
@@ -155,6 +159,12 @@ int pgrc_stream_block_arrived(pgrc_match_ctx *c, uint64_t lo, uint64_t cnt, bool
     c->range_n = cnt;
     c->range_skip_n = true;
     int e;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (c->opt.stream_timing && c->st_tbase) {
+        HIP_TRY(c, hipEventCreate(&t0));
+        HIP_TRY(c, hipEventCreate(&t1));
+        HIP_TRY(c, hipEventRecord(t0, c->stream));
+    }
     if (c->st_dual) {
         e = pgrc_copmem_match_dual(c);                               // active set = strand 1, alternate = strand 0
     } else {
@@ -166,6 +176,10 @@ int pgrc_stream_block_arrived(pgrc_match_ctx *c, uint64_t lo, uint64_t cnt, bool
     c->range_lo = 0;
     c->range_n = ~0ull;
     c->range_skip_n = false;
+    if (t1) {
+        (void)hipEventRecord(t1, c->stream);
+        c->st_tev.emplace_back(t0, t1);
+    }
     if (e) return e;
     hipEvent_t done = nullptr;
     HIP_TRY(c, hipEventCreateWithFlags(&done, hipEventDisableTiming));
@@ -195,7 +209,19 @@ extern "C" int pgrc_match_stream_end(pgrc_match_ctx *c, uint64_t hist[256], uint
         if (!e) e = pgrc_copmem_join_nreads(c);
         c->n_after = nullptr;
     }
-    if (c->opt.stream_timing) { (void)hipStreamSynchronize(c->stream); ST_MARK(c, "all blocks matched, reads with N done"); }
+    if (c->opt.stream_timing) {
+        (void)hipStreamSynchronize(c->stream);
+        ST_MARK(c, "all blocks matched, reads with N done");
+        for (auto &ev : c->st_tev) {                                 // (device clock, from the event recorded in stream_begin)
+            float a = 0, b = 0;
+            (void)hipEventElapsedTime(&a, c->st_tbase, ev.first);
+            (void)hipEventElapsedTime(&b, c->st_tbase, ev.second);
+            fprintf(stderr, "pgrc stream:   a block's match launches on the device: %8.2f .. %8.2f ms after the main stream reached stream_begin's mark\n", a, b);
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        c->st_tev.clear();
+    }
     if (!e) e = pgrc_launch_hist(c);                                 // synchronises the main stream: every block is done
     ST_MARK(c, "histogram done");
     if (!e && c->n_nreads) {
