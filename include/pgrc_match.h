@@ -299,10 +299,10 @@ int pgrc_match_get_redo_flags(pgrc_match_ctx *ctx, uint8_t *flags);
  *     PGRC_MATCH_STAGE=0     the per-strand match kernel without staged refills
  *   index build:  PGRC_INDEX_SORT=sweep|own (front end), PGRC_INDEX_FINISH=general (the general finish kernel for every
  *                 partition), PGRC_INDEX_CFG=0 (the passes without the XCD-aware tile order: A/B runs)
- *   modes d/i/e:  PGRC_SEED_FILTER=0|1, PGRC_SEED_HEAVY=n, PGRC_SEED_READ_BATCH=n, PGRC_SEED_SEGMENT=n, PGRC_SEED_BUILD=n
+ *   modes d/i/e:  PGRC_SEED_FILTER=0|1, PGRC_SEED_HEAVY=n, PGRC_SEED_READ_BATCH=n, PGRC_SEED_SEGMENT=n
  *   hand-over:    PGRC_UPLOAD_CHUNK_MB=n (staging chunk of append_reads_*), PGRC_STREAM_TIMING (milestones on stderr),
- *                 PGRC_HOST_PACK=0 (an ASCII text is packed by a kernel, not on the host), PGRC_HOST_THREADS=n (host threads that
- *                 pack it, default up to 16), PGRC_STREAM_GRID=n (blocks per CU of the dual kernel on the blocks of a streamed run)
+ *                 PGRC_HOST_PACK=0 (an ASCII text goes up as bytes and a kernel packs it; default: host threads pack it
+ *                 into pinned buffers), PGRC_HOST_THREADS=n (those threads, default up to 8)
  *   tests:        PGRC_FORCE_POS64=1, PGRC_TEST_NO_SECOND_INDEX, PGRC_MEM_EVENT_CAP=n, PGRC_ALLGATHER=rccl|copy
  *   process-wide, read once per process: PGRC_DEVICE_POOL_GB (above), PGRC_DEBUG_ALLOC (log every device allocation)
  * pgrc_match_reload_options reads the environment again for a LIVE context (tests and A/B tools that change a variable

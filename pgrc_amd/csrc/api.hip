@@ -142,15 +142,14 @@ PgrcOptions pgrc_options_from_env() {
     o.force_pos64 = flag("PGRC_FORCE_POS64") == 1;
     o.test_no_second_index = getenv("PGRC_TEST_NO_SECOND_INDEX") != nullptr;
     o.stream_timing = getenv("PGRC_STREAM_TIMING") != nullptr;
+    if (num("PGRC_DUAL_NT") >= 0) o.dual_nt = (uint32_t)num("PGRC_DUAL_NT") & 7u;
     o.host_pack = flag("PGRC_HOST_PACK") != 0;
     if (num("PGRC_HOST_THREADS") > 0) o.host_threads = (uint32_t)std::min<long long>(256, num("PGRC_HOST_THREADS"));
-    if (num("PGRC_STREAM_GRID") > 0) o.stream_blocks_per_cu = (uint32_t)std::min<long long>(8, num("PGRC_STREAM_GRID"));
     if (num("PGRC_UPLOAD_CHUNK_MB") > 0) o.upload_chunk_mb = (uint64_t)std::min<long long>(4096, num("PGRC_UPLOAD_CHUNK_MB"));
     o.seed_filter = flag("PGRC_SEED_FILTER");
     if (num("PGRC_SEED_HEAVY") > 0) o.seed_heavy = (uint32_t)std::min<long long>(4096, num("PGRC_SEED_HEAVY"));
     if (num("PGRC_SEED_READ_BATCH") > 0) o.seed_read_batch = (uint64_t)num("PGRC_SEED_READ_BATCH");
     if (num("PGRC_SEED_SEGMENT") > 0) o.seed_segment = (uint64_t)num("PGRC_SEED_SEGMENT");
-    o.seed_build = (int)num("PGRC_SEED_BUILD");
     if (num("PGRC_MEM_EVENT_CAP") > 0) o.mem_event_cap = (uint64_t)num("PGRC_MEM_EVENT_CAP");
     if (const char *ag = getenv("PGRC_ALLGATHER")) o.allgather = !strcmp(ag, "rccl") ? 1 : !strcmp(ag, "copy") ? 2 : 0;
     o.dual_variant = (int)num("PGRC_DUAL_VARIANT");
@@ -345,6 +344,7 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
     pgrc_buf_free(c->up_flag);
     pgrc_buf_free(c->up_lidx);
     if (c->st_ready) (void)hipEventDestroy(c->st_ready);
+    if (c->st_tbase) (void)hipEventDestroy(c->st_tbase);
     if (c->side_stream) {
         (void)hipStreamDestroy(c->side_stream);
         (void)hipEventDestroy(c->side_ev[0]);
@@ -604,6 +604,7 @@ int pgrc_match_begin_reads(pgrc_match_ctx *c, uint64_t n) {
     HIP_TRY(c, hipMemsetAsync(c->nread_flag.p, 0, n ? n : 1, c->up_stream[0]));
     HIP_TRY(c, hipStreamSynchronize(c->up_stream[0]));
     c->up_next = 0;
+    c->up_chunk = 0;
     c->up_nidx.clear();
     c->up_nmany = 0;
     for (DevBuf &b : c->up_nchunks) pgrc_buf_free(b);

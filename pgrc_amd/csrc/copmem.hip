@@ -813,11 +813,8 @@ int pgrc_copmem_match_dual_r04(pgrc_match_ctx *c);    // tools/variants/dual_r04
 template <int NW, int WAVES>
 static void launch_dual_w(pgrc_match_ctx *c, const DualArgs &a) {
     const uint64_t want = (a.n + MATCH_TPB - 1) / MATCH_TPB;
-    // A persistent grid: more blocks than fit (six per CU at 150 bp) simply queue.  On the blocks of a STREAMED run (stream.hip) the
-    // grid leaves a wave slot per SIMD free (five blocks per CU): the upload side's small kernels -- unpacking the next chunk, the
-    // rows of the reads with N -- otherwise wait for a whole launch of this kernel to end before they get a CU
-    // (PGRC_STREAM_GRID = blocks per CU; profiles/r05_boundary_stream_grid_ab.txt).
-    const uint32_t per_cu = (c->st_on && c->range_n != ~0ull) ? (c->opt.stream_blocks_per_cu ? c->opt.stream_blocks_per_cu : 8u) : 8u;
+    // A persistent grid: more blocks than fit (six per CU at 150 bp) simply queue.
+    const uint32_t per_cu = 8u;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)c->num_cus * per_cu);
     const bool pos64 = c->G + 256 >= (1ull << 32) || c->opt.force_pos64;
     const bool k28 = a.K == 28;
@@ -879,6 +876,7 @@ int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     a.k2 = (uint32_t)c->cp.k2;
     a.mask = c->cp.hash_size - 1;
     a.kmax = c->prm.max_mismatches;
+    a.nt = c->opt.dual_nt;
     switch (c->nw) {
 #define CASE_NW(N) case N: launch_dual<N>(c, a); break;
         CASE_NW(2) CASE_NW(3) CASE_NW(4) CASE_NW(5) CASE_NW(6) CASE_NW(7) CASE_NW(8) CASE_NW(9)

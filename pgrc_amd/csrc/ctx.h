@@ -54,15 +54,14 @@ struct PgrcOptions {
     bool force_pos64 = false;       // PGRC_FORCE_POS64=1: the 64-bit-position kernels on a small text (tests)
     bool test_no_second_index = false;   // PGRC_TEST_NO_SECOND_INDEX: the second index set "does not fit" (tests)
     bool stream_timing = false;     // PGRC_STREAM_TIMING: milestones of a streamed run on stderr
+    uint32_t dual_nt = 0;           // PGRC_DUAL_NT: bit 0 / 1 / 2 = the dual kernel loads heads / entries / text windows with the non-temporal hint
     bool host_pack = true;          // PGRC_HOST_PACK=0: an ASCII text goes up as bytes and a kernel packs it (rounds 1-4); default: host threads pack it into pinned buffers
     uint32_t host_threads = 0;      // PGRC_HOST_THREADS: host threads that pack the text (0 = up to 8)
-    uint32_t stream_blocks_per_cu = 0;   // PGRC_STREAM_GRID: blocks per CU of the dual kernel on the blocks of a streamed run (0 = default)
     uint64_t upload_chunk_mb = 0;   // PGRC_UPLOAD_CHUNK_MB: staging chunk of append_reads_* (0 = 256, or 1024 for a streamed run)
     int seed_filter = -1;           // PGRC_SEED_FILTER  modes d/i/e: -1 where it pays, 0 never, 1 always
     uint32_t seed_heavy = 0;        // PGRC_SEED_HEAVY   modes d/i/e: entries of a window above which the persistent grid expands it (0 = default)
     uint64_t seed_read_batch = 0;   // PGRC_SEED_READ_BATCH / PGRC_SEED_SEGMENT: reads per batch / window starts per launch (tests; 0 = default)
     uint64_t seed_segment = 0;
-    int seed_build = -1;            // PGRC_SEED_BUILD   modes d/i/e: how the table is built (A/B runs; -1 = default)
     uint64_t mem_event_cap = 0;     // PGRC_MEM_EVENT_CAP: first guess of the Pg-vs-Pg matcher's event buffer (tests; 0 = default)
     int allgather = 0;              // PGRC_ALLGATHER    multi-device contexts: 0 by device list, 1 "rccl", 2 "copy" (tests)
     int dual_variant = -1;          // PGRC_DUAL_VARIANT which build of the dual kernel runs (A/B builds only; -1 = default)

@@ -118,6 +118,10 @@ extern "C" int pgrc_match_stream_begin(pgrc_match_ctx *c, uint64_t *pos, uint8_t
     memset(&c->ctr, 0, sizeof c->ctr);
     if (!c->st_ready) HIP_TRY(c, hipEventCreateWithFlags(&c->st_ready, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->st_ready, c->stream));              // both indexes built, per-read state initialised
+    // (Round 5, tried and dropped, profiles/r05_boundary_stream_variants.txt: the blocks' launches on two streams in turn, so that
+    //  one block's launch fills the CUs while the previous one drains -- no gain, the two launches slow each other down; one CU per
+    //  XCD masked out of the match stream for the upload side's kernels -- 10 % slower; a first block of a quarter of the size -- the
+    //  first copy's blit kernels wait for the index builds anyway; five blocks per CU instead of eight -- no difference.)
     // (Tried and dropped: the blocks' match kernels on a CU-masked stream that leaves two CUs per XCD to the small kernels of
     //  the upload side, which otherwise wait for a persistent launch to end -- the whole job was 2 % slower, A/B in one process.)
     for (int k = 0; k < 2; k++) {
