@@ -805,6 +805,7 @@ __global__ void __launch_bounds__(NREAD_TPB) k_copmem_match_n(const NReadArgs a)
 
 #ifdef PGRC_AB_DUAL
 int pgrc_copmem_match_dual_r04(pgrc_match_ctx *c);    // tools/variants/dual_r04.hip: round 4's kernel, for in-context A/B runs
+#include "../../tools/variants/dualkern_r05a.h"       // round 5's kernel before the VALU diet (PGRC_DUAL_VARIANT=5)
 #endif
 #ifndef DUAL_WAVES
 #define DUAL_WAVES 6             // waves per SIMD the dual kernel is built for at read lengths up to 160 (NW <= 10)
@@ -830,8 +831,13 @@ static void launch_dual_w(pgrc_match_ctx *c, const DualArgs &a) {
 template <int NW>
 static void launch_dual(pgrc_match_ctx *c, const DualArgs &a) {
 #ifdef PGRC_AB_DUAL
-    // A/B builds carry the same kernel at five waves per SIMD too (PGRC_DUAL_VARIANT=5) -- for 100 / 150 bp reads only
-    if (c->opt.dual_variant == 5 && (NW == 7 || NW == 10)) { launch_dual_w<(NW == 7 || NW == 10) ? NW : 10, 5>(c, a); return; }
+    // A/B builds carry round 5's first kernel too (PGRC_DUAL_VARIANT=5) -- 100 / 150 bp reads, K = 28, 32-bit positions only
+    if (c->opt.dual_variant == 5 && (NW == 7 || NW == 10) && a.K == 28 && !(c->G + 256 >= (1ull << 32) || c->opt.force_pos64)) {
+        const uint64_t want = (a.n + MATCH_TPB - 1) / MATCH_TPB;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)c->num_cus * 8u);
+        hipLaunchKernelGGL((k_copmem_match_dual_r05a<(NW == 7 || NW == 10) ? NW : 10, 7, false, 6>), dim3(grid), dim3(MATCH_TPB), 0, c->stream, a);
+        return;
+    }
 #endif
     launch_dual_w<NW, (NW <= 10 ? DUAL_WAVES : 4)>(c, a);
 }
@@ -876,7 +882,6 @@ int pgrc_copmem_match_dual(pgrc_match_ctx *c) {
     a.k2 = (uint32_t)c->cp.k2;
     a.mask = c->cp.hash_size - 1;
     a.kmax = c->prm.max_mismatches;
-    a.nt = c->opt.dual_nt;
     switch (c->nw) {
 #define CASE_NW(N) case N: launch_dual<N>(c, a); break;
         CASE_NW(2) CASE_NW(3) CASE_NW(4) CASE_NW(5) CASE_NW(6) CASE_NW(7) CASE_NW(8) CASE_NW(9)

@@ -1,71 +1,13 @@
-// dualkern.h -- the dual kernel of mode c: ONE query per read over both strands' indexes (included by copmem.hip).
-//
-// Reference behaviour restated (not translated): CopMEMMatcher::processApproxMatchQueryTight, matching/copmem/
-// CopMEMMatcher.cpp:483-566, run by CopMEMReadsApproxMatcher::executeMatching (matching/ReadsMatchers.cpp:421-451) once on the
-// text and once on its reverse complement (DefaultReadsMatcher::matchConstantLengthReads, :162-172).
-//
-// A two-pass run (min_mismatches == 0) as ONE query per read over both strands' indexes.  A read window hashes to the same
-// bucket number in both tables, so every seed probes the forward and the RC head together (the pair table puts them into one
-// 128-byte line: one request); the forward bucket's entries are judged first, then the RC bucket's.  Each strand is a query
-// of its own whose limit is additionally capped by what the other strand has found -- forward by the RC count (a forward
-// alignment only matters if it is at least as good), RC by the forward count - 1 (it must be strictly better) -- and each
-// stops by the early-stop rule against its capped limit.  Why the result is the reference's (all forward seeds, then all RC
-// seeds): a query under ANY sequence of limits that never falls below the smallest count m_min among its candidates accepts
-// the FIRST candidate with m_min and nothing after it, which is the reference's final alignment; the caps never fall below
-// the counts that still matter.  All of it presupposes that no run would have cut a bucket by the falses budget: U bounds the
-// falses of any run over the candidates seen so far (1 for a candidate whose head count -- or already its fingerprint --
-// exceeds the starting limit or whose tail is clean, else 2); U > budget when a bucket of more than 4 entries is opened (a
-// bucket of at most 4 is the same bucket whatever the falses count: CopMEMMatcher.cpp:510-514) -> the lane does that read
-// again in the reference's order, right here (F_SEQ: the real forward query with its falses count and bucket truncation,
-// then the real RC query from its result) -- hidden behind the other lanes.  oracle/pgrc_oracle.c restates the scheme
-// (pgrc_or_match_copmem_dual); tests/test_early_stop_rule.py expects it to equal the reference's two passes on every input.
-//
-// Round 5: the per-read state machine on a register diet, so that SIX waves per SIMD are resident (80 registers; round 4: 96
-// and five waves).  What went: the shifting copy of the read (10 registers at L = 150: a seed's window is now cut out of the
-// read's LDS copy -- three ds_read_b32 and two alignbits -- and nothing is shifted when a lane moves to its next seed); the
-// per-read counters, which now share five registers (`sr`, `cc`, `uu`, `ll`, `jn` below: every field is read with one v_bfe);
-// the speculative first attempt, the redo rule and the hand-out direction as run-time parameters (measured in round 4, kept
-// in DESIGN.md's appendix of dead ends).  16 staged reads per wave instead of 32 keep a block at 26.1 KB of LDS: six blocks
-// per CU.
+// dualkern_r05a.h -- A/B builds only (make -C pgrc_amd/csrc AB_DUAL=1): the dual kernel as it was at commit 143e9af (round 5,
+// six waves, before the VALU diet), so that the current kernel can be measured against it IN ONE CONTEXT
+// (PGRC_DUAL_VARIANT=5, 100 / 150 bp reads, K = 28, 32-bit positions; tools/ab_match.py).  Not part of the product library.
+// Restates CopMEMMatcher::processApproxMatchQueryTight (matching/copmem/CopMEMMatcher.cpp:483-566) as dualkern.h does.
 #pragma once
-
-#include "ctx.h"
-#include "matchdev.h"
-
-struct DualArgs {
-    const uint32_t *pg[2];        // packed text, forward and reverse complement
-    uint64_t G;
-    const uint32_t *reads;
-    uint64_t n, stride;
-    const uint8_t *nflag;         // reads with N: 1 = the byte path of the ordinary passes, 3 = taken here, its N positions in npos
-    const uint32_t *npos;         // (ctx.h nread_npos; nullptr: every flagged read goes the byte path)
-    const ulonglong2 *head[2];    // head of bucket h of strand x at head[x][head_slot(h, hsh)] (headfmt.h); the pair table: the two
-    uint32_t hsh;                 // heads of a bucket number share a line (one line request and one translation for both gathers)
-    const uint64_t *ent[2];
-    uint64_t *pos;
-    uint8_t *rc;
-    uint8_t *mism;
-    unsigned long long *counters; // [0] searched [1] candidates [2] heads probed [3] entry fetches [4] verifies [5] redo [6] seeds probed
-    unsigned long long *work;
-    uint8_t *redo_flag;           // per read: 2 = done again in the reference's order (F_SEQ); introspection only
-    uint32_t L, K, k1, k2, mask, kmax;
-    uint32_t chunk;               // reads a wave reserves per visit to the work counter (pgrc_match_chunk)
-};
-
-// reads a wave stages in LDS per burst of full-line loads: 16 at six waves per SIMD (LDS for six blocks per CU), else 32
-template <int WAVES> struct DualStage { static constexpr int SW = WAVES >= 6 ? 16 : 32; };
-
-// 16-byte gathers with the non-temporal hint (global_load_dwordx4 ... nt): the same 128-byte line request, 11 % more of them per second
-// on random lines (tools/ubench/gather_modes.hip, profiles/r05_ubench_gather_modes.txt)
-typedef unsigned long long dk_v2u64 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ ulonglong2 dk_ld_nt(const ulonglong2 *p) {
-    const dk_v2u64 v = __builtin_nontemporal_load(reinterpret_cast<const dk_v2u64 *>(p));
-    return make_ulonglong2(v.x, v.y);
-}
+#include "dualkern.h"
 
 template <int NW, int KQ, bool POS64, int WAVES>
 __global__ void __launch_bounds__(MATCH_TPB) __attribute__((amdgpu_waves_per_eu(WAVES)))
-k_copmem_match_dual(const DualArgs a) {
+k_copmem_match_dual_r05a(const DualArgs a) {
     typedef typename std::conditional<POS64, uint64_t, uint32_t>::type pos_t;
     constexpr pos_t POS_NONE = (pos_t)~(pos_t)0;
     constexpr uint32_t EPOCH_BITS = POS64 ? 12u : 14u;   // the verify cache's tag: epoch | strand | (POS64: position bits 32..39)
@@ -234,9 +176,8 @@ k_copmem_match_dual(const DualArgs a) {
             else
                 h = hash_fp_window<KQ>(w[0], w[1], w[2], w[3], a.K, lut, &fp_read) & a.mask;
             ulonglong2 hr = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
-            // (the non-temporal hint: in-context A/B 63.4 -> 62.6 ms at C3; on the entry pairs it costs 1 %, on the text windows nothing)
-            if (fl & F_ACT0) hdF = dk_ld_nt(&a.head[0][head_slot(h, a.hsh)]);
-            if (fl & F_ACT1) hr = dk_ld_nt(&a.head[1][head_slot(h, a.hsh)]);
+            if (fl & F_ACT0) hdF = a.head[0][head_slot(h, a.hsh)];
+            if (fl & F_ACT1) hr = a.head[1][head_slot(h, a.hsh)];
             hdR_lds[threadIdx.x] = hr;
             nprobe_it = ((fl & F_ACT0) ? 1u : 0u) + ((fl & F_ACT1) ? 1u : 0u);
         } else if (m0 == M_ENTRY) {
@@ -252,19 +193,92 @@ k_copmem_match_dual(const DualArgs a) {
                 counted_ent = true;
             }
         }
-        // ---- consume.  What a lane does with this iteration's load is a short chain -- open a bucket -> look at an entry ->
-        // judge a verified alignment -> what follows -- and its mode says at which link it enters.  The chain runs at most
-        // twice: a forward bucket that ends in this iteration hands over to the RC head of the same seed.  Every link is ONE
-        // piece of code.  (Up to round 5a the links were lambdas inlined at every call site -- three copies of the entry
-        // link, four of the judge -- and every copy ran in every iteration for the few lanes that needed it: the kernel is
-        // bound by the VALU instructions it issues, 95 % of the SIMD cycles, not by its memory requests.)
+        // ---- consume
         uint32_t next = m0;
         bool bdone = false;           // the current strand's bucket is finished
-        bool op = false, tp = false, jp = false;                     // pending: a bucket to open, an entry to look at, an alignment to judge
-        ulonglong2 oh = make_ulonglong2(HEAD_EMPTY, HEAD_EMPTY);
-        uint64_t te = 0;
-        uint32_t jmh = 0, jmt = 0;
-        pos_t jpos = 0;
+        // a verified alignment of the current strand (head count mh, tail count mt)
+        auto judge = [&](uint32_t mh, uint32_t mt, pos_t p) {
+            const uint32_t x = DK_X();
+            const int m = (int)(mh + mt);
+            uint32_t u;
+            if (fl & F_SEQ) {                                        // the real count of CopMEMMatcher.cpp:536-551
+                const int lm = eff(x);
+                u = ((int)mh > lm) ? 1u : (m > lm) ? 2u : 0u;
+            } else {
+                // what any run can count for this candidate: 1 if the head alone exceeds every limit a run can have, or if
+                // the tail is clean (then it is a head reject or an acceptance), else 2 (a tail reject is counted twice)
+                u = ((int)mh > DK_L0() || mt == 0u) ? 1u : 2u;
+            }
+            uu += u << (16u * x);
+            if (m > eff(x)) return;
+            set_cur(x, (uint32_t)m);
+            set_lim(x, m - 1);
+            if (x == 0u) { best0 = p; fl |= F_FOUND0; }
+            else { best1 = p; fl |= F_FOUND1; }
+            if (m == 0) {                                            // m <= min_mismatches: this strand's query returns
+                fl &= ~(x == 0u ? (uint32_t)F_ACT0 : (uint32_t)F_ACT1);
+                if (x == 0u) fl |= F_FWDEXACT;                       // ... and the RC pass would skip the read
+            }
+        };
+        // what follows an examined entry
+        auto after_entry = [&]() {
+            if (fl & F_FWDEXACT) next = M_NEED;
+            else if (!(fl & (DK_X() == 0u ? (uint32_t)F_ACT0 : (uint32_t)F_ACT1))) bdone = true;   // an exact RC alignment: that query is over
+            else if (DK_J() < DK_NB()) next = M_ENTRY;
+            else bdone = true;
+        };
+        auto take_entry = [&](const uint64_t e) {
+            const uint32_t x = DK_X(), si = DK_SI();
+            const uint32_t s = si * a.k2;
+            const uint64_t sp = e >> PGRC_FP_BITS;
+            if ((uint64_t)s <= sp && sp - s + a.L <= a.G) {          // :517-520
+                ncand_it++;
+                const pos_t p = (pos_t)(sp - s);
+                const uint32_t xr = ((uint32_t)e ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
+                const int fpc = __popc((xr | (xr >> 1)) & fpm_tab[si]);   // a lower bound of the head count
+                if (fpc > eff(x)) {
+                    const uint32_t u = ((fl & F_SEQ) || fpc > DK_L0()) ? 1u : 2u;   // (sequential: a certain head reject)
+                    uu += u << (16u * x);
+                } else {
+                    const uint32_t epoch = DK_EPOCH();
+                    const uint2 cv = vcache[((uint32_t)p * 0x9E3779B1u + x) >> (32 - VC_BITS)][threadIdx.x];
+                    const bool hit = POS64 ? (cv.x == (uint32_t)p && (cv.y >> 20) == epoch && ((cv.y >> 19) & 1u) == x &&
+                                              ((cv.y >> 11) & 0xFFu) == (uint32_t)((uint64_t)p >> 32))
+                                           : (cv.x == (uint32_t)p && (cv.y >> 17) == epoch && ((cv.y >> 16) & 1u) == x);
+                    if (hit) judge(cv.y & 0xFFu, (cv.y >> 8) & (POS64 ? 0x7u : 0xFFu), p);
+                    else {
+                        cand_p = p;
+                        next = M_VERIFY;
+                        return;
+                    }
+                }
+            }
+            after_entry();
+        };
+        // open the bucket of strand x for the current seed
+        auto open_bucket = [&](const ulonglong2 hx) {
+            const uint32_t x = DK_X();
+            const uint32_t cnt = head_count(hx);
+            if (!cnt) {
+                bdone = true;
+                return;
+            }
+            // some run could have cut THIS bucket to its first 4 entries by now (:510-514 -- all the budget ever does; a bucket
+            // of at most 4 is the same bucket whatever the falses count): not decidable this way -> the read again, in the
+            // reference's order
+            if (!(fl & F_SEQ) && DK_U(x) > budget && cnt > PGRC_TRUNC_BUCKET) {
+                fl |= F_REDO;
+                next = M_NEED;
+                return;
+            }
+            uint32_t nb = cnt;
+            if ((fl & F_SEQ) && DK_U(x) > budget) nb = min(nb, PGRC_TRUNC_BUCKET);   // :510-514
+            if (DK_RQ() < a.k1 && (cnt >= PGRC_BUCKET_CAP || nb < cnt)) fl |= (x == 0u ? (uint32_t)F_DIRTY0 : (uint32_t)F_DIRTY1);
+            pend_e = hx.y;
+            lo = (pos_t)(hx.y & W1_BASE_MASK);
+            jn = 1u | (nb << 4) | (x << 8) | ((cnt == 2 && nb > 1) ? 1u << 9 : 0u);    // j = 1; entry 1 of a two-entry bucket sits in the head
+            take_entry(hx.x & ENT_MASK);
+        };
         if (m0 == M_VERIFY) {
             const uint32_t x = DK_X();
             uint32_t pw[PWN];
@@ -290,146 +304,33 @@ k_copmem_match_dual(const DualArgs a) {
                     mt += (uint32_t)__popc(d & sym_mask(k, H, (int)a.L));
                 }
             } else {
-                // all differing symbols in one running count; the tail (symbols H .. L - 1, fewer than 8: H = 8 * (L / 8), and
-                // 16 (NW - 1) < L <= 16 NW) lies inside the read's LAST word
-                uint32_t tot = 0, dl = 0;
 #pragma unroll
                 for (int k = 0; k < NW; k++) {
-                    const uint32_t xr = funnel_r(pw[k], pw[k + 1], b) ^ rd_lds[k][threadIdx.x];
-                    const uint32_t d = (xr | (xr >> 1)) & (k < NW - 1 ? 0x55555555u : sym_mask(NW - 1, 0, (int)a.L));
-                    tot += (uint32_t)__popc(d);
-                    if (k == NW - 1) dl = d;
+                    const uint32_t tw = funnel_r(pw[k], pw[k + 1], b);
+                    const uint32_t rw = rd_lds[k][threadIdx.x];
+                    mh += mism2(tw, rw, sym_mask(k, 0, H));
+                    mt += mism2(tw, rw, sym_mask(k, H, (int)a.L));
                 }
-                mt = (uint32_t)__popc(dl & sym_mask(NW - 1, H, (int)a.L));
-                mh = tot - mt;
             }
             const uint32_t epoch = DK_EPOCH();
             vcache[((uint32_t)cand_p * 0x9E3779B1u + x) >> (32 - VC_BITS)][threadIdx.x] =
                 make_uint2((uint32_t)cand_p, POS64 ? (mh | (mt << 8) | ((uint32_t)((uint64_t)cand_p >> 32) << 11) | (x << 19) | (epoch << 20))
                                                    : (mh | (mt << 8) | (x << 16) | (epoch << 17)));
-            jmh = mh;
-            jmt = mt;
-            jpos = cand_p;
-            jp = true;
+            judge(mh, mt, cand_p);
+            after_entry();
         } else if (m0 == M_ENTRY) {
             jn++;                                                    // j++ (j <= 13: no carry into nb)
-            te = v;
-            tp = true;
+            take_entry(v);
         } else if (m0 == M_PROBE) {
             const uint32_t x = (fl & F_ACT0) ? 0u : 1u;
             jn = x << 8;
-            oh = x == 0u ? hdF : hdR_lds[threadIdx.x];
-            op = true;
+            open_bucket(x == 0u ? hdF : hdR_lds[threadIdx.x]);
         }
-#pragma nounroll
-        for (int trip = 0; trip < 2; trip++) {
-            if (op) {                                                // open the bucket of strand x for the current seed
-                op = false;
-                const uint32_t x = DK_X();
-                const uint32_t cnt = head_count(oh);
-                if (!cnt) {
-                    bdone = true;
-                } else if (!(fl & F_SEQ) && DK_U(x) > budget && cnt > PGRC_TRUNC_BUCKET) {
-                    // some run could have cut THIS bucket to its first 4 entries by now (:510-514 -- all the budget ever does; a
-                    // bucket of at most 4 is the same bucket whatever the falses count): not decidable this way -> the read again,
-                    // in the reference's order
-                    fl |= F_REDO;
-                    next = M_NEED;
-                } else {
-                    uint32_t nb = cnt;
-                    if ((fl & F_SEQ) && DK_U(x) > budget) nb = min(nb, PGRC_TRUNC_BUCKET);   // :510-514
-                    if (DK_RQ() < a.k1 && (cnt >= PGRC_BUCKET_CAP || nb < cnt)) fl |= (x == 0u ? (uint32_t)F_DIRTY0 : (uint32_t)F_DIRTY1);
-                    pend_e = oh.y;
-                    lo = (pos_t)(oh.y & W1_BASE_MASK);
-                    jn = 1u | (nb << 4) | (x << 8) | ((cnt == 2 && nb > 1) ? 1u << 9 : 0u);    // j = 1; entry 1 of a two-entry bucket sits in the head
-                    te = oh.x & ENT_MASK;
-                    tp = true;
-                }
-            }
-            bool ap = false;                                         // an entry was examined: what follows it
-            if (tp) {                                                // an entry of the current strand's bucket
-                tp = false;
-                ap = true;
-                const uint32_t x = DK_X(), si = DK_SI();
-                const uint32_t s = si * a.k2;
-                bool inside;                                         // :517-520
-                pos_t p;
-                if (POS64) {
-                    const uint64_t sp = te >> PGRC_FP_BITS;
-                    inside = (uint64_t)s <= sp && sp - s + a.L <= a.G;
-                    p = (pos_t)(sp - s);
-                } else {                                             // (G + 256 < 2^32: positions, and position + L, fit 32 bits)
-                    const uint32_t sp = (uint32_t)(te >> PGRC_FP_BITS);
-                    inside = s <= sp && sp - s + a.L <= (uint32_t)a.G;
-                    p = (pos_t)(sp - s);
-                }
-                if (inside) {
-                    ncand_it++;
-                    const uint32_t xr = ((uint32_t)te ^ fp_read) & ((1u << PGRC_FP_BITS) - 1u);
-                    const int fpc = __popc((xr | (xr >> 1)) & fpm_tab[si]);   // a lower bound of the head count
-                    if (fpc > eff(x)) {
-                        const uint32_t u = ((fl & F_SEQ) || fpc > DK_L0()) ? 1u : 2u;   // (sequential: a certain head reject)
-                        uu += u << (16u * x);
-                    } else {
-                        const uint32_t epoch = DK_EPOCH();
-                        const uint2 cv = vcache[((uint32_t)p * 0x9E3779B1u + x) >> (32 - VC_BITS)][threadIdx.x];
-                        const bool hit = POS64 ? (cv.x == (uint32_t)p && (cv.y >> 20) == epoch && ((cv.y >> 19) & 1u) == x &&
-                                                  ((cv.y >> 11) & 0xFFu) == (uint32_t)((uint64_t)p >> 32))
-                                               : (cv.x == (uint32_t)p && (cv.y >> 17) == epoch && ((cv.y >> 16) & 1u) == x);
-                        if (hit) {
-                            jmh = cv.y & 0xFFu;
-                            jmt = (cv.y >> 8) & (POS64 ? 0x7u : 0xFFu);
-                            jpos = p;
-                            jp = true;
-                        } else {
-                            cand_p = p;
-                            next = M_VERIFY;
-                            ap = false;
-                        }
-                    }
-                }
-            }
-            if (jp) {                                                // a verified alignment of the current strand (head count jmh, tail count jmt)
-                jp = false;
-                ap = true;
-                const uint32_t x = DK_X();
-                const int m = (int)(jmh + jmt);
-                uint32_t u;
-                if (fl & F_SEQ) {                                    // the real count of CopMEMMatcher.cpp:536-551
-                    const int lm = eff(x);
-                    u = ((int)jmh > lm) ? 1u : (m > lm) ? 2u : 0u;
-                } else {
-                    // what any run can count for this candidate: 1 if the head alone exceeds every limit a run can have, or if
-                    // the tail is clean (then it is a head reject or an acceptance), else 2 (a tail reject is counted twice)
-                    u = ((int)jmh > DK_L0() || jmt == 0u) ? 1u : 2u;
-                }
-                uu += u << (16u * x);
-                if (m <= eff(x)) {
-                    set_cur(x, (uint32_t)m);
-                    set_lim(x, m - 1);
-                    if (x == 0u) { best0 = jpos; fl |= F_FOUND0; }
-                    else { best1 = jpos; fl |= F_FOUND1; }
-                    if (m == 0) {                                    // m <= min_mismatches: this strand's query returns
-                        fl &= ~(x == 0u ? (uint32_t)F_ACT0 : (uint32_t)F_ACT1);
-                        if (x == 0u) fl |= F_FWDEXACT;               // ... and the RC pass would skip the read
-                    }
-                }
-            }
-            if (ap) {                                                // what follows an examined entry
-                if (fl & F_FWDEXACT) next = M_NEED;
-                else if (!(fl & (DK_X() == 0u ? (uint32_t)F_ACT0 : (uint32_t)F_ACT1))) bdone = true;   // an exact RC alignment: that query is over
-                else if (DK_J() < DK_NB()) next = M_ENTRY;
-                else bdone = true;
-            }
-            // the forward bucket is done: the RC head of the same seed waits in LDS
-            const bool chain = bdone && DK_X() == 0u && (fl & F_ACT1);
-            if (!__any(chain)) break;
-            if (chain) {
-                bdone = false;
-                jn = 1u << 8;
-                oh = hdR_lds[threadIdx.x];
-                op = true;
-            }
+        // the forward bucket is done: the RC head of the same seed waits in LDS
+        if (bdone && DK_X() == 0u && (fl & F_ACT1)) {
+            bdone = false;
+            jn = 1u << 8;
+            open_bucket(hdR_lds[threadIdx.x]);
         }
         if (bdone) next = M_ADV;
         if (next == M_ADV) {                                         // to the next seed
