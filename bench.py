@@ -294,9 +294,9 @@ def main():
                        "copmem": cp, "matched_fraction": matched / n_per,
                        "parallelism": f"reads sharded x{world}, Pg replicated" + (" (1 all-gather/step)" if world > 1 else "")},
             # `bound` keeps to the two values the bench contract knows: the kernel is priced against the HBM byte roofline
-            # (`frac`, SURVEY 8d bytes).  What it actually runs into is named in `binding_limit`: the rate of random 64-B line
-            # requests / address translations (`gather_frac`), which caps any hash-probe design at 12.5-25 % of the byte roofline.
-            "roofline": {"bound": "hbm", "binding_limit": "random 128-B line requests / address translations and, since the pair table, the number of requests the resident lanes keep in flight (not HBM bytes)",
+            # (`frac`, SURVEY 8d bytes).  What it actually runs into is named in `binding_limit`: its memory waits -- random 128-B
+            # line requests at 0.77 of the rate the chip serves them (`gather_frac`), one per lane in flight (profiles/r05_dual_sq_counters.txt).
+            "roofline": {"bound": "hbm", "binding_limit": "memory waits: random 128-B line requests (a 16-byte head costs a line), one per lane in flight at six waves per SIMD; waves wait for a memory counter 59 % of their time, VALU issue 78 % busy (profiles/r05_dual_sq_counters.txt)",
                          "index": dict(index_roofline(ctr, cp, G, n_strands=2), traffic=(2 * index_traffic if index_traffic else None),
                                        traffic_note="HBM bytes of both strands' builds from the same committed PMC passes as `traffic`"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -311,7 +311,7 @@ def main():
                          "match_launches_mean_ms": (ctr["ms_screen"] + sum(ctr["ms_match"])) / (3 if ctr["screened"] else 2),
                          "kernel_bytes": kernel_bytes, "achieved_kernel_bytes": kernel_gbs,
                          "frac_kernel_bytes": kernel_gbs / HBM_PEAK_GBS,
-                         "limiter": "random accesses (one per probed seed -- its two heads share a 128-B line --, entry pair, text window): each costs a line request and an address translation; the chip serves ~48 G single-load lines/s (41 G/s with two loads per line) and the UTCL2s ~43 G translations/s; at 5 waves per SIMD with one request per lane in flight the kernel now sits at ~0.7 of that and responds to occupancy (DESIGN.md 4.2, 9)",
+                         "limiter": "random accesses (one per probed seed -- its two heads share a 128-B line --, entry pair, text window): each costs a 128-byte line; the chip serves ~49 G random lines/s (54 G/s with the non-temporal hint, tools/ubench/gather_modes.hip); the kernel asks for ~38 G/s with one request per lane in flight, its waves waiting for memory 59 % of the time and its SIMDs issuing VALU instructions 78 % of the time (27-33 % of the lanes active in an average instruction): DESIGN.md 4.2",
                          "head_line_requests": int(head_lines), "heads_probed": int(kc["probes"]),
                          "random_gathers": gathers, "gather_rate_G_per_s": gather_rate,
                          "gather_ceiling_G_per_s": GATHER_CEILING_GPS, "gather_frac": gather_rate / GATHER_CEILING_GPS},

@@ -142,7 +142,6 @@ PgrcOptions pgrc_options_from_env() {
     o.force_pos64 = flag("PGRC_FORCE_POS64") == 1;
     o.test_no_second_index = getenv("PGRC_TEST_NO_SECOND_INDEX") != nullptr;
     o.stream_timing = getenv("PGRC_STREAM_TIMING") != nullptr;
-    if (num("PGRC_SEED_NT") >= 0) o.seed_nt = (uint32_t)num("PGRC_SEED_NT") & 3u;
     o.host_pack = flag("PGRC_HOST_PACK") != 0;
     if (num("PGRC_HOST_THREADS") > 0) o.host_threads = (uint32_t)std::min<long long>(256, num("PGRC_HOST_THREADS"));
     if (num("PGRC_UPLOAD_CHUNK_MB") > 0) o.upload_chunk_mb = (uint64_t)std::min<long long>(4096, num("PGRC_UPLOAD_CHUNK_MB"));

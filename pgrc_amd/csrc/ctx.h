@@ -54,7 +54,6 @@ struct PgrcOptions {
     bool force_pos64 = false;       // PGRC_FORCE_POS64=1: the 64-bit-position kernels on a small text (tests)
     bool test_no_second_index = false;   // PGRC_TEST_NO_SECOND_INDEX: the second index set "does not fit" (tests)
     bool stream_timing = false;     // PGRC_STREAM_TIMING: milestones of a streamed run on stderr
-    uint32_t seed_nt = 0;           // PGRC_SEED_NT: modes d/i/e, bit 0 = table slots, bit 1 = read rows of the hits, with the non-temporal hint
     bool host_pack = true;          // PGRC_HOST_PACK=0: an ASCII text goes up as bytes and a kernel packs it (rounds 1-4); default: host threads pack it into pinned buffers
     uint32_t host_threads = 0;      // PGRC_HOST_THREADS: host threads that pack the text (0 = up to 8)
     uint64_t upload_chunk_mb = 0;   // PGRC_UPLOAD_CHUNK_MB: staging chunk of append_reads_* (0 = 256, or 1024 for a streamed run)

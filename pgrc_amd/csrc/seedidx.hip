@@ -79,7 +79,6 @@ struct SeedArgs {
     const uint16_t *nmask;     // [nn][nwr]: bit k of entry w = symbol 16 w + k of that read is an N
     uint32_t nwr;
     uint64_t nn;
-    uint32_t nt;               // PGRC_SEED_NT: bit 0 = the probe's table slots, bit 1 = a hit's read row: loaded with the non-temporal hint
     uint32_t L, m, P, cstride; // m = pattern length, P = parts, cstride = symbol stride inside a part (P for mode i)
     uint32_t mode;             // 'd', 'i', 'e'
     uint32_t kmax, kmin;
@@ -314,27 +313,13 @@ __global__ void __launch_bounds__(ROWS_TPB) k_seed_rows(const SeedArgs a, uint32
     for (uint64_t k = threadIdx.x; k < nrows * rw; k += ROWS_TPB) rows[i0 * rw + k] = rt[(k % rw) * (ROWS_TPB + 1) + k / rw];
 }
 
-// 16-byte gathers, optionally with the non-temporal hint (PGRC_SEED_NT; tools/ubench/gather_modes.hip: random lines 11 % faster)
-typedef unsigned long long sx_v2u64 __attribute__((ext_vector_type(2)));
-typedef unsigned sx_v4u32 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ ulonglong2 sx_ld_slot(const ulonglong2 *p, bool nt) {
-    if (!nt) return *p;
-    const sx_v2u64 v = __builtin_nontemporal_load(reinterpret_cast<const sx_v2u64 *>(p));
-    return make_ulonglong2(v.x, v.y);
-}
-__device__ __forceinline__ uint4 sx_ld_row(const uint4 *p, bool nt) {
-    if (!nt) return *p;
-    const sx_v4u32 v = __builtin_nontemporal_load(reinterpret_cast<const sx_v4u32 *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-
 template <int RW4>   // rw / 4
 __device__ __forceinline__ uint32_t hamming_row_vs_text(const SeedArgs &a, const uint32_t *text, uint64_t text_w0, const uint32_t *__restrict__ rows, uint64_t i, uint64_t p) {
     const uint4 *row = (const uint4 *)(rows + i * (uint64_t)(RW4 * 4));
     uint32_t r[RW4 * 4];
 #pragma unroll
     for (int q = 0; q < RW4; q++) {
-        const uint4 v = sx_ld_row(row + q, (a.nt & 2u) != 0u);
+        const uint4 v = row[q];
         r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
     }
     const uint32_t *src = text + ((p >> 4) - text_w0);      // (text: a stretch of the packed text staged in LDS, first word text_w0)
@@ -429,7 +414,7 @@ k_seed_probe(const SeedArgs a, uint64_t wbase, uint64_t nwin, uint64_t pg_words_
         fw[b] = (worker && t < nwin) ? (FILTER ? a.filter[fw[b]] : 1u) : 0u;
     }
 #pragma unroll
-    for (int b = 0; b < SCAN_R; b++) kv[b] = ((fw[b] >> fbit[b]) & 1u) ? sx_ld_slot(a.tab + slotv[b], (a.nt & 1u) != 0u) : make_ulonglong2(SX_EMPTY, 0ull);
+    for (int b = 0; b < SCAN_R; b++) kv[b] = ((fw[b] >> fbit[b]) & 1u) ? a.tab[slotv[b]] : make_ulonglong2(SX_EMPTY, 0ull);   // (the non-temporal hint buys nothing here and costs 13 % on the hits' read rows: profiles/r05_seed_nt_ab.txt)
     // collisions (the slot holds another key) are resolved together: every round issues the next-slot loads of all starts
     // still searching before any of them is looked at
     uint32_t srch = 0, fnd = 0;
@@ -443,7 +428,7 @@ k_seed_probe(const SeedArgs a, uint64_t wbase, uint64_t nwin, uint64_t pg_words_
         for (int b = 0; b < SCAN_R; b++)
             if (srch & (1u << b)) {
                 slotv[b] = slotv[b] + 1u;                 // (no wrap: SX_PAD slots lie behind the last home slot, and one of them is empty)
-                kv[b] = sx_ld_slot(a.tab + slotv[b], (a.nt & 1u) != 0u);
+                kv[b] = a.tab[slotv[b]];
             }
 #pragma unroll
         for (int b = 0; b < SCAN_R; b++)
@@ -746,7 +731,6 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
     a.tab = (ulonglong2 *)c->s_keys.p;
     a.tmask = tsize - 1;
     a.tbits = tbits;
-    a.nt = c->opt.seed_nt;
     uint64_t *kA = (uint64_t *)c->s_vals.p, *kB = kA + nent, *vA = kB + nent, *vB = vA + nent;
     uint32_t *first = (uint32_t *)c->s_tab.p, *dnum = first + nent, *dstart = dnum + nent, *hb = dstart + nent + 1, *pm = hb + nent;
     a.ent = pm + nent;
