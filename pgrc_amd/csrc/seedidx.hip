@@ -149,17 +149,28 @@ __device__ __forceinline__ void seed_pair(const SeedArgs &a, uint64_t kf, uint64
 }
 
 __global__ void __launch_bounds__(256) k_seed_keys(const SeedArgs a, uint64_t *__restrict__ keys, uint64_t *__restrict__ vals) {
+    // (the two tables side by side in LDS: one 8-byte read per symbol instead of two chains of selects -- the kernel was bound by
+    //  its VALU instructions, 21 per symbol; and a word of the read is loaded when the part's next symbol lies in another one,
+    //  not once per symbol: 12.9 -> 8.9 -> ... ms at C3)
+    __shared__ uint2 tabs[4];
+    if (threadIdx.x < 4) tabs[threadIdx.x] = make_uint2(cyc_t0(threadIdx.x), cyc_t1(threadIdx.x));
+    __syncthreads();
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= a.n * a.P) return;
     const uint64_t i = e / a.P;
     const uint32_t j = (uint32_t)(e % a.P);
     if (a.nflag && a.nflag[i]) return; // the entries of the reads with N come from their ASCII rows (k_seed_keys_ascii)
-    const uint32_t off = part_offset(a, j);
+    uint32_t x = part_offset(a, j);
     uint32_t h0 = 0, h1 = 0;
-    for (uint32_t k = 0; k < a.m; k++) {
-        const uint32_t c = read_code(a, i, off + k * a.cstride);
-        h0 = rotl1(h0) ^ cyc_t0(c);
-        h1 = rotl1(h1) ^ cyc_t1(c);
+    uint32_t cw = 0xFFFFFFFFu, cur = 0;
+    for (uint32_t k = 0; k < a.m; k++, x += a.cstride) {
+        if ((x >> 4) != cw) {
+            cw = x >> 4;
+            cur = a.reads[(uint64_t)cw * a.stride + i];
+        }
+        const uint2 t = tabs[(cur >> (2u * (x & 15u))) & 3u];
+        h0 = rotl1(h0) ^ t.x;
+        h1 = rotl1(h1) ^ t.y;
     }
     seed_pair(a, key_fix(h0, h1), key_fix(key_rc32(h0, a.m), key_rc32(h1, a.m)), (uint32_t)e, keys, vals);
 }
@@ -209,17 +220,46 @@ k_seed_compact(const uint64_t *__restrict__ ks, const uint32_t *__restrict__ fir
     }
 }
 
-// key d goes to slot d + (prefix maximum of home - j over j <= d)
+// key d goes to slot final(d) = d + (prefix maximum of home - j over j <= d).  The table is WRITTEN tile by tile, every line whole: a
+// block owns PL_TILE consecutive slots, finds the keys that land there (final() ascends: two 64-ary searches, one per wave), puts
+// them into an LDS image of its slots that starts out empty, and stores the image.  (First form: one kernel filled the 17 GB table
+// with "empty", another stored each key's 16 bytes into a line of its own -- 3.2 + 7.5 ms at C3 for what is 17 GB of stores.)
+#define PL_TILE 1024u
 __global__ void __launch_bounds__(256)
-k_seed_place(const uint64_t *__restrict__ ks, const uint32_t *__restrict__ dstart, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nd_p,
-             uint64_t tslots, ulonglong2 *__restrict__ tab, uint32_t *__restrict__ ovf) {
+k_seed_place_tiles(const uint64_t *__restrict__ ks, const uint32_t *__restrict__ dstart, const uint32_t *__restrict__ pm, const uint32_t *__restrict__ nd_p,
+                   uint64_t tslots, ulonglong2 *__restrict__ tab, uint32_t *__restrict__ ovf) {
+    __shared__ ulonglong2 tile[PL_TILE];
+    __shared__ uint32_t bnd[2];
     const uint32_t nd = *nd_p;
-    for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < nd; d += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t slot = d + (uint64_t)pm[d] - SX_BIAS;
-        if (slot >= tslots) { *ovf = 1u; continue; }
-        const uint32_t s0 = dstart[d], s1 = dstart[d + 1];
-        tab[slot] = make_ulonglong2(ks[s0], (uint64_t)s0 | ((uint64_t)(s1 - s0) << 32));
+    const uint64_t S = (uint64_t)blockIdx.x * PL_TILE, E = S + PL_TILE < tslots ? S + PL_TILE : tslots;
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (wv < 2u) {                                            // the first key whose slot is >= X (nd: none), X = S / E
+        const uint64_t X = wv ? E : S;
+        uint32_t lo = 0, hi = nd;                             // the answer lies in [lo, hi]
+        while (hi > lo) {
+            const uint32_t step = (hi - lo + 63u) / 64u;
+            const uint64_t q = (uint64_t)lo + (uint64_t)lane * step;
+            const bool below = q < hi && q + (uint64_t)pm[q] - SX_BIAS < X;       // final(q) < X: the answer lies behind q
+            const uint32_t c = (uint32_t)__popcll(__ballot(below));               // (final() ascends: the lanes that say so are a prefix)
+            if (c == 0u) {
+                hi = lo;
+            } else {
+                const uint64_t nhi = (uint64_t)lo + (uint64_t)c * step;
+                lo = lo + (c - 1u) * step + 1u;
+                if (nhi < hi) hi = (uint32_t)nhi;
+            }
+        }
+        if (lane == 0) bnd[wv] = lo;
     }
+    for (uint32_t x = threadIdx.x; x < PL_TILE; x += 256u) tile[x] = make_ulonglong2(SX_EMPTY, 0ull);
+    __syncthreads();
+    for (uint32_t d = bnd[0] + threadIdx.x; d < bnd[1]; d += 256u) {
+        const uint32_t s0 = dstart[d], s1 = dstart[d + 1];
+        tile[(uint32_t)((uint64_t)d + (uint64_t)pm[d] - SX_BIAS - S)] = make_ulonglong2(ks[s0], (uint64_t)s0 | ((uint64_t)(s1 - s0) << 32));
+    }
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; S + x < E; x += 256u) tab[S + x] = tile[x];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nd && (uint64_t)(nd - 1u) + (uint64_t)pm[nd - 1u] - SX_BIAS >= tslots) *ovf = 1u;   // the last cluster ran over the pad slots
 }
 
 struct SeedMaxOp { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
@@ -313,15 +353,17 @@ __global__ void __launch_bounds__(ROWS_TPB) k_seed_rows(const SeedArgs a, uint32
     for (uint64_t k = threadIdx.x; k < nrows * rw; k += ROWS_TPB) rows[i0 * rw + k] = rt[(k % rw) * (ROWS_TPB + 1) + k / rw];
 }
 
-template <int RW4>   // rw / 4
-__device__ __forceinline__ uint32_t hamming_row_vs_text(const SeedArgs &a, const uint32_t *text, uint64_t text_w0, const uint32_t *__restrict__ rows, uint64_t i, uint64_t p) {
+template <int RW4>   // rw / 4: the read's row -> registers
+__device__ __forceinline__ void load_row(const uint32_t *__restrict__ rows, uint64_t i, uint32_t (&r)[RW4 * 4]) {
     const uint4 *row = (const uint4 *)(rows + i * (uint64_t)(RW4 * 4));
-    uint32_t r[RW4 * 4];
 #pragma unroll
     for (int q = 0; q < RW4; q++) {
         const uint4 v = row[q];
         r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
     }
+}
+template <int RW4>
+__device__ __forceinline__ uint32_t hamming_regs_vs_text(const SeedArgs &a, const uint32_t *text, uint64_t text_w0, const uint32_t (&r)[RW4 * 4], uint64_t p) {
     const uint32_t *src = text + ((p >> 4) - text_w0);      // (text: a stretch of the packed text staged in LDS, first word text_w0)
     const uint32_t b = ((uint32_t)p & 15u) * 2u;
     uint32_t mm = 0, lo = src[0];
@@ -468,13 +510,24 @@ __device__ __forceinline__ void seed_tile_load(uint32_t *tile, const uint32_t *_
 // One hit: entry word `ew` of a window of the forward text at start tf (wflag: the window's RC key is the canonical one; pal: its
 // two keys are equal; rep: the second turn of such a window, for the other strand).  tile_fw / tile_rc: the stretch of the forward / the
 // RC text that every alignment of the caller's windows lies in, in LDS, from word w0_fw / w0_rc on (seed_tile_span).
+// ... in two halves, so that a caller can have the NEXT hit's loads in flight while it counts this one's mismatches:
+//   seed_hit_a   decides whether the pair is a hit at all and asks for what the count needs: the read's row, the read's key;
+//   seed_hit_b   the count, the key, the minimum.
 template <int RW4>
-__device__ __forceinline__ void seed_hit(const SeedArgs &a, uint32_t ew, uint32_t wflag, uint32_t pal, uint32_t rep, uint64_t tf,
-                                         const uint32_t *__restrict__ rows, uint64_t *__restrict__ best, uint32_t &cnt0, uint32_t &cnt1,
-                                         const uint32_t *tile_fw, uint64_t w0_fw, const uint32_t *tile_rc, uint64_t w0_rc) {
+struct SeedHit {
+    uint32_t r[RW4 * 4];       // the read's row
+    uint64_t bestv;            // the read's key when the hit was set up (a key only ever falls: a stale value can cost an atomic, never a result)
+    uint64_t t;                // the window's start in its strand's text
+    uint32_t i;                // the read (of the batch)
+    uint32_t js;               // part | strand << 8 | live << 16 | the read holds an N << 17
+};
+template <int RW4>
+__device__ __forceinline__ void seed_hit_a(const SeedArgs &a, uint32_t ew, uint32_t wflag, uint32_t pal, uint32_t rep, uint64_t tf,
+                                           const uint32_t *__restrict__ rows, const uint64_t *__restrict__ best, uint32_t &cnt0, uint32_t &cnt1, SeedHit<RW4> &h) {
+    h.js = 0;
     const uint32_t e = ew & ~SX_FLAG, ef = ew >> 31;
     if (pal && ef) return;                                // (not a candidate: SeedArgs)
-    const uint64_t i = e / a.P;
+    const uint32_t i = e / a.P;
     const uint32_t j = e % a.P;
     const uint64_t shift = part_offset(a, j);
     const uint32_t strand = wflag ^ ef ^ rep;             // the flags of part and window agree = forward
@@ -482,18 +535,38 @@ __device__ __forceinline__ void seed_hit(const SeedArgs &a, uint32_t ew, uint32_
     // ReadsMatchers.cpp:308-309 / :375-376 and :311-312 / :378-379: the alignment the hit stands for lies inside the text
     if (!((a.want >> strand) & 1u) || t >= a.nwin_all || shift > t || t - shift + a.L > a.G) return;
     if (strand) cnt1++; else cnt0++;
-    const uint64_t p = t - shift;
+    const uint32_t nread = (a.nflag && a.nflag[i]) ? 1u : 0u;
+    if (!nread) load_row<RW4>(rows, i, h.r);
+    h.bestv = best[i];
+    h.t = t;
+    h.i = i;
+    h.js = j | (strand << 8) | (1u << 16) | (nread << 17);
+}
+template <int RW4>
+__device__ __forceinline__ void seed_hit_b(const SeedArgs &a, const SeedHit<RW4> &h, uint64_t *__restrict__ best,
+                                           const uint32_t *tile_fw, uint64_t w0_fw, const uint32_t *tile_rc, uint64_t w0_rc) {
+    if (!((h.js >> 16) & 1u)) return;
+    const uint32_t j = h.js & 0xFFu, strand = (h.js >> 8) & 1u;
+    const uint64_t i = h.i, t = h.t, p = t - part_offset(a, j);
     // the text of the strand around the window: staged in LDS by the caller (a hit's eleven text words were eleven gathers of a
     // kernel whose vector-memory instructions, not its bytes, are the limit)
     const uint32_t *text = strand ? tile_rc : tile_fw;
     const uint64_t text_w0 = strand ? w0_rc : w0_fw;
     uint32_t mm;
-    if (a.nflag && a.nflag[i]) mm = hamming_vs_text_n(a, text, text_w0, i, lower_bound_u32(a.nidx, a.nn, (uint32_t)(i + a.ibase)), p);   // a read with N
-    else mm = hamming_row_vs_text<RW4>(a, text, text_w0, rows, i, p);
+    if ((h.js >> 17) & 1u) mm = hamming_vs_text_n(a, text, text_w0, i, lower_bound_u32(a.nidx, a.nn, (uint32_t)(i + a.ibase)), p);   // a read with N
+    else mm = hamming_regs_vs_text<RW4>(a, text, text_w0, h.r, p);
     if (a.mode == 'e' ? mm != 0u : mm > a.kmax) return;   // ReadsMatchers.cpp:315-319 / :214: no limit a read can have lets it in
     const uint64_t key = ((uint64_t)(mm <= a.kmin ? 0u : mm) << 56) | ((uint64_t)strand << 55) | (t << 15) | ((uint64_t)(15u - j) << 11) | mm;
-    if (best[i] <= key) return;                           // (a plain load: the key only ever falls; random 64-bit atomics run at a sixth of the rate of loads)
+    if (h.bestv <= key) return;                           // (a plain load: the key only ever falls; random 64-bit atomics run at a sixth of the rate of loads)
     atomicMin((unsigned long long *)&best[i], (unsigned long long)key);
+}
+template <int RW4>
+__device__ __forceinline__ void seed_hit(const SeedArgs &a, uint32_t ew, uint32_t wflag, uint32_t pal, uint32_t rep, uint64_t tf,
+                                         const uint32_t *__restrict__ rows, uint64_t *__restrict__ best, uint32_t &cnt0, uint32_t &cnt1,
+                                         const uint32_t *tile_fw, uint64_t w0_fw, const uint32_t *tile_rc, uint64_t w0_rc) {
+    SeedHit<RW4> h;
+    seed_hit_a<RW4>(a, ew, wflag, pal, rep, tf, rows, best, cnt0, cnt1, h);
+    seed_hit_b<RW4>(a, h, best, tile_fw, w0_fw, tile_rc, w0_rc);
 }
 
 #define EXP_TPB 256
@@ -658,6 +731,8 @@ k_seed_heavy(const SeedArgs a, uint64_t wbase, const uint64_t *__restrict__ wrec
         __threadfence_block();                            // the wave's LDS writes before its lanes' reads
         __builtin_amdgcn_wave_barrier();
         for (uint32_t rep = 0; rep <= pal; rep++) {
+            // (measured and dropped: the NEXT hit's row and key requested before this hit's mismatches are counted -- seed_hit_a /
+            //  seed_hit_b one hit apart: 80 registers instead of 62, mode d's heavy windows 25.5 -> 23.1 ms, mode i's 51.7 -> 54.2)
             uint32_t n_ew = lane < cnt ? a.ent[off + lane] : 0u;           // (one entry ahead)
             for (uint32_t k = lane; k < cnt; k += 64u) {
                 const uint32_t ew = n_ew;
@@ -687,10 +762,6 @@ __global__ void __launch_bounds__(256) k_seed_best_store(const SeedArgs a, const
 }
 
 
-__global__ void __launch_bounds__(256) k_seed_table_init(ulonglong2 *tab, uint64_t n) {
-    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (uint64_t)gridDim.x * blockDim.x)
-        tab[s] = make_ulonglong2(SX_EMPTY, 0ull);
-}
 
 
 // One batch of reads (at most 2^30 entries: an entry index and a slot number leave a bit for the flag) against both strands.
@@ -746,7 +817,6 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
     HIP_TRY(c, hipMemsetAsync(c->s_tmp.p, 0, 128, c->stream));
     // 1. the table (section 1): pairs, sort, distinct keys, prefix maximum, placement
     const uint32_t egrid = (uint32_t)std::min<uint64_t>((nent + 255) / 256, 65536ull * 4);
-    hipLaunchKernelGGL(k_seed_table_init, dim3(8192), dim3(256), 0, c->stream, a.tab, tslots);
     hipLaunchKernelGGL(k_seed_keys, dim3((uint32_t)((nent + 255) / 256)), dim3(256), 0, c->stream, a, kA, vA);
     if (a.nn)
         hipLaunchKernelGGL(k_seed_keys_ascii, dim3((uint32_t)((a.nn * a.P + 255) / 256)), dim3(256), 0, c->stream, a, kA, vA);
@@ -758,7 +828,8 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
     HIP_TRY(c, hipMemsetAsync(hb, 0, nent * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(k_seed_compact, dim3(egrid), dim3(256), 0, c->stream, (const uint64_t *)ks, (const uint32_t *)first, (const uint32_t *)dnum, nent, tbits, dstart, hb, nd_dev);
     HIP_TRY(c, (sco_scan<true>(c->stream, (const uint32_t *)hb, pm, nent, ScoIdentity(), SeedMaxOp(), 0u, bsum)));
-    hipLaunchKernelGGL(k_seed_place, dim3(egrid), dim3(256), 0, c->stream, (const uint64_t *)ks, (const uint32_t *)dstart, (const uint32_t *)pm, (const uint32_t *)nd_dev, tslots, a.tab, ovf_dev);
+    hipLaunchKernelGGL(k_seed_place_tiles, dim3((uint32_t)((tslots + PL_TILE - 1) / PL_TILE)), dim3(256), 0, c->stream, (const uint64_t *)ks, (const uint32_t *)dstart,
+                       (const uint32_t *)pm, (const uint32_t *)nd_dev, tslots, a.tab, ovf_dev);
     HIP_TRY(c, hipGetLastError());
 
     // a read's hits become its result by the atomic minimum of section 3b: a start key per read, the batch's reads row by row
