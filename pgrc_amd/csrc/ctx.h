@@ -58,6 +58,7 @@ struct PgrcOptions {
     uint32_t host_threads = 0;      // PGRC_HOST_THREADS: host threads that pack the text (0 = up to 8)
     uint64_t upload_chunk_mb = 0;   // PGRC_UPLOAD_CHUNK_MB: staging chunk of append_reads_* (0 = 256, or 1024 for a streamed run)
     int seed_filter = -1;           // PGRC_SEED_FILTER  modes d/i/e: -1 where it pays, 0 never, 1 always
+    int seed_sort = -1;             // PGRC_SEED_SORT=full|segments: how modes d/i/e sort their (key, entry) pairs (-1: by the batch's size)
     uint32_t seed_heavy = 0;        // PGRC_SEED_HEAVY   modes d/i/e: entries of a window above which the persistent grid expands it (0 = default)
     uint64_t seed_read_batch = 0;   // PGRC_SEED_READ_BATCH / PGRC_SEED_SEGMENT: reads per batch / window starts per launch (tests; 0 = default)
     uint64_t seed_segment = 0;
@@ -179,7 +180,7 @@ struct pgrc_match_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> st_tev;
 
     // read-side seed index (modes d / i / e)
-    DevBuf s_keys, s_vals, s_tab, s_hits, s_tmp, s_sort;
+    DevBuf s_keys, s_vals, s_tab, s_hits, s_tmp, s_sort, s_seg;
     DevBuf s_filter;        // modes d/i/e: one bit per slice of the key space (seedidx.hip)
     DevBuf s_nmask;                             // N masks of the reads with N (modes d/i/e)
     DevBuf s_best, s_rows;                      // the atomic-minimum reduction: one key per read, the batch's reads row by row (seedidx.hip 3c)
@@ -309,6 +310,9 @@ int pgrc_radix_sort_u64(pgrc_match_ctx *c, uint64_t *d_a, uint64_t *d_b, uint64_
                         uint64_t **sorted);
 int pgrc_radix_sort_pairs_u64(pgrc_match_ctx *c, uint64_t *k_a, uint64_t *k_b, uint64_t *v_a, uint64_t *v_b, uint64_t n, uint32_t bit_lo, uint32_t bit_hi,
                               DevBuf &scratch, uint64_t **ksorted, uint64_t **vsorted);
+#define PGRC_RX_SEGMENT_MAX 8192u      // pairs a segment of pgrc_radix_sort_segments_pairs_u64 may hold (radix.hip RX_TILE)
+int pgrc_radix_sort_segments_pairs_u64(pgrc_match_ctx *c, uint64_t *keys, uint64_t *vals, const uint32_t *seg, uint32_t nseg, uint32_t bit_lo, uint32_t bit_hi,
+                                       uint32_t *ovl, uint32_t cap);
 
 // seedidx.hip (modes d / i / e)
 int pgrc_seedidx_run(pgrc_match_ctx *c, int first_strand, int last_strand);

@@ -159,6 +159,112 @@ k_rx_scatter(const uint64_t *__restrict__ in, const uint64_t *__restrict__ vin, 
     }
 }
 
+// ---- segments: every block sorts ONE segment of at most RX_TILE (key, value) pairs completely, by the key bits [bit_lo, bit_hi),
+// in LDS -- LSD passes of 8 bits with the ranking of k_rx_scatter, nothing leaves the CU between the passes -- and writes it back
+// in place.  For arrays that a few global passes over the TOP bits have cut into many small segments (seedidx.hip: 300 M pairs,
+// two global passes, 65 536 segments of ~4 600: 2 + 1 trips through HBM instead of 8).  A segment larger than RX_TILE is left as
+// it is and reported: ovl[0] counts them, ovl[1 .. cap] lists their numbers (the caller sorts those ranges with rx_sort).
+__global__ void __launch_bounds__(RX_TPB)
+k_rx_segments(uint64_t *__restrict__ keys, uint64_t *__restrict__ vals, const uint32_t *__restrict__ seg, uint32_t bit_lo, uint32_t bit_hi,
+              uint32_t *__restrict__ ovl, uint32_t cap) {
+    __shared__ RxLds s;
+    extern __shared__ __attribute__((aligned(16))) uint64_t valS[];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t s0 = seg[blockIdx.x], n = seg[blockIdx.x + 1] - s0;
+    if (n < 2u) return;
+    if (n > RX_TILE) {
+        if (threadIdx.x == 0) {
+            const uint32_t k = atomicAdd(&ovl[0], 1u);
+            if (k < cap) ovl[1u + k] = blockIdx.x;
+        }
+        return;
+    }
+    uint64_t rec[RX_E], val[RX_E];
+#pragma unroll
+    for (int i = 0; i < RX_E; i++) {
+        const uint32_t x = wv * RX_WSPAN + (uint32_t)i * 64u + lane;
+        rec[i] = x < n ? keys[(uint64_t)s0 + x] : 0ull;
+        val[i] = x < n ? vals[(uint64_t)s0 + x] : 0ull;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t shift = bit_lo; shift < bit_hi; shift += 8u) {
+        const uint32_t dbits = bit_hi - shift < 8u ? bit_hi - shift : 8u, D = 1u << dbits, dmask = D - 1u;
+        for (uint32_t x = threadIdx.x; x < RX_NW * RX_MAXD; x += RX_TPB) (&s.hist[0][0])[x] = (uint16_t)0;
+        __syncthreads();
+        uint32_t rank[RX_E];
+#pragma unroll
+        for (int i = 0; i < RX_E; i++) {
+            const bool valid = wv * RX_WSPAN + (uint32_t)i * 64u + lane < n;
+            const uint32_t d = (uint32_t)(rec[i] >> shift) & dmask;
+            unsigned long long peers = __ballot(valid);
+            for (uint32_t b = 0; b < dbits; b++) {
+                const unsigned long long bal = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? bal : ~bal;
+            }
+            const uint32_t leader = valid ? (uint32_t)__ffsll((long long)peers) - 1u : lane;
+            uint32_t old = 0;
+            if (valid && lane == leader) {
+                old = s.hist[wv][d];
+                s.hist[wv][d] = (uint16_t)(old + (uint32_t)__popcll(peers));
+            }
+            old = __shfl(old, leader, 64);
+            rank[i] = old + (uint32_t)__popcll(peers & lt);
+        }
+        __syncthreads();
+        uint32_t tot = 0;
+        if (threadIdx.x < D) {
+            const uint32_t d = threadIdx.x;
+            for (uint32_t w = 0; w < RX_NW; w++) {
+                const uint32_t t = s.hist[w][d];
+                s.hist[w][d] = (uint16_t)tot;
+                tot += t;
+            }
+        }
+        uint32_t all;
+        const uint32_t ex = rx_block_scan(tot, s.scan_tmp, &all);
+        if (threadIdx.x < D) s.dstart[threadIdx.x] = ex;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RX_E; i++) {
+            if (wv * RX_WSPAN + (uint32_t)i * 64u + lane < n) {
+                const uint32_t d = (uint32_t)(rec[i] >> shift) & dmask;
+                const uint32_t slot = s.dstart[d] + s.hist[wv][d] + rank[i];
+                s.recS[slot] = rec[i];
+                valS[slot] = val[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RX_E; i++) {                       // back in the input layout: slot order = the order of this pass
+            const uint32_t x = wv * RX_WSPAN + (uint32_t)i * 64u + lane;
+            if (x < n) {
+                rec[i] = s.recS[x];
+                val[i] = valS[x];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < RX_E; i++) {
+        const uint32_t x = wv * RX_WSPAN + (uint32_t)i * 64u + lane;
+        if (x < n) {
+            keys[(uint64_t)s0 + x] = rec[i];
+            vals[(uint64_t)s0 + x] = val[i];
+        }
+    }
+}
+
+// seg[0 .. nseg]: the bounds of the segments of keys[] / vals[] (device; ascending, seg[nseg] = the number of pairs); ovl: cap + 1
+// words on the device, ovl[0] zeroed by the caller.  On c->stream, no synchronisation.
+int pgrc_radix_sort_segments_pairs_u64(pgrc_match_ctx *c, uint64_t *keys, uint64_t *vals, const uint32_t *seg, uint32_t nseg, uint32_t bit_lo, uint32_t bit_hi,
+                                       uint32_t *ovl, uint32_t cap) {
+    if (!nseg || bit_hi <= bit_lo) return PGRC_OK;
+    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_rx_segments), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RX_TILE * sizeof(uint64_t))));
+    hipLaunchKernelGGL(k_rx_segments, dim3(nseg), dim3(RX_TPB), RX_TILE * sizeof(uint64_t), c->stream, keys, vals, seg, bit_lo, bit_hi, ovl, cap);
+    HIP_TRY(c, hipGetLastError());
+    return PGRC_OK;
+}
+
 // Sorts d_a[0 .. n) by the bits [bit_lo, bit_hi) of every record, stable; d_b: n records of scratch; `scratch` grows as
 // needed (count matrix).  *sorted = d_a or d_b, wherever the last pass put the records.  With v_a / v_b (both or neither): every
 // record carries a 64-bit value that moves with it; *vsorted = where the values ended up.  All on c->stream, no synchronisation.

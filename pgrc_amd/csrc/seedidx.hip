@@ -33,6 +33,7 @@
 #include <cstring>
 
 #include <algorithm>
+#include <vector>
 
 #include "ctx.h"
 #include "devutil.h"
@@ -260,6 +261,19 @@ k_seed_place_tiles(const uint64_t *__restrict__ ks, const uint32_t *__restrict__
     __syncthreads();
     for (uint32_t x = threadIdx.x; S + x < E; x += 256u) tab[S + x] = tile[x];
     if (blockIdx.x == 0 && threadIdx.x == 0 && nd && (uint64_t)(nd - 1u) + (uint64_t)pm[nd - 1u] - SX_BIAS >= tslots) *ovf = 1u;   // the last cluster ran over the pad slots
+}
+
+// the pairs are sorted by their keys' top SX_SEG_BITS bits: seg[p] = the first pair whose top bits are >= p (seg[2^bits] = nent)
+#define SX_SEG_BITS 16u
+__global__ void __launch_bounds__(256) k_seed_bounds(const uint64_t *__restrict__ ks, uint32_t nent, uint32_t *__restrict__ seg) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > (1u << SX_SEG_BITS)) return;
+    uint32_t lo = 0, hi = nent;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((ks[mid] >> (64u - SX_SEG_BITS)) < (uint64_t)p) lo = mid + 1u; else hi = mid;
+    }
+    seg[p] = lo;
 }
 
 struct SeedMaxOp { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
@@ -822,7 +836,46 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
         hipLaunchKernelGGL(k_seed_keys_ascii, dim3((uint32_t)((a.nn * a.P + 255) / 256)), dim3(256), 0, c->stream, a, kA, vA);
     HIP_TRY(c, hipGetLastError());
     uint64_t *ks = nullptr, *vs = nullptr;
-    if ((e = pgrc_radix_sort_pairs_u64(c, kA, kB, vA, vB, nent, 0, 64, c->s_sort, &ks, &vs))) return e;
+    // the sort.  A large batch: two global passes over the keys' top 16 bits cut the pairs into 65 536 segments (~4 600 pairs at
+    // C3: the keys are hash values), and every segment is sorted by the other 48 bits inside ONE block's LDS (radix.hip,
+    // k_rx_segments): three trips through HBM instead of eight (31 -> ~12 ms at C3).  The few segments that hold more than a block
+    // takes -- a key with thousands of entries sits in them -- are sorted as ranges of their own with the global passes.
+    // PGRC_SEED_SORT=full / segments forces the one or the other (tests).
+    bool by_segments = nent >= (1ull << 20);
+    if (c->opt.seed_sort >= 0) by_segments = c->opt.seed_sort != 0;
+    if (by_segments) {
+        const uint32_t nseg = 1u << SX_SEG_BITS, OVL_CAP = 255u;
+        if ((e = pgrc_buf_ensure(c, c->s_seg, ((size_t)nseg + 1 + OVL_CAP + 1) * sizeof(uint32_t)))) return e;
+        uint32_t *seg = (uint32_t *)c->s_seg.p, *ovl = seg + nseg + 1;
+        if ((e = pgrc_radix_sort_pairs_u64(c, kA, kB, vA, vB, nent, 64u - SX_SEG_BITS, 64, c->s_sort, &ks, &vs))) return e;
+        uint64_t *ko = ks == kA ? kB : kA, *vo = vs == vA ? vB : vA;     // the other halves of the ping-pong: scratch from here on
+        HIP_TRY(c, hipMemsetAsync(ovl, 0, sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(k_seed_bounds, dim3((nseg + 1 + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)ks, (uint32_t)nent, seg);
+        HIP_TRY(c, hipGetLastError());
+        if ((e = pgrc_radix_sort_segments_pairs_u64(c, ks, vs, seg, nseg, 0, 64u - SX_SEG_BITS, ovl, OVL_CAP))) return e;
+        uint32_t h_ovl[OVL_CAP + 1];
+        HIP_TRY(c, hipMemcpyAsync(h_ovl, ovl, sizeof h_ovl, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (h_ovl[0] > OVL_CAP) {
+            // (more large segments than the list holds: the whole array once more, by all its bits)
+            if ((e = pgrc_radix_sort_pairs_u64(c, ks, ko, vs, vo, nent, 0, 64, c->s_sort, &ks, &vs))) return e;
+        } else if (h_ovl[0]) {
+            std::vector<uint32_t> bounds(2 * (size_t)h_ovl[0]);
+            for (uint32_t k = 0; k < h_ovl[0]; k++)
+                HIP_TRY(c, hipMemcpyAsync(&bounds[2 * k], seg + h_ovl[1 + k], 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            for (uint32_t k = 0; k < h_ovl[0]; k++) {
+                const uint64_t s0 = bounds[2 * k], n = bounds[2 * k + 1] - s0;
+                uint64_t *kr = nullptr, *vr = nullptr;
+                if ((e = pgrc_radix_sort_pairs_u64(c, ks + s0, ko + s0, vs + s0, vo + s0, n, 0, 64u - SX_SEG_BITS, c->s_sort, &kr, &vr))) return e;
+                if (kr != ks + s0) {
+                    HIP_TRY(c, hipMemcpyAsync(ks + s0, kr, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+                    HIP_TRY(c, hipMemcpyAsync(vs + s0, vr, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+                }
+            }
+        }
+    } else if ((e = pgrc_radix_sort_pairs_u64(c, kA, kB, vA, vB, nent, 0, 64, c->s_sort, &ks, &vs)))
+        return e;
     hipLaunchKernelGGL(k_seed_mark, dim3(egrid), dim3(256), 0, c->stream, (const uint64_t *)ks, (const uint64_t *)vs, nent, first, a.ent);
     HIP_TRY(c, (sco_scan<true>(c->stream, (const uint32_t *)first, dnum, nent, ScoIdentity(), ScoPlus(), 0u, bsum)));
     HIP_TRY(c, hipMemsetAsync(hb, 0, nent * sizeof(uint32_t), c->stream));
@@ -831,7 +884,6 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
     hipLaunchKernelGGL(k_seed_place_tiles, dim3((uint32_t)((tslots + PL_TILE - 1) / PL_TILE)), dim3(256), 0, c->stream, (const uint64_t *)ks, (const uint32_t *)dstart,
                        (const uint32_t *)pm, (const uint32_t *)nd_dev, tslots, a.tab, ovf_dev);
     HIP_TRY(c, hipGetLastError());
-
     // a read's hits become its result by the atomic minimum of section 3b: a start key per read, the batch's reads row by row
     const uint32_t rw = (a.nwr + 3u) & ~3u;                 // <= 16: reads have at most 255 symbols (pgrc_match_create)
     if (c->G >= (1ull << 40)) { c->err = "modes d/i/e: texts below 2^40 symbols"; return PGRC_E_PARAM; }
