@@ -61,9 +61,10 @@ def main():
         pairk = str(rng.choice(["", "", "0", "1", "2", "3", "4"]))
         inline = "0" if rng.random() < 0.3 else ""
         heavy = str(rng.choice(["", "", "1", "4", "4096"]))   # modes d / i / e: entries of a window above which the persistent grid takes it
+        ssort = str(rng.choice(["", "", "segments", "full"]))  # round 5: the table's pairs sorted by segments in LDS / by global passes
         for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_CFG", icfg), ("PGRC_INDEX_FINISH", finish), ("PGRC_SEED_SEGMENT", seg), ("PGRC_SEED_READ_BATCH", batch),
                          ("PGRC_MATCH_STAGE", stage), ("PGRC_EARLY_STOP", early), ("PGRC_SCREEN", screen), ("PGRC_DUAL", dual),
-                         ("PGRC_HEAD_PAIR", pairk), ("PGRC_NREAD_INLINE", inline), ("PGRC_SEED_HEAVY", heavy)):
+                         ("PGRC_HEAD_PAIR", pairk), ("PGRC_NREAD_INLINE", inline), ("PGRC_SEED_HEAVY", heavy), ("PGRC_SEED_SORT", ssort)):
             if val:
                 os.environ[key] = val
             else:
@@ -72,7 +73,7 @@ def main():
                       n_nset=nn if packed else None)
         what = dict(mode=mode, L=L, seed_len=seed_len, M=M, kmin=kmin, G=G, n=n, nn=nn, rev=rev, seed=seed, shards=shards,
                     packed=packed, variant=variant, finish=finish, seg=seg, batch=batch, stage=stage, early=early, screen=screen, dual=dual,
-                    pairk=pairk, inline=inline, icfg=icfg, heavy=heavy)
+                    pairk=pairk, inline=inline, icfg=icfg, heavy=heavy, ssort=ssort)
         for k in ("pos", "rc", "mism", "hist"):
             if not np.array_equal(np.asarray(g[k]), np.asarray(o[k])):
                 print("READS MISMATCH", what, k, flush=True)

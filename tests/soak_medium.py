@@ -61,12 +61,13 @@ def main():
             kn = km if (mode != "e" and rng.random() < 0.15) else 0
             heavy = str(rng.choice(["", "", "1", "4096"]))
             seg = str(int(rng.integers(1 << 20, 1 << 24))) if rng.random() < 0.3 else ""
-            for key, val in (("PGRC_SEED_HEAVY", heavy), ("PGRC_SEED_SEGMENT", seg)):
+            ssort = str(rng.choice(["", "", "segments", "full"]))
+            for key, val in (("PGRC_SEED_HEAVY", heavy), ("PGRC_SEED_SEGMENT", seg), ("PGRC_SEED_SORT", ssort)):
                 if val:
                     os.environ[key] = val
                 else:
                     os.environ.pop(key, None)
-            what = dict(mode=mode, L=L, seed_len=sl, kmax=km, kmin=kn, G=Gs, n=ns, nn=nn, seed=seed, shards=shards, heavy=heavy, seg=seg)
+            what = dict(mode=mode, L=L, seed_len=sl, kmax=km, kmin=kn, G=Gs, n=ns, nn=nn, seed=seed, shards=shards, heavy=heavy, seg=seg, sort=ssort)
             pg, reads = pg[:Gs], reads[:ns]
             o = orc.oracle_match(mode, pg, reads, sl, km, kn)
             g = gpu_match(mode, pg, reads, sl, km, kn, True, devices=[0] * shards if shards else None)
