@@ -192,8 +192,11 @@ k_rx_segments(uint64_t *__restrict__ keys, uint64_t *__restrict__ vals, const ui
         for (uint32_t x = threadIdx.x; x < RX_NW * RX_MAXD; x += RX_TPB) (&s.hist[0][0])[x] = (uint16_t)0;
         __syncthreads();
         uint32_t rank[RX_E];
+        const bool wave_has = wv * RX_WSPAN < n;                  // (a segment fills the first waves only: ~4 600 of 8 192 slots at C3)
 #pragma unroll
         for (int i = 0; i < RX_E; i++) {
+            rank[i] = 0;
+            if (!wave_has || wv * RX_WSPAN + (uint32_t)i * 64u >= n) continue;    // (wave-uniform)
             const bool valid = wv * RX_WSPAN + (uint32_t)i * 64u + lane < n;
             const uint32_t d = (uint32_t)(rec[i] >> shift) & dmask;
             unsigned long long peers = __ballot(valid);
