@@ -27,7 +27,7 @@
 //      computed on the spot, and the reference's sequential rule over a read's hits -- walked in scan order: ascending text
 //      position, equal positions in descending part index -- is taken as the lexicographic minimum it amounts to, one atomicMin
 //      per acceptable hit on a 64-bit key per read (section 3b).
-// No hit records, no sort, no guess of a buffer size (the first run of a context is as fast as the next), no library kernel, and
+// No hit records, no sort of hits, no guess of a buffer size (the first run of a context is as fast as the next), no library kernel, and
 // the host waits once per batch of reads.
 #include <cstdlib>
 #include <cstring>
@@ -121,13 +121,14 @@ __device__ __forceinline__ uint32_t part_offset(const SeedArgs &a, uint32_t j) {
 // ---- 1. the table, built by sorting (round 5; rounds 3-4 claimed slots with atomicCAS and ranks with atomicAdd: two returning
 // random atomics per entry, then a scan over the whole table and a placement pass: 63 of a C3 run's 185 ms in mode d).
 //   keys     every (read, part) entry -> the pair (table key of its canonical key, entry index | flag << 31), in entry order;
-//   sort     the pairs by the key, all 64 bits, stable (radix.hip): equal keys are adjacent, home slots ascend, and the sorted
-//            value column IS the entry array, grouped by key;
+//   sort     the pairs by the key, all 64 bits (radix.hip): equal keys are adjacent, home slots ascend, and the sorted value column
+//            IS the entry array, grouped by key.  A large batch is sorted in three trips through HBM instead of eight: two global
+//            passes over the top 16 key bits, then every one of the 65 536 segments in one block's LDS (seedidx_batch);
 //   place    the distinct keys d = 0, 1, ... in sorted order take the slots  final(d) = max(home(d), final(d - 1) + 1)
 //            = d + max_{j <= d} (home(j) - j):  a prefix MAXIMUM (scanops.h) -- exactly the table that inserting the keys in that
 //            order with linear probing would leave, so a lookup that walks upwards from the home slot until it meets the key or an
 //            empty slot finds every key: all slots between a key's home and its slot are taken by keys with homes no larger.
-// Nothing random is written: the slots are filled in ascending order.
+// Nothing random is written: the table goes out tile by tile, every line whole (k_seed_place_tiles).
 #define SX_PAD 65536ull                  // slots behind the 2^tbits home slots (a cluster at the very end of the table grows into them)
 
 // the key as the table holds it: the mixed key rotated so that its home slot (its low tbits bits) comes first -- ascending table
