@@ -194,32 +194,150 @@ __global__ void __launch_bounds__(256) k_seed_keys_ascii(const SeedArgs a, uint6
     seed_pair(a, key_fix(h0, h1), key_fix(key_rc32(h0, a.m), key_rc32(h1, a.m)), (uint32_t)(i * a.P + j), keys, vals);
 }
 
-// sorted pairs -> first[i] = 1 where a new key starts, ent[i] = the entry word
-__global__ void __launch_bounds__(256)
-k_seed_mark(const uint64_t *__restrict__ ks, const uint64_t *__restrict__ vs, uint64_t nent, uint32_t *__restrict__ first, uint32_t *__restrict__ ent) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nent; i += (uint64_t)gridDim.x * blockDim.x) {
-        first[i] = (i == 0 || ks[i] != ks[i - 1]) ? 1u : 0u;
-        ent[i] = (uint32_t)vs[i];
+// From the sorted pairs to what the placement needs -- dstart[d] = where key d's entries start (dstart[nd] = nent), pm[d] = the
+// prefix maximum of home(j) - j + SX_BIAS over the keys j <= d, ent[] = the entry words -- segment by segment (any cut of the sorted
+// array into consecutive pieces: the sort's 65 536 segments, or pieces of SG_EVEN pairs after the global sort), in two kernels around a
+// scan over the SEGMENTS' summaries.  (First form: a flag per pair, a scan over the pairs, a compaction, a second scan over the pairs:
+// 7.2 ms at C3 for what is one pass over the keys and one over keys and values.)
+//   k_seed_seg_summary   per segment: the keys that start in it, and the maximum of home - rank + SX_BIAS over them, rank counted
+//                        from the segment's first key;
+//   k_seed_seg_scan      per segment: the number of its first key (exclusive sum) and the prefix maximum that reaches it --
+//                        a key's global value is its local one minus the number of its segment's first key;
+//   k_seed_seg_write     per segment: dstart, pm, ent.
+// (0 is the maximum's identity: a real value is at least SX_BIAS - d > 0.)
+#define SX_BIAS (1u << 30)
+#define SG_TPB 256
+#define SG_EVEN 4096u
+__device__ __forceinline__ bool seed_key_starts(const uint64_t *__restrict__ ks, uint32_t i) { return i == 0u || ks[i] != ks[i - 1u]; }
+
+// a block's exclusive sum / inclusive maximum over its threads in thread order (SG_TPB threads), and the block's total / maximum
+__device__ __forceinline__ uint32_t sg_block_excl_sum(uint32_t v, uint32_t *smem, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(inc, o, 64);
+        if (lane >= (uint32_t)o) inc += u;
+    }
+    if (lane == 63u) smem[wv] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (uint32_t k = 0; k < SG_TPB / 64; k++) {
+        const uint32_t x = smem[k];
+        if (k < wv) woff += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + inc - v;
+}
+__device__ __forceinline__ uint32_t sg_block_incl_max(uint32_t v, uint32_t *smem, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(inc, o, 64);
+        if (lane >= (uint32_t)o && u > inc) inc = u;
+    }
+    if (lane == 63u) smem[wv] = inc;
+    __syncthreads();
+    uint32_t wmax = 0, tot = 0;
+    for (uint32_t k = 0; k < SG_TPB / 64; k++) {
+        const uint32_t x = smem[k];
+        if (k < wv && x > wmax) wmax = x;
+        if (x > tot) tot = x;
+    }
+    __syncthreads();
+    *total = tot;
+    return inc > wmax ? inc : wmax;
+}
+
+__global__ void __launch_bounds__(256) k_seed_even_bounds(uint32_t nent, uint32_t nseg, uint32_t *__restrict__ seg) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > nseg) return;
+    const uint64_t x = (uint64_t)p * SG_EVEN;
+    seg[p] = x < nent ? (uint32_t)x : nent;
+}
+
+__global__ void __launch_bounds__(SG_TPB)
+k_seed_seg_summary(const uint64_t *__restrict__ ks, const uint32_t *__restrict__ seg, uint32_t tbits, uint32_t *__restrict__ seg_nd, uint32_t *__restrict__ seg_m) {
+    __shared__ uint32_t smem[SG_TPB / 64];
+    const uint32_t s0 = seg[blockIdx.x], s1 = seg[blockIdx.x + 1];
+    uint32_t c = 0, m = 0;
+    for (uint32_t base = s0; base < s1; base += SG_TPB) {
+        const uint32_t i = base + threadIdx.x;
+        const bool f = i < s1 && seed_key_starts(ks, i);
+        uint32_t tot;
+        const uint32_t r = c + sg_block_excl_sum(f ? 1u : 0u, smem, &tot);
+        if (f) {
+            const uint32_t v = (uint32_t)(ks[i] >> (64u - tbits)) - r + SX_BIAS;
+            if (v > m) m = v;
+        }
+        c += tot;
+    }
+    uint32_t mm;
+    (void)sg_block_incl_max(m, smem, &mm);
+    if (threadIdx.x == 0) {
+        seg_nd[blockIdx.x] = c;
+        seg_m[blockIdx.x] = mm;
     }
 }
 
-// dnum[i] = distinct keys up to and including i (inclusive scan of first[]): key d = dnum - 1 starts at dstart[d]; its home, as the
-// biased difference home - d that the prefix maximum runs over (hb[] zeroed by the caller beyond the last key: the maximum's identity)
-#define SX_BIAS (1u << 30)
-__global__ void __launch_bounds__(256)
-k_seed_compact(const uint64_t *__restrict__ ks, const uint32_t *__restrict__ first, const uint32_t *__restrict__ dnum, uint64_t nent, uint32_t tbits,
-               uint32_t *__restrict__ dstart, uint32_t *__restrict__ hb, uint32_t *__restrict__ nd_out) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nent; i += (uint64_t)gridDim.x * blockDim.x) {
-        if (first[i]) {
-            const uint32_t d = dnum[i] - 1u;
-            dstart[d] = (uint32_t)i;
-            hb[d] = (uint32_t)(ks[i] >> (64u - tbits)) - d + SX_BIAS;        // (home < 2^30, d < 2^30: no wrap)
+// one block walks the segments: base_d[p] = keys before segment p, pin[p] = the maximum over the segments q < p that hold a key of
+// (seg_m[q] - base_d[q]); *nd_out = all keys
+__global__ void __launch_bounds__(SG_TPB)
+k_seed_seg_scan(const uint32_t *__restrict__ seg_nd, const uint32_t *__restrict__ seg_m, uint32_t nseg, uint32_t *__restrict__ base_d, uint32_t *__restrict__ pin,
+                uint32_t *__restrict__ nd_out) {
+    __shared__ uint32_t smem[SG_TPB / 64];
+    uint32_t c = 0, carry = 0;
+    for (uint32_t base = 0; base < nseg; base += SG_TPB) {
+        const uint32_t p = base + threadIdx.x;
+        const uint32_t n = p < nseg ? seg_nd[p] : 0u;
+        uint32_t tot;
+        const uint32_t b = c + sg_block_excl_sum(n, smem, &tot);
+        const uint32_t v = (p < nseg && n) ? seg_m[p] - b : 0u;           // the segment's maximum in global numbering
+        uint32_t vmax;
+        const uint32_t inc = sg_block_incl_max(v, smem, &vmax);
+        // exclusive: what reaches segment p is the maximum over the segments before it
+        uint32_t prev = __shfl_up(inc, 1, 64);
+        __shared__ uint32_t wlast[SG_TPB / 64];
+        if ((threadIdx.x & 63u) == 63u) wlast[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        if ((threadIdx.x & 63u) == 0u) prev = threadIdx.x ? wlast[(threadIdx.x >> 6) - 1u] : 0u;
+        __syncthreads();
+        if (p < nseg) {
+            base_d[p] = b;
+            pin[p] = prev > carry ? prev : carry;
         }
-        if (i == nent - 1) {
-            dstart[dnum[i]] = (uint32_t)nent;                                // the end of the last key's range
-            *nd_out = dnum[i];
-        }
+        c += tot;
+        if (vmax > carry) carry = vmax;
     }
+    if (threadIdx.x == 0) *nd_out = c;
+}
+
+__global__ void __launch_bounds__(SG_TPB)
+k_seed_seg_write(const uint64_t *__restrict__ ks, const uint64_t *__restrict__ vs, const uint32_t *__restrict__ seg, uint32_t nseg, uint32_t nent, uint32_t tbits,
+                 const uint32_t *__restrict__ base_d, const uint32_t *__restrict__ pin, uint32_t *__restrict__ dstart, uint32_t *__restrict__ pm,
+                 uint32_t *__restrict__ ent) {
+    __shared__ uint32_t smem[SG_TPB / 64];
+    const uint32_t s0 = seg[blockIdx.x], s1 = seg[blockIdx.x + 1];
+    const uint32_t d0 = base_d[blockIdx.x];
+    uint32_t c = 0, carry = pin[blockIdx.x];
+    for (uint32_t base = s0; base < s1; base += SG_TPB) {
+        const uint32_t i = base + threadIdx.x;
+        const bool f = i < s1 && seed_key_starts(ks, i);
+        uint32_t tot;
+        const uint32_t r = c + sg_block_excl_sum(f ? 1u : 0u, smem, &tot);
+        const uint32_t v = f ? (uint32_t)(ks[i] >> (64u - tbits)) - (d0 + r) + SX_BIAS : 0u;      // home - d + bias (home < 2^31, d < 2^30: no wrap)
+        uint32_t vmax;
+        const uint32_t inc = sg_block_incl_max(v, smem, &vmax);
+        if (f) {
+            dstart[d0 + r] = i;
+            pm[d0 + r] = inc > carry ? inc : carry;
+        }
+        if (i < s1) ent[i] = (uint32_t)vs[i];
+        c += tot;
+        if (vmax > carry) carry = vmax;
+    }
+    if (blockIdx.x == nseg - 1u && threadIdx.x == 0) dstart[d0 + c] = nent;     // the end of the last key's range
 }
 
 // key d goes to slot final(d) = d + (prefix maximum of home - j over j <= d).  The table is WRITTEN tile by tile, every line whole: a
@@ -792,12 +910,15 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
     while (tsize < 2 * nent) { tsize <<= 1; tbits++; }   // (4 / 8 * nent: the exact matcher at C3 12 / 16 % faster, modes d / i unchanged; the filter below does better)
     const uint64_t tslots = tsize + SX_PAD;
     int e;
-    // the table; the (key, entry) pairs twice (the sort's ping-pong); per entry: first-of-its-key flag, running number of keys, the
-    // entry array; per distinct key (at most nent): start of its range, home - number (and its prefix maximum)
+    // the table; the (key, entry) pairs twice (the sort's ping-pong); the entry array; per distinct key (at most nent): start of its
+    // range, prefix maximum of home - number; per segment of the sorted pairs: bounds, keys, maximum, first key's number, maximum before it
+    const bool by_segments = c->opt.seed_sort >= 0 ? c->opt.seed_sort != 0 : nent >= (1ull << 20);
+    const uint32_t nseg = by_segments ? 1u << SX_SEG_BITS : (uint32_t)((nent + SG_EVEN - 1) / SG_EVEN), OVL_CAP = 255u;
     if ((e = pgrc_buf_ensure(c, c->s_keys, tslots * sizeof(ulonglong2)))) return e;
     if ((e = pgrc_buf_ensure(c, c->s_vals, 4 * nent * sizeof(uint64_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->s_tab, (6 * nent + 8) * sizeof(uint32_t)))) return e;
-    if ((e = pgrc_buf_ensure(c, c->s_tmp, 128 + sco_scratch_words(nent) * sizeof(uint32_t)))) return e;        // counters, flags, the scans' block folds
+    if ((e = pgrc_buf_ensure(c, c->s_tab, (3 * nent + 8) * sizeof(uint32_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->s_seg, (5 * ((size_t)nseg + 1) + OVL_CAP + 1) * sizeof(uint32_t)))) return e;
+    if ((e = pgrc_buf_ensure(c, c->s_tmp, 128))) return e;        // counters, flags
     // the filter: 32 bits per indexed key (3 % of the windows of a random text pass it by chance), at most 2^36 bits.  It
     // pays when most windows of the text equal no key -- the exact matcher at C3: 100 M keys against 1.9 G windows, 0.20 ->
     // 0.16 s -- and costs a dependent round trip where many do (modes d / i with four parts per read: 0.42 -> 0.43 s): used
@@ -818,8 +939,10 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
     a.tmask = tsize - 1;
     a.tbits = tbits;
     uint64_t *kA = (uint64_t *)c->s_vals.p, *kB = kA + nent, *vA = kB + nent, *vB = vA + nent;
-    uint32_t *first = (uint32_t *)c->s_tab.p, *dnum = first + nent, *dstart = dnum + nent, *hb = dstart + nent + 1, *pm = hb + nent;
+    uint32_t *dstart = (uint32_t *)c->s_tab.p, *pm = dstart + nent + 1;
     a.ent = pm + nent;
+    uint32_t *seg = (uint32_t *)c->s_seg.p, *seg_nd = seg + nseg + 1, *seg_m = seg_nd + nseg + 1, *seg_base = seg_m + nseg + 1, *seg_pin = seg_base + nseg + 1,
+             *ovl = seg_pin + nseg + 1;
     if (a.nn) {
         if ((e = pgrc_buf_ensure(c, c->s_nmask, a.nn * a.nwr * sizeof(uint16_t)))) return e;
         a.nmask = (const uint16_t *)c->s_nmask.p;
@@ -828,10 +951,8 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
     }
     unsigned long long *counters = (unsigned long long *)c->s_tmp.p;   // [0 / 1] hits of the forward / the RC strand
     uint32_t *nd_dev = (uint32_t *)((char *)c->s_tmp.p + 64), *ovf_dev = nd_dev + 1;   // distinct keys; "the table ran over"
-    uint32_t *bsum = (uint32_t *)((char *)c->s_tmp.p + 128);
     HIP_TRY(c, hipMemsetAsync(c->s_tmp.p, 0, 128, c->stream));
     // 1. the table (section 1): pairs, sort, distinct keys, prefix maximum, placement
-    const uint32_t egrid = (uint32_t)std::min<uint64_t>((nent + 255) / 256, 65536ull * 4);
     hipLaunchKernelGGL(k_seed_keys, dim3((uint32_t)((nent + 255) / 256)), dim3(256), 0, c->stream, a, kA, vA);
     if (a.nn)
         hipLaunchKernelGGL(k_seed_keys_ascii, dim3((uint32_t)((a.nn * a.P + 255) / 256)), dim3(256), 0, c->stream, a, kA, vA);
@@ -842,12 +963,7 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
     // k_rx_segments): three trips through HBM instead of eight (31 -> ~12 ms at C3).  The few segments that hold more than a block
     // takes -- a key with thousands of entries sits in them -- are sorted as ranges of their own with the global passes.
     // PGRC_SEED_SORT=full / segments forces the one or the other (tests).
-    bool by_segments = nent >= (1ull << 20);
-    if (c->opt.seed_sort >= 0) by_segments = c->opt.seed_sort != 0;
     if (by_segments) {
-        const uint32_t nseg = 1u << SX_SEG_BITS, OVL_CAP = 255u;
-        if ((e = pgrc_buf_ensure(c, c->s_seg, ((size_t)nseg + 1 + OVL_CAP + 1) * sizeof(uint32_t)))) return e;
-        uint32_t *seg = (uint32_t *)c->s_seg.p, *ovl = seg + nseg + 1;
         if ((e = pgrc_radix_sort_pairs_u64(c, kA, kB, vA, vB, nent, 64u - SX_SEG_BITS, 64, c->s_sort, &ks, &vs))) return e;
         uint64_t *ko = ks == kA ? kB : kA, *vo = vs == vA ? vB : vA;     // the other halves of the ping-pong: scratch from here on
         HIP_TRY(c, hipMemsetAsync(ovl, 0, sizeof(uint32_t), c->stream));
@@ -875,13 +991,15 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
                 }
             }
         }
-    } else if ((e = pgrc_radix_sort_pairs_u64(c, kA, kB, vA, vB, nent, 0, 64, c->s_sort, &ks, &vs)))
-        return e;
-    hipLaunchKernelGGL(k_seed_mark, dim3(egrid), dim3(256), 0, c->stream, (const uint64_t *)ks, (const uint64_t *)vs, nent, first, a.ent);
-    HIP_TRY(c, (sco_scan<true>(c->stream, (const uint32_t *)first, dnum, nent, ScoIdentity(), ScoPlus(), 0u, bsum)));
-    HIP_TRY(c, hipMemsetAsync(hb, 0, nent * sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(k_seed_compact, dim3(egrid), dim3(256), 0, c->stream, (const uint64_t *)ks, (const uint32_t *)first, (const uint32_t *)dnum, nent, tbits, dstart, hb, nd_dev);
-    HIP_TRY(c, (sco_scan<true>(c->stream, (const uint32_t *)hb, pm, nent, ScoIdentity(), SeedMaxOp(), 0u, bsum)));
+    } else {
+        if ((e = pgrc_radix_sort_pairs_u64(c, kA, kB, vA, vB, nent, 0, 64, c->s_sort, &ks, &vs))) return e;
+        hipLaunchKernelGGL(k_seed_even_bounds, dim3((nseg + 1 + 255) / 256), dim3(256), 0, c->stream, (uint32_t)nent, nseg, seg);   // (pieces of SG_EVEN pairs)
+    }
+    // dstart, pm, ent (and the number of keys) from the sorted pairs, segment by segment
+    hipLaunchKernelGGL(k_seed_seg_summary, dim3(nseg), dim3(SG_TPB), 0, c->stream, (const uint64_t *)ks, (const uint32_t *)seg, tbits, seg_nd, seg_m);
+    hipLaunchKernelGGL(k_seed_seg_scan, dim3(1), dim3(SG_TPB), 0, c->stream, (const uint32_t *)seg_nd, (const uint32_t *)seg_m, nseg, seg_base, seg_pin, nd_dev);
+    hipLaunchKernelGGL(k_seed_seg_write, dim3(nseg), dim3(SG_TPB), 0, c->stream, (const uint64_t *)ks, (const uint64_t *)vs, (const uint32_t *)seg, nseg, (uint32_t)nent, tbits,
+                       (const uint32_t *)seg_base, (const uint32_t *)seg_pin, dstart, pm, a.ent);
     hipLaunchKernelGGL(k_seed_place_tiles, dim3((uint32_t)((tslots + PL_TILE - 1) / PL_TILE)), dim3(256), 0, c->stream, (const uint64_t *)ks, (const uint32_t *)dstart,
                        (const uint32_t *)pm, (const uint32_t *)nd_dev, tslots, a.tab, ovf_dev);
     HIP_TRY(c, hipGetLastError());
@@ -907,12 +1025,12 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
     const uint32_t *rows = (const uint32_t *)c->s_rows.p;
     uint64_t *best = (uint64_t *)c->s_best.p;
     const uint64_t pgw = c->pg_words + PGRC_PG_PAD_WORDS;
-    const uint64_t seg = std::min<uint64_t>(seg_windows, nscan);
-    if ((e = pgrc_buf_ensure(c, c->s_hits, std::max<uint64_t>(seg, 1) * (sizeof(uint64_t) + sizeof(uint32_t))))) return e;     // one word per window start of a launch + the list of the heavy ones
+    const uint64_t wseg = std::min<uint64_t>(seg_windows, nscan);
+    if ((e = pgrc_buf_ensure(c, c->s_hits, std::max<uint64_t>(wseg, 1) * (sizeof(uint64_t) + sizeof(uint32_t))))) return e;     // one word per window start of a launch + the list of the heavy ones
     uint64_t *wrec = (uint64_t *)c->s_hits.p;
-    uint32_t *hlist = (uint32_t *)(wrec + std::max<uint64_t>(seg, 1));
-    for (uint64_t w0 = 0; w0 < nscan; w0 += seg) {
-        const uint64_t nwin = std::min(nscan, w0 + seg);
+    uint32_t *hlist = (uint32_t *)(wrec + std::max<uint64_t>(wseg, 1));
+    for (uint64_t w0 = 0; w0 < nscan; w0 += wseg) {
+        const uint64_t nwin = std::min(nscan, w0 + wseg);
         const dim3 pgrid((uint32_t)((nwin - w0 + per_block - 1) / per_block)), egrid((uint32_t)((nwin - w0 + EXP_WIN - 1) / EXP_WIN));
         if (a.filter) hipLaunchKernelGGL(k_seed_probe<true>, pgrid, dim3(SCAN_TPB), 0, c->stream, a, w0, nwin, pgw, wrec);
         else hipLaunchKernelGGL(k_seed_probe<false>, pgrid, dim3(SCAN_TPB), 0, c->stream, a, w0, nwin, pgw, wrec);
