@@ -304,7 +304,7 @@ int pgrc_match_get_redo_flags(pgrc_match_ctx *ctx, uint8_t *flags);
  *   hand-over:    PGRC_UPLOAD_CHUNK_MB=n (staging chunk of append_reads_*), PGRC_STREAM_TIMING (milestones on stderr),
  *                 PGRC_HOST_PACK=0 (an ASCII text goes up as bytes and a kernel packs it; default: host threads pack it
  *                 into pinned buffers), PGRC_HOST_THREADS=n (those threads, default up to 8)
- *   tests:        PGRC_FORCE_POS64=1, PGRC_TEST_NO_SECOND_INDEX, PGRC_MEM_EVENT_CAP=n, PGRC_ALLGATHER=rccl|copy
+ *   tests:        PGRC_FORCE_POS64=1, PGRC_TEST_NO_SECOND_INDEX, PGRC_TEST_SEGMENT_TOP_BITS=n, PGRC_MEM_EVENT_CAP=n, PGRC_ALLGATHER=rccl|copy
  *   process-wide, read once per process: PGRC_DEVICE_POOL_GB (above), PGRC_DEBUG_ALLOC (log every device allocation)
  * pgrc_match_reload_options reads the environment again for a LIVE context (tests and A/B tools that change a variable
  * between two runs of one context). */

@@ -146,6 +146,7 @@ PgrcOptions pgrc_options_from_env() {
     if (num("PGRC_HOST_THREADS") > 0) o.host_threads = (uint32_t)std::min<long long>(256, num("PGRC_HOST_THREADS"));
     if (num("PGRC_UPLOAD_CHUNK_MB") > 0) o.upload_chunk_mb = (uint64_t)std::min<long long>(4096, num("PGRC_UPLOAD_CHUNK_MB"));
     o.seed_filter = flag("PGRC_SEED_FILTER");
+    if (num("PGRC_TEST_SEGMENT_TOP_BITS") > 0) o.test_segment_top_bits = (uint32_t)std::min<long long>(64, num("PGRC_TEST_SEGMENT_TOP_BITS")) & ~7u;
     if (const char *ss = getenv("PGRC_SEED_SORT")) o.seed_sort = !strcmp(ss, "full") ? 0 : !strcmp(ss, "segments") ? 1 : -1;
     if (num("PGRC_SEED_HEAVY") > 0) o.seed_heavy = (uint32_t)std::min<long long>(4096, num("PGRC_SEED_HEAVY"));
     if (num("PGRC_SEED_READ_BATCH") > 0) o.seed_read_batch = (uint64_t)num("PGRC_SEED_READ_BATCH");

@@ -166,7 +166,7 @@ k_rx_scatter(const uint64_t *__restrict__ in, const uint64_t *__restrict__ vin, 
 // it is and reported: ovl[0] counts them, ovl[1 .. cap] lists their numbers (the caller sorts those ranges with rx_sort).
 __global__ void __launch_bounds__(RX_TPB)
 k_rx_segments(uint64_t *__restrict__ keys, uint64_t *__restrict__ vals, const uint32_t *__restrict__ seg, uint32_t bit_lo, uint32_t bit_hi,
-              uint32_t *__restrict__ ovl, uint32_t cap) {
+              uint32_t top_bits, uint32_t *__restrict__ ovl, uint32_t cap) {
     __shared__ RxLds s;
     extern __shared__ __attribute__((aligned(16))) uint64_t valS[];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -187,7 +187,14 @@ k_rx_segments(uint64_t *__restrict__ keys, uint64_t *__restrict__ vals, const ui
         val[i] = x < n ? vals[(uint64_t)s0 + x] : 0ull;
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (uint32_t shift = bit_lo; shift < bit_hi; shift += 8u) {
+    // A field wider than 32 bits: the passes over its TOP 32 bits first.  At most RX_TILE keys that differ anywhere almost surely
+    // differ there (two of 8 192 random keys agree in 32 given bits with probability 2^-7 per segment), and keys that are EQUAL
+    // need no order: if no neighbours with equal top bits are out of order afterwards, the segment is sorted -- four passes
+    // instead of six for a 48-bit field.  Otherwise (rare) all the passes run, from the lowest bit, on what is there by then.
+    // (top_bits = 32; tests pass fewer, so that the long way is taken)
+    uint32_t first_shift = bit_hi - bit_lo > top_bits ? bit_lo + ((bit_hi - bit_lo - top_bits) & ~7u) : bit_lo;
+    __shared__ uint32_t unsorted;
+    for (uint32_t shift = first_shift; shift < bit_hi; shift += 8u) {
         const uint32_t dbits = bit_hi - shift < 8u ? bit_hi - shift : 8u, D = 1u << dbits, dmask = D - 1u;
         for (uint32_t x = threadIdx.x; x < RX_NW * RX_MAXD; x += RX_TPB) (&s.hist[0][0])[x] = (uint16_t)0;
         __syncthreads();
@@ -237,6 +244,8 @@ k_rx_segments(uint64_t *__restrict__ keys, uint64_t *__restrict__ vals, const ui
             }
         }
         __syncthreads();
+        const bool last = shift + 8u >= bit_hi;
+        if (last && first_shift != bit_lo && threadIdx.x == 0) unsorted = 0u;
 #pragma unroll
         for (int i = 0; i < RX_E; i++) {                       // back in the input layout: slot order = the order of this pass
             const uint32_t x = wv * RX_WSPAN + (uint32_t)i * 64u + lane;
@@ -246,6 +255,22 @@ k_rx_segments(uint64_t *__restrict__ keys, uint64_t *__restrict__ vals, const ui
             }
         }
         __syncthreads();
+        if (last && first_shift != bit_lo) {                   // the short way: is the segment sorted by the whole field?
+            const uint64_t fmask = (bit_hi >= 64u ? ~0ull : (1ull << bit_hi) - 1ull) & ~((1ull << bit_lo) - 1ull);
+            bool bad = false;
+#pragma unroll
+            for (int i = 0; i < RX_E; i++) {
+                const uint32_t x = wv * RX_WSPAN + (uint32_t)i * 64u + lane;
+                if (x > 0u && x < n && (s.recS[x] & fmask) < (s.recS[x - 1u] & fmask)) bad = true;
+            }
+            if (bad) unsorted = 1u;
+            __syncthreads();
+            if (unsorted) {                                    // (block-uniform) all the passes after all
+                first_shift = bit_lo;
+                shift = bit_lo - 8u;                           // (the loop's increment brings it to bit_lo)
+            }
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int i = 0; i < RX_E; i++) {
@@ -261,9 +286,10 @@ k_rx_segments(uint64_t *__restrict__ keys, uint64_t *__restrict__ vals, const ui
 // words on the device, ovl[0] zeroed by the caller.  On c->stream, no synchronisation.
 int pgrc_radix_sort_segments_pairs_u64(pgrc_match_ctx *c, uint64_t *keys, uint64_t *vals, const uint32_t *seg, uint32_t nseg, uint32_t bit_lo, uint32_t bit_hi,
                                        uint32_t *ovl, uint32_t cap) {
+    const uint32_t top_bits = c->opt.test_segment_top_bits ? c->opt.test_segment_top_bits : 32u;
     if (!nseg || bit_hi <= bit_lo) return PGRC_OK;
     HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_rx_segments), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RX_TILE * sizeof(uint64_t))));
-    hipLaunchKernelGGL(k_rx_segments, dim3(nseg), dim3(RX_TPB), RX_TILE * sizeof(uint64_t), c->stream, keys, vals, seg, bit_lo, bit_hi, ovl, cap);
+    hipLaunchKernelGGL(k_rx_segments, dim3(nseg), dim3(RX_TPB), RX_TILE * sizeof(uint64_t), c->stream, keys, vals, seg, bit_lo, bit_hi, top_bits, ovl, cap);
     HIP_TRY(c, hipGetLastError());
     return PGRC_OK;
 }

@@ -136,13 +136,17 @@ def test_seedindex_scan_filter_on_and_off(monkeypatch, mode, filt):
 
 
 @pytest.mark.parametrize("mode", ["d", "i", "e"])
-@pytest.mark.parametrize("sort", ["full", "segments"])
+@pytest.mark.parametrize("sort", ["full", "segments", "segments-long"])
 def test_seedindex_table_sort_forms(monkeypatch, mode, sort):
     """The (key, entry) pairs of the table are sorted by all 64 key bits with global passes (small batches) or by two global passes
     over the top 16 bits and one in-LDS sort per segment (large batches; radix.hip k_rx_segments); PGRC_SEED_SORT forces either.
     Same results and hits per strand -- with few reads (most segments empty or of one pair), with tandem repeats, and with a pool
     of repeated reads large enough that the segments holding their keys exceed what a block takes (sorted as ranges of their own)."""
-    monkeypatch.setenv("PGRC_SEED_SORT", sort)
+    monkeypatch.setenv("PGRC_SEED_SORT", sort.split("-")[0])
+    if sort == "segments-long":    # a segment is first sorted by its keys' top 32 bits and checked: with 8 the check fails and all the passes run
+        monkeypatch.setenv("PGRC_TEST_SEGMENT_TOP_BITS", "8")
+    else:
+        monkeypatch.delenv("PGRC_TEST_SEGMENT_TOP_BITS", raising=False)
     L = 100
     seed_len, kmax = (L, 0) if mode == "e" else (38, 2)
     pg, reads = make_inputs(200_000, 6000, L, seed=79, n_with_n=100, pool_div=64, tandem_every=3)
@@ -151,6 +155,9 @@ def test_seedindex_table_sort_forms(monkeypatch, mode, sort):
     pg, _ = make_inputs(100_000, 16, L, seed=80)
     reads = np.ascontiguousarray(np.stack([pg[s:s + L] for s in (1000, 20_000, 50_000, 90_000)] * 10_000))
     assert_same_results(gpu_match(mode, pg, reads, seed_len, kmax, 0), orc.oracle_match(mode, pg, reads, seed_len, kmax, 0), f"mode {mode} sort {sort}, repeated reads")
+    if sort != "full" and mode == "d":   # enough entries for segments of ~14 keys each (65 536 segments)
+        pg, reads = make_inputs(2_000_000, 300_000, L, seed=81)
+        assert_same_results(gpu_match(mode, pg, reads, seed_len, kmax, 0), orc.oracle_match(mode, pg, reads, seed_len, kmax, 0), f"mode {mode} sort {sort}, 900 k entries")
 
 
 CASES = [
