@@ -816,7 +816,11 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
 
     // ---- 1. events
     if ((e = pgrc_buf_ensure(c, m->d_cursor, 8))) { m->err = c->err; return e; }
-    uint64_t cap = std::max<uint64_t>(nprobes / 64 + 65536, m->d_evk[0].bytes / 8);
+    // room for the events (32 bytes each, in four arrays): one per probe for a short text -- a low-quality text against the high-quality
+    // one makes 0.6 events per probe --, one per four probes for a long one (a text against itself, forward: 0.18; against its reverse
+    // complement, the encoder's call: 0.004); a probe that finds more is run again with what it counted (rounds 1-5a started at one
+    // event per 64 probes: the event-rich calls probed twice the first time)
+    uint64_t cap = std::max<uint64_t>((nprobes <= (64ull << 20) ? nprobes : nprobes / 4) + 65536, m->d_evk[0].bytes / 8);
     if (c->opt.mem_event_cap) cap = c->opt.mem_event_cap;   // (PGRC_MEM_EVENT_CAP, test knob: start tiny to exercise the regrow-and-rerun path)
     unsigned long long nev = 0;
     (void)hipEventRecord(ev[0], c->stream);
@@ -853,11 +857,12 @@ int pgrc_mem_match_texts(pgrc_mem_ctx *m, const char *dest, uint64_t N2, int des
     const uint64_t *ek = ksorted, *ep = vsorted;
 
     // ---- 3. side contexts; extents per run of connected events on a diagonal
-    if ((e = pgrc_buf_ensure(c, m->d_orun, cap * 4)) || (e = pgrc_buf_ensure(c, m->d_oflag, cap)) || (e = pgrc_buf_ensure(c, m->d_first, cap * 4)) ||
-        (e = pgrc_buf_ensure(c, m->d_runid, cap * 4)) || (e = pgrc_buf_ensure(c, m->d_rstart, cap * 8)) || (e = pgrc_buf_ensure(c, m->d_rend, cap * 8)) ||
-        (e = pgrc_buf_ensure(c, m->d_rdend, cap * 8)) || (e = pgrc_buf_ensure(c, m->d_outc, cap)) || (e = pgrc_buf_ensure(c, m->d_small, 64))) { m->err = c->err; return e; }
+    const uint64_t ecap = nev + nev / 8 + 4096;               // per-event arrays: by the events there are (with room for a similar call), not by the first guess
+    if ((e = pgrc_buf_ensure(c, m->d_orun, ecap * 4)) || (e = pgrc_buf_ensure(c, m->d_oflag, ecap)) || (e = pgrc_buf_ensure(c, m->d_first, ecap * 4)) ||
+        (e = pgrc_buf_ensure(c, m->d_runid, ecap * 4)) || (e = pgrc_buf_ensure(c, m->d_rstart, ecap * 8)) || (e = pgrc_buf_ensure(c, m->d_rend, ecap * 8)) ||
+        (e = pgrc_buf_ensure(c, m->d_rdend, ecap * 8)) || (e = pgrc_buf_ensure(c, m->d_outc, ecap)) || (e = pgrc_buf_ensure(c, m->d_small, 64))) { m->err = c->err; return e; }
     for (int k = 0; k < 2; k++)
-        if ((e = pgrc_buf_ensure(c, m->d_skey[k], cap * 8)) || (e = pgrc_buf_ensure(c, m->d_sidx[k], cap * 8))) { m->err = c->err; return e; }
+        if ((e = pgrc_buf_ensure(c, m->d_skey[k], ecap * 8)) || (e = pgrc_buf_ensure(c, m->d_sidx[k], ecap * 8))) { m->err = c->err; return e; }
     // d_small: [0] "a block was replayed" flag, [1] first stale event, [2] events with a context outside a text, [4..7] two u64 of a range
     uint32_t *d_changed = (uint32_t *)m->d_small.p, *d_first_stale = d_changed + 1, *d_nstale = d_changed + 2;
     uint64_t *d_range = (uint64_t *)m->d_small.p + 2;
