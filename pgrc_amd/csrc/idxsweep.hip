@@ -474,9 +474,10 @@ int pgrc_os_build_index(pgrc_match_ctx *c, int strand, uint32_t hbits) {
     // the other stores.  Measured at C3 in round 3, per strand (profiles/r03_os_cfgs.txt): pass 1 / pass 2 = 3.0 / 1.8 ms with 1024
     // x 8 (one block per CU), 1.8 / 1.75 with 1024 x 6, 2.2 / 2.1 with 512 x 8 (three per CU), 3.3 / 2.75 with 512 x 16, 3.0 / 2.4
     // with a persistent, prefetching pass 2.  Nine-bit digits in BOTH passes (tables of 2^30 buckets and more: 16-bit digit
-    // arrays) take the 8-record shape, one block per CU.
+    // arrays) take 1024 x 5: two blocks per CU fit (round 5; 1024 x 8, one per CU, until then: the C5 shard's pair of builds 39.8 ->
+    // 38.3 ms, P64's 50.8 -> 48.9 in one context -- a tile's run of one of 512 digits is 10 records, 80 bytes, either way).
     const bool aux16 = pl.b2 > 8;
-    const uint64_t n = pl.n, tile = aux16 ? 8192u : 6144u;
+    const uint64_t n = pl.n, tile = aux16 ? 5120u : 6144u;
     const uint32_t D1 = 1u << pl.b1, D2 = 1u << pl.b2, np = 1u << (pl.hbits - pl.cb);
     pl.ntiles1 = (n + tile - 1) / tile;
     pl.ntiles2_max = pl.ntiles1 + D1;
@@ -503,7 +504,7 @@ int pgrc_os_build_index(pgrc_match_ctx *c, int strand, uint32_t hbits) {
     b.recB = (uint64_t *)c->d_sval[1].p;
     b.aux = c->d_skey[0].p;
     HIP_TRY(c, hipMemsetAsync(b.slow, 0, flag_words * sizeof(uint32_t), c->stream));
-    if (aux16) e = os_passes<1024, 8, 1, uint16_t, uint16_t>(c, strand, pl, b);
+    if (aux16) e = os_passes<1024, 5, 2, uint16_t, uint16_t>(c, strand, pl, b);
     else e = os_passes<1024, 6, 2, uint8_t, uint8_t>(c, strand, pl, b);
     if (e) return e;
     return pgrc_ps_finish_packed(c, b.recB, b.pstart, b.slow, np, pl.cb, pl.rec_sh, b.recA);
