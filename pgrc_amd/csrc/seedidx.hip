@@ -817,12 +817,25 @@ k_seed_expand(const SeedArgs a, uint64_t wbase, uint64_t nwin, const uint64_t *_
         }
         return a.ent[f_off[flo] + k];
     };
-    uint32_t n_meta = 0, n_rep = 0, n_ew = 0;
-    if (threadIdx.x < total) n_ew = locate(threadIdx.x, &n_meta, &n_rep);
-    for (uint32_t o = threadIdx.x; o < total; o += EXP_TPB) {
-        const uint32_t meta = n_meta, rep = n_rep, ew = n_ew;
-        if (o + EXP_TPB < total) n_ew = locate(o + EXP_TPB, &n_meta, &n_rep);
-        seed_hit<RW4>(a, ew, (meta >> 14) & 1u, meta >> 15, rep, b0 + (meta & 0x3FFFu), rows, best, cnt0, cnt1, t_fw, w0_fw, t_rc, w0_rc);
+    // two hits per lane and turn: the row and the key of both are asked for before either's mismatches are counted (the kernel
+    // waits for memory two thirds of its time: a hit is entry word -> row and key -> count, three loads in a row)
+    uint32_t n_meta[2] = {0, 0}, n_rep[2] = {0, 0}, n_ew[2] = {0, 0};
+    for (int u = 0; u < 2; u++)
+        if (threadIdx.x + (uint32_t)u * EXP_TPB < total) n_ew[u] = locate(threadIdx.x + (uint32_t)u * EXP_TPB, &n_meta[u], &n_rep[u]);
+    for (uint32_t o = threadIdx.x; o < total; o += 2u * EXP_TPB) {
+        SeedHit<RW4> h[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t meta = n_meta[u], rep = n_rep[u], ew = n_ew[u];
+            h[u].js = 0;
+            if (o + (uint32_t)u * EXP_TPB < total)
+                seed_hit_a<RW4>(a, ew, (meta >> 14) & 1u, meta >> 15, rep, b0 + (meta & 0x3FFFu), rows, best, cnt0, cnt1, h[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (o + (2u + (uint32_t)u) * EXP_TPB < total) n_ew[u] = locate(o + (2u + (uint32_t)u) * EXP_TPB, &n_meta[u], &n_rep[u]);
+#pragma unroll
+        for (int u = 0; u < 2; u++) seed_hit_b<RW4>(a, h[u], best, t_fw, w0_fw, t_rc, w0_rc);
     }
     if (cnt0) atomicAdd(&hitcnt[0], cnt0);
     if (cnt1) atomicAdd(&hitcnt[1], cnt1);
