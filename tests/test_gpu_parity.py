@@ -155,6 +155,10 @@ def test_seedindex_table_sort_forms(monkeypatch, mode, sort):
     pg, _ = make_inputs(100_000, 16, L, seed=80)
     reads = np.ascontiguousarray(np.stack([pg[s:s + L] for s in (1000, 20_000, 50_000, 90_000)] * 10_000))
     assert_same_results(gpu_match(mode, pg, reads, seed_len, kmax, 0), orc.oracle_match(mode, pg, reads, seed_len, kmax, 0), f"mode {mode} sort {sort}, repeated reads")
+    if sort == "segments" and mode == "e":   # more over-full segments than the list of them holds (255): the whole array is sorted by all its bits instead
+        pg, _ = make_inputs(400_000, 16, L, seed=82)
+        reads = np.ascontiguousarray(np.stack([pg[s:s + L] for s in range(1000, 1000 + 300 * 1200, 1200)] * 9000).reshape(9000, 300, L).transpose(1, 0, 2).reshape(-1, L))
+        assert_same_results(gpu_match(mode, pg, reads, seed_len, kmax, 0), orc.oracle_match(mode, pg, reads, seed_len, kmax, 0), f"mode {mode} sort {sort}, 300 keys of 9000 entries")
     if sort != "full" and mode == "d":   # enough entries for segments of ~14 keys each (65 536 segments)
         pg, reads = make_inputs(2_000_000, 300_000, L, seed=81)
         assert_same_results(gpu_match(mode, pg, reads, seed_len, kmax, 0), orc.oracle_match(mode, pg, reads, seed_len, kmax, 0), f"mode {mode} sort {sort}, 900 k entries")
