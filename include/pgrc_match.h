@@ -300,7 +300,8 @@ int pgrc_match_get_redo_flags(pgrc_match_ctx *ctx, uint8_t *flags);
  *   index build:  PGRC_INDEX_SORT=sweep|own (front end), PGRC_INDEX_FINISH=general (the general finish kernel for every
  *                 partition), PGRC_INDEX_CFG=0 (the passes without the XCD-aware tile order: A/B runs)
  *   modes d/i/e:  PGRC_SEED_FILTER=0|1, PGRC_SEED_HEAVY=n, PGRC_SEED_READ_BATCH=n, PGRC_SEED_SEGMENT=n,
- *                 PGRC_SEED_SORT=full|segments (the table's pairs sorted by global passes / by segments in LDS; default by size)
+ *                 PGRC_SEED_SORT=full|segments (the table's pairs sorted by global passes / by segments in LDS; default by size),
+ *                 PGRC_SEED_HEAVY_FORM=window|grouped (windows on keys with many entries: a wave per window / grouped by key, default)
  *   hand-over:    PGRC_UPLOAD_CHUNK_MB=n (staging chunk of append_reads_*), PGRC_STREAM_TIMING (milestones on stderr),
  *                 PGRC_HOST_PACK=0 (an ASCII text goes up as bytes and a kernel packs it; default: host threads pack it
  *                 into pinned buffers), PGRC_HOST_THREADS=n (those threads, default up to 8)

@@ -147,6 +147,7 @@ PgrcOptions pgrc_options_from_env() {
     if (num("PGRC_UPLOAD_CHUNK_MB") > 0) o.upload_chunk_mb = (uint64_t)std::min<long long>(4096, num("PGRC_UPLOAD_CHUNK_MB"));
     o.seed_filter = flag("PGRC_SEED_FILTER");
     if (num("PGRC_TEST_SEGMENT_TOP_BITS") > 0) o.test_segment_top_bits = (uint32_t)std::min<long long>(64, num("PGRC_TEST_SEGMENT_TOP_BITS")) & ~7u;
+    if (const char *hf = getenv("PGRC_SEED_HEAVY_FORM")) o.seed_heavy_form = !strcmp(hf, "window") ? 0 : 1;
     if (const char *ss = getenv("PGRC_SEED_SORT")) o.seed_sort = !strcmp(ss, "full") ? 0 : !strcmp(ss, "segments") ? 1 : -1;
     if (num("PGRC_SEED_HEAVY") > 0) o.seed_heavy = (uint32_t)std::min<long long>(4096, num("PGRC_SEED_HEAVY"));
     if (num("PGRC_SEED_READ_BATCH") > 0) o.seed_read_batch = (uint64_t)num("PGRC_SEED_READ_BATCH");
@@ -359,7 +360,7 @@ void pgrc_match_destroy(pgrc_match_ctx *c) {
     DevBuf *bufs[] = {&c->pg2[0], &c->pg2[1], &c->reads_own, &c->nread_idx, &c->nread_ascii, &c->nread_flag, &c->nread_npos, &c->d_pos,
                       &c->d_rc, &c->d_mism, &c->d_hist, &c->d_counters, &c->d_head, &c->d_headpair, &c->d_skey[0], &c->d_skey[1], &c->d_sval[0], &c->d_sval[1], &c->d_sorttmp,
                       &c->alt_head, &c->alt_skey[0], &c->alt_skey[1], &c->alt_sval[0], &c->alt_sval[1], &c->alt_sorttmp, &c->d_scr_pos, &c->d_scr_flag,
-                      &c->s_keys, &c->s_filter, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp, &c->s_sort, &c->s_seg, &c->s_nmask, &c->s_best, &c->s_rows};
+                      &c->s_keys, &c->s_filter, &c->s_vals, &c->s_tab, &c->s_hits, &c->s_tmp, &c->s_sort, &c->s_seg, &c->s_hv, &c->s_hvu, &c->s_nmask, &c->s_best, &c->s_rows};
     pgrc_buf_free_all(bufs, sizeof bufs / sizeof bufs[0]);       // (the device is idle: waited for above)
     for (DevBuf &b : c->up_nchunks) pgrc_buf_free(b);
     if (c->have_events)

@@ -59,6 +59,7 @@ struct PgrcOptions {
     uint64_t upload_chunk_mb = 0;   // PGRC_UPLOAD_CHUNK_MB: staging chunk of append_reads_* (0 = 256, or 1024 for a streamed run)
     int seed_filter = -1;           // PGRC_SEED_FILTER  modes d/i/e: -1 where it pays, 0 never, 1 always
     uint32_t test_segment_top_bits = 0;   // PGRC_TEST_SEGMENT_TOP_BITS: the segment sort's short way over this many top bits (tests: 8 makes it fail and the long way run)
+    int seed_heavy_form = 1;        // PGRC_SEED_HEAVY_FORM=window|grouped: heavy windows a wave each / grouped by their key (default)
     int seed_sort = -1;             // PGRC_SEED_SORT=full|segments: how modes d/i/e sort their (key, entry) pairs (-1: by the batch's size)
     uint32_t seed_heavy = 0;        // PGRC_SEED_HEAVY   modes d/i/e: entries of a window above which the persistent grid expands it (0 = default)
     uint64_t seed_read_batch = 0;   // PGRC_SEED_READ_BATCH / PGRC_SEED_SEGMENT: reads per batch / window starts per launch (tests; 0 = default)
@@ -181,7 +182,7 @@ struct pgrc_match_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> st_tev;
 
     // read-side seed index (modes d / i / e)
-    DevBuf s_keys, s_vals, s_tab, s_hits, s_tmp, s_sort, s_seg;
+    DevBuf s_keys, s_vals, s_tab, s_hits, s_tmp, s_sort, s_seg, s_hv, s_hvu;
     DevBuf s_filter;        // modes d/i/e: one bit per slice of the key space (seedidx.hip)
     DevBuf s_nmask;                             // N masks of the reads with N (modes d/i/e)
     DevBuf s_best, s_rows;                      // the atomic-minimum reduction: one key per read, the batch's reads row by row (seedidx.hip 3c)

@@ -893,6 +893,147 @@ k_seed_heavy(const SeedArgs a, uint64_t wbase, const uint64_t *__restrict__ wrec
     if (threadIdx.x < 2 && hitcnt[threadIdx.x]) atomicAdd(counters + threadIdx.x, (unsigned long long)hitcnt[threadIdx.x]);
 }
 
+// ---- the heavy windows, grouped by their KEY (round 5).  The windows of a launch that found a key with many entries are few
+// KEYS met many times -- 563 keys at C3 in mode d, 0.7 M windows of the text on them: repeats of the text --, and going window by
+// window (k_seed_heavy) every (window, entry) pair loads the entry's read again and looks at the read's key in memory: a kernel that
+// waits.  Here the list of heavy windows is sorted by key, a block takes up to HVG_WC windows of ONE key, and a thread keeps ITS entry
+// -- the read's row in registers, the smallest key of its hits so far -- while the windows pass: per pair only the text words come
+// from memory (staged in LDS, HVG_SB windows at a time), and a read's key in memory is touched once per (entry, unit).
+//   k_seed_hv_records   heavy window x -> (first entry of its key) << 32 | window        (sorted by the key with radix.hip)
+//   k_seed_hv_units     runs of one key, cut into units of at most HVG_WC windows: first | count << 32
+//   k_seed_heavy_grouped  a persistent grid takes the units (counters[3]; counters[4] = their number)
+#define HVG_TPB 256
+#define HVG_WC 256u
+#define HVG_SB 16u
+#define HVG_EC 1024u      // entries of a key per unit
+__global__ void __launch_bounds__(256)
+k_seed_hv_records(const uint64_t *__restrict__ wrec, const uint32_t *__restrict__ hlist, uint32_t nh, uint64_t *__restrict__ recs) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nh) return;
+    const uint32_t w = hlist[x];
+    recs[x] = ((wrec[w] & WREC_OFF_MASK) << 32) | w;
+}
+__global__ void __launch_bounds__(256)
+k_seed_hv_units(const uint64_t *__restrict__ recs, const uint64_t *__restrict__ wrec, uint32_t nh, uint64_t *__restrict__ units, unsigned long long cap,
+                unsigned long long *__restrict__ nunits) {
+    // units == nullptr: only counted.  A unit: first record (32 bits) | windows (9) << 32 | which HVG_EC entries of the key (23) << 41
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nh) return;
+    const uint32_t key = (uint32_t)(recs[x] >> 32);
+    if (x && (uint32_t)(recs[x - 1] >> 32) == key) return;            // not the first window of its key
+    uint32_t lo = x + 1u, hi = nh;                                    // the first record of the next key
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((uint32_t)(recs[mid] >> 32) == key) lo = mid + 1u; else hi = mid;
+    }
+    const uint32_t glen = lo - x;
+    const uint32_t cnt = (uint32_t)((wrec[(uint32_t)recs[x]] >> WREC_CNT_SH) & WREC_CNT_MASK);
+    const uint32_t nec = (cnt + HVG_EC - 1u) / HVG_EC, nwc = (glen + HVG_WC - 1u) / HVG_WC;
+    if (!units) {
+        atomicAdd(nunits, (unsigned long long)nec * nwc);
+        return;
+    }
+    unsigned long long at = atomicAdd(nunits, (unsigned long long)nec * nwc);
+    for (uint32_t wc = 0; wc < glen; wc += HVG_WC) {
+        const uint32_t n = glen - wc < HVG_WC ? glen - wc : HVG_WC;
+        for (uint32_t k = 0; k < nec; k++, at++)
+            if (at < cap) units[at] = (uint64_t)(x + wc) | ((uint64_t)n << 32) | ((uint64_t)k << 41);
+    }
+}
+template <int RW4>
+__global__ void __launch_bounds__(HVG_TPB)
+k_seed_heavy_grouped(const SeedArgs a, uint64_t wbase, const uint64_t *__restrict__ wrec, const uint64_t *__restrict__ recs, const uint64_t *__restrict__ units,
+                     const uint32_t *__restrict__ rows, uint64_t *__restrict__ best, unsigned long long *__restrict__ counters, uint64_t pg_words_alloc) {
+    __shared__ uint32_t t_fw[HVG_SB][HV_TILE_WORDS], t_rc[HVG_SB][HV_TILE_WORDS];      // the two texts around each of the staged windows
+    __shared__ uint64_t s_tf[HVG_SB], s_w0f[HVG_SB], s_w0r[HVG_SB];
+    __shared__ uint32_t s_fl[HVG_SB];                                                // wflag | pal << 1
+    __shared__ uint32_t hitcnt[2];
+    __shared__ unsigned long long s_unit;
+    if (threadIdx.x == 0) { hitcnt[0] = 0; hitcnt[1] = 0; }
+    const unsigned long long nunits = counters[4];
+    uint32_t cnt0 = 0, cnt1 = 0;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_unit = atomicAdd(counters + 3, 1ull);
+        __syncthreads();
+        const unsigned long long it = s_unit;
+        if (it >= nunits) break;
+        const uint64_t u = units[it];
+        const uint32_t x0 = (uint32_t)u, nw = (uint32_t)(u >> 32) & 0x1FFu, ek = (uint32_t)(u >> 41);
+        const uint64_t r0 = wrec[(uint32_t)recs[x0]];
+        const uint32_t cnt_all = (uint32_t)((r0 >> WREC_CNT_SH) & WREC_CNT_MASK);
+        const uint32_t off = (uint32_t)(r0 & WREC_OFF_MASK) + ek * HVG_EC, cnt = cnt_all - ek * HVG_EC < HVG_EC ? cnt_all - ek * HVG_EC : HVG_EC;   // this unit's entries
+        // the entries of the key, ew at a time side by side; with fewer than HVG_TPB of them several threads share an entry and
+        // split the windows between them
+        uint32_t ew_ = 1u;
+        while (ew_ < cnt && ew_ < (uint32_t)HVG_TPB) ew_ <<= 1;
+        const uint32_t streams = (uint32_t)HVG_TPB / ew_, stream = threadIdx.x / ew_;
+        for (uint32_t ec = 0; ec < cnt; ec += ew_) {
+            const uint32_t eidx = ec + (threadIdx.x & (ew_ - 1u));
+            const bool live = eidx < cnt;
+            const uint32_t ew = live ? a.ent[off + eidx] : 0u;
+            const uint32_t e = ew & ~SX_FLAG, ef = ew >> 31;
+            const uint32_t i = e / a.P, j = e % a.P;
+            const uint64_t shift = part_offset(a, j);
+            const bool nread = live && a.nflag && a.nflag[i];
+            const uint64_t trow = nread ? lower_bound_u32(a.nidx, a.nn, (uint32_t)(i + a.ibase)) : 0ull;
+            uint32_t row[RW4 * 4];
+            if (live && !nread) load_row<RW4>(rows, i, row);
+            uint64_t mine = BK_NONE;                                  // the smallest key of this entry's hits in this unit
+            for (uint32_t sb = 0; sb < nw; sb += HVG_SB) {
+                const uint32_t nsb = nw - sb < HVG_SB ? nw - sb : HVG_SB;
+                __syncthreads();                                      // (the previous windows' tiles are done with)
+                {
+                    const uint32_t q = threadIdx.x / (HVG_TPB / HVG_SB), sub = threadIdx.x % (HVG_TPB / HVG_SB);   // 16 threads per window
+                    if (q < nsb) {
+                        const uint32_t w = (uint32_t)recs[x0 + sb + q];
+                        const uint64_t r = wrec[w];
+                        const uint64_t tf = wbase + w, trc = a.rc_top >= tf ? a.rc_top - tf : 0ull;
+                        uint64_t w0f, w0r;
+                        uint32_t nwf, nwr2;
+                        seed_tile_span(tf, tf, a.L, &w0f, &nwf);
+                        seed_tile_span(trc, trc, a.L, &w0r, &nwr2);
+                        seed_tile_load(t_fw[q], a.pg, w0f, nwf, pg_words_alloc, sub, HVG_TPB / HVG_SB);
+                        if (a.want & 2u) seed_tile_load(t_rc[q], a.pg_rc, w0r, nwr2, pg_words_alloc, sub, HVG_TPB / HVG_SB);
+                        if (sub == 0) {
+                            s_tf[q] = tf;
+                            s_w0f[q] = w0f;
+                            s_w0r[q] = w0r;
+                            s_fl[q] = ((uint32_t)(r >> 62) & 1u) | ((uint32_t)(r >> 63) << 1);
+                        }
+                    }
+                }
+                __syncthreads();
+                if (live) {
+                    for (uint32_t q = stream; q < nsb; q += streams) {
+                        const uint64_t tf = s_tf[q];
+                        const uint32_t wflag = s_fl[q] & 1u, pal = s_fl[q] >> 1;
+                        if (pal && ef) continue;                      // (not a candidate: SeedArgs)
+                        for (uint32_t rep = 0; rep <= pal; rep++) {
+                            const uint32_t strand = wflag ^ ef ^ rep;
+                            const uint64_t t = strand ? a.rc_top - tf : tf;
+                            if (!((a.want >> strand) & 1u) || t >= a.nwin_all || shift > t || t - shift + a.L > a.G) continue;   // (seed_hit_a)
+                            if (strand) cnt1++; else cnt0++;
+                            const uint64_t p = t - shift;
+                            const uint32_t *text = strand ? t_rc[q] : t_fw[q];
+                            const uint64_t text_w0 = strand ? s_w0r[q] : s_w0f[q];
+                            const uint32_t mm = nread ? hamming_vs_text_n(a, text, text_w0, i, trow, p) : hamming_regs_vs_text<RW4>(a, text, text_w0, row, p);
+                            if (a.mode == 'e' ? mm != 0u : mm > a.kmax) continue;
+                            const uint64_t key = ((uint64_t)(mm <= a.kmin ? 0u : mm) << 56) | ((uint64_t)strand << 55) | (t << 15) | ((uint64_t)(15u - j) << 11) | mm;
+                            if (key < mine) mine = key;
+                        }
+                    }
+                }
+            }
+            if (live && mine != BK_NONE && mine < best[i]) atomicMin((unsigned long long *)&best[i], (unsigned long long)mine);
+        }
+    }
+    if (cnt0) atomicAdd(&hitcnt[0], cnt0);
+    if (cnt1) atomicAdd(&hitcnt[1], cnt1);
+    __syncthreads();
+    if (threadIdx.x < 2 && hitcnt[threadIdx.x]) atomicAdd(counters + threadIdx.x, (unsigned long long)hitcnt[threadIdx.x]);
+}
+
 __global__ void __launch_bounds__(256) k_seed_best_store(const SeedArgs a, const uint64_t *__restrict__ best) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
@@ -1047,12 +1188,13 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
         const dim3 pgrid((uint32_t)((nwin - w0 + per_block - 1) / per_block)), egrid((uint32_t)((nwin - w0 + EXP_WIN - 1) / EXP_WIN));
         if (a.filter) hipLaunchKernelGGL(k_seed_probe<true>, pgrid, dim3(SCAN_TPB), 0, c->stream, a, w0, nwin, pgw, wrec);
         else hipLaunchKernelGGL(k_seed_probe<false>, pgrid, dim3(SCAN_TPB), 0, c->stream, a, w0, nwin, pgw, wrec);
-        HIP_TRY(c, hipMemsetAsync(counters + 2, 0, 2 * sizeof(unsigned long long), c->stream));       // heavy windows listed / taken
+        HIP_TRY(c, hipMemsetAsync(counters + 2, 0, 3 * sizeof(unsigned long long), c->stream));       // heavy windows listed / units taken / units
         const dim3 hgrid((uint32_t)c->num_cus * 8u);
         const uint32_t heavy_thr = c->opt.seed_heavy ? c->opt.seed_heavy : EXP_HEAVY;
+        const bool grouped = c->opt.seed_heavy_form != 0;            // PGRC_SEED_HEAVY_FORM=window: a wave per heavy window (rounds 4-5a)
 #define EXP_LAUNCH(R)                                                                                                                                       \
         hipLaunchKernelGGL((k_seed_expand<R>), egrid, dim3(EXP_TPB), 0, c->stream, a, w0, nwin, (const uint64_t *)wrec, rows, best, counters, hlist, heavy_thr, pgw); \
-        hipLaunchKernelGGL((k_seed_heavy<R>), hgrid, dim3(EXP_TPB), 0, c->stream, a, w0, (const uint64_t *)wrec, (const uint32_t *)hlist, rows, best, counters, pgw)
+        if (!grouped) hipLaunchKernelGGL((k_seed_heavy<R>), hgrid, dim3(EXP_TPB), 0, c->stream, a, w0, (const uint64_t *)wrec, (const uint32_t *)hlist, rows, best, counters, pgw)
         switch (rw / 4u) {
         case 1: EXP_LAUNCH(1); break;
         case 2: EXP_LAUNCH(2); break;
@@ -1061,6 +1203,37 @@ static int seedidx_batch(pgrc_match_ctx *c, SeedArgs a, uint64_t seg_windows, in
         }
 #undef EXP_LAUNCH
         HIP_TRY(c, hipGetLastError());
+        if (grouped) {
+            // the heavy windows by key (k_seed_heavy_grouped): their number decides the sort's launches -- the one wait per launch
+            unsigned long long nheavy = 0;
+            HIP_TRY(c, hipMemcpyAsync(&nheavy, counters + 2, sizeof nheavy, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (nheavy) {
+                const uint32_t nhv = (uint32_t)nheavy;
+                if ((e = pgrc_buf_ensure(c, c->s_hv, 2 * (size_t)nhv * sizeof(uint64_t)))) return e;
+                uint64_t *recA = (uint64_t *)c->s_hv.p, *recB = recA + nhv, *recs = nullptr;
+                hipLaunchKernelGGL(k_seed_hv_records, dim3((nhv + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)wrec, (const uint32_t *)hlist, nhv, recA);
+                if ((e = pgrc_radix_sort_u64(c, recA, recB, nhv, 32, 32 + WREC_CNT_SH, c->s_sort, &recs))) return e;
+                // the units: counted, then listed (a key's windows x its entries, in pieces of HVG_WC x HVG_EC)
+                hipLaunchKernelGGL(k_seed_hv_units, dim3((nhv + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)recs, (const uint64_t *)wrec, nhv, (uint64_t *)nullptr, 0ull, counters + 4);
+                unsigned long long nunits = 0;
+                HIP_TRY(c, hipMemcpyAsync(&nunits, counters + 4, sizeof nunits, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if ((e = pgrc_buf_ensure(c, c->s_hvu, (size_t)nunits * sizeof(uint64_t)))) return e;
+                uint64_t *units = (uint64_t *)c->s_hvu.p;
+                HIP_TRY(c, hipMemsetAsync(counters + 4, 0, sizeof(unsigned long long), c->stream));
+                hipLaunchKernelGGL(k_seed_hv_units, dim3((nhv + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)recs, (const uint64_t *)wrec, nhv, units, nunits, counters + 4);
+#define HVG_LAUNCH(R) hipLaunchKernelGGL((k_seed_heavy_grouped<R>), hgrid, dim3(HVG_TPB), 0, c->stream, a, w0, (const uint64_t *)wrec, (const uint64_t *)recs, (const uint64_t *)units, rows, best, counters, pgw)
+                switch (rw / 4u) {
+                case 1: HVG_LAUNCH(1); break;
+                case 2: HVG_LAUNCH(2); break;
+                case 3: HVG_LAUNCH(3); break;
+                default: HVG_LAUNCH(4); break;
+                }
+#undef HVG_LAUNCH
+                HIP_TRY(c, hipGetLastError());
+            }
+        }
     }
     // the keys that a hit has lowered become the reads' results
     hipLaunchKernelGGL(k_seed_best_store, dim3((uint32_t)((a.n + 255) / 256)), dim3(256), 0, c->stream, a, (const uint64_t *)c->s_best.p);

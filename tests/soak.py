@@ -62,9 +62,10 @@ def main():
         inline = "0" if rng.random() < 0.3 else ""
         heavy = str(rng.choice(["", "", "1", "4", "4096"]))   # modes d / i / e: entries of a window above which the persistent grid takes it
         ssort = str(rng.choice(["", "", "segments", "full"]))  # round 5: the table's pairs sorted by segments in LDS / by global passes
+        hform = str(rng.choice(["", "", "window"]))            # ... heavy windows grouped by key (default) / a wave per window
         for key, val in (("PGRC_INDEX_SORT", variant), ("PGRC_INDEX_CFG", icfg), ("PGRC_INDEX_FINISH", finish), ("PGRC_SEED_SEGMENT", seg), ("PGRC_SEED_READ_BATCH", batch),
                          ("PGRC_MATCH_STAGE", stage), ("PGRC_EARLY_STOP", early), ("PGRC_SCREEN", screen), ("PGRC_DUAL", dual),
-                         ("PGRC_HEAD_PAIR", pairk), ("PGRC_NREAD_INLINE", inline), ("PGRC_SEED_HEAVY", heavy), ("PGRC_SEED_SORT", ssort)):
+                         ("PGRC_HEAD_PAIR", pairk), ("PGRC_NREAD_INLINE", inline), ("PGRC_SEED_HEAVY", heavy), ("PGRC_SEED_SORT", ssort), ("PGRC_SEED_HEAVY_FORM", hform)):
             if val:
                 os.environ[key] = val
             else:
@@ -73,7 +74,7 @@ def main():
                       n_nset=nn if packed else None)
         what = dict(mode=mode, L=L, seed_len=seed_len, M=M, kmin=kmin, G=G, n=n, nn=nn, rev=rev, seed=seed, shards=shards,
                     packed=packed, variant=variant, finish=finish, seg=seg, batch=batch, stage=stage, early=early, screen=screen, dual=dual,
-                    pairk=pairk, inline=inline, icfg=icfg, heavy=heavy, ssort=ssort)
+                    pairk=pairk, inline=inline, icfg=icfg, heavy=heavy, ssort=ssort, hform=hform)
         for k in ("pos", "rc", "mism", "hist"):
             if not np.array_equal(np.asarray(g[k]), np.asarray(o[k])):
                 print("READS MISMATCH", what, k, flush=True)

@@ -62,12 +62,13 @@ def main():
             heavy = str(rng.choice(["", "", "1", "4096"]))
             seg = str(int(rng.integers(1 << 20, 1 << 24))) if rng.random() < 0.3 else ""
             ssort = str(rng.choice(["", "", "segments", "full"]))
-            for key, val in (("PGRC_SEED_HEAVY", heavy), ("PGRC_SEED_SEGMENT", seg), ("PGRC_SEED_SORT", ssort)):
+            hform = str(rng.choice(["", "", "window"]))
+            for key, val in (("PGRC_SEED_HEAVY", heavy), ("PGRC_SEED_SEGMENT", seg), ("PGRC_SEED_SORT", ssort), ("PGRC_SEED_HEAVY_FORM", hform)):
                 if val:
                     os.environ[key] = val
                 else:
                     os.environ.pop(key, None)
-            what = dict(mode=mode, L=L, seed_len=sl, kmax=km, kmin=kn, G=Gs, n=ns, nn=nn, seed=seed, shards=shards, heavy=heavy, seg=seg, sort=ssort)
+            what = dict(mode=mode, L=L, seed_len=sl, kmax=km, kmin=kn, G=Gs, n=ns, nn=nn, seed=seed, shards=shards, heavy=heavy, seg=seg, sort=ssort, hform=hform)
             pg, reads = pg[:Gs], reads[:ns]
             o = orc.oracle_match(mode, pg, reads, sl, km, kn)
             g = gpu_match(mode, pg, reads, sl, km, kn, True, devices=[0] * shards if shards else None)

@@ -547,7 +547,7 @@ def test_seedindex_modes_parity(mode, L, seed_len, M, shortcut, G, n, n_with_n):
         assert_same_results(g, r, "vs real reference")
 
 
-@pytest.mark.parametrize("heavy", ["1", "32", "4096"])
+@pytest.mark.parametrize("heavy", ["1", "32", "4096", "1-window", "32-window"])
 @pytest.mark.parametrize("mode", ["d", "i", "e"])
 def test_seedindex_hits_reduced_by_atomic_minimum(monkeypatch, mode, heavy):
     """Round 4: the reference's sequential rule over a read's hits is taken as what it amounts to -- a lexicographic minimum of
@@ -556,7 +556,10 @@ def test_seedindex_hits_reduced_by_atomic_minimum(monkeypatch, mode, heavy):
     text are expanded by the block that holds them, those with more than PGRC_SEED_HEAVY entries (default 32) by the waves of a
     persistent grid -- 1 / 4096: (nearly) every window takes the one road / the other.  Repeat families and a tandem tract: dozens
     to thousands of hits per read, arriving in arbitrary order, many of them on the same key at once."""
-    monkeypatch.setenv("PGRC_SEED_HEAVY", heavy)
+    # (round 5: the heavy windows are grouped by their key and a thread keeps its entry while the key's windows pass; "-window":
+    #  a wave per heavy window, the form of rounds 4-5a)
+    monkeypatch.setenv("PGRC_SEED_HEAVY", heavy.split("-")[0])
+    monkeypatch.setenv("PGRC_SEED_HEAVY_FORM", "window" if heavy.endswith("-window") else "grouped")
     L, seed_len = (100, 25) if mode != "e" else (100, 100)
     pg, reads = make_inputs(300_000, 9000, L, seed=4242, pool_div=4, tandem_every=2)      # repeat families: runs of dozens of hits
     rng = np.random.default_rng(3)
