@@ -904,8 +904,8 @@ k_seed_heavy(const SeedArgs a, uint64_t wbase, const uint64_t *__restrict__ wrec
 //   k_seed_heavy_grouped  a persistent grid takes the units (counters[3]; counters[4] = their number)
 #define HVG_TPB 256
 #define HVG_WC 256u
-#define HVG_SB 16u
-#define HVG_EC 1024u      // entries of a key per unit
+#define HVG_SB 32u
+#define HVG_EC 256u       // entries of a key per unit
 __global__ void __launch_bounds__(256)
 k_seed_hv_records(const uint64_t *__restrict__ wrec, const uint32_t *__restrict__ hlist, uint32_t nh, uint64_t *__restrict__ recs) {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
