@@ -22,7 +22,8 @@
 //   2. ONE scan of the forward text serves both strands (canonical keys, SeedArgs), in two kernels: k_seed_probe finds every
 //      window's range (one 8-byte word per window start); k_seed_expand shares the entries of the windows of its stretch among its
 //      lanes (prefix sums over the range lengths, a binary search per entry), and the windows with many entries -- repeats, tandem
-//      tracts: whole runs of them in one stretch -- go to a list that k_seed_heavy's waves take from all over the chip.
+//      tracts: whole runs of them in one stretch -- go to a list that is sorted by key and taken in units by k_seed_heavy_grouped's
+//      blocks from all over the chip (round 5; a wave per window, k_seed_heavy, until then).
 //   3. Every (window, entry) pair is a HIT: its Hamming count (popcount on 2-bit words, the read taken from a row-major copy) is
 //      computed on the spot, and the reference's sequential rule over a read's hits -- walked in scan order: ascending text
 //      position, equal positions in descending part index -- is taken as the lexicographic minimum it amounts to, one atomicMin
