@@ -164,6 +164,27 @@ def test_seedindex_table_sort_forms(monkeypatch, mode, sort):
         assert_same_results(gpu_match(mode, pg, reads, seed_len, kmax, 0), orc.oracle_match(mode, pg, reads, seed_len, kmax, 0), f"mode {mode} sort {sort}, 900 k entries")
 
 
+@pytest.mark.parametrize("host_pack", ["1", "0"])
+def test_text_upload_both_packers(monkeypatch, host_pack):
+    """An ASCII text is packed on the host (AVX2 / scalar, several threads, pinned buffers: the default since round 5) or goes up as
+    bytes and is packed by a kernel (PGRC_HOST_PACK=0): the same packed text -- texts that are no multiple of 16 or of a packing
+    chunk's share of a thread, and one above 4 Mi symbols (below it the host path is not taken) -- and a symbol outside ACGT is
+    refused by both with PGRC_E_SYMBOL, wherever it stands."""
+    from pgrc_amd import MatchContext
+    monkeypatch.setenv("PGRC_HOST_PACK", host_pack)
+    L = 100
+    for G in (300_001, 5_000_019):
+        pg, reads = make_inputs(G, 4000, L, seed=900 + G % 7)
+        assert_same_results(gpu_match("c", pg, reads, 38, 2, 0), orc.oracle_match("c", pg, reads, 38, 2, 0), f"host_pack={host_pack} G={G}")
+        for at in (0, G // 3 + 5, G - 1):
+            bad = pg.copy()
+            bad[at] = ord("N")
+            ctx = MatchContext(L, 38, 2, 0, "c")
+            with pytest.raises(Exception) as e:
+                ctx.set_pg_ascii(bad)
+            assert "ACGT" in str(e.value) or getattr(e.value, "code", None) == 5, str(e.value)
+
+
 CASES = [
     # L, seed, M, mode, G, n
     (100, 38, 50, "c", 400000, 20000),
